@@ -1,0 +1,102 @@
+"""ORACLE helper (test infrastructure) -- the reference's state_dict key schema and a
+machine-independent deterministic weight generator shared by golden generation (build container)
+and the parity tests (GPU box).  Values come from numpy's PCG64 stream, so no tensor file has to be
+committed: the goldens store only inputs' seeds and the reference's outputs.
+
+Schema source: models/margipose_model.py:25-100 (ResidualBlock / HeatmapColumn), :142-177
+(HeatmapCombiner / MargiPoseModelInner); pinned by tests/golden/state_dict_keys.json, which was
+dumped from the imported reference.
+"""
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+PLANES = ('xy', 'zy', 'xz')
+
+
+def _bn_entries(prefix, c):
+    return [(prefix + '.weight', (c,)), (prefix + '.bias', (c,)), (prefix + '.running_mean', (c,)),
+            (prefix + '.running_var', (c,)), (prefix + '.num_batches_tracked', ())]
+
+
+def _block_entries(prefix, cin, cout, kind):
+    if kind == 'up':      # ConvTranspose2d weight is (Cin, Cout, k, k)
+        w_in, w_sc = (cin, cout, 3, 3), (cin, cout, 1, 1)
+    else:
+        w_in, w_sc = (cout, cin, 3, 3), (cout, cin, 1, 1)
+    e = [(prefix + '.module.0.weight', w_in)]
+    e += _bn_entries(prefix + '.module.1', cout)
+    e += [(prefix + '.module.3.weight', (cout, cout, 3, 3))]
+    e += _bn_entries(prefix + '.module.4', cout)
+    e += [(prefix + '.shortcut.0.weight', w_sc)]
+    e += _bn_entries(prefix + '.shortcut.1', cout)
+    return e
+
+
+def column_entries(prefix, n_joints=17):
+    down = [(128, 128, 'regular'), (128, 128, 'regular'), (128, 192, 'down'), (192, 192, 'regular'),
+            (192, 192, 'regular')]
+    up = [(192, 192, 'regular'), (192, 192, 'regular'), (192, 128, 'up'), (128, 128, 'regular'),
+          (128, n_joints, 'regular')]
+    e = []
+    for i, (a, b, k) in enumerate(down):
+        e += _block_entries('%s.down_layers.%d' % (prefix, i), a, b, k)
+    for i, (a, b, k) in enumerate(up):
+        e += _block_entries('%s.up_layers.%d' % (prefix, i), a, b, k)
+    return e
+
+
+def schema(n_stages, n_joints=17):
+    """Ordered key -> shape map of MargiPoseModel(n_stages) with the patch8 stem."""
+    e = [('inner.in_cnn.0.weight', (128, 3, 8, 8))] + _bn_entries('inner.in_cnn.1', 128)
+    # nn.ModuleList registration order (models/margipose_model.py:158-162): all xy columns, then zy,
+    # then xz, then the combiners.
+    for p in PLANES:
+        for t in range(n_stages):
+            e += column_entries('inner.%s_hm_cnns.%d' % (p, t), n_joints)
+    for t in range(n_stages - 1):
+        e += [('inner.hm_combiners.%d.conv.weight' % t, (128, 3 * n_joints, 1, 1))]
+    return OrderedDict(e)
+
+
+def fill_like(shapes, seed, dtype=torch.float32):
+    """Deterministic values for an ordered key->shape map (conv weights Kaiming-scaled as
+    nn_helpers.py:7-21 would; BN affine/running stats deliberately NON-trivial so tests exercise them)."""
+    rng = np.random.default_rng(seed)
+    sd = OrderedDict()
+    for key, shape in shapes.items():
+        shape = tuple(shape)
+        if key.endswith('num_batches_tracked'):
+            sd[key] = torch.zeros((), dtype=torch.long)
+            continue
+        if key.endswith('running_var'):
+            v = rng.uniform(0.5, 1.5, shape)
+        elif key.endswith('running_mean'):
+            v = rng.standard_normal(shape) * 0.1
+        elif len(shape) == 1 and key.endswith('.weight'):
+            v = rng.uniform(0.5, 1.5, shape)
+        elif len(shape) == 1:
+            v = rng.standard_normal(shape) * 0.1
+        else:
+            fan_out = shape[0] * shape[2] * shape[3]          # kaiming_normal_(mode='fan_out')
+            v = rng.standard_normal(shape) * np.sqrt(2.0 / fan_out)
+        sd[key] = torch.from_numpy(np.asarray(v)).to(dtype)
+    return sd
+
+
+def make_state_dict(n_stages, seed, dtype=torch.float32):
+    return fill_like(schema(n_stages), seed, dtype)
+
+
+def column_state_dict(prefix, seed, dtype=torch.float32):
+    return fill_like(OrderedDict(column_entries(prefix)), seed, dtype)
+
+
+def seeded_inputs(seed, batch, size=256, dtype=torch.float32):
+    """Synthetic frames / targets / mask as SURVEY.md §8(d) prescribes (numpy stream, portable)."""
+    rng = np.random.default_rng(seed)
+    x = torch.from_numpy(rng.standard_normal((batch, 3, size, size))).to(dtype)
+    target = torch.from_numpy(rng.uniform(-1.0, 1.0, (batch, 17, 3))).to(dtype)
+    mask = torch.ones(batch, 17, dtype=dtype)
+    return x, target, mask
