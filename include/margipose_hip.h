@@ -1,0 +1,298 @@
+/*
+ * margipose_hip.h -- C ABI of libmargipose_hip.so, the MI355X (gfx950) implementation of the
+ * MargiPose forward/backward hot path.
+ *
+ * The reference (anibali/margipose) has NO native/FFI boundary: its hot path is Python calling
+ * torch.nn.  This header is therefore the boundary a maintainer would bind if the
+ * reference grew one; each entry point names the reference code it replaces (paths relative to
+ * src/margipose/ in the reference tree).  The Python host side (margipose_amd/) binds it with
+ * ctypes; INTEGRATION.md shows the stub.
+ *
+ * Conventions
+ *   - plain pointers + sizes only; every pointer is DEVICE memory owned by the caller;
+ *   - no hidden allocation, no host synchronisation; work is enqueued on `stream` (hipStream_t);
+ *   - return value: 0 on success, otherwise a hipError_t value, or a negative MPOSE_E* code for
+ *     invalid arguments;
+ *   - activations inside the backbone are NHWC fp32 (channel stride `C`), heatmaps/logits at the
+ *     model boundary are NCHW fp32 exactly as the reference's tensors.
+ */
+#ifndef MARGIPOSE_HIP_H
+#define MARGIPOSE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MPOSE_EINVAL (-22)
+#define MPOSE_ENOSYS (-38)
+
+#define MPOSE_MAX_GROUP 3   /* the xy / zy / xz columns of one stage run as one grouped launch */
+#define MPOSE_MAX_TAPS 12
+#define MPOSE_MAX_CLASSES 4
+
+int mpose_abi_version(void);
+/* sizeof() of the ABI structs, for binding self-checks: which = 0 geom, 1 conv operands, 2 wgrad
+ * operands, 3 pack job, 4 unpack job, 5 bn job, 6 bn coef job, 7 bn_add ops, 8 reduce ops, 9 apply ops. */
+int mpose_sizeof(int which);
+
+/* ------------------------------------------------------------------------------------------
+ * Soft-argmax tail (dsntnn.py, models/margipose_model.py:215-261)
+ * A "row" is one (batch, joint) heatmap of n = H*W fp32 values, n % 4 == 0, n <= 4096.
+ * Kernels use one 64-lane wavefront per (row, plane); planes = xy, zy, xz.
+ * ------------------------------------------------------------------------------------------ */
+
+/* flat_softmax (dsntnn.py:124-130) fused with dsnt (dsntnn.py:39-62,84-96) and, when n_planes == 3,
+ * MargiPoseModel.heatmaps_to_coords (models/margipose_model.py:254-261).
+ *   logits[p], heatmaps[p]: (rows, H, W) for plane p (heatmaps[p] may be NULL: coordinates only)
+ *   plane_coords: (n_planes, rows, 2) = (mu_x, mu_y) per plane, may be NULL
+ *   xyz: (rows, 3), only written when n_planes == 3, may be NULL
+ *   io_dtype: 0 = fp32 logits/heatmaps, 1 = bf16 logits/heatmaps (arithmetic is fp32 either way) */
+int mpose_softmax_dsnt_fwd(const void* const* logits, void* const* heatmaps, float* plane_coords,
+                           float* xyz, int n_planes, int rows, int H, int W, int io_dtype,
+                           void* stream);
+
+/* dsnt alone on already-normalised heatmaps (MargiPoseModel.heatmaps_to_coords on arbitrary input). */
+int mpose_dsnt_fwd(const float* const* heatmaps, float* plane_coords, float* xyz, int n_planes,
+                   int rows, int H, int W, void* stream);
+
+/* backward of dsnt: d_heatmap[r,h,w] (+)= d_mu_x[r] * x_w + d_mu_y[r] * y_h.
+ * d_plane_coords: (n_planes, rows, 2).  accumulate != 0 adds into d_heatmaps. */
+int mpose_dsnt_bwd(const float* d_plane_coords, float* const* d_heatmaps, int n_planes, int rows,
+                   int H, int W, int accumulate, void* stream);
+
+/* backward of flat_softmax: dlogits = p * (g - sum_k p_k g_k), g = g1 (+ g2 when non-NULL). */
+int mpose_softmax_bwd(const float* const* heatmaps, const float* const* g1, const float* const* g2,
+                      float* const* dlogits, int n_planes, int rows, int n, void* stream);
+
+/* One stage of MargiPoseModel.forward_3d_losses / forward_2d_losses
+ * (models/margipose_model.py:223-252): per (b,j)
+ *     sum over planes of js_reg_losses (dsntnn.py:154-232, sigma in pixels)   [if pixelwise]
+ *   + euclidean_losses(heatmaps_to_coords(...), target) (dsntnn.py:133-151).
+ *   heatmaps: 3 planes (rows, H, W); target: (rows, 3); three_d == 0 selects the 2D variant
+ *   (xy plane only).  losses: (rows); accumulate != 0 adds the stage into `losses` (the
+ *   reference's `losses += ...`).  xyz_out: (rows, 3) coordinates saved for the backward. */
+int mpose_stage_loss_fwd(const float* const* heatmaps, const float* target, float* losses,
+                         float* xyz_out, int rows, int H, int W, float sigma, int pixelwise,
+                         int three_d, int accumulate, void* stream);
+
+/* Backward of the above w.r.t. the heatmaps (SURVEY.md §8 row a-T): g[p] = dloss[r] * dL_r/dp.
+ * The Gaussian targets are regenerated in registers.  accumulate != 0 adds into g. */
+int mpose_stage_loss_bwd(const float* const* heatmaps, const float* target, const float* xyz,
+                         const float* dloss, float* const* g, int rows, int H, int W, float sigma,
+                         int pixelwise, int three_d, int accumulate, void* stream);
+
+/* js_reg_losses alone (dsntnn.py:220-232) for one plane: mu (rows, 2) -> js (rows). */
+int mpose_js_fwd(const float* heatmaps, const float* mu, float* js, int rows, int H, int W,
+                 float sigma, void* stream);
+int mpose_js_bwd(const float* heatmaps, const float* mu, const float* djs, float* g, int rows,
+                 int H, int W, float sigma, void* stream);
+
+/* average_loss (dsntnn.py:99-121): out[0] = sum(l*m)/max(sum(m),1); out[1] = the denominator. */
+int mpose_average_loss_fwd(const float* losses, const float* mask, float* out2, int n, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Backbone (models/margipose_model.py:25-200).  Declared in the sections below as they land.
+ * ------------------------------------------------------------------------------------------ */
+
+/* Geometry of one implicit-GEMM convolution launch (all Conv2d / ConvTranspose2d of
+ * models/margipose_model.py:33,67-82 and their data-gradients are instances):
+ * the launch enumerates a grid of GH x GW "slots" per image and per class; slot (gy,gx) of class
+ * c reads input pixels (gy*in_mul + dy_t, gx*in_mul + dx_t) for every tap t of the class and
+ * writes output pixel (gy*out_mul + oy_c, gx*out_mul + ox_c). */
+typedef struct {
+  int8_t dy, dx;      /* input offset of the tap */
+  int8_t widx;        /* which packed weight slice the tap multiplies with */
+  int8_t acc;         /* 0: main accumulator (output 0), 1: second accumulator (output 1) */
+} mpose_tap;
+
+typedef struct {
+  int n_taps;
+  int oy, ox;                          /* output phase of the class */
+  mpose_tap taps[MPOSE_MAX_TAPS];
+} mpose_tap_class;
+
+typedef struct {
+  int B, IH, IW, Cin;                  /* input  (B, IH, IW, Cin) NHWC, Cin % 32 == 0 */
+  int OH, OW, Cout0, Cout1;            /* outputs (B, OH, OW, CoutX) NHWC (storage channel counts) */
+  int GH, GW;                          /* slot grid per image and class */
+  int in_mul, out_mul;                 /* 1 or 2 */
+  int n_classes;
+  int Npad0, Npad1;                    /* padded N of the packed weights for acc 0 / acc 1 */
+  mpose_tap_class cls[MPOSE_MAX_CLASSES];
+} mpose_conv_geom;
+
+/* Per-group (column) operands of a conv launch. */
+typedef struct {
+  const float* in;                     /* input activations */
+  const float* in_scale;               /* optional per-channel prologue a*x+b then ReLU (BN+ReLU of */
+  const float* in_shift;               /*   models/margipose_model.py:31-32,34-35); NULL = identity  */
+  const float* w0;                     /* packed weights [widx][Cin/4][Npad0][4] */
+  const float* w1;                     /* packed weights of the second accumulator, or NULL */
+  float* out0;
+  float* out1;
+  double* stats0;                      /* optional (Cout0, 2) sum / sum-of-squares accumulators */
+  double* stats1;
+  const float* mask_src;               /* epilogue ReLU-mask source (pre-BN activations), or NULL */
+  const float* mask_scale;
+  const float* mask_shift;
+} mpose_conv_operands;
+
+/* Conv forward / data-gradient.  flags: bit0 = accumulate into out0 (out0 += result);
+ * when mask_src != NULL the result is multiplied by [mask_scale*mask_src+mask_shift > 0] before it
+ * is stored, and stats0 receives (sum d, sum d*mask_src) instead of (sum, sum of squares). */
+int mpose_conv_fwd(const mpose_conv_geom* geom, const mpose_conv_operands* ops, int n_groups,
+                   int flags, void* stream);
+
+/* Weight-gradient of the same family: for every tap slice `widx`,
+ *   dWp[split][widx][Cin/4][Npad][4] = sum over the split's slots of in(tap-shifted)^T * gout.
+ * `gout` is indexed like an output of the forward geometry (acc 0 taps use gout0, acc 1 gout1). */
+typedef struct {
+  const float* in;
+  const float* in_scale;
+  const float* in_shift;
+  const float* gout0;
+  const float* gout1;
+  float* dw0;                          /* (n_split, n_widx0, Cin/4, Npad0, 4) partial sums */
+  float* dw1;
+} mpose_wgrad_operands;
+
+int mpose_conv_wgrad(const mpose_conv_geom* geom, const mpose_wgrad_operands* ops, int n_groups,
+                     int n_split, void* stream);
+
+/* Batched weight (re)packing and gradient un-packing; jobs live in device memory. */
+typedef struct {
+  const float* src;                    /* torch-layout weight */
+  float* dst;                          /* packed [T][K/4][Npad][4] */
+  int N, K, T, Npad, Kpad;
+  int64_t sn, sk, st;                  /* element strides of n, k, tap in src */
+} mpose_pack_job;
+
+int mpose_pack_weights(const mpose_pack_job* jobs_dev, int n_jobs, int max_elems_per_job,
+                       void* stream);
+
+typedef struct {
+  const float* src;                    /* packed partial sums (n_split, T, Kpad/4, Npad, 4) */
+  float* dst;                          /* torch-layout gradient */
+  int N, K, T, Npad, Kpad, n_split;
+  int64_t sn, sk, st;
+  int accumulate;                      /* dst += (like autograd) or dst = */
+} mpose_unpack_job;
+
+int mpose_unpack_wgrads(const mpose_unpack_job* jobs_dev, int n_jobs, int max_elems_per_job,
+                        void* stream);
+
+/* BatchNorm pieces (models/margipose_model.py:31,34,37; train = batch statistics, biased variance,
+ * eps 1e-5; running update momentum 0.1 with unbiased variance). */
+typedef struct {
+  const double* stats;                 /* (C, 2) sum, sumsq from the producing conv, or NULL in eval */
+  const float* gamma;
+  const float* beta;
+  float* running_mean;
+  float* running_var;
+  float* scale;                        /* out: gamma * invstd */
+  float* shift;                        /* out: beta - mean * scale */
+  float* mean;                         /* out (train): batch mean */
+  float* invstd;                       /* out (train): 1/sqrt(var + eps) */
+  int C;
+  int count;                           /* B*H*W of the normalised tensor */
+} mpose_bn_job;
+
+/* For every job: derive scale/shift (+ mean/invstd); train != 0 also updates the running stats. */
+int mpose_bn_finalize(const mpose_bn_job* jobs_dev, int n_jobs, int train, float eps,
+                      float momentum, void* stream);
+
+/* out = relu(a_scale*a + a_shift) + (b_scale*b + b_shift): the tail of ResidualBlock.forward
+ * (models/margipose_model.py:34-40 -- second BN + ReLU of the main branch, BN of the shortcut, add).  layout: 0 = NHWC out with C channels, 1 = NCHW out keeping
+ * the first `c_keep` channels (the column's logits). */
+typedef struct {
+  const float* a; const float* a_scale; const float* a_shift;
+  const float* b; const float* b_scale; const float* b_shift;
+  float* out;
+} mpose_bn_add_operands;
+
+int mpose_bn_add_fwd(const mpose_bn_add_operands* ops, int n_groups, int pixels_per_image, int B,
+                     int C, int layout, int c_keep, void* stream);
+
+/* out = relu(x*scale + shift) over an NHWC tensor of n elements with C channels (the stem's BN+ReLU,
+ * materialised because every column of every stage reads it), and the ReLU backward gm = g*[y>0]. */
+int mpose_bn_relu_fwd(const float* x, const float* scale, const float* shift, float* out, int64_t n,
+                      int C, void* stream);
+int mpose_relu_bwd(const float* g, const float* y, float* gm, int64_t n, void* stream);
+
+/* Backward reductions/applications of BatchNorm, see csrc/bn.hip for the algebra. */
+typedef struct {
+  const float* g;                      /* upstream gradient, NHWC */
+  const float* a;                      /* pre-BN activation of branch a */
+  const float* b;                      /* pre-BN activation of branch b, or NULL */
+  const float* a_scale;                /* when non-NULL, branch a sees g * [a_scale*a + a_shift > 0] */
+  const float* a_shift;                /*   (the ReLU that follows branch a's BatchNorm) */
+  double* sums;                        /* (C, 4): sum ga, sum ga*a, sum g, sum g*b */
+} mpose_bn_bwd_reduce_operands;
+
+int mpose_bn_bwd_reduce(const mpose_bn_bwd_reduce_operands* ops, int n_groups, int pixels_per_image,
+                        int B, int C, int layout, int c_keep, void* stream);
+
+typedef struct {
+  const float* g;
+  const float* a; const float* b;
+  const float* coef_a;                 /* (3, C): da = ca0*ga + ca1*a + ca2, ga = g * relu-mask (see below) */
+  const float* coef_b;                 /* (3, C): db = cb0*g + cb1*b + cb2 */
+  const float* a_scale;                /* optional ReLU mask of branch a, as in the reduce step */
+  const float* a_shift;
+  float* da; float* db;
+} mpose_bn_bwd_apply_operands;
+
+int mpose_bn_bwd_apply(const mpose_bn_bwd_apply_operands* ops, int n_groups, int pixels_per_image,
+                       int B, int C, int layout, int c_keep, void* stream);
+
+typedef struct {
+  const double* sums;                  /* (Cs, 3) from mpose_bn_bwd_reduce, or (Cs, 2) from a conv epilogue */
+  const float* gamma; const float* mean; const float* invstd;
+  float* coef;                         /* out (3, c_stride) */
+  float* dgamma; float* dbeta;         /* out (written, not accumulated), may be NULL */
+  int sums_stride;                     /* 4 (mpose_bn_bwd_reduce) or 2 (conv epilogue) */
+  int which;                           /* column of `sums` holding sum g*x for this BN */
+  int C;                               /* logical channels */
+  int c_stride;                        /* storage channels (row length of coef) */
+  int count;
+  int sg_col;                          /* column of `sums` holding sum g for this BN */
+} mpose_bn_bwd_coef_job;
+
+int mpose_bn_bwd_coef(const mpose_bn_bwd_coef_job* jobs_dev, int n_jobs, void* stream);
+
+/* Layout / glue kernels. */
+/* NCHW image (B,3,S,S) -> NHWC space-to-depth (B, S/8, S/8, 192) for the patch8 stem, and back. */
+int mpose_space_to_depth8(const float* x, float* out, int B, int S, void* stream);
+int mpose_depth_to_space8(const float* g, float* dx, int B, int S, void* stream);
+
+/* The column's axis permutation (models/margipose_model.py:91-97) on NHWC (B,S,S,C) tensors.
+ * space: 1 = zy, 2 = xz.  The permutation is an involution, so backward = forward. */
+int mpose_axis_permute(const float* const* in, float* const* out, const int* spaces, int n_groups,
+                       int B, int S, int C, void* stream);
+
+/* HeatmapCombiner (models/margipose_model.py:142-150) + the cumulative add (:195):
+ *   out[b,y,x,c] = inp[b,y,x,c] + sum_{p,j} W[c, p*J+j] * hm[p][b,j,y,x]   (hm NCHW, inp/out NHWC) */
+int mpose_combiner_fwd(const float* const* hm, const float* w, const float* inp, float* out, int B,
+                       int J, int HW, int C, void* stream);
+/* d_hm[p][b,j,y,x] = sum_c W[c,p*J+j] * g[b,y,x,c];  dw partial sums (n_blocks, C, 3J). */
+int mpose_combiner_bwd(const float* const* hm, const float* w, const float* g, float* const* d_hm,
+                       float* dw_partial, int n_partial, int B, int J, int HW, int C, void* stream);
+
+/* out = a + b elementwise (gradient fan-in), n % 4 == 0. */
+int mpose_add(const float* a, const float* b, float* out, int64_t n, void* stream);
+
+/* (B, J, P) NCHW -> (B, P, Cpad) NHWC with channels >= J zero-filled (logits gradient entering the
+ * last ResidualBlock's backward). */
+int mpose_nchw_to_nhwc_pad(const float* const* in, float* const* out, int n_groups, int B, int J,
+                           int P, int Cpad, void* stream);
+
+/* dst[i] (+)= sum_p src[p*n + i]  (second stage of deterministic block-partial reductions). */
+int mpose_reduce_partials(const float* src, float* dst, int n_partial, int64_t n, int accumulate,
+                          void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MARGIPOSE_HIP_H */

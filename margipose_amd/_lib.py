@@ -1,0 +1,124 @@
+"""ctypes binding of libmargipose_hip.so (include/margipose_hip.h).
+
+There is NO fallback: if the library is missing or a tensor is not a ROCm device tensor the call
+raises.  (`python -m margipose_amd.build` or `__graft_entry__.build()` compiles the library.)
+"""
+import ctypes
+import os
+
+import torch
+
+from . import build as _build
+
+_LIB = None
+
+c_void_p = ctypes.c_void_p
+c_int = ctypes.c_int
+c_float = ctypes.c_float
+c_int64 = ctypes.c_int64
+
+MAX_GROUP = 3
+MAX_TAPS = 12
+MAX_CLASSES = 4
+
+
+class MposeError(RuntimeError):
+    pass
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = _build.LIB_PATH
+        if not os.path.exists(path):
+            raise MposeError('libmargipose_hip.so is missing (%s). Build it with `python -m margipose_amd.build`; '
+                             'there is no CPU/PyTorch fallback for the MargiPose hot path.' % path)
+        _LIB = ctypes.CDLL(path)
+        _LIB.mpose_abi_version.restype = c_int
+        if _LIB.mpose_abi_version() != 1:
+            raise MposeError('libmargipose_hip.so ABI version mismatch')
+    return _LIB
+
+
+def check(rc, what):
+    if rc != 0:
+        raise MposeError('%s failed with code %d' % (what, rc))
+
+
+def stream_ptr():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def dev_f32(t, name='tensor'):
+    """Validate a device fp32 contiguous tensor and return it."""
+    if not isinstance(t, torch.Tensor):
+        raise MposeError('%s must be a torch.Tensor' % name)
+    if not t.is_cuda:
+        raise MposeError('%s must live on a ROCm device (got %s): margipose_amd has no CPU path' % (name, t.device))
+    if t.dtype != torch.float32:
+        raise MposeError('%s must be float32 (got %s)' % (name, t.dtype))
+    if not t.is_contiguous():
+        raise MposeError('%s must be contiguous' % name)
+    return t
+
+
+def ptr(t):
+    return c_void_p(t.data_ptr()) if t is not None else c_void_p(None)
+
+
+def ptr_array(tensors, n=MAX_GROUP):
+    arr = (c_void_p * n)()
+    for i, t in enumerate(tensors):
+        arr[i] = t.data_ptr() if t is not None else None
+    return arr
+
+
+# ---- structs mirroring include/margipose_hip.h ------------------------------------------------
+class Tap(ctypes.Structure):
+    _fields_ = [('dy', ctypes.c_int8), ('dx', ctypes.c_int8), ('widx', ctypes.c_int8), ('acc', ctypes.c_int8)]
+
+
+class TapClass(ctypes.Structure):
+    _fields_ = [('n_taps', c_int), ('oy', c_int), ('ox', c_int), ('taps', Tap * MAX_TAPS)]
+
+
+class ConvGeom(ctypes.Structure):
+    _fields_ = [('B', c_int), ('IH', c_int), ('IW', c_int), ('Cin', c_int),
+                ('OH', c_int), ('OW', c_int), ('Cout0', c_int), ('Cout1', c_int),
+                ('GH', c_int), ('GW', c_int), ('in_mul', c_int), ('out_mul', c_int),
+                ('n_classes', c_int), ('Npad0', c_int), ('Npad1', c_int),
+                ('cls', TapClass * MAX_CLASSES)]
+
+
+class ConvOperands(ctypes.Structure):
+    _fields_ = [('in_', c_void_p), ('in_scale', c_void_p), ('in_shift', c_void_p),
+                ('w0', c_void_p), ('w1', c_void_p), ('out0', c_void_p), ('out1', c_void_p),
+                ('stats0', c_void_p), ('stats1', c_void_p),
+                ('mask_src', c_void_p), ('mask_scale', c_void_p), ('mask_shift', c_void_p)]
+
+
+class WgradOperands(ctypes.Structure):
+    _fields_ = [('in_', c_void_p), ('in_scale', c_void_p), ('in_shift', c_void_p),
+                ('gout0', c_void_p), ('gout1', c_void_p), ('dw0', c_void_p), ('dw1', c_void_p)]
+
+
+class BnAddOperands(ctypes.Structure):
+    _fields_ = [('a', c_void_p), ('a_scale', c_void_p), ('a_shift', c_void_p),
+                ('b', c_void_p), ('b_scale', c_void_p), ('b_shift', c_void_p), ('out', c_void_p)]
+
+
+class BnBwdReduceOperands(ctypes.Structure):
+    _fields_ = [('g', c_void_p), ('a', c_void_p), ('b', c_void_p), ('a_scale', c_void_p), ('a_shift', c_void_p),
+                ('sums', c_void_p)]
+
+
+class BnBwdApplyOperands(ctypes.Structure):
+    _fields_ = [('g', c_void_p), ('a', c_void_p), ('b', c_void_p), ('coef_a', c_void_p), ('coef_b', c_void_p),
+                ('a_scale', c_void_p), ('a_shift', c_void_p), ('da', c_void_p), ('db', c_void_p)]
+
+
+# Host-side mirrors of the device-resident job tables (filled into int64 tensors, see engine.py).
+PACK_JOB_WORDS = 8        # src, dst, (N,K), (T,Npad), (Kpad,pad), sn, sk, st      -> 8 x int64
+UNPACK_JOB_WORDS = 9
+BN_JOB_WORDS = 10
+BN_COEF_JOB_WORDS = 9

@@ -1,0 +1,330 @@
+// BatchNorm2d pieces for gfx950 (reference models/margipose_model.py:31,34,37 -- nn.BatchNorm2d
+// defaults: eps 1e-5, momentum 0.1, biased batch variance for normalisation, unbiased for the running
+// estimate).  The expensive parts of BN never run as their own pass over the activations:
+//   * batch sums are reduced in the producing conv's epilogue (conv.hip, fp64 atomics),
+//   * normalise(+ReLU) is applied while the consuming conv stages its input tile,
+//   * here: the per-channel finalisation, the residual "BN(a) + BN(b)" add, and the backward
+//     reductions / coefficient algebra.  All HBM-bound, float4 NHWC accesses.
+//
+// Backward algebra (x = pre-BN activation, g = upstream gradient, N = B*H*W):
+//   xhat = (x - mean) * invstd ; dgamma = sum g*xhat ; dbeta = sum g
+//   dx = gamma*invstd * (g - mean(g) - xhat * mean(g*xhat)) = c0*g + c1*x + c2
+//   with c0 = gamma*invstd, c1 = -c0*invstd*mean(g*xhat), c2 = -c0*mean(g) - c1*mean.
+#include "common.h"
+
+namespace mpose {
+namespace {
+
+__global__ __launch_bounds__(256) void bn_finalize_k(const mpose_bn_job* __restrict__ jobs, int train, float eps, float momentum) {
+  const mpose_bn_job j = jobs[blockIdx.x];
+  for (int c = threadIdx.x; c < j.C; c += 256) {
+    double mean, var;
+    if (train) {
+      const double n = (double)j.count;
+      mean = j.stats[2 * c] / n;
+      var = j.stats[2 * c + 1] / n - mean * mean;
+      if (var < 0.0) var = 0.0;
+      if (j.running_mean != nullptr) {
+        const double unbiased = (j.count > 1) ? var * n / (n - 1.0) : var;
+        j.running_mean[c] = (float)((1.0 - momentum) * (double)j.running_mean[c] + momentum * mean);
+        j.running_var[c] = (float)((1.0 - momentum) * (double)j.running_var[c] + momentum * unbiased);
+      }
+    } else {
+      mean = (double)j.running_mean[c];
+      var = (double)j.running_var[c];
+    }
+    const double invstd = 1.0 / sqrt(var + (double)eps);
+    const double sc = (double)j.gamma[c] * invstd;
+    j.scale[c] = (float)sc;
+    j.shift[c] = (float)((double)j.beta[c] - mean * sc);
+    if (j.mean != nullptr) { j.mean[c] = (float)mean; j.invstd[c] = (float)invstd; }
+  }
+}
+
+struct BnAddArgs {
+  mpose_bn_add_operands op[MPOSE_MAX_GROUP];
+  long total4;            // B*P*C/4
+  int C, P, c_keep;
+};
+
+__global__ __launch_bounds__(256) void bn_add_nhwc_k(BnAddArgs a) {
+  const mpose_bn_add_operands& op = a.op[blockIdx.y];
+  const int c4n = a.C >> 2;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < a.total4; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % c4n) * 4;
+    const float4 x = reinterpret_cast<const float4*>(op.a)[i];
+    const float4 y = reinterpret_cast<const float4*>(op.b)[i];
+    const float4 sa = *reinterpret_cast<const float4*>(op.a_scale + c), ta = *reinterpret_cast<const float4*>(op.a_shift + c);
+    const float4 sb = *reinterpret_cast<const float4*>(op.b_scale + c), tb = *reinterpret_cast<const float4*>(op.b_shift + c);
+    float4 o;
+    o.x = fmaxf(fmaf(x.x, sa.x, ta.x), 0.f) + fmaf(y.x, sb.x, tb.x);
+    o.y = fmaxf(fmaf(x.y, sa.y, ta.y), 0.f) + fmaf(y.y, sb.y, tb.y);
+    o.z = fmaxf(fmaf(x.z, sa.z, ta.z), 0.f) + fmaf(y.z, sb.z, tb.z);
+    o.w = fmaxf(fmaf(x.w, sa.w, ta.w), 0.f) + fmaf(y.w, sb.w, tb.w);
+    reinterpret_cast<float4*>(op.out)[i] = o;
+  }
+}
+
+// NHWC (B, P, C) inputs -> NCHW (B, c_keep, P) output: one thread per pixel, writes coalesced over pixels.
+__global__ __launch_bounds__(256) void bn_add_nchw_k(BnAddArgs a, int B) {
+  const mpose_bn_add_operands& op = a.op[blockIdx.y];
+  const long npix = (long)B * a.P;
+  for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < npix; p += (long)gridDim.x * 256) {
+    const long b = p / a.P;
+    const int px = (int)(p - b * a.P);
+    for (int c = 0; c < a.c_keep; c += 4) {
+      const float4 x = *reinterpret_cast<const float4*>(op.a + p * a.C + c);
+      const float4 y = *reinterpret_cast<const float4*>(op.b + p * a.C + c);
+      const float xs[4] = {x.x, x.y, x.z, x.w}, ys[4] = {y.x, y.y, y.z, y.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int cc = c + e;
+        if (cc < a.c_keep)
+          op.out[(b * a.c_keep + cc) * a.P + px] = fmaxf(fmaf(xs[e], op.a_scale[cc], op.a_shift[cc]), 0.f) + fmaf(ys[e], op.b_scale[cc], op.b_shift[cc]);
+      }
+    }
+  }
+}
+
+struct BnReduceArgs {
+  mpose_bn_bwd_reduce_operands op[MPOSE_MAX_GROUP];
+  long npix;
+  int C, pix_per_block;
+};
+
+__global__ __launch_bounds__(256) void bn_bwd_reduce_k(BnReduceArgs a) {
+  extern __shared__ float sred[];      // [rows_per_pass][C][4]
+  const mpose_bn_bwd_reduce_operands& op = a.op[blockIdx.y];
+  const int c4n = a.C >> 2;
+  const int rows_per_pass = 256 / c4n;
+  const int col4 = threadIdx.x % c4n, row0 = threadIdx.x / c4n;
+  const bool active = row0 < rows_per_pass;
+  const bool has_b = op.b != nullptr;
+  const bool masked = op.a_scale != nullptr;
+  float4 sga0 = make_float4(0.f, 0.f, 0.f, 0.f), sga1 = sga0, sg = sga0, sgb = sga0;
+  const long p_begin = (long)blockIdx.x * a.pix_per_block;
+  const long p_end = min(a.npix, p_begin + a.pix_per_block);
+  if (active) {
+    float4 ms = make_float4(0.f, 0.f, 0.f, 0.f), mt = ms;
+    if (masked) { ms = *reinterpret_cast<const float4*>(op.a_scale + col4 * 4); mt = *reinterpret_cast<const float4*>(op.a_shift + col4 * 4); }
+    for (long p = p_begin + row0; p < p_end; p += rows_per_pass) {
+      const long o = p * c4n + col4;
+      const float4 g = reinterpret_cast<const float4*>(op.g)[o];
+      const float4 x = reinterpret_cast<const float4*>(op.a)[o];
+      float4 ga = g;
+      if (masked) {
+        if (!(fmaf(x.x, ms.x, mt.x) > 0.f)) ga.x = 0.f;
+        if (!(fmaf(x.y, ms.y, mt.y) > 0.f)) ga.y = 0.f;
+        if (!(fmaf(x.z, ms.z, mt.z) > 0.f)) ga.z = 0.f;
+        if (!(fmaf(x.w, ms.w, mt.w) > 0.f)) ga.w = 0.f;
+      }
+      sga0.x += ga.x; sga0.y += ga.y; sga0.z += ga.z; sga0.w += ga.w;
+      sga1.x = fmaf(ga.x, x.x, sga1.x); sga1.y = fmaf(ga.y, x.y, sga1.y); sga1.z = fmaf(ga.z, x.z, sga1.z); sga1.w = fmaf(ga.w, x.w, sga1.w);
+      if (has_b) {
+        const float4 y = reinterpret_cast<const float4*>(op.b)[o];
+        sg.x += g.x; sg.y += g.y; sg.z += g.z; sg.w += g.w;
+        sgb.x = fmaf(g.x, y.x, sgb.x); sgb.y = fmaf(g.y, y.y, sgb.y); sgb.z = fmaf(g.z, y.z, sgb.z); sgb.w = fmaf(g.w, y.w, sgb.w);
+      }
+    }
+    float* d = sred + ((long)row0 * a.C + col4 * 4) * 4;
+    d[0] = sga0.x; d[1] = sga1.x; d[2] = sg.x; d[3] = sgb.x;
+    d[4] = sga0.y; d[5] = sga1.y; d[6] = sg.y; d[7] = sgb.y;
+    d[8] = sga0.z; d[9] = sga1.z; d[10] = sg.z; d[11] = sgb.z;
+    d[12] = sga0.w; d[13] = sga1.w; d[14] = sg.w; d[15] = sgb.w;
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < a.C; c += 256) {
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    for (int r = 0; r < rows_per_pass; ++r) {
+      const float* d = sred + ((long)r * a.C + c) * 4;
+      s0 += d[0]; s1 += d[1]; s2 += d[2]; s3 += d[3];
+    }
+    atomicAdd(op.sums + (size_t)c * 4, s0);
+    atomicAdd(op.sums + (size_t)c * 4 + 1, s1);
+    if (has_b) { atomicAdd(op.sums + (size_t)c * 4 + 2, s2); atomicAdd(op.sums + (size_t)c * 4 + 3, s3); }
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_coef_k(const mpose_bn_bwd_coef_job* __restrict__ jobs) {
+  const mpose_bn_bwd_coef_job j = jobs[blockIdx.x];
+  const double n = (double)j.count;
+  for (int c = threadIdx.x; c < j.C; c += 256) {
+    const double sg = j.sums[(size_t)c * j.sums_stride + j.sg_col];
+    const double sgx = j.sums[(size_t)c * j.sums_stride + j.which];
+    const double mean = (double)j.mean[c], invstd = (double)j.invstd[c], gamma = (double)j.gamma[c];
+    const double sgxhat = invstd * (sgx - mean * sg);
+    const double c0 = gamma * invstd;
+    const double c1 = -c0 * invstd * (sgxhat / n);
+    const double c2 = -c0 * (sg / n) - c1 * mean;
+    j.coef[c] = (float)c0;
+    j.coef[j.c_stride + c] = (float)c1;
+    j.coef[2 * j.c_stride + c] = (float)c2;
+    if (j.dgamma != nullptr) { j.dgamma[c] = (float)sgxhat; j.dbeta[c] = (float)sg; }
+  }
+}
+
+struct BnApplyArgs {
+  mpose_bn_bwd_apply_operands op[MPOSE_MAX_GROUP];
+  long total4;
+  int C;
+};
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_k(BnApplyArgs a) {
+  const mpose_bn_bwd_apply_operands& op = a.op[blockIdx.y];
+  const int c4n = a.C >> 2;
+  const bool has_b = op.b != nullptr;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < a.total4; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % c4n) * 4;
+    const float4 g = reinterpret_cast<const float4*>(op.g)[i];
+    {
+      const float4 x = reinterpret_cast<const float4*>(op.a)[i];
+      float4 ga = g;
+      if (op.a_scale != nullptr) {
+        const float4 ms = *reinterpret_cast<const float4*>(op.a_scale + c), mt = *reinterpret_cast<const float4*>(op.a_shift + c);
+        if (!(fmaf(x.x, ms.x, mt.x) > 0.f)) ga.x = 0.f;
+        if (!(fmaf(x.y, ms.y, mt.y) > 0.f)) ga.y = 0.f;
+        if (!(fmaf(x.z, ms.z, mt.z) > 0.f)) ga.z = 0.f;
+        if (!(fmaf(x.w, ms.w, mt.w) > 0.f)) ga.w = 0.f;
+      }
+      const float4 k0 = *reinterpret_cast<const float4*>(op.coef_a + c);
+      const float4 k1 = *reinterpret_cast<const float4*>(op.coef_a + a.C + c);
+      const float4 k2 = *reinterpret_cast<const float4*>(op.coef_a + 2 * a.C + c);
+      float4 o;
+      o.x = fmaf(k0.x, ga.x, fmaf(k1.x, x.x, k2.x)); o.y = fmaf(k0.y, ga.y, fmaf(k1.y, x.y, k2.y));
+      o.z = fmaf(k0.z, ga.z, fmaf(k1.z, x.z, k2.z)); o.w = fmaf(k0.w, ga.w, fmaf(k1.w, x.w, k2.w));
+      reinterpret_cast<float4*>(op.da)[i] = o;
+    }
+    if (has_b) {
+      const float4 x = reinterpret_cast<const float4*>(op.b)[i];
+      const float4 k0 = *reinterpret_cast<const float4*>(op.coef_b + c);
+      const float4 k1 = *reinterpret_cast<const float4*>(op.coef_b + a.C + c);
+      const float4 k2 = *reinterpret_cast<const float4*>(op.coef_b + 2 * a.C + c);
+      float4 o;
+      o.x = fmaf(k0.x, g.x, fmaf(k1.x, x.x, k2.x)); o.y = fmaf(k0.y, g.y, fmaf(k1.y, x.y, k2.y));
+      o.z = fmaf(k0.z, g.z, fmaf(k1.z, x.z, k2.z)); o.w = fmaf(k0.w, g.w, fmaf(k1.w, x.w, k2.w));
+      reinterpret_cast<float4*>(op.db)[i] = o;
+    }
+  }
+}
+
+// out = relu(a*scale + shift)  (the stem's BN + ReLU, materialised because the stage input is shared)
+__global__ __launch_bounds__(256) void bn_relu_k(const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
+                                                 float* __restrict__ out, long total4, int C) {
+  const int c4n = C >> 2;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % c4n) * 4;
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    const float4 s = *reinterpret_cast<const float4*>(scale + c), t = *reinterpret_cast<const float4*>(shift + c);
+    reinterpret_cast<float4*>(out)[i] = make_float4(fmaxf(fmaf(v.x, s.x, t.x), 0.f), fmaxf(fmaf(v.y, s.y, t.y), 0.f),
+                                                    fmaxf(fmaf(v.z, s.z, t.z), 0.f), fmaxf(fmaf(v.w, s.w, t.w), 0.f));
+  }
+}
+// gm = g where y > 0 else 0
+__global__ __launch_bounds__(256) void relu_bwd_k(const float4* __restrict__ g, const float4* __restrict__ y, float4* __restrict__ gm, long total4) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
+    const float4 a = g[i], b = y[i];
+    gm[i] = make_float4(b.x > 0.f ? a.x : 0.f, b.y > 0.f ? a.y : 0.f, b.z > 0.f ? a.z : 0.f, b.w > 0.f ? a.w : 0.f);
+  }
+}
+
+inline int grid_for(long work_items, int per_block) {
+  long b = (work_items + per_block - 1) / per_block;
+  if (b < 1) b = 1;
+  if (b > 2048) b = 2048;      // 256 CUs x 8 blocks, grid-stride beyond that
+  return (int)b;
+}
+
+}  // namespace
+}  // namespace mpose
+
+using namespace mpose;
+
+extern "C" int mpose_sizeof(int which) {
+  switch (which) {
+    case 0: return (int)sizeof(mpose_conv_geom);
+    case 1: return (int)sizeof(mpose_conv_operands);
+    case 2: return (int)sizeof(mpose_wgrad_operands);
+    case 3: return (int)sizeof(mpose_pack_job);
+    case 4: return (int)sizeof(mpose_unpack_job);
+    case 5: return (int)sizeof(mpose_bn_job);
+    case 6: return (int)sizeof(mpose_bn_bwd_coef_job);
+    case 7: return (int)sizeof(mpose_bn_add_operands);
+    case 8: return (int)sizeof(mpose_bn_bwd_reduce_operands);
+    case 9: return (int)sizeof(mpose_bn_bwd_apply_operands);
+    default: return -1;
+  }
+}
+
+extern "C" int mpose_bn_finalize(const mpose_bn_job* jobs_dev, int n_jobs, int train, float eps, float momentum, void* stream) {
+  if (n_jobs <= 0) return 0;
+  bn_finalize_k<<<n_jobs, 256, 0, (hipStream_t)stream>>>(jobs_dev, train, eps, momentum);
+  return launch_status();
+}
+
+extern "C" int mpose_bn_add_fwd(const mpose_bn_add_operands* ops, int n_groups, int pixels_per_image, int B, int C, int layout,
+                                int c_keep, void* stream) {
+  if (n_groups < 1 || n_groups > MPOSE_MAX_GROUP || (C & 3)) return MPOSE_EINVAL;
+  BnAddArgs a{};
+  for (int i = 0; i < n_groups; ++i) a.op[i] = ops[i];
+  a.C = C; a.P = pixels_per_image; a.c_keep = c_keep;
+  a.total4 = (long)B * pixels_per_image * C / 4;
+  if (a.total4 == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  if (layout == 0) {
+    bn_add_nhwc_k<<<dim3(grid_for(a.total4, 256), n_groups), 256, 0, s>>>(a);
+  } else {
+    if (c_keep < 1 || c_keep > C) return MPOSE_EINVAL;
+    bn_add_nchw_k<<<dim3(grid_for((long)B * pixels_per_image, 256), n_groups), 256, 0, s>>>(a, B);
+  }
+  return launch_status();
+}
+
+extern "C" int mpose_bn_bwd_reduce(const mpose_bn_bwd_reduce_operands* ops, int n_groups, int pixels_per_image, int B, int C,
+                                   int layout, int c_keep, void* stream) {
+  if (n_groups < 1 || n_groups > MPOSE_MAX_GROUP || (C & 3) || C > 1024 || layout != 0) return MPOSE_EINVAL;
+  BnReduceArgs a{};
+  for (int i = 0; i < n_groups; ++i) a.op[i] = ops[i];
+  a.npix = (long)B * pixels_per_image;
+  if (a.npix == 0) return 0;
+  a.C = C;
+  const int rows_per_pass = 256 / (C / 4);
+  int blocks = grid_for(a.npix, rows_per_pass * 16);
+  if (blocks > 512) blocks = 512;
+  a.pix_per_block = (int)((a.npix + blocks - 1) / blocks);
+  const int lds = rows_per_pass * C * 4 * 4;
+  bn_bwd_reduce_k<<<dim3(blocks, n_groups), 256, lds, (hipStream_t)stream>>>(a);
+  return launch_status();
+}
+
+extern "C" int mpose_bn_bwd_coef(const mpose_bn_bwd_coef_job* jobs_dev, int n_jobs, void* stream) {
+  if (n_jobs <= 0) return 0;
+  bn_bwd_coef_k<<<n_jobs, 256, 0, (hipStream_t)stream>>>(jobs_dev);
+  return launch_status();
+}
+
+extern "C" int mpose_bn_bwd_apply(const mpose_bn_bwd_apply_operands* ops, int n_groups, int pixels_per_image, int B, int C,
+                                  int layout, int c_keep, void* stream) {
+  if (n_groups < 1 || n_groups > MPOSE_MAX_GROUP || (C & 3) || layout != 0) return MPOSE_EINVAL;
+  BnApplyArgs a{};
+  for (int i = 0; i < n_groups; ++i) a.op[i] = ops[i];
+  a.C = C;
+  a.total4 = (long)B * pixels_per_image * C / 4;
+  if (a.total4 == 0) return 0;
+  bn_bwd_apply_k<<<dim3(grid_for(a.total4, 256), n_groups), 256, 0, (hipStream_t)stream>>>(a);
+  return launch_status();
+}
+
+extern "C" int mpose_bn_relu_fwd(const float* x, const float* scale, const float* shift, float* out, int64_t n, int C, void* stream) {
+  if (n < 0 || (C & 3) || C <= 0 || (n % C)) return MPOSE_EINVAL;
+  if (n == 0) return 0;
+  bn_relu_k<<<grid_for(n / 4, 256), 256, 0, (hipStream_t)stream>>>(x, scale, shift, out, n / 4, C);
+  return launch_status();
+}
+
+extern "C" int mpose_relu_bwd(const float* g, const float* y, float* gm, int64_t n, void* stream) {
+  if (n < 0 || (n & 3)) return MPOSE_EINVAL;
+  if (n == 0) return 0;
+  relu_bwd_k<<<grid_for(n / 4, 256), 256, 0, (hipStream_t)stream>>>(reinterpret_cast<const float4*>(g), reinterpret_cast<const float4*>(y),
+                                                                    reinterpret_cast<float4*>(gm), n / 4);
+  return launch_status();
+}

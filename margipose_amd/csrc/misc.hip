@@ -1,0 +1,309 @@
+// Layout / glue kernels of the MargiPose hot path on gfx950 (all HBM-bound, small):
+//   * patch8 stem input transform (NCHW image -> NHWC space-to-depth) and its inverse,
+//   * the HeatmapColumn axis permutation (reference models/margipose_model.py:91-97) on NHWC,
+//   * HeatmapCombiner + cumulative add (models/margipose_model.py:142-150, :195), fwd and bwd,
+//   * gradient fan-in add, NCHW->NHWC padding of the logits gradient, partial-sum reduction.
+#include "common.h"
+
+namespace mpose {
+namespace {
+
+inline int grid_for(long work_items, int per_block) {
+  long b = (work_items + per_block - 1) / per_block;
+  if (b < 1) b = 1;
+  if (b > 2048) b = 2048;
+  return (int)b;
+}
+
+// out[b][y][x][c*64 + ky*8 + kx] = in[b][c][y*8+ky][x*8+kx]; one thread per 4 consecutive kx.
+template <bool INVERSE>
+__global__ __launch_bounds__(256) void space_to_depth8_k(const float* __restrict__ src, float* __restrict__ dst, int B, int S) {
+  const int G = S / 8;
+  const long total4 = (long)B * G * G * 48;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
+    const int k4 = (int)(i % 48);
+    long r = i / 48;
+    const int x = (int)(r % G); r /= G;
+    const int y = (int)(r % G);
+    const long b = r / G;
+    const int k = k4 * 4, c = k >> 6, ky = (k >> 3) & 7, kx = k & 7;
+    const long nchw = ((b * 3 + c) * S + (y * 8 + ky)) * S + x * 8 + kx;
+    if (!INVERSE) reinterpret_cast<float4*>(dst)[i] = *reinterpret_cast<const float4*>(src + nchw);
+    else *reinterpret_cast<float4*>(dst + nchw) = reinterpret_cast<const float4*>(src)[i];
+  }
+}
+
+struct PermArgs {
+  const float* in[MPOSE_MAX_GROUP];
+  float* out[MPOSE_MAX_GROUP];
+  int space[MPOSE_MAX_GROUP];
+  int B, S, C;
+};
+
+// NHWC (B,S,S,C), C = n_chunks*S.  zy: out[b][h][w=j][kS+i] = in[b][h][w=i][kS+j]
+//                                  xz: out[b][h=j][w][kS+i] = in[b][h=i][w][kS+j]
+__global__ __launch_bounds__(256) void axis_permute_k(PermArgs a) {
+  const int grp = blockIdx.y;
+  const float* __restrict__ in = a.in[grp];
+  float* __restrict__ out = a.out[grp];
+  const int space = a.space[grp];
+  const int S = a.S, C = a.C, c4n = C >> 2;
+  const long total4 = (long)a.B * S * S * c4n;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total4; idx += (long)gridDim.x * 256) {
+    const int c = (int)(idx % c4n) * 4;
+    long r = idx / c4n;
+    const int w = (int)(r % S); r /= S;
+    const int h = (int)(r % S);
+    const long b = r / S;
+    float4 v;
+    if (space == 0) {
+      v = reinterpret_cast<const float4*>(in)[idx];
+    } else {
+      const int k = c / S, i = c - k * S;      // i..i+3 stay inside the chunk since S % 4 == 0
+      float e[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const long src = (space == 1) ? (((b * S + h) * S + (i + t)) * C + k * S + w)
+                                      : (((b * S + (i + t)) * S + w) * C + k * S + h);
+        e[t] = in[src];
+      }
+      v = make_float4(e[0], e[1], e[2], e[3]);
+    }
+    reinterpret_cast<float4*>(out)[idx] = v;
+  }
+}
+
+// ---- HeatmapCombiner ----------------------------------------------------------------------
+constexpr int CT = 64;        // pixels per tile
+constexpr int CC = 128;       // feature channels
+
+struct CombArgs {
+  const float* hm[MPOSE_MAX_GROUP];
+  float* d_hm[MPOSE_MAX_GROUP];
+  const float* w;             // (C, 3J)
+  const float* inp;
+  float* out;
+  const float* g;
+  float* dw_partial;
+  int B, J, HW, Q;            // Q = 3J
+};
+
+__global__ __launch_bounds__(256) void combiner_fwd_k(CombArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* sW = sm;                       // [Q][CC]
+  float* sH = sm + a.Q * CC;            // [Q][CT]
+  const int tid = threadIdx.x;
+  for (int i = tid; i < a.Q * CC; i += 256) { const int q = i / CC, c = i - q * CC; sW[i] = a.w[c * a.Q + q]; }
+  const int tiles_per_img = a.HW / CT;
+  const int b = blockIdx.x / tiles_per_img, p0 = (blockIdx.x - b * tiles_per_img) * CT;
+  for (int i = tid; i < a.Q * CT; i += 256) {
+    const int q = i / CT, px = i - q * CT;
+    const int pl = q / a.J, j = q - pl * a.J;
+    sH[i] = a.hm[pl][((long)b * a.J + j) * a.HW + p0 + px];
+  }
+  __syncthreads();
+  const int c4 = tid & 31, pr = tid >> 5;
+  float4 acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int q = 0; q < a.Q; ++q) {
+    const float4 wv = *reinterpret_cast<const float4*>(sW + q * CC + c4 * 4);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float h = sH[q * CT + pr * 8 + e];
+      acc[e].x = fmaf(h, wv.x, acc[e].x); acc[e].y = fmaf(h, wv.y, acc[e].y);
+      acc[e].z = fmaf(h, wv.z, acc[e].z); acc[e].w = fmaf(h, wv.w, acc[e].w);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const long o = (((long)b * a.HW + p0 + pr * 8 + e) * CC + c4 * 4);
+    const float4 x = *reinterpret_cast<const float4*>(a.inp + o);
+    *reinterpret_cast<float4*>(a.out + o) = make_float4(x.x + acc[e].x, x.y + acc[e].y, x.z + acc[e].z, x.w + acc[e].w);
+  }
+}
+
+constexpr int G_STRIDE = CC + 4;
+constexpr int QH_MAX = 32;    // per-thread dW accumulators (Q <= 64)
+
+__global__ __launch_bounds__(256) void combiner_bwd_k(CombArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* sW = sm;                                // [Q][CC]
+  float* sH = sm + a.Q * CC;                     // [Q][CT]
+  float* sG = sH + a.Q * CT;                     // [CT][G_STRIDE]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  for (int i = tid; i < a.Q * CC; i += 256) { const int q = i / CC, c = i - q * CC; sW[i] = a.w[c * a.Q + q]; }
+  const int tiles_per_img = a.HW / CT;
+  const int n_tiles = a.B * tiles_per_img;
+  const int qh = (a.Q + 1) / 2;
+  const int dwc = tid & 127, dwq0 = (tid >> 7) * qh;
+  float dwacc[QH_MAX];
+#pragma unroll
+  for (int e = 0; e < QH_MAX; ++e) dwacc[e] = 0.f;
+
+  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int b = tile / tiles_per_img, p0 = (tile - b * tiles_per_img) * CT;
+    __syncthreads();
+    for (int i = tid; i < a.Q * CT; i += 256) {
+      const int q = i / CT, px = i - q * CT;
+      const int pl = q / a.J, j = q - pl * a.J;
+      sH[i] = a.hm[pl][((long)b * a.J + j) * a.HW + p0 + px];
+    }
+    for (int i = tid; i < CT * (CC / 4); i += 256) {
+      const int px = i / (CC / 4), c4 = i - px * (CC / 4);
+      *reinterpret_cast<float4*>(sG + px * G_STRIDE + c4 * 4) =
+          *reinterpret_cast<const float4*>(a.g + ((long)b * a.HW + p0 + px) * CC + c4 * 4);
+    }
+    __syncthreads();
+    // d_hm[q][px] = sum_c W[c][q] * g[px][c]; wave w handles q = w, w+4, ...; lane = pixel
+    for (int q = wave; q < a.Q; q += 4) {
+      float s = 0.f;
+#pragma unroll 8
+      for (int c4 = 0; c4 < CC / 4; ++c4) {
+        const float4 gv = *reinterpret_cast<const float4*>(sG + lane * G_STRIDE + c4 * 4);
+        const float4 wv = *reinterpret_cast<const float4*>(sW + q * CC + c4 * 4);
+        s = fmaf(gv.x, wv.x, s); s = fmaf(gv.y, wv.y, s); s = fmaf(gv.z, wv.z, s); s = fmaf(gv.w, wv.w, s);
+      }
+      const int pl = q / a.J, j = q - pl * a.J;
+      a.d_hm[pl][((long)b * a.J + j) * a.HW + p0 + lane] = s;
+    }
+    // dW[c][q] += sum_px g[px][c] * hm[q][px]
+    for (int px = 0; px < CT; ++px) {
+      const float gv = sG[px * G_STRIDE + dwc];
+#pragma unroll
+      for (int e = 0; e < QH_MAX; ++e)
+        if (e < qh && dwq0 + e < a.Q) dwacc[e] = fmaf(gv, sH[(dwq0 + e) * CT + px], dwacc[e]);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < QH_MAX; ++e)
+    if (e < qh && dwq0 + e < a.Q) a.dw_partial[((long)blockIdx.x * CC + dwc) * a.Q + dwq0 + e] = dwacc[e];
+}
+
+__global__ __launch_bounds__(256) void add_k(const float4* __restrict__ x, const float4* __restrict__ y, float4* __restrict__ o, long n4) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const float4 p = x[i], q = y[i];
+    o[i] = make_float4(p.x + q.x, p.y + q.y, p.z + q.z, p.w + q.w);
+  }
+}
+
+// (B, J, P) NCHW -> (B, P, Cpad) NHWC, channels >= J zero-filled.
+struct PadArgs {
+  const float* in[MPOSE_MAX_GROUP];
+  float* out[MPOSE_MAX_GROUP];
+  int B, J, P, Cpad;
+};
+__global__ __launch_bounds__(256) void nchw_to_nhwc_pad_k(PadArgs a) {
+  const float* __restrict__ in = a.in[blockIdx.y];
+  float* __restrict__ out = a.out[blockIdx.y];
+  const long npix = (long)a.B * a.P;
+  for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < npix; p += (long)gridDim.x * 256) {
+    const long b = p / a.P;
+    const int px = (int)(p - b * a.P);
+    for (int c = 0; c < a.Cpad; c += 4) {
+      float e[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) e[t] = (c + t < a.J) ? in[(b * a.J + c + t) * a.P + px] : 0.f;
+      *reinterpret_cast<float4*>(out + p * a.Cpad + c) = make_float4(e[0], e[1], e[2], e[3]);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void reduce_partials_k(const float* __restrict__ src, float* __restrict__ dst, int n_partial, long n, int accumulate) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    float s = 0.f;
+    for (int p = 0; p < n_partial; ++p) s += src[(long)p * n + i];
+    dst[i] = accumulate ? dst[i] + s : s;
+  }
+}
+
+}  // namespace
+}  // namespace mpose
+
+using namespace mpose;
+
+extern "C" int mpose_space_to_depth8(const float* x, float* out, int B, int S, void* stream) {
+  if (B < 0 || S <= 0 || (S % 8)) return MPOSE_EINVAL;
+  if (B == 0) return 0;
+  const long total4 = (long)B * (S / 8) * (S / 8) * 48;
+  space_to_depth8_k<false><<<grid_for(total4, 256), 256, 0, (hipStream_t)stream>>>(x, out, B, S);
+  return launch_status();
+}
+
+extern "C" int mpose_depth_to_space8(const float* g, float* dx, int B, int S, void* stream) {
+  if (B < 0 || S <= 0 || (S % 8)) return MPOSE_EINVAL;
+  if (B == 0) return 0;
+  const long total4 = (long)B * (S / 8) * (S / 8) * 48;
+  space_to_depth8_k<true><<<grid_for(total4, 256), 256, 0, (hipStream_t)stream>>>(g, dx, B, S);
+  return launch_status();
+}
+
+extern "C" int mpose_axis_permute(const float* const* in, float* const* out, const int* spaces, int n_groups, int B, int S, int C,
+                                  void* stream) {
+  if (n_groups < 1 || n_groups > MPOSE_MAX_GROUP || (S & 3) || (C % S)) return MPOSE_EINVAL;
+  PermArgs a{};
+  for (int i = 0; i < n_groups; ++i) {
+    a.in[i] = in[i]; a.out[i] = out[i]; a.space[i] = spaces[i];
+    if (spaces[i] < 0 || spaces[i] > 2) return MPOSE_EINVAL;
+  }
+  a.B = B; a.S = S; a.C = C;
+  const long total4 = (long)B * S * S * C / 4;
+  if (total4 == 0) return 0;
+  axis_permute_k<<<dim3(grid_for(total4, 256), n_groups), 256, 0, (hipStream_t)stream>>>(a);
+  return launch_status();
+}
+
+extern "C" int mpose_combiner_fwd(const float* const* hm, const float* w, const float* inp, float* out, int B, int J, int HW, int C,
+                                  void* stream) {
+  if (C != CC || (HW % CT) || J < 1 || 3 * J > 2 * QH_MAX) return MPOSE_EINVAL;
+  if (B == 0) return 0;
+  CombArgs a{};
+  for (int p = 0; p < 3; ++p) a.hm[p] = hm[p];
+  a.w = w; a.inp = inp; a.out = out; a.B = B; a.J = J; a.HW = HW; a.Q = 3 * J;
+  const int lds = (a.Q * CC + a.Q * CT) * 4;
+  combiner_fwd_k<<<B * (HW / CT), 256, lds, (hipStream_t)stream>>>(a);
+  return launch_status();
+}
+
+extern "C" int mpose_combiner_bwd(const float* const* hm, const float* w, const float* g, float* const* d_hm, float* dw_partial,
+                                  int n_partial, int B, int J, int HW, int C, void* stream) {
+  if (C != CC || (HW % CT) || J < 1 || 3 * J > 2 * QH_MAX || n_partial < 1) return MPOSE_EINVAL;
+  CombArgs a{};
+  for (int p = 0; p < 3; ++p) { a.hm[p] = hm[p]; a.d_hm[p] = d_hm[p]; }
+  a.w = w; a.g = g; a.dw_partial = dw_partial; a.B = B; a.J = J; a.HW = HW; a.Q = 3 * J;
+  const int lds = (a.Q * CC + a.Q * CT + CT * G_STRIDE) * 4;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(combiner_bwd_k), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  combiner_bwd_k<<<n_partial, 256, lds, (hipStream_t)stream>>>(a);
+  return launch_status();
+}
+
+extern "C" int mpose_add(const float* x, const float* y, float* out, int64_t n, void* stream) {
+  if (n < 0 || (n & 3)) return MPOSE_EINVAL;
+  if (n == 0) return 0;
+  add_k<<<grid_for(n / 4, 256 * 4), 256, 0, (hipStream_t)stream>>>(reinterpret_cast<const float4*>(x), reinterpret_cast<const float4*>(y),
+                                                                  reinterpret_cast<float4*>(out), n / 4);
+  return launch_status();
+}
+
+extern "C" int mpose_nchw_to_nhwc_pad(const float* const* in, float* const* out, int n_groups, int B, int J, int P, int Cpad,
+                                      void* stream) {
+  if (n_groups < 1 || n_groups > MPOSE_MAX_GROUP || (Cpad & 3) || J > Cpad) return MPOSE_EINVAL;
+  PadArgs a{};
+  for (int i = 0; i < n_groups; ++i) { a.in[i] = in[i]; a.out[i] = out[i]; }
+  a.B = B; a.J = J; a.P = P; a.Cpad = Cpad;
+  if ((long)B * P == 0) return 0;
+  nchw_to_nhwc_pad_k<<<dim3(grid_for((long)B * P, 256), n_groups), 256, 0, (hipStream_t)stream>>>(a);
+  return launch_status();
+}
+
+extern "C" int mpose_reduce_partials(const float* src, float* dst, int n_partial, int64_t n, int accumulate, void* stream) {
+  if (n_partial < 1 || n < 0) return MPOSE_EINVAL;
+  if (n == 0) return 0;
+  reduce_partials_k<<<grid_for(n, 256), 256, 0, (hipStream_t)stream>>>(src, dst, n_partial, n, accumulate);
+  return launch_status();
+}

@@ -1,0 +1,613 @@
+// Soft-argmax tail for gfx950: flat_softmax + DSNT + JS/Euclidean stage loss, forward and backward.
+//
+// Replaces (reference src/margipose): dsntnn.py:12-62,84-232 and
+// models/margipose_model.py:215-261.  HBM-bound: every kernel reads each heatmap element exactly
+// once and writes each result element exactly once; all reductions are wave64 shuffles.
+//
+// Work decomposition: one workgroup per heatmap row (= one (batch, joint) pair), one 64-lane
+// wavefront per plane (xy / zy / xz).  A row of n = H*W <= 4096 fp32 values lives in registers as
+// NV float4 per lane (NV = 4 for 32x32, 9 for 48x48, 16 for 64x64), loaded with 16-byte coalesced
+// accesses (1 KiB per wave instruction).
+#include "common.h"
+
+namespace mpose {
+namespace {
+
+constexpr float kEps = 1e-24f;   // dsntnn.py:194,199
+
+struct RowGeom {
+  int H, W, n4;            // n4 = H*W/4
+  float two_over_w, first_w, two_over_h, first_h;
+};
+
+__device__ __forceinline__ RowGeom make_geom(int H, int W) {
+  RowGeom g;
+  g.H = H; g.W = W; g.n4 = (H * W) >> 2;
+  g.two_over_w = 2.0f / (float)W; g.first_w = -((float)W - 1.0f) / (float)W;
+  g.two_over_h = 2.0f / (float)H; g.first_h = -((float)H - 1.0f) / (float)H;
+  return g;
+}
+
+template <int NV>
+__device__ __forceinline__ void load_row(const float* __restrict__ src, int lane, int n4, float4 (&v)[NV], float fill) {
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int idx = i * 64 + lane;
+    v[i] = (idx < n4) ? reinterpret_cast<const float4*>(src)[idx] : make_float4(fill, fill, fill, fill);
+  }
+}
+
+template <int NV>
+__device__ __forceinline__ void store_row(float* __restrict__ dst, int lane, int n4, const float4 (&v)[NV]) {
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int idx = i * 64 + lane;
+    if (idx < n4) reinterpret_cast<float4*>(dst)[idx] = v[i];
+  }
+}
+
+__device__ __forceinline__ float bf16_to_f32(unsigned short u) { return __uint_as_float(((unsigned)u) << 16); }
+__device__ __forceinline__ unsigned short f32_to_bf16(float f) {   // round to nearest even
+  unsigned u = __float_as_uint(f);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+
+template <int NV>
+__device__ __forceinline__ void load_row_bf16(const unsigned short* __restrict__ src, int lane, int n4, float4 (&v)[NV], float fill) {
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int idx = i * 64 + lane;
+    if (idx < n4) {
+      const uint2 r = reinterpret_cast<const uint2*>(src)[idx];
+      v[i] = make_float4(bf16_to_f32(r.x & 0xffff), bf16_to_f32(r.x >> 16), bf16_to_f32(r.y & 0xffff), bf16_to_f32(r.y >> 16));
+    } else {
+      v[i] = make_float4(fill, fill, fill, fill);
+    }
+  }
+}
+
+template <int NV>
+__device__ __forceinline__ void store_row_bf16(unsigned short* __restrict__ dst, int lane, int n4, const float4 (&v)[NV]) {
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int idx = i * 64 + lane;
+    if (idx < n4) {
+      uint2 r;
+      r.x = (unsigned)f32_to_bf16(v[i].x) | ((unsigned)f32_to_bf16(v[i].y) << 16);
+      r.y = (unsigned)f32_to_bf16(v[i].z) | ((unsigned)f32_to_bf16(v[i].w) << 16);
+      reinterpret_cast<uint2*>(dst)[idx] = r;
+    }
+  }
+}
+
+// Coordinates of the 4 elements held in v[i] by `lane`: same row h, columns w0..w0+3 (W % 4 == 0).
+__device__ __forceinline__ void elem_hw(const RowGeom& g, int i, int lane, int& h, int& w0) {
+  const int e0 = (i * 64 + lane) * 4;
+  h = e0 / g.W;
+  w0 = e0 - h * g.W;
+}
+
+// ---------------------------------------------------------------------------------------------
+// flat_softmax + dsnt (+ heatmaps_to_coords)
+// ---------------------------------------------------------------------------------------------
+struct SoftmaxArgs {
+  const void* logits[MPOSE_MAX_GROUP];
+  void* heatmaps[MPOSE_MAX_GROUP];
+  float* plane_coords;
+  float* xyz;
+  int n_planes, rows, H, W;
+};
+
+template <int NV, bool BF16, bool EXP>
+__global__ __launch_bounds__(64 * MPOSE_MAX_GROUP) void softmax_dsnt_fwd_k(SoftmaxArgs a) {
+  __shared__ float s_mu[MPOSE_MAX_GROUP][2];
+  const int plane = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int row = blockIdx.x;
+  const RowGeom g = make_geom(a.H, a.W);
+  const size_t off = (size_t)row * (size_t)(a.H * a.W);
+
+  float4 v[NV];
+  if (BF16) load_row_bf16<NV>(reinterpret_cast<const unsigned short*>(a.logits[plane]) + off, lane, g.n4, v, EXP ? -INFINITY : 0.0f);
+  else load_row<NV>(reinterpret_cast<const float*>(a.logits[plane]) + off, lane, g.n4, v, EXP ? -INFINITY : 0.0f);
+
+  float inv = 1.0f;
+  if (EXP) {
+    float m = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) m = fmaxf(m, fmaxf(fmaxf(v[i].x, v[i].y), fmaxf(v[i].z, v[i].w)));
+    m = wave_max(m);
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      v[i].x = expf(v[i].x - m); v[i].y = expf(v[i].y - m); v[i].z = expf(v[i].z - m); v[i].w = expf(v[i].w - m);
+      s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    s = wave_sum(s);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { v[i].x /= s; v[i].y /= s; v[i].z /= s; v[i].w /= s; }
+  }
+  (void)inv;
+
+  float sx = 0.0f, sy = 0.0f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    int h, w0;
+    elem_hw(g, i, lane, h, w0);
+    const float y = cell_coord(h, g.two_over_h, g.first_h);
+    const float x0 = cell_coord(w0, g.two_over_w, g.first_w);
+    const float rs = (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    sy = fmaf(rs, y, sy);
+    sx += v[i].x * x0 + v[i].y * (x0 + g.two_over_w) + v[i].z * (x0 + 2.0f * g.two_over_w) + v[i].w * (x0 + 3.0f * g.two_over_w);
+  }
+  sx = wave_sum(sx);
+  sy = wave_sum(sy);
+
+  if (EXP && a.heatmaps[plane] != nullptr) {
+    if (BF16) store_row_bf16<NV>(reinterpret_cast<unsigned short*>(a.heatmaps[plane]) + off, lane, g.n4, v);
+    else store_row<NV>(reinterpret_cast<float*>(a.heatmaps[plane]) + off, lane, g.n4, v);
+  }
+  if (lane == 0) {
+    s_mu[plane][0] = sx; s_mu[plane][1] = sy;
+    if (a.plane_coords != nullptr) {
+      float* pc = a.plane_coords + ((size_t)plane * a.rows + row) * 2;
+      pc[0] = sx; pc[1] = sy;
+    }
+  }
+  if (a.n_planes == 3 && a.xyz != nullptr) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float* o = a.xyz + (size_t)row * 3;
+      o[0] = s_mu[0][0];
+      o[1] = s_mu[0][1];
+      o[2] = 0.5f * (s_mu[1][0] + s_mu[2][1]);     // models/margipose_model.py:259
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Gaussian target of one plane, regenerated per lane (dsntnn.py:154-195)
+// ---------------------------------------------------------------------------------------------
+struct Gauss {
+  float tx, ty, kx, ky, inv_norm;
+};
+
+__device__ __forceinline__ Gauss make_gauss(const RowGeom& g, int lane, float tx, float ty, float sigma) {
+  Gauss q;
+  q.tx = tx; q.ty = ty;
+  const float sdx = 2.0f * sigma / (float)g.W, sdy = 2.0f * sigma / (float)g.H;   // dsntnn.py:179
+  q.kx = -0.5f * (1.0f / sdx) * (1.0f / sdx);
+  q.ky = -0.5f * (1.0f / sdy) * (1.0f / sdy);
+  float ex = 0.0f, ey = 0.0f;
+  for (int w = lane; w < g.W; w += 64) { const float d = cell_coord(w, g.two_over_w, g.first_w) - tx; ex += expf(d * d * q.kx); }
+  for (int h = lane; h < g.H; h += 64) { const float d = cell_coord(h, g.two_over_h, g.first_h) - ty; ey += expf(d * d * q.ky); }
+  ex = wave_sum(ex);
+  ey = wave_sum(ey);
+  q.inv_norm = 1.0f / (ex * ey + kEps);
+  return q;
+}
+
+// JS integrand for one element (dsntnn.py:198-207) and its derivative w.r.t. p (SURVEY §8 a-T).
+__device__ __forceinline__ float js_term(float p, float gq) {
+  const float m = 0.5f * (p + gq);
+  const float rm = __frcp_rn(m + kEps);
+  const float lp = __logf((p + kEps) * rm);
+  const float lg = __logf((gq + kEps) * rm);
+  return 0.5f * (p * lp + gq * lg);
+}
+__device__ __forceinline__ float js_dp(float p, float gq) {
+  const float m = 0.5f * (p + gq);
+  const float rm = __frcp_rn(m + kEps);
+  const float lp = __logf((p + kEps) * rm);
+  return 0.5f * (lp + p * __frcp_rn(p + kEps) - m * rm);
+}
+
+struct LossArgs {
+  const float* hm[MPOSE_MAX_GROUP];
+  float* g[MPOSE_MAX_GROUP];
+  const float* target;   // (rows, 3)
+  const float* xyz_in;   // (rows, 3)  (backward)
+  const float* dloss;    // (rows)     (backward)
+  float* losses;         // (rows)     (forward)
+  float* xyz_out;        // (rows, 3)  (forward)
+  int rows, H, W;
+  float sigma;
+  int pixelwise, three_d, accumulate;
+};
+
+// target (x,y) of plane: xy->(t0,t1), zy->(t2,t1), xz->(t0,t2)   (models/margipose_model.py:240-242)
+__device__ __forceinline__ void plane_target(int plane, const float* t, float& tx, float& ty) {
+  tx = (plane == 1) ? t[2] : t[0];
+  ty = (plane == 2) ? t[2] : t[1];
+}
+
+template <int NV>
+__global__ __launch_bounds__(64 * MPOSE_MAX_GROUP) void stage_loss_fwd_k(LossArgs a) {
+  __shared__ float s_part[MPOSE_MAX_GROUP][3];
+  const int plane = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int row = blockIdx.x;
+  const RowGeom g = make_geom(a.H, a.W);
+  const size_t off = (size_t)row * (size_t)(a.H * a.W);
+  const float* t = a.target + (size_t)row * 3;
+  const bool active = a.three_d || plane == 0;
+
+  float sx = 0.0f, sy = 0.0f, js = 0.0f;
+  if (active) {
+    float4 v[NV];
+    load_row<NV>(a.hm[plane] + off, lane, g.n4, v, 0.0f);
+    float tx, ty;
+    plane_target(plane, t, tx, ty);
+    Gauss q;
+    if (a.pixelwise) q = make_gauss(g, lane, tx, ty, a.sigma);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      int h, w0;
+      elem_hw(g, i, lane, h, w0);
+      const float y = cell_coord(h, g.two_over_h, g.first_h);
+      const float x0 = cell_coord(w0, g.two_over_w, g.first_w);
+      const float pv[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+      const float rs = (pv[0] + pv[1]) + (pv[2] + pv[3]);
+      sy = fmaf(rs, y, sy);
+      float gy = 0.0f;
+      if (a.pixelwise) { const float d = y - q.ty; gy = expf(d * d * q.ky) * q.inv_norm; }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float x = x0 + (float)c * g.two_over_w;
+        sx = fmaf(pv[c], x, sx);
+        if (a.pixelwise && (i * 64 + lane) < g.n4) {
+          const float d = x - q.tx;
+          js += js_term(pv[c], gy * expf(d * d * q.kx));
+        }
+      }
+    }
+    sx = wave_sum(sx); sy = wave_sum(sy); js = wave_sum(js);
+  }
+  if (lane == 0) { s_part[plane][0] = sx; s_part[plane][1] = sy; s_part[plane][2] = js; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float x = s_part[0][0], y = s_part[0][1];
+    float z = 0.0f, loss;
+    if (a.three_d) {
+      z = 0.5f * (s_part[1][0] + s_part[2][1]);
+      const float dx = x - t[0], dy = y - t[1], dz = z - t[2];
+      loss = sqrtf(dx * dx + dy * dy + dz * dz);                         // dsntnn.py:147-150
+      loss += (s_part[0][2] + s_part[1][2]) + s_part[2][2];
+    } else {
+      const float dx = x - t[0], dy = y - t[1];
+      loss = sqrtf(dx * dx + dy * dy) + s_part[0][2];
+    }
+    float* lo = a.losses + row;
+    *lo = a.accumulate ? (*lo + loss) : loss;
+    if (a.xyz_out != nullptr) { float* o = a.xyz_out + (size_t)row * 3; o[0] = x; o[1] = y; o[2] = z; }
+  }
+}
+
+template <int NV>
+__global__ __launch_bounds__(64 * MPOSE_MAX_GROUP) void stage_loss_bwd_k(LossArgs a) {
+  const int plane = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int row = blockIdx.x;
+  const RowGeom g = make_geom(a.H, a.W);
+  const size_t off = (size_t)row * (size_t)(a.H * a.W);
+  const float* t = a.target + (size_t)row * 3;
+  const float* mu = a.xyz_in + (size_t)row * 3;
+  const float wgt = a.dloss[row];
+  const bool active = a.three_d || plane == 0;
+  float* dst = a.g[plane] + off;
+
+  float4 o[NV];
+  if (!active) {
+    if (a.accumulate) return;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) o[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    store_row<NV>(dst, lane, g.n4, o);
+    return;
+  }
+  // e = (mu - t)/|mu - t|  (NaN at zero distance, exactly like the reference's sqrt backward)
+  float cx, cy;
+  {
+    const float dx = mu[0] - t[0], dy = mu[1] - t[1], dz = a.three_d ? (mu[2] - t[2]) : 0.0f;
+    const float dist = sqrtf(dx * dx + dy * dy + dz * dz);
+    const float ex = dx / dist, ey = dy / dist, ez = dz / dist;
+    cx = (plane == 0) ? ex : (plane == 1 ? 0.5f * ez : 0.0f);    // zy: width axis is z
+    cy = (plane == 0) ? ey : (plane == 2 ? 0.5f * ez : 0.0f);    // xz: height axis is z
+  }
+  float4 v[NV];
+  load_row<NV>(a.hm[plane] + off, lane, g.n4, v, 0.0f);
+  if (a.accumulate) load_row<NV>(dst, lane, g.n4, o, 0.0f);
+  float tx, ty;
+  plane_target(plane, t, tx, ty);
+  Gauss q;
+  if (a.pixelwise) q = make_gauss(g, lane, tx, ty, a.sigma);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    int h, w0;
+    elem_hw(g, i, lane, h, w0);
+    const float y = cell_coord(h, g.two_over_h, g.first_h);
+    const float x0 = cell_coord(w0, g.two_over_w, g.first_w);
+    float gy = 0.0f;
+    if (a.pixelwise) { const float d = y - q.ty; gy = expf(d * d * q.ky) * q.inv_norm; }
+    const float pv[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+    float r[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float x = x0 + (float)c * g.two_over_w;
+      float d = cx * x + cy * y;
+      if (a.pixelwise) { const float dd = x - q.tx; d += js_dp(pv[c], gy * expf(dd * dd * q.kx)); }
+      r[c] = wgt * d;
+    }
+    if (a.accumulate) { o[i].x += r[0]; o[i].y += r[1]; o[i].z += r[2]; o[i].w += r[3]; }
+    else o[i] = make_float4(r[0], r[1], r[2], r[3]);
+  }
+  store_row<NV>(dst, lane, g.n4, o);
+}
+
+// ---------------------------------------------------------------------------------------------
+// softmax backward, dsnt backward
+// ---------------------------------------------------------------------------------------------
+struct SoftmaxBwdArgs {
+  const float* hm[MPOSE_MAX_GROUP];
+  const float* g1[MPOSE_MAX_GROUP];
+  const float* g2[MPOSE_MAX_GROUP];
+  float* dlogits[MPOSE_MAX_GROUP];
+  int n;
+};
+
+template <int NV>
+__global__ __launch_bounds__(64 * MPOSE_MAX_GROUP) void softmax_bwd_k(SoftmaxBwdArgs a) {
+  const int plane = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int n4 = a.n >> 2;
+  const size_t off = (size_t)blockIdx.x * (size_t)a.n;
+  float4 p[NV], gg[NV];
+  load_row<NV>(a.hm[plane] + off, lane, n4, p, 0.0f);
+  load_row<NV>(a.g1[plane] + off, lane, n4, gg, 0.0f);
+  if (a.g2[plane] != nullptr) {
+    float4 h[NV];
+    load_row<NV>(a.g2[plane] + off, lane, n4, h, 0.0f);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { gg[i].x += h[i].x; gg[i].y += h[i].y; gg[i].z += h[i].z; gg[i].w += h[i].w; }
+  }
+  float s = 0.0f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) s += (p[i].x * gg[i].x + p[i].y * gg[i].y) + (p[i].z * gg[i].z + p[i].w * gg[i].w);
+  s = wave_sum(s);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    gg[i].x = p[i].x * (gg[i].x - s); gg[i].y = p[i].y * (gg[i].y - s);
+    gg[i].z = p[i].z * (gg[i].z - s); gg[i].w = p[i].w * (gg[i].w - s);
+  }
+  store_row<NV>(a.dlogits[plane] + off, lane, n4, gg);
+}
+
+struct DsntBwdArgs {
+  const float* d_plane_coords;   // (n_planes, rows, 2)
+  float* d_hm[MPOSE_MAX_GROUP];
+  int rows, H, W, accumulate;
+};
+
+template <int NV>
+__global__ __launch_bounds__(64 * MPOSE_MAX_GROUP) void dsnt_bwd_k(DsntBwdArgs a) {
+  const int plane = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int row = blockIdx.x;
+  const RowGeom g = make_geom(a.H, a.W);
+  const size_t off = (size_t)row * (size_t)(a.H * a.W);
+  const float* d = a.d_plane_coords + ((size_t)plane * a.rows + row) * 2;
+  const float dmx = d[0], dmy = d[1];
+  float4 o[NV];
+  if (a.accumulate) load_row<NV>(a.d_hm[plane] + off, lane, g.n4, o, 0.0f);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    int h, w0;
+    elem_hw(g, i, lane, h, w0);
+    const float yv = dmy * cell_coord(h, g.two_over_h, g.first_h);
+    const float x0 = cell_coord(w0, g.two_over_w, g.first_w);
+    float4 r = make_float4(fmaf(dmx, x0, yv), fmaf(dmx, x0 + g.two_over_w, yv),
+                           fmaf(dmx, x0 + 2.0f * g.two_over_w, yv), fmaf(dmx, x0 + 3.0f * g.two_over_w, yv));
+    if (a.accumulate) { r.x += o[i].x; r.y += o[i].y; r.z += o[i].z; r.w += o[i].w; }
+    o[i] = r;
+  }
+  store_row<NV>(a.d_hm[plane] + off, lane, g.n4, o);
+}
+
+// ---------------------------------------------------------------------------------------------
+// js_reg_losses alone (one plane, explicit means)
+// ---------------------------------------------------------------------------------------------
+struct JsArgs {
+  const float* hm; const float* mu; const float* djs; float* js; float* g;
+  int H, W; float sigma;
+};
+
+template <int NV, bool BWD>
+__global__ __launch_bounds__(64) void js_k(JsArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x;
+  const RowGeom g = make_geom(a.H, a.W);
+  const size_t off = (size_t)row * (size_t)(a.H * a.W);
+  float4 v[NV], o[NV];
+  load_row<NV>(a.hm + off, lane, g.n4, v, 0.0f);
+  const Gauss q = make_gauss(g, lane, a.mu[(size_t)row * 2], a.mu[(size_t)row * 2 + 1], a.sigma);
+  const float wgt = BWD ? a.djs[row] : 0.0f;
+  float js = 0.0f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    int h, w0;
+    elem_hw(g, i, lane, h, w0);
+    const float dy = cell_coord(h, g.two_over_h, g.first_h) - q.ty;
+    const float gy = expf(dy * dy * q.ky) * q.inv_norm;
+    const float x0 = cell_coord(w0, g.two_over_w, g.first_w);
+    const float pv[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+    float r[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float dx = x0 + (float)c * g.two_over_w - q.tx;
+      const float gq = gy * expf(dx * dx * q.kx);
+      if (BWD) r[c] = wgt * js_dp(pv[c], gq);
+      else if ((i * 64 + lane) < g.n4) js += js_term(pv[c], gq);
+    }
+    if (BWD) o[i] = make_float4(r[0], r[1], r[2], r[3]);
+  }
+  if (BWD) {
+    store_row<NV>(a.g + off, lane, g.n4, o);
+  } else {
+    js = wave_sum(js);
+    if (lane == 0) a.js[row] = js;
+  }
+}
+
+// average_loss (dsntnn.py:99-121): single workgroup, n is B*17.
+__global__ __launch_bounds__(256) void average_loss_k(const float* __restrict__ losses, const float* __restrict__ mask, float* out2, int n) {
+  __shared__ float s_a[4], s_b[4];
+  float num = 0.0f, den = 0.0f;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const float m = (mask != nullptr) ? mask[i] : 1.0f;
+    num = fmaf(losses[i], m, num);
+    den += m;
+  }
+  num = wave_sum(num); den = wave_sum(den);
+  if ((threadIdx.x & 63) == 0) { s_a[threadIdx.x >> 6] = num; s_b[threadIdx.x >> 6] = den; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float a = (s_a[0] + s_a[1]) + (s_a[2] + s_a[3]);
+    const float b = fmaxf((s_b[0] + s_b[1]) + (s_b[2] + s_b[3]), 1.0f);
+    out2[0] = a / b;
+    out2[1] = b;
+  }
+}
+
+inline int pick_nv(int n) {
+  if (n <= 0 || (n & 3) || n > 4096) return 0;
+  const int nv = (n / 4 + 63) / 64;
+  return nv <= 4 ? 4 : (nv <= 9 ? 9 : 16);
+}
+
+}  // namespace
+}  // namespace mpose
+
+using namespace mpose;
+
+#define MPOSE_DISPATCH_NV(nv, CALL)            \
+  switch (nv) {                                \
+    case 4: { constexpr int NV = 4; CALL; } break;   \
+    case 9: { constexpr int NV = 9; CALL; } break;   \
+    case 16: { constexpr int NV = 16; CALL; } break; \
+    default: return MPOSE_EINVAL;              \
+  }
+
+extern "C" int mpose_abi_version(void) { return 1; }
+
+extern "C" int mpose_softmax_dsnt_fwd(const void* const* logits, void* const* heatmaps, float* plane_coords, float* xyz,
+                                      int n_planes, int rows, int H, int W, int io_dtype, void* stream) {
+  if (n_planes < 1 || n_planes > MPOSE_MAX_GROUP || rows < 0 || (W & 3)) return MPOSE_EINVAL;
+  if (rows == 0) return 0;
+  const int nv = pick_nv(H * W);
+  SoftmaxArgs a{};
+  for (int p = 0; p < n_planes; ++p) { a.logits[p] = logits[p]; a.heatmaps[p] = heatmaps ? heatmaps[p] : nullptr; }
+  a.plane_coords = plane_coords; a.xyz = xyz; a.n_planes = n_planes; a.rows = rows; a.H = H; a.W = W;
+  hipStream_t s = (hipStream_t)stream;
+  if (io_dtype == 0) {
+    MPOSE_DISPATCH_NV(nv, (softmax_dsnt_fwd_k<NV, false, true><<<rows, 64 * n_planes, 0, s>>>(a)));
+  } else if (io_dtype == 1) {
+    MPOSE_DISPATCH_NV(nv, (softmax_dsnt_fwd_k<NV, true, true><<<rows, 64 * n_planes, 0, s>>>(a)));
+  } else {
+    return MPOSE_EINVAL;
+  }
+  return launch_status();
+}
+
+extern "C" int mpose_dsnt_fwd(const float* const* heatmaps, float* plane_coords, float* xyz, int n_planes, int rows, int H,
+                              int W, void* stream) {
+  if (n_planes < 1 || n_planes > MPOSE_MAX_GROUP || rows < 0 || (W & 3)) return MPOSE_EINVAL;
+  if (rows == 0) return 0;
+  const int nv = pick_nv(H * W);
+  SoftmaxArgs a{};
+  for (int p = 0; p < n_planes; ++p) { a.logits[p] = heatmaps[p]; a.heatmaps[p] = nullptr; }
+  a.plane_coords = plane_coords; a.xyz = xyz; a.n_planes = n_planes; a.rows = rows; a.H = H; a.W = W;
+  MPOSE_DISPATCH_NV(nv, (softmax_dsnt_fwd_k<NV, false, false><<<rows, 64 * n_planes, 0, (hipStream_t)stream>>>(a)));
+  return launch_status();
+}
+
+extern "C" int mpose_dsnt_bwd(const float* d_plane_coords, float* const* d_heatmaps, int n_planes, int rows, int H, int W,
+                              int accumulate, void* stream) {
+  if (n_planes < 1 || n_planes > MPOSE_MAX_GROUP || rows < 0 || (W & 3)) return MPOSE_EINVAL;
+  if (rows == 0) return 0;
+  const int nv = pick_nv(H * W);
+  DsntBwdArgs a{};
+  a.d_plane_coords = d_plane_coords;
+  for (int p = 0; p < n_planes; ++p) a.d_hm[p] = d_heatmaps[p];
+  a.rows = rows; a.H = H; a.W = W; a.accumulate = accumulate;
+  MPOSE_DISPATCH_NV(nv, (dsnt_bwd_k<NV><<<rows, 64 * n_planes, 0, (hipStream_t)stream>>>(a)));
+  return launch_status();
+}
+
+extern "C" int mpose_softmax_bwd(const float* const* heatmaps, const float* const* g1, const float* const* g2,
+                                 float* const* dlogits, int n_planes, int rows, int n, void* stream) {
+  if (n_planes < 1 || n_planes > MPOSE_MAX_GROUP || rows < 0) return MPOSE_EINVAL;
+  if (rows == 0) return 0;
+  const int nv = pick_nv(n);
+  SoftmaxBwdArgs a{};
+  for (int p = 0; p < n_planes; ++p) {
+    a.hm[p] = heatmaps[p]; a.g1[p] = g1[p]; a.g2[p] = g2 ? g2[p] : nullptr; a.dlogits[p] = dlogits[p];
+  }
+  a.n = n;
+  MPOSE_DISPATCH_NV(nv, (softmax_bwd_k<NV><<<rows, 64 * n_planes, 0, (hipStream_t)stream>>>(a)));
+  return launch_status();
+}
+
+static int fill_loss_args(LossArgs& a, const float* const* heatmaps, const float* target, int rows, int H, int W, float sigma,
+                          int pixelwise, int three_d, int accumulate) {
+  if (rows < 0 || (W & 3) || sigma <= 0.0f) return MPOSE_EINVAL;
+  for (int p = 0; p < 3; ++p) a.hm[p] = heatmaps[p];
+  a.target = target; a.rows = rows; a.H = H; a.W = W; a.sigma = sigma;
+  a.pixelwise = pixelwise; a.three_d = three_d; a.accumulate = accumulate;
+  return 0;
+}
+
+extern "C" int mpose_stage_loss_fwd(const float* const* heatmaps, const float* target, float* losses, float* xyz_out, int rows,
+                                    int H, int W, float sigma, int pixelwise, int three_d, int accumulate, void* stream) {
+  LossArgs a{};
+  const int rc = fill_loss_args(a, heatmaps, target, rows, H, W, sigma, pixelwise, three_d, accumulate);
+  if (rc) return rc;
+  if (rows == 0) return 0;
+  a.losses = losses; a.xyz_out = xyz_out;
+  const int nv = pick_nv(H * W);
+  MPOSE_DISPATCH_NV(nv, (stage_loss_fwd_k<NV><<<rows, 64 * 3, 0, (hipStream_t)stream>>>(a)));
+  return launch_status();
+}
+
+extern "C" int mpose_stage_loss_bwd(const float* const* heatmaps, const float* target, const float* xyz, const float* dloss,
+                                    float* const* g, int rows, int H, int W, float sigma, int pixelwise, int three_d,
+                                    int accumulate, void* stream) {
+  LossArgs a{};
+  const int rc = fill_loss_args(a, heatmaps, target, rows, H, W, sigma, pixelwise, three_d, accumulate);
+  if (rc) return rc;
+  if (rows == 0) return 0;
+  a.xyz_in = xyz; a.dloss = dloss;
+  for (int p = 0; p < 3; ++p) a.g[p] = g[p];
+  const int nv = pick_nv(H * W);
+  MPOSE_DISPATCH_NV(nv, (stage_loss_bwd_k<NV><<<rows, 64 * 3, 0, (hipStream_t)stream>>>(a)));
+  return launch_status();
+}
+
+extern "C" int mpose_js_fwd(const float* heatmaps, const float* mu, float* js, int rows, int H, int W, float sigma, void* stream) {
+  if (rows < 0 || (W & 3) || sigma <= 0.0f) return MPOSE_EINVAL;
+  if (rows == 0) return 0;
+  JsArgs a{heatmaps, mu, nullptr, js, nullptr, H, W, sigma};
+  const int nv = pick_nv(H * W);
+  MPOSE_DISPATCH_NV(nv, (js_k<NV, false><<<rows, 64, 0, (hipStream_t)stream>>>(a)));
+  return launch_status();
+}
+
+extern "C" int mpose_js_bwd(const float* heatmaps, const float* mu, const float* djs, float* g, int rows, int H, int W,
+                            float sigma, void* stream) {
+  if (rows < 0 || (W & 3) || sigma <= 0.0f) return MPOSE_EINVAL;
+  if (rows == 0) return 0;
+  JsArgs a{heatmaps, mu, djs, nullptr, g, H, W, sigma};
+  const int nv = pick_nv(H * W);
+  MPOSE_DISPATCH_NV(nv, (js_k<NV, true><<<rows, 64, 0, (hipStream_t)stream>>>(a)));
+  return launch_status();
+}
+
+extern "C" int mpose_average_loss_fwd(const float* losses, const float* mask, float* out2, int n, void* stream) {
+  if (n < 0) return MPOSE_EINVAL;
+  average_loss_k<<<1, 256, 0, (hipStream_t)stream>>>(losses, mask, out2, n);
+  return launch_status();
+}

@@ -1,0 +1,725 @@
+"""Launch sequencing of the MargiPose backbone on MI355X: the host-side "runtime" that turns
+MargiPoseModelInner.forward (reference models/margipose_model.py:179-200) and its autograd backward
+into a fixed sequence of gfx950 kernel launches through the C ABI (include/margipose_hip.h).
+
+What lives here (and nowhere in torch): which kernel runs when, on which buffers; the packed-weight,
+BatchNorm-statistics and coefficient arenas; the device-resident job tables; the convolution
+geometries (tap lists).  PyTorch supplies device memory, the stream, and the autograd edge.
+
+Data layout in HBM
+  * activations: NHWC fp32, the three columns (xy, zy, xz) of a stage are separate tensors processed by
+    one grouped launch (blockIdx.z = column);
+  * 17-channel tensors of the last ResidualBlock are stored with 32 channels (zero padded);
+  * weights: torch layout in the nn.Parameters (state_dict contract) + a packed arena
+    [widx][K/4][Npad][4] rebuilt by ONE launch per step (fwd and dgrad flavours);
+  * BatchNorm: per layer (sum, sumsq) fp64 accumulators filled by the producing conv's epilogue, and a
+    float arena holding scale / shift / mean / invstd / backward coefficients.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import (BnAddOperands, BnBwdApplyOperands, BnBwdReduceOperands, ConvGeom, ConvOperands, WgradOperands, c_int,
+                   c_int64, c_void_p, check, lib, ptr, ptr_array, stream_ptr)
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+TAPS3 = [(ky, kx) for ky in range(3) for kx in range(3)]
+
+
+def _rup(a, b):
+    return (a + b - 1) // b * b
+
+
+# numpy mirrors of the device-resident job structs (checked against mpose_sizeof at start-up)
+PACK_DT = np.dtype([('src', 'u8'), ('dst', 'u8'), ('N', 'i4'), ('K', 'i4'), ('T', 'i4'), ('Npad', 'i4'), ('Kpad', 'i4'),
+                    ('sn', 'i8'), ('sk', 'i8'), ('st', 'i8')], align=True)
+UNPACK_DT = np.dtype([('src', 'u8'), ('dst', 'u8'), ('N', 'i4'), ('K', 'i4'), ('T', 'i4'), ('Npad', 'i4'), ('Kpad', 'i4'),
+                      ('n_split', 'i4'), ('sn', 'i8'), ('sk', 'i8'), ('st', 'i8'), ('accumulate', 'i4')], align=True)
+BN_DT = np.dtype([('stats', 'u8'), ('gamma', 'u8'), ('beta', 'u8'), ('running_mean', 'u8'), ('running_var', 'u8'),
+                  ('scale', 'u8'), ('shift', 'u8'), ('mean', 'u8'), ('invstd', 'u8'), ('C', 'i4'), ('count', 'i4')], align=True)
+COEF_DT = np.dtype([('sums', 'u8'), ('gamma', 'u8'), ('mean', 'u8'), ('invstd', 'u8'), ('coef', 'u8'), ('dgamma', 'u8'),
+                    ('dbeta', 'u8'), ('sums_stride', 'i4'), ('which', 'i4'), ('C', 'i4'), ('c_stride', 'i4'), ('count', 'i4'),
+                    ('sg_col', 'i4')], align=True)
+
+_SIZES_CHECKED = False
+
+
+def _check_struct_sizes():
+    global _SIZES_CHECKED
+    if _SIZES_CHECKED:
+        return
+    L = lib()
+    expect = {0: ctypes.sizeof(ConvGeom), 1: ctypes.sizeof(ConvOperands), 2: ctypes.sizeof(WgradOperands),
+              3: PACK_DT.itemsize, 4: UNPACK_DT.itemsize, 5: BN_DT.itemsize, 6: COEF_DT.itemsize,
+              7: ctypes.sizeof(BnAddOperands), 8: ctypes.sizeof(BnBwdReduceOperands), 9: ctypes.sizeof(BnBwdApplyOperands)}
+    for which, size in expect.items():
+        got = L.mpose_sizeof(which)
+        if got != size:
+            raise _lib.MposeError('ABI struct %d: library says %d bytes, binding says %d' % (which, got, size))
+    _SIZES_CHECKED = True
+
+
+# ---------------------------------------------------------------------------------------------
+# geometry builders (see include/margipose_hip.h: mpose_conv_geom)
+# ---------------------------------------------------------------------------------------------
+def _geom(B, IH, Cin, OH, Cout0, Cout1, GH, in_mul, out_mul, classes, Npad0, Npad1=0):
+    g = ConvGeom()
+    g.B, g.IH, g.IW, g.Cin = B, IH, IH, Cin
+    g.OH, g.OW, g.Cout0, g.Cout1 = OH, OH, Cout0, Cout1
+    g.GH, g.GW, g.in_mul, g.out_mul = GH, GH, in_mul, out_mul
+    g.n_classes = len(classes)
+    g.Npad0, g.Npad1 = Npad0, Npad1
+    for ci, (oy, ox, taps) in enumerate(classes):
+        c = g.cls[ci]
+        c.n_taps, c.oy, c.ox = len(taps), oy, ox
+        for ti, (dy, dx, widx, acc) in enumerate(taps):
+            c.taps[ti].dy, c.taps[ti].dx, c.taps[ti].widx, c.taps[ti].acc = dy, dx, widx, acc
+    return g
+
+
+def _up_classes(with_shortcut, single_tap=False):
+    """Output-parity classes of a stride-2 transposed 3x3 (pad 1, output_padding 1):
+    out[2y'+py] receives kernel rows ky with ky = (py+1) mod 2; input row y' + (py+1-ky)/2."""
+    classes = []
+    for py in range(2):
+        for px in range(2):
+            taps = []
+            if not single_tap:
+                for ky, kx in TAPS3:
+                    if (py + 1 - ky) % 2 == 0 and (px + 1 - kx) % 2 == 0:
+                        taps.append(((py + 1 - ky) // 2, (px + 1 - kx) // 2, ky * 3 + kx, 0))
+            elif py == 0 and px == 0:
+                taps.append((0, 0, 0, 0))
+            if with_shortcut and py == 0 and px == 0:
+                taps.append((0, 0, 0, 1))
+            classes.append((py, px, taps))
+    return classes
+
+
+class _Conv:
+    """One convolution's weights: torch-layout parameter + slots in the packed arena."""
+
+    def __init__(self, param, transposed, k, cin, cout, cin_s, cout_s, stem=False):
+        self.param, self.transposed, self.k = param, transposed, k
+        self.cin, self.cout, self.cin_s, self.cout_s = cin, cout, cin_s, cout_s
+        self.T = 1 if stem else k * k
+        self.stem = stem
+        self.npad_f = _rup(cout, 64)             # forward pack: N = cout, K = cin_s
+        self.npad_d = _rup(cin, 64)              # dgrad pack:   N = cin,  K = cout_s
+        self.size_f = self.T * cin_s * self.npad_f
+        self.size_d = self.T * cout_s * self.npad_d
+        self.off_f = self.off_d = self.off_g = -1
+
+    def strides(self, dgrad):
+        """(sn, sk, st): element strides of (n, k, tap) in the torch-layout weight."""
+        kk = self.k * self.k
+        if self.stem:                            # (128, 3, 8, 8) seen as (128, 192) 1x1
+            return (192, 1, 0) if not dgrad else (1, 192, 0)
+        if not self.transposed:                  # (Cout, Cin, k, k)
+            return (self.cin * kk, kk, 1) if not dgrad else (kk, self.cin * kk, 1)
+        return (kk, self.cout * kk, 1) if not dgrad else (self.cout * kk, kk, 1)   # (Cin, Cout, k, k)
+
+
+class _BN:
+    def __init__(self, module, C, Cs):
+        self.m, self.C, self.Cs = module, C, Cs
+        self.f_off = self.s_off = -1             # offsets into the float / double arenas
+
+
+class _Block:
+    """One ResidualBlock (reference models/margipose_model.py:25-40) of one column."""
+
+    def __init__(self, rb, kind, cin, cout):
+        self.kind = kind
+        self.cin, self.cout = cin, cout
+        self.cin_s, self.cout_s = _rup(cin, 32), _rup(cout, 32)
+        tr = kind == 'up'
+        self.conv_in = _Conv(rb.module[0].weight, tr, 3, cin, cout, self.cin_s, self.cout_s)
+        self.conv2 = _Conv(rb.module[3].weight, False, 3, cout, cout, self.cout_s, self.cout_s)
+        self.conv_sc = _Conv(rb.shortcut[0].weight, tr, 1, cin, cout, self.cin_s, self.cout_s)
+        self.bn1 = _BN(rb.module[1], cout, self.cout_s)
+        self.bn2 = _BN(rb.module[4], cout, self.cout_s)
+        self.bns = _BN(rb.shortcut[1], cout, self.cout_s)
+
+
+def _jobs_to_device(arr, device):
+    return torch.from_numpy(arr.view(np.uint8).copy()).to(device)
+
+
+class Engine:
+    """Owns the launch plan of one MargiPoseModelInner instance."""
+
+    def __init__(self, inner):
+        self.inner = inner
+        self.T = inner.n_stages
+        self.J = inner.n_joints
+        self.spaces = inner.spaces                 # e.g. (0, 1, 2): xy, zy, xz
+        self.device = None
+        self.stage_blocks = []                     # [stage][block index 0..9] -> list of 3 _Block
+        cols = (inner.xy_hm_cnns, inner.zy_hm_cnns, inner.xz_hm_cnns)
+        kinds = ['regular', 'regular', 'down', 'regular', 'regular', 'regular', 'regular', 'up', 'regular', 'regular']
+        chans = [(128, 128), (128, 128), (128, 192), (192, 192), (192, 192), (192, 192), (192, 192), (192, 128), (128, 128),
+                 (128, self.J)]
+        for t in range(self.T):
+            blocks = []
+            for i in range(10):
+                grp = []
+                for c in range(3):
+                    col = cols[c][t]
+                    rb = col.down_layers[i] if i < 5 else col.up_layers[i - 5]
+                    grp.append(_Block(rb, kinds[i], chans[i][0], chans[i][1]))
+                blocks.append(grp)
+            self.stage_blocks.append(blocks)
+        self.stem_conv = _Conv(inner.in_cnn[0].weight, False, 1, 192, 128, 192, 128, stem=True)
+        self.stem_bn = _BN(inner.in_cnn[1], 128, 128)
+        self.combiners = [m.conv.weight for m in inner.hm_combiners]
+        self._all_blocks = [b for st in self.stage_blocks for grp in st for b in grp]
+        self._convs = [self.stem_conv] + [c for b in self._all_blocks for c in (b.conv_in, b.conv2, b.conv_sc)]
+        self._bns = [self.stem_bn] + [n for b in self._all_blocks for n in (b.bn1, b.bn2, b.bns)]
+        self._geoms = {}
+        self._tables = {}
+        self._arena_key = None
+
+    # ------------------------------------------------------------------ parameters / arenas
+    def param_list(self):
+        """Every learnable tensor, in the order grads are returned by the autograd Function."""
+        ps = []
+        for c in self._convs:
+            ps.append(c.param)
+        for n in self._bns:
+            ps += [n.m.weight, n.m.bias]
+        ps += self.combiners
+        return ps
+
+    def invalidate(self):
+        self._arena_key = None
+        self._tables = {}
+
+    def _ensure_arenas(self, device):
+        key = (str(device),) + tuple(p.data_ptr() for p in self.param_list()[:4])
+        if self._arena_key == key:
+            return
+        _check_struct_sizes()
+        for p in self.param_list():
+            _lib.dev_f32(p.data, 'parameter')
+        self.device = device
+        # packed weights (fwd + dgrad) and wgrad partial offsets
+        off = 0
+        for c in self._convs:
+            c.off_f = off; off += c.size_f
+            c.off_d = off; off += c.size_d
+        self.wpack = torch.zeros(off, dtype=torch.float32, device=device)
+        # float arena per BN: scale, shift, mean, invstd, coef[3] -> 7*Cs ; double arena: fwd stats 2*Cs + bwd sums 4*Cs
+        foff = soff = 0
+        for n in self._bns:
+            n.f_off = foff; foff += 7 * n.Cs
+            n.s_off = soff; soff += 6 * n.Cs
+        self.bnf = torch.zeros(foff, dtype=torch.float32, device=device)
+        self.stat_arena = torch.zeros(soff, dtype=torch.float64, device=device)
+        # grad layout: offsets of every parameter in the flat gradient buffer
+        goff = 0
+        self._grad_offsets = []
+        for p in self.param_list():
+            self._grad_offsets.append(goff)
+            goff += _rup(p.numel(), 4)
+        self._grad_total = goff
+        self.gflat = torch.zeros(goff, dtype=torch.float32, device=device)
+        # num_batches_tracked of every BN becomes a view of one int64 vector: one increment per step
+        self._nbt = torch.stack([n.m.num_batches_tracked.to(device) for n in self._bns]).contiguous()
+        for i, n in enumerate(self._bns):
+            n.m.num_batches_tracked = self._nbt[i]
+        # pack job table
+        jobs = np.zeros(2 * len(self._convs), dtype=PACK_DT)
+        mx = 0
+        base = self.wpack.data_ptr()
+        for i, c in enumerate(self._convs):
+            for d in (0, 1):
+                j = jobs[2 * i + d]
+                sn, sk, st = c.strides(bool(d))
+                j['src'] = c.param.data_ptr()
+                j['dst'] = base + 4 * (c.off_d if d else c.off_f)
+                j['N'], j['K'] = (c.cin, c.cout) if d else (c.cout, c.cin)
+                j['T'] = c.T
+                j['Npad'] = c.npad_d if d else c.npad_f
+                j['Kpad'] = c.cout_s if d else c.cin_s
+                j['sn'], j['sk'], j['st'] = sn, sk, st
+                mx = max(mx, int(j['T']) * int(j['Kpad']) * int(j['Npad']))
+        self._pack_jobs = _jobs_to_device(jobs, device)
+        self._pack_max = mx
+        self._tables = {}
+        self._arena_key = key
+
+    # views into the BN arenas --------------------------------------------------------------
+    def _bnf_ptr(self, n, slot):
+        """slot: 0 scale, 1 shift, 2 mean, 3 invstd, 4 coef(3*Cs)."""
+        return self.bnf.data_ptr() + 4 * (n.f_off + slot * n.Cs)
+
+    def _stats_ptr(self, n, bwd=False):
+        return self.stat_arena.data_ptr() + 8 * (n.s_off + (2 * n.Cs if bwd else 0))
+
+    # ------------------------------------------------------------------ job tables per batch size
+    def _tables_for(self, B, F):
+        """Device-resident job tables + persistent workspaces for one (batch, heatmap size).  Everything they
+        point at (parameters, arenas, the flat gradient buffer, the wgrad partial arena) has a fixed address,
+        so a whole step is replayable from a hipGraph."""
+        key = (B, F)
+        if key in self._tables:
+            return self._tables[key]
+        S = F // 2
+        dev = self.device
+        tb = {}
+
+        def hw_out(i):
+            return F if (i < 2 or i >= 7) else S
+
+        def hw_in(i):
+            return F if (i <= 2 or i >= 8) else S
+
+        def bn_job(j, n, count):
+            j['stats'] = self._stats_ptr(n)
+            j['gamma'] = n.m.weight.data_ptr(); j['beta'] = n.m.bias.data_ptr()
+            j['running_mean'] = n.m.running_mean.data_ptr(); j['running_var'] = n.m.running_var.data_ptr()
+            j['scale'] = self._bnf_ptr(n, 0); j['shift'] = self._bnf_ptr(n, 1)
+            j['mean'] = self._bnf_ptr(n, 2); j['invstd'] = self._bnf_ptr(n, 3)
+            j['C'] = n.C; j['count'] = count
+
+        gbase = self.gflat.data_ptr()
+        goff = dict((id(p), o) for p, o in zip(self.param_list(), self._grad_offsets))
+
+        def coef_job(j, n, sums_from, stride, sg_col, which, count):
+            j['sums'] = self._stats_ptr(sums_from, True)
+            j['sg_col'] = sg_col
+            j['gamma'] = n.m.weight.data_ptr(); j['mean'] = self._bnf_ptr(n, 2); j['invstd'] = self._bnf_ptr(n, 3)
+            j['coef'] = self._bnf_ptr(n, 4)
+            j['dgamma'] = gbase + 4 * goff[id(n.m.weight)]; j['dbeta'] = gbase + 4 * goff[id(n.m.bias)]
+            j['sums_stride'], j['which'], j['C'], j['c_stride'], j['count'] = stride, which, n.C, n.Cs, count
+
+        # forward finalize jobs: [stem] then per (stage, block): bn1 x3, bns x3, bn2 x3
+        fj = np.zeros(1 + self.T * 90, dtype=BN_DT)
+        # backward coefficient jobs: per (stage, block): bn2 x3, bns x3, bn1 x3 ; stem last
+        cj = np.zeros(self.T * 90 + 1, dtype=COEF_DT)
+        # wgrad partial arena + unpack jobs: per (stage, block, column): conv2, conv_in, conv_sc ; stem last
+        uj = np.zeros(self.T * 90 + 1, dtype=UNPACK_DT)
+        bn_job(fj[0], self.stem_bn, B * F * F)
+        part_off = 0
+        part_offs = {}
+        mx = 0
+
+        def unpack_job(j, conv, nsp):
+            nonlocal part_off, mx
+            sn, sk, stt = conv.strides(False)
+            j['src'] = part_off            # patched to an absolute address below
+            j['dst'] = gbase + 4 * goff[id(conv.param)]
+            j['N'], j['K'], j['T'], j['Npad'], j['Kpad'], j['n_split'] = conv.cout, conv.cin, conv.T, conv.npad_f, conv.cin_s, nsp
+            j['sn'], j['sk'], j['st'], j['accumulate'] = sn, sk, stt, 0
+            part_offs[id(conv)] = part_off
+            part_off += nsp * conv.size_f
+            mx = max(mx, conv.cout * conv.cin * conv.T)
+
+        k = 1
+        for t in range(self.T):
+            for i in range(10):
+                cnt = B * hw_out(i) * hw_out(i)
+                grp = self.stage_blocks[t][i]
+                base = (t * 10 + i) * 9
+                for c, b in enumerate(grp):
+                    bn_job(fj[1 + base + c], b.bn1, cnt)
+                    bn_job(fj[1 + base + 3 + c], b.bns, cnt)
+                    bn_job(fj[1 + base + 6 + c], b.bn2, cnt)
+                    coef_job(cj[base + c], b.bn2, b.bn2, 4, 0, 1, cnt)
+                    coef_job(cj[base + 3 + c], b.bns, b.bn2, 4, 2, 3, cnt)
+                    coef_job(cj[base + 6 + c], b.bn1, b.bn1, 2, 0, 1, cnt)
+                    slots_in = B * (hw_in(i) if b.kind == 'up' else hw_out(i)) ** 2
+                    unpack_job(uj[base + 3 * c], b.conv2, self._n_split(cnt))
+                    unpack_job(uj[base + 3 * c + 1], b.conv_in, self._n_split(slots_in))
+                    unpack_job(uj[base + 3 * c + 2], b.conv_sc, self._n_split(slots_in))
+        coef_job(cj[self.T * 90], self.stem_bn, self.stem_bn, 4, 0, 1, B * F * F)
+        unpack_job(uj[self.T * 90], self.stem_conv, self._n_split(B * F * F))
+        tb['partials'] = torch.empty(part_off, dtype=torch.float32, device=dev)
+        pbase = tb['partials'].data_ptr()
+        uj['src'] = pbase + 4 * uj['src']
+        tb['part_ptr'] = dict((k_, pbase + 4 * v) for k_, v in part_offs.items())
+        tb['fin'] = _jobs_to_device(fj, dev)
+        tb['coef'] = _jobs_to_device(cj, dev)
+        tb['unpack'] = _jobs_to_device(uj, dev)
+        tb['unpack_max'] = mx
+        self._tables[key] = tb
+        return tb
+
+    def fin_index(self, t, i, which):
+        """Index of the first of the 3 finalize jobs: which = 0 (bn1), 1 (bns), 2 (bn2)."""
+        return 1 + (t * 10 + i) * 9 + which * 3
+
+    # ------------------------------------------------------------------ geometries
+    def geom(self, name, B, H, blk=None):
+        key = (name, B, H, None if blk is None else (blk.cin_s, blk.cout_s))
+        g = self._geoms.get(key)
+        if g is not None:
+            return g
+        ci, co = (blk.cin_s, blk.cout_s) if blk is not None else (0, 0)
+        np_f = _rup(blk.cout, 64) if blk is not None else 0      # forward N padding
+        np_d = _rup(blk.cin, 64) if blk is not None else 0       # dgrad N padding (N = cin)
+        t9 = [(ky - 1, kx - 1, ky * 3 + kx, 0) for ky, kx in TAPS3]
+        if name == 'f_in_regular':       # 3x3 + fused 1x1 shortcut
+            g = _geom(B, H, ci, H, co, co, H, 1, 1, [(0, 0, t9 + [(0, 0, 0, 1)])], np_f, np_f)
+        elif name == 'f_conv2':
+            g = _geom(B, H, co, H, co, 0, H, 1, 1, [(0, 0, t9)], np_f)
+        elif name == 'f_in_down':        # H = input size
+            g = _geom(B, H, ci, H // 2, co, co, H // 2, 2, 1, [(0, 0, t9 + [(0, 0, 0, 1)])], np_f, np_f)
+        elif name == 'f_in_up':          # H = input size
+            g = _geom(B, H, ci, 2 * H, co, co, H, 1, 2, _up_classes(True), np_f, np_f)
+        elif name == 'd_conv2':          # dgrad of the block's second 3x3: K = N = cout
+            g = _geom(B, H, co, H, co, 0, H, 1, 1, [(0, 0, [(1 - ky, 1 - kx, ky * 3 + kx, 0) for ky, kx in TAPS3])], np_f)
+        elif name == 'd_in3_regular':    # dgrad of conv_in: K = cout_s, N = cin
+            g = _geom(B, H, co, H, ci, 0, H, 1, 1, [(0, 0, [(1 - ky, 1 - kx, ky * 3 + kx, 0) for ky, kx in TAPS3])], np_d)
+        elif name == 'd_in1_regular':
+            g = _geom(B, H, co, H, ci, 0, H, 1, 1, [(0, 0, [(0, 0, 0, 0)])], np_d)
+        elif name == 'd_in3_down':       # H = size of the conv OUTPUT (gradient input); result is 2H
+            g = _geom(B, H, co, 2 * H, ci, 0, H, 1, 2, _up_classes(False), np_d)
+        elif name == 'd_in1_down':
+            g = _geom(B, H, co, 2 * H, ci, 0, H, 1, 2, _up_classes(False, single_tap=True), np_d)
+        elif name == 'd_in3_up':         # H = size of the convT OUTPUT (gradient input); result is H/2
+            g = _geom(B, H, co, H // 2, ci, 0, H // 2, 2, 1, [(0, 0, t9)], np_d)
+        elif name == 'd_in1_up':
+            g = _geom(B, H, co, H // 2, ci, 0, H // 2, 2, 1, [(0, 0, [(0, 0, 0, 0)])], np_d)
+        elif name == 'f_stem':
+            g = _geom(B, H, 192, H, 128, 0, H, 1, 1, [(0, 0, [(0, 0, 0, 0)])], 128)
+        elif name == 'd_stem':
+            g = _geom(B, H, 128, H, 192, 0, H, 1, 1, [(0, 0, [(0, 0, 0, 0)])], 192)
+        else:
+            raise KeyError(name)
+        self._geoms[key] = g
+        return g
+
+    # ------------------------------------------------------------------ launch helpers
+    def _wptr(self, conv, dgrad=False):
+        return self.wpack.data_ptr() + 4 * (conv.off_d if dgrad else conv.off_f)
+
+    def conv(self, g, ops, flags=0):
+        arr = (ConvOperands * 3)(*ops)
+        check(lib().mpose_conv_fwd(ctypes.byref(g), arr, len(ops), flags, stream_ptr()), 'mpose_conv_fwd')
+
+    def wgrad(self, g, ops, n_split):
+        arr = (WgradOperands * 3)(*ops)
+        check(lib().mpose_conv_wgrad(ctypes.byref(g), arr, len(ops), n_split, stream_ptr()), 'mpose_conv_wgrad')
+
+    def finalize(self, tb, first, n, train):
+        base = tb['fin'].data_ptr() + first * BN_DT.itemsize
+        check(lib().mpose_bn_finalize(c_void_p(base), n, int(train), ctypes.c_float(BN_EPS), ctypes.c_float(BN_MOMENTUM),
+                                      stream_ptr()), 'mpose_bn_finalize')
+
+    def pack_weights(self):
+        check(lib().mpose_pack_weights(ptr(self._pack_jobs), 2 * len(self._convs), self._pack_max, stream_ptr()),
+              'mpose_pack_weights')
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x, train, save):
+        """x: (B, 3, S, S) NCHW device tensor.  Returns (heatmap lists [3][T], xyz of last stage, ctx)."""
+        L = lib()
+        x = _lib.dev_f32(x.contiguous(), 'input')
+        B, C3, S, S2 = x.shape
+        if C3 != 3 or S != S2 or S % 16 != 0:
+            raise _lib.MposeError('expected a (B, 3, S, S) input with S %% 16 == 0, got %s' % (tuple(x.shape),))
+        F = S // 8
+        Sm = F // 2
+        if 192 % Sm != 0 or (Sm % 4) != 0 or (F * F) % 64 != 0 or F * F > 4096:
+            raise _lib.MposeError('unsupported input size %d (mid size %d must divide 192 and be a multiple of 4)' % (S, Sm))
+        dev = x.device
+        self._ensure_arenas(dev)
+        tb = self._tables_for(B, F)
+        st = stream_ptr
+        f32 = dict(dtype=torch.float32, device=dev)
+        ctx = {'B': B, 'F': F, 'train': train, 'blocks': [], 'x_shape': tuple(x.shape)}
+
+        self.pack_weights()
+        if train:
+            self.stat_arena.zero_()
+        else:
+            self.finalize(tb, 0, 1 + self.T * 90, False)     # scale/shift from the running statistics
+
+        # ---- stem: space-to-depth + 1x1 conv (192->128) + BN + ReLU ----
+        s2d = torch.empty(B, F, F, 192, **f32)
+        check(L.mpose_space_to_depth8(ptr(x), ptr(s2d), B, S, st()), 'mpose_space_to_depth8')
+        stem_raw = torch.empty(B, F, F, 128, **f32)
+        op = ConvOperands()
+        op.in_, op.w0, op.out0 = s2d.data_ptr(), self._wptr(self.stem_conv), stem_raw.data_ptr()
+        if train:
+            op.stats0 = self._stats_ptr(self.stem_bn)
+        self.conv(self.geom('f_stem', B, F), [op])
+        if train:
+            self.finalize(tb, 0, 1, True)
+        inp = torch.empty(B, F, F, 128, **f32)
+        check(L.mpose_bn_relu_fwd(ptr(stem_raw), c_void_p(self._bnf_ptr(self.stem_bn, 0)), c_void_p(self._bnf_ptr(self.stem_bn, 1)),
+                                  ptr(inp), c_int64(inp.numel()), 128, st()), 'mpose_bn_relu_fwd')
+        ctx['s2d'], ctx['stem_raw'], ctx['stem_out'] = s2d, stem_raw, inp
+        ctx['inps'] = []
+
+        hms = [[], [], []]
+        xyz = None
+        for t in range(self.T):
+            if t > 0:
+                new_inp = torch.empty_like(inp)
+                check(L.mpose_combiner_fwd(ptr_array([hms[p][t - 1] for p in range(3)]), ptr(self.combiners[t - 1]), ptr(inp),
+                                           ptr(new_inp), B, self.J, F * F, 128, st()), 'mpose_combiner_fwd')
+                inp = new_inp
+            ctx['inps'].append(inp)
+            cur = [inp, inp, inp]
+            stage_saved = []
+            for i in range(10):
+                grp = self.stage_blocks[t][i]
+                b0 = grp[0]
+                Hin = F if (i <= 2 or i >= 8) else Sm          # input spatial size of block i
+                Hout = F if (i < 2 or i >= 7) else Sm
+                if i == 5 and any(sp != 0 for sp in self.spaces):
+                    outs = [cur[c] if self.spaces[c] == 0 else torch.empty_like(cur[c]) for c in range(3)]
+                    spaces = (c_int * 3)(*self.spaces)
+                    check(L.mpose_axis_permute(ptr_array(cur), ptr_array(outs), spaces, 3, B, Sm, 192, st()), 'mpose_axis_permute')
+                    cur = outs
+                gname = {'regular': 'f_in_regular', 'down': 'f_in_down', 'up': 'f_in_up'}[b0.kind]
+                g1 = self.geom(gname, B, Hin, b0)
+                c1 = [torch.empty(B, Hout, Hout, b0.cout_s, **f32) for _ in range(3)]
+                sc = [torch.empty(B, Hout, Hout, b0.cout_s, **f32) for _ in range(3)]
+                ops = []
+                for c, b in enumerate(grp):
+                    op = ConvOperands()
+                    op.in_, op.w0, op.w1 = cur[c].data_ptr(), self._wptr(b.conv_in), self._wptr(b.conv_sc)
+                    op.out0, op.out1 = c1[c].data_ptr(), sc[c].data_ptr()
+                    if train:
+                        op.stats0, op.stats1 = self._stats_ptr(b.bn1), self._stats_ptr(b.bns)
+                    ops.append(op)
+                self.conv(g1, ops)
+                if train:
+                    self.finalize(tb, self.fin_index(t, i, 0), 6, True)
+                c2 = [torch.empty(B, Hout, Hout, b0.cout_s, **f32) for _ in range(3)]
+                ops = []
+                for c, b in enumerate(grp):
+                    op = ConvOperands()
+                    op.in_, op.w0, op.out0 = c1[c].data_ptr(), self._wptr(b.conv2), c2[c].data_ptr()
+                    op.in_scale, op.in_shift = self._bnf_ptr(b.bn1, 0), self._bnf_ptr(b.bn1, 1)
+                    if train:
+                        op.stats0 = self._stats_ptr(b.bn2)
+                    ops.append(op)
+                self.conv(self.geom('f_conv2', B, Hout, b0), ops)
+                if train:
+                    self.finalize(tb, self.fin_index(t, i, 2), 3, True)
+                last = i == 9
+                if last:
+                    outs = [torch.empty(B, self.J, F, F, **f32) for _ in range(3)]
+                else:
+                    outs = [torch.empty(B, Hout, Hout, b0.cout_s, **f32) for _ in range(3)]
+                aops = []
+                for c, b in enumerate(grp):
+                    ao = BnAddOperands()
+                    ao.a, ao.a_scale, ao.a_shift = c2[c].data_ptr(), self._bnf_ptr(b.bn2, 0), self._bnf_ptr(b.bn2, 1)
+                    ao.b, ao.b_scale, ao.b_shift = sc[c].data_ptr(), self._bnf_ptr(b.bns, 0), self._bnf_ptr(b.bns, 1)
+                    ao.out = outs[c].data_ptr()
+                    aops.append(ao)
+                check(L.mpose_bn_add_fwd((BnAddOperands * 3)(*aops), 3, Hout * Hout, B, b0.cout_s, 1 if last else 0, self.J, st()),
+                      'mpose_bn_add_fwd')
+                if save:
+                    stage_saved.append({'x': cur, 'c1': c1, 'sc': sc, 'c2': c2})
+                cur = outs
+            logits = cur
+            heat = [torch.empty_like(l) for l in logits]
+            want_xyz = t == self.T - 1
+            if want_xyz:
+                xyz = torch.empty(B, self.J, 3, **f32)
+            check(L.mpose_softmax_dsnt_fwd(ptr_array(logits), ptr_array(heat), None, ptr(xyz) if want_xyz else None, 3, B * self.J, F,
+                                           F, 0, st()), 'mpose_softmax_dsnt_fwd')
+            for p in range(3):
+                hms[p].append(heat[p])
+            ctx['blocks'].append(stage_saved)
+        if train:
+            self._nbt.add_(1)
+        return hms, xyz, ctx
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, ctx, hms, g_hms, need_dx):
+        """hms[p][t]: heatmaps of the forward; g_hms[p][t]: gradient w.r.t. them (or None).
+        Returns (persistent flat gradient buffer, dx or None)."""
+        L = lib()
+        if not ctx['train']:
+            raise _lib.MposeError('backward through eval-mode BatchNorm is not implemented: call model.train()')
+        B, F = ctx['B'], ctx['F']
+        Sm = F // 2
+        dev = self.device
+        st = stream_ptr
+        f32 = dict(dtype=torch.float32, device=dev)
+        J = self.J
+        tb = self._tables_for(B, F)
+        self.gflat.zero_()
+        self.stat_arena.zero_()        # forward sums are consumed (mean/invstd live in the float arena)
+        goff = dict((id(p), o) for p, o in zip(self.param_list(), self._grad_offsets))
+        coef_base = tb['coef'].data_ptr()
+
+        def run_coef(first, n):
+            check(L.mpose_bn_bwd_coef(c_void_p(coef_base + first * COEF_DT.itemsize), n, st()), 'mpose_bn_bwd_coef')
+
+        D = None            # gradient w.r.t. the stage input, cumulative over later stages (:195 is `inp = inp + ...`)
+        g_comb = None
+        for t in reversed(range(self.T)):
+            heat = [hms[p][t] for p in range(3)]
+            g1 = [g_hms[p][t] for p in range(3)]
+            if all(g is None for g in g1) and g_comb is None and D is None:
+                continue
+            g1 = [_lib.dev_f32(g.contiguous(), 'grad') if g is not None else torch.zeros_like(heat[p]) for p, g in enumerate(g1)]
+            dlog = [torch.empty_like(h) for h in heat]
+            check(L.mpose_softmax_bwd(ptr_array(heat), ptr_array(g1), ptr_array(g_comb) if g_comb is not None else None,
+                                      ptr_array(dlog), 3, B * J, F * F, st()), 'mpose_softmax_bwd')
+            g = [torch.empty(B, F, F, 32, **f32) for _ in range(3)]
+            check(L.mpose_nchw_to_nhwc_pad(ptr_array(dlog), ptr_array(g), 3, B, J, F * F, 32, st()), 'mpose_nchw_to_nhwc_pad')
+
+            saved = ctx['blocks'][t]
+            for i in reversed(range(10)):
+                grp = self.stage_blocks[t][i]
+                b0 = grp[0]
+                sv = saved[i]
+                Hin = F if (i <= 2 or i >= 8) else Sm
+                Hout = F if (i < 2 or i >= 7) else Sm
+                cnt = B * Hout * Hout
+                Cs = b0.cout_s
+                jb = (t * 10 + i) * 9
+                # (1) sums of g, g*c2, g*sc -> BN2 / BN_shortcut backward coefficients, dgamma, dbeta
+                rops = []
+                for c, b in enumerate(grp):
+                    ro = BnBwdReduceOperands()
+                    ro.g, ro.a, ro.b = g[c].data_ptr(), sv['c2'][c].data_ptr(), sv['sc'][c].data_ptr()
+                    ro.a_scale, ro.a_shift = self._bnf_ptr(b.bn2, 0), self._bnf_ptr(b.bn2, 1)     # ReLU after the second BN
+                    ro.sums = self._stats_ptr(b.bn2, True)
+                    rops.append(ro)
+                check(L.mpose_bn_bwd_reduce((BnBwdReduceOperands * 3)(*rops), 3, Hout * Hout, B, Cs, 0, 0, st()), 'mpose_bn_bwd_reduce')
+                run_coef(jb, 6)
+                d_c2 = [torch.empty(B, Hout, Hout, Cs, **f32) for _ in range(3)]
+                d_sc = [torch.empty(B, Hout, Hout, Cs, **f32) for _ in range(3)]
+                aops = []
+                for c, b in enumerate(grp):
+                    ao = BnBwdApplyOperands()
+                    ao.g, ao.a, ao.b = g[c].data_ptr(), sv['c2'][c].data_ptr(), sv['sc'][c].data_ptr()
+                    ao.coef_a, ao.coef_b = self._bnf_ptr(b.bn2, 4), self._bnf_ptr(b.bns, 4)
+                    ao.a_scale, ao.a_shift = self._bnf_ptr(b.bn2, 0), self._bnf_ptr(b.bn2, 1)
+                    ao.da, ao.db = d_c2[c].data_ptr(), d_sc[c].data_ptr()
+                    aops.append(ao)
+                check(L.mpose_bn_bwd_apply((BnBwdApplyOperands * 3)(*aops), 3, Hout * Hout, B, Cs, 0, 0, st()), 'mpose_bn_bwd_apply')
+                # (2) dgrad of the second 3x3; ReLU mask and the BN1-backward sums happen in its epilogue
+                d_a1 = [torch.empty(B, Hout, Hout, Cs, **f32) for _ in range(3)]
+                ops = []
+                for c, b in enumerate(grp):
+                    op = ConvOperands()
+                    op.in_, op.w0, op.out0 = d_c2[c].data_ptr(), self._wptr(b.conv2, True), d_a1[c].data_ptr()
+                    op.mask_src = sv['c1'][c].data_ptr()
+                    op.mask_scale, op.mask_shift = self._bnf_ptr(b.bn1, 0), self._bnf_ptr(b.bn1, 1)
+                    op.stats0 = self._stats_ptr(b.bn1, True)
+                    ops.append(op)
+                self.conv(self.geom('d_conv2', B, Hout, b0), ops)
+                # (3) wgrad of the second 3x3 (its input relu(bn1(c1)) is recomputed while staging)
+                wops = []
+                for c, b in enumerate(grp):
+                    wo = WgradOperands()
+                    wo.in_, wo.in_scale, wo.in_shift = sv['c1'][c].data_ptr(), self._bnf_ptr(b.bn1, 0), self._bnf_ptr(b.bn1, 1)
+                    wo.gout0, wo.dw0 = d_c2[c].data_ptr(), tb['part_ptr'][id(b.conv2)]
+                    wops.append(wo)
+                self.wgrad(self.geom('f_conv2', B, Hout, b0), wops, self._n_split(cnt))
+                # (4) BN1 backward
+                run_coef(jb + 6, 3)
+                d_c1 = [torch.empty(B, Hout, Hout, Cs, **f32) for _ in range(3)]
+                aops = []
+                for c, b in enumerate(grp):
+                    ao = BnBwdApplyOperands()
+                    ao.g, ao.a, ao.coef_a, ao.da = d_a1[c].data_ptr(), sv['c1'][c].data_ptr(), self._bnf_ptr(b.bn1, 4), d_c1[c].data_ptr()
+                    aops.append(ao)
+                check(L.mpose_bn_bwd_apply((BnBwdApplyOperands * 3)(*aops), 3, Hout * Hout, B, Cs, 0, 0, st()), 'mpose_bn_bwd_apply')
+                # (5) wgrad of conv_in + shortcut: one launch over the fused forward geometry
+                gname = {'regular': 'f_in_regular', 'down': 'f_in_down', 'up': 'f_in_up'}[b0.kind]
+                slots = B * (Hin if b0.kind == 'up' else Hout) ** 2
+                wops = []
+                for c, b in enumerate(grp):
+                    wo = WgradOperands()
+                    wo.in_ = sv['x'][c].data_ptr()
+                    wo.gout0, wo.gout1 = d_c1[c].data_ptr(), d_sc[c].data_ptr()
+                    wo.dw0, wo.dw1 = tb['part_ptr'][id(b.conv_in)], tb['part_ptr'][id(b.conv_sc)]
+                    wops.append(wo)
+                self.wgrad(self.geom(gname, B, Hin, b0), wops, self._n_split(slots))
+                # (6) dgrad of conv_in, then the shortcut's dgrad accumulated on top
+                d_x = [torch.empty(B, Hin, Hin, b0.cin_s, **f32) for _ in range(3)]
+                k3 = {'regular': 'd_in3_regular', 'down': 'd_in3_down', 'up': 'd_in3_up'}[b0.kind]
+                k1 = {'regular': 'd_in1_regular', 'down': 'd_in1_down', 'up': 'd_in1_up'}[b0.kind]
+                for name, src, conv, flags in ((k3, d_c1, 'conv_in', 0), (k1, d_sc, 'conv_sc', 1)):
+                    ops = []
+                    for c, b in enumerate(grp):
+                        op = ConvOperands()
+                        op.in_, op.w0, op.out0 = src[c].data_ptr(), self._wptr(getattr(b, conv), True), d_x[c].data_ptr()
+                        ops.append(op)
+                    self.conv(self.geom(name, B, Hout, b0), ops, flags)
+                g = d_x
+                if i == 5 and any(sp != 0 for sp in self.spaces):     # the permutation is an involution
+                    outs = [g[c] if self.spaces[c] == 0 else torch.empty_like(g[c]) for c in range(3)]
+                    spaces = (c_int * 3)(*self.spaces)
+                    check(L.mpose_axis_permute(ptr_array(g), ptr_array(outs), spaces, 3, B, Sm, 192, st()), 'mpose_axis_permute')
+                    g = outs
+            # fan-in of the three columns (+ the cumulative gradient from later stages)
+            tot = torch.empty_like(g[0])
+            check(L.mpose_add(ptr(g[0]), ptr(g[1]), ptr(tot), c_int64(tot.numel()), st()), 'mpose_add')
+            check(L.mpose_add(ptr(tot), ptr(g[2]), ptr(tot), c_int64(tot.numel()), st()), 'mpose_add')
+            if D is not None:
+                check(L.mpose_add(ptr(tot), ptr(D), ptr(tot), c_int64(tot.numel()), st()), 'mpose_add')
+            D = tot
+            if t > 0:
+                n_part = 256
+                w = self.combiners[t - 1]
+                dwp = torch.empty(n_part * w.numel(), **f32)
+                g_comb = [torch.empty_like(heat[0]) for _ in range(3)]
+                prev = [hms[p][t - 1] for p in range(3)]
+                check(L.mpose_combiner_bwd(ptr_array(prev), ptr(w), ptr(D), ptr_array(g_comb), ptr(dwp), n_part, B, J, F * F, 128, st()),
+                      'mpose_combiner_bwd')
+                check(L.mpose_reduce_partials(ptr(dwp), c_void_p(self.gflat.data_ptr() + 4 * goff[id(w)]), n_part, c_int64(w.numel()),
+                                              0, st()), 'mpose_reduce_partials')
+            else:
+                g_comb = None
+
+        dx = None
+        if D is not None:
+            # ---- stem backward: ReLU mask, BN backward, wgrad (+ dgrad when the input wants a gradient) ----
+            n = self.stem_bn
+            gm = torch.empty_like(D)
+            check(L.mpose_relu_bwd(ptr(D), ptr(ctx['stem_out']), ptr(gm), c_int64(gm.numel()), st()), 'mpose_relu_bwd')
+            ro = BnBwdReduceOperands()
+            ro.g, ro.a, ro.sums = gm.data_ptr(), ctx['stem_raw'].data_ptr(), self._stats_ptr(n, True)
+            check(L.mpose_bn_bwd_reduce((BnBwdReduceOperands * 3)(ro), 1, F * F, B, 128, 0, 0, st()), 'mpose_bn_bwd_reduce')
+            run_coef(self.T * 90, 1)
+            d_raw = torch.empty_like(D)
+            ao = BnBwdApplyOperands()
+            ao.g, ao.a, ao.coef_a, ao.da = gm.data_ptr(), ctx['stem_raw'].data_ptr(), self._bnf_ptr(n, 4), d_raw.data_ptr()
+            check(L.mpose_bn_bwd_apply((BnBwdApplyOperands * 3)(ao), 1, F * F, B, 128, 0, 0, st()), 'mpose_bn_bwd_apply')
+            wo = WgradOperands()
+            wo.in_, wo.gout0, wo.dw0 = ctx['s2d'].data_ptr(), d_raw.data_ptr(), tb['part_ptr'][id(self.stem_conv)]
+            self.wgrad(self.geom('f_stem', B, F), [wo], self._n_split(B * F * F))
+            if need_dx:
+                d_s2d = torch.empty_like(ctx['s2d'])
+                op = ConvOperands()
+                op.in_, op.w0, op.out0 = d_raw.data_ptr(), self._wptr(self.stem_conv, True), d_s2d.data_ptr()
+                self.conv(self.geom('d_stem', B, F), [op])
+                dx = torch.empty(ctx['x_shape'], **f32)
+                check(L.mpose_depth_to_space8(ptr(d_s2d), ptr(dx), B, ctx['x_shape'][2], st()), 'mpose_depth_to_space8')
+            # ---- ONE launch turns every packed partial sum into torch-layout gradients ----
+            check(L.mpose_unpack_wgrads(ptr(tb['unpack']), self.T * 90 + 1, tb['unpack_max'], st()), 'mpose_unpack_wgrads')
+        return self.gflat, dx
+
+    @staticmethod
+    def _n_split(slots):
+        """Split-K factor of the weight-gradient GEMMs: enough workgroups to fill 256 CUs."""
+        if slots >= 32768:
+            return 8
+        if slots >= 8192:
+            return 4
+        if slots >= 2048:
+            return 2
+        return 1
+
+    def grads_from_flat(self, flat):
+        out = []
+        for p, o in zip(self.param_list(), self._grad_offsets):
+            out.append(flat[o:o + p.numel()].view(p.shape))
+        return out

@@ -1,0 +1,234 @@
+"""MargiPoseModel on MI355X: same constructor, attributes, methods, state_dict keys and error
+behaviour as the reference model (reference src/margipose/models/margipose_model.py:203-284), with
+every FLOP of forward and backward executed by the gfx950 kernels behind include/margipose_hip.h.
+
+The nn.Module tree below exists ONLY to own parameters/buffers under the reference's key schema
+(`inner.in_cnn.*`, `inner.{xy,zy,xz}_hm_cnns.<t>.{down,up}_layers.<i>.{module,shortcut}.<k>.*`,
+`inner.hm_combiners.<t>.conv.weight`); none of the torch.nn layers is ever called.  The compute is
+one autograd Function around margipose_amd.engine.Engine.
+
+Stem: `feature_extractor='patch8'` is the in-repo deterministic stem (8x8/stride-8 conv + BN + ReLU).
+The reference's 'inceptionv4' / 'resnet*' stems depend on pretrainedmodels / torchvision ImageNet
+weights that are not in the reference tree: they raise the reference's exception text.
+"""
+from collections import namedtuple
+
+import torch
+from torch import nn
+
+from .. import _lib, dsntnn
+from ..engine import Engine
+from ..nn_helpers import init_parameters
+
+Default_MargiPose_Desc = {
+    'type': 'margipose',
+    'version': '6.0.1',
+    'settings': {
+        'n_stages': 4,
+        'axis_permutation': True,
+        'feature_extractor': 'patch8',
+        'pixelwise_loss': 'jsd',
+    },
+}
+
+# data_specs stand-ins with the attributes the reference drivers read (data_specs.py:26-64)
+ImageSpecs = namedtuple('ImageSpecs', ['size', 'mean', 'stddev'])
+JointsSpecs = namedtuple('JointsSpecs', ['skeleton', 'n_dims'])
+DataSpecs = namedtuple('DataSpecs', ['input_specs', 'output_specs'])
+IMAGENET_MEAN = [0.485, 0.456, 0.406]
+IMAGENET_STDDEV = [0.229, 0.224, 0.225]
+SkeletonDesc = namedtuple('SkeletonDesc', ['joint_names', 'n_joints'])
+# data/skeleton.py:51-74 -- only n_joints == 17 touches the hot path
+CanonicalSkeletonDesc = SkeletonDesc(
+    joint_names=['head_top', 'neck', 'right_shoulder', 'right_elbow', 'right_wrist', 'left_shoulder', 'left_elbow',
+                 'left_wrist', 'right_hip', 'right_knee', 'right_ankle', 'left_hip', 'left_knee', 'left_ankle', 'pelvis',
+                 'spine', 'head'],
+    n_joints=17)
+
+_BLOCK_TABLE = (   # (sequential name, index, kind, cin, cout) -- models/margipose_model.py:47-60
+    ('down_layers', 0, 'regular', 128, 128), ('down_layers', 1, 'regular', 128, 128), ('down_layers', 2, 'down', 128, 192),
+    ('down_layers', 3, 'regular', 192, 192), ('down_layers', 4, 'regular', 192, 192),
+    ('up_layers', 0, 'regular', 192, 192), ('up_layers', 1, 'regular', 192, 192), ('up_layers', 2, 'up', 192, 128),
+    ('up_layers', 3, 'regular', 128, 128), ('up_layers', 4, 'regular', 128, None))
+
+
+def _conv_holder(kind, cin, cout, k):
+    if kind == 'up':
+        return nn.ConvTranspose2d(cin, cout, kernel_size=k, padding=k // 2, stride=2, output_padding=1, bias=False)
+    return nn.Conv2d(cin, cout, kernel_size=k, padding=k // 2, stride=2 if kind == 'down' else 1, bias=False)
+
+
+class _ParamBlock(nn.Module):
+    """Parameter holder with ResidualBlock's key layout: module.{0,1,3,4}, shortcut.{0,1}."""
+
+    def __init__(self, kind, cin, cout):
+        super().__init__()
+        self.module = nn.Sequential(_conv_holder(kind, cin, cout, 3), nn.BatchNorm2d(cout), nn.Identity(),
+                                    nn.Conv2d(cout, cout, kernel_size=3, padding=1, bias=False), nn.BatchNorm2d(cout),
+                                    nn.Identity())
+        self.shortcut = nn.Sequential(_conv_holder(kind, cin, cout, 1), nn.BatchNorm2d(cout))
+
+
+class HeatmapColumn(nn.Module):
+    """Parameter holder of one column (10 residual blocks, 4,739,599 parameters for 17 joints)."""
+
+    def __init__(self, n_joints, heatmap_space):
+        super().__init__()
+        if heatmap_space not in ('xy', 'zy', 'xz'):
+            raise Exception()
+        self.n_joints = n_joints
+        self.heatmap_space = heatmap_space
+        seqs = {'down_layers': [], 'up_layers': []}
+        for seq, _, kind, cin, cout in _BLOCK_TABLE:
+            seqs[seq].append(_ParamBlock(kind, cin, n_joints if cout is None else cout))
+        self.down_layers = nn.Sequential(*seqs['down_layers'])
+        self.up_layers = nn.Sequential(*seqs['up_layers'])
+        init_parameters(self)
+
+
+class HeatmapCombiner(nn.Module):
+    def __init__(self, n_joints):
+        super().__init__()
+        self.conv = nn.Conv2d(n_joints * 3, 128, kernel_size=1, bias=False)
+        init_parameters(self)
+
+
+def make_image_feature_extractor(model_name):
+    if model_name == 'patch8':
+        return nn.Sequential(nn.Conv2d(3, 128, kernel_size=8, stride=8, bias=False), nn.BatchNorm2d(128), nn.Identity())
+    raise Exception('unsupported image feature extractor model name: ' + model_name)
+
+
+class _BackboneFn(torch.autograd.Function):
+    """Whole backbone (stem, stages of 3 columns, combiners, softmax) as ONE autograd node."""
+
+    @staticmethod
+    def forward(ctx, engine, train, x, *params):
+        hms, xyz, ectx = engine.forward(x, train, save=True)
+        flat = tuple(hms[0]) + tuple(hms[1]) + tuple(hms[2])
+        ctx.engine, ctx.ectx = engine, ectx
+        ctx.save_for_backward(*flat)
+        return flat
+
+    @staticmethod
+    def backward(ctx, *grads):
+        engine, T = ctx.engine, ctx.engine.T
+        saved = ctx.saved_tensors
+        hms = [list(saved[p * T:(p + 1) * T]) for p in range(3)]
+        g_hms = [list(grads[p * T:(p + 1) * T]) for p in range(3)]
+        gflat, dx = engine.backward(ctx.ectx, hms, g_hms, ctx.needs_input_grad[2])
+        ctx.ectx = None
+        out = engine.grads_from_flat(gflat.clone())
+        return (None, None, dx) + tuple(out)
+
+
+class MargiPoseModelInner(nn.Module):
+    def __init__(self, n_joints, n_stages, axis_permutation, feature_extractor):
+        super().__init__()
+        self.n_stages = n_stages
+        self.n_joints = n_joints
+        self.in_cnn = make_image_feature_extractor(feature_extractor)
+        self.xy_hm_cnns = nn.ModuleList()
+        self.zy_hm_cnns = nn.ModuleList()
+        self.xz_hm_cnns = nn.ModuleList()
+        self.hm_combiners = nn.ModuleList()
+        names = ('xy', 'zy', 'xz') if axis_permutation else ('xy', 'xy', 'xy')
+        self.spaces = tuple({'xy': 0, 'zy': 1, 'xz': 2}[n] for n in names)
+        for t in range(n_stages):
+            if t > 0:
+                self.hm_combiners.append(HeatmapCombiner(n_joints))
+            self.xy_hm_cnns.append(HeatmapColumn(n_joints, heatmap_space=names[0]))
+            self.zy_hm_cnns.append(HeatmapColumn(n_joints, heatmap_space=names[1]))
+            self.xz_hm_cnns.append(HeatmapColumn(n_joints, heatmap_space=names[2]))
+        self._engine = None
+
+    def engine(self):
+        if self._engine is None:
+            object.__setattr__(self, '_engine', Engine(self))
+        return self._engine
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        if self._engine is not None:
+            self._engine.invalidate()
+        return out
+
+    def forward(self, *inputs):
+        x = inputs[0]
+        eng = self.engine()
+        params = eng.param_list()
+        T = self.n_stages
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params)):
+            flat = _BackboneFn.apply(eng, self.training, x, *params)
+            return list(flat[0:T]), list(flat[T:2 * T]), list(flat[2 * T:3 * T])
+        hms, _, _ = eng.forward(x, self.training, save=False)
+        return hms[0], hms[1], hms[2]
+
+
+class MargiPoseModel(nn.Module):
+    def __init__(self, skel_desc, n_stages, axis_permutation, feature_extractor, pixelwise_loss):
+        super().__init__()
+        self.data_specs = DataSpecs(ImageSpecs(256, mean=IMAGENET_MEAN, stddev=IMAGENET_STDDEV),
+                                    JointsSpecs(skel_desc, n_dims=3))
+        self.pixelwise_loss = pixelwise_loss
+        self.inner = MargiPoseModelInner(skel_desc.n_joints, n_stages, axis_permutation, feature_extractor)
+        self.xy_heatmaps = self.zy_heatmaps = self.xz_heatmaps = None
+
+    def _pixelwise_flag(self):
+        if self.pixelwise_loss == 'jsd':
+            return True
+        if self.pixelwise_loss is None:
+            return False
+        raise Exception('unrecognised pixelwise loss: {}'.format(self.pixelwise_loss))
+
+    def _calculate_pixelwise_loss(self, hm, target_coords):
+        sigma = 1.0
+        if self._pixelwise_flag():
+            return dsntnn.js_reg_losses(hm, target_coords.contiguous(), sigma)
+        return 0
+
+    def _stage_loop(self, target_var, three_d):
+        pix = self._pixelwise_flag()
+        target = target_var.narrow(-1, 0, 3).contiguous() if target_var.size(-1) >= 3 else \
+            torch.cat([target_var.narrow(-1, 0, 2), torch.zeros_like(target_var.narrow(-1, 0, 1))], -1).contiguous()
+        losses = 0
+        for xy_hm, zy_hm, xz_hm in zip(self.xy_heatmaps, self.zy_heatmaps, self.xz_heatmaps):
+            # one fused launch per stage: JS of the plane(s) + DSNT + z-merge + Euclidean
+            losses = losses + dsntnn.stage_losses(xy_hm, zy_hm, xz_hm, target, 1.0, pix, three_d)
+        return losses
+
+    def forward_2d_losses(self, out_var, target_var):
+        """JS(xy) + Euclid(xy) summed over stages (reference :223-234)."""
+        return self._stage_loop(target_var, three_d=False)
+
+    def forward_3d_losses(self, out_var, target_var):
+        """JS(xy) + JS(zy) + JS(xz) + Euclid(xyz) summed over stages (reference :236-252)."""
+        return self._stage_loop(target_var, three_d=True)
+
+    @staticmethod
+    def heatmaps_to_coords(xy_hm, zy_hm, xz_hm):
+        return dsntnn.heatmaps_to_coords(xy_hm, zy_hm, xz_hm)
+
+    def forward(self, *inputs):
+        self.xy_heatmaps, self.zy_heatmaps, self.xz_heatmaps = self.inner(*inputs)
+        return self.heatmaps_to_coords(self.xy_heatmaps[-1], self.zy_heatmaps[-1], self.xz_heatmaps[-1])
+
+
+def create_model(model_desc):
+    """Registry entry point of reference models/__init__.py:16-27 for type 'margipose' (^6.0.0)."""
+    type_name, version = model_desc['type'], str(model_desc['version'])
+    if type_name != 'margipose' or version.split('.')[0] != '6':
+        raise Exception('unrecognised model {} v{}'.format(type_name, version))
+    s = model_desc['settings']
+    return MargiPoseModel(skel_desc=CanonicalSkeletonDesc, n_stages=s.get('n_stages', 4),
+                          axis_permutation=s.get('axis_permutation', True),
+                          feature_extractor=s.get('feature_extractor', 'patch8'),
+                          pixelwise_loss=s.get('pixelwise_loss', 'jsd'))
+
+
+def load_model(model_file):
+    """reference models/__init__.py:30-34: {'model_desc', 'state_dict'} checkpoints."""
+    details = torch.load(model_file, map_location='cpu')
+    model = create_model(details['model_desc'])
+    model.load_state_dict(details['state_dict'])
+    return model

@@ -184,6 +184,20 @@ def average_loss(losses, mask):
     return (losses * mask).sum() / mask.sum().clamp(1)
 
 
+def calibrate_running_stats(sd, x, n_stages, axis_permutation=True):
+    """Make the synthetic BN running statistics consistent with the activations (one train-mode pass with
+    momentum 1): without this, eval-mode logits of a randomly initialised net reach +-3000 and every
+    comparison through the softmax is ill-conditioned.  Mirrors tools/make_golden.py::gen_model."""
+    global BN_MOMENTUM
+    old, BN_MOMENTUM = BN_MOMENTUM, 1.0
+    try:
+        with torch.no_grad():
+            inner_forward(sd, x, n_stages, True, axis_permutation)
+    finally:
+        BN_MOMENTUM = old
+    return sd
+
+
 def train_step_reference(sd, x, target, mask, n_stages, axis_permutation=True):
     """One fwd + 3D loss + backward on CPU.  `sd` float tensors that require grad get .grad filled.
     Returns (coords, heatmap lists, per-(b,j) losses, scalar loss)."""

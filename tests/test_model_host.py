@@ -1,0 +1,64 @@
+"""CPU: host-side contract of the drop-in module (no kernels run): state_dict key schema, constructor /
+registry behaviour, error messages (reference models/margipose_model.py:203-284, models/__init__.py:16-34)."""
+import hashlib
+import json
+import os
+
+import pytest
+import torch
+
+
+def test_state_dict_schema_matches_reference(golden_dir):
+    from margipose_amd.models import CanonicalSkeletonDesc, MargiPoseModel
+    with open(os.path.join(golden_dir, 'state_dict_keys.json')) as f:
+        ref = json.load(f)
+    for T in (1, 2, 3):
+        m = MargiPoseModel(CanonicalSkeletonDesc, T, True, 'patch8', 'jsd')
+        items = [[k, list(v.shape)] for k, v in m.state_dict().items()]
+        assert len(items) == ref[str(T)]['n_keys']
+        assert sum(p.numel() for p in m.parameters()) == ref[str(T)]['n_params']
+        assert hashlib.sha256(json.dumps(items).encode()).hexdigest() == ref[str(T)]['sha256']
+
+
+def test_columns_have_equal_param_counts():
+    """reference tests/test_models.py:11-16."""
+    from margipose_amd.models.margipose_model import HeatmapColumn
+    a = HeatmapColumn(17, heatmap_space='xy')
+    b = HeatmapColumn(17, heatmap_space='zy')
+    assert sum(p.numel() for p in a.parameters()) == sum(p.numel() for p in b.parameters()) == 4739599
+
+
+def test_registry_and_errors():
+    from margipose_amd.models import Default_MargiPose_Desc, create_model
+    from margipose_amd.models.margipose_model import MargiPoseModel, CanonicalSkeletonDesc
+    m = create_model({'type': 'margipose', 'version': '6.0.1', 'settings': {'n_stages': 1}})
+    assert m.inner.n_stages == 1 and m.data_specs.input_specs.size == 256 and m.xy_heatmaps is None
+    assert Default_MargiPose_Desc['settings']['n_stages'] == 4
+    with pytest.raises(Exception, match='unrecognised model'):
+        create_model({'type': 'chatterbox', 'version': '1.0.0', 'settings': {}})
+    with pytest.raises(Exception, match='unsupported image feature extractor'):
+        MargiPoseModel(CanonicalSkeletonDesc, 1, True, 'resnet19', 'jsd')
+    bad = MargiPoseModel(CanonicalSkeletonDesc, 1, True, 'patch8', 'l2')
+    bad.xy_heatmaps = bad.zy_heatmaps = bad.xz_heatmaps = []
+    with pytest.raises(Exception, match='unrecognised pixelwise loss'):
+        bad.forward_3d_losses(None, torch.zeros(1, 17, 3))
+
+
+def test_state_dict_roundtrip_with_oracle_weights():
+    from oracle import weights as W
+    from margipose_amd.models import CanonicalSkeletonDesc, MargiPoseModel
+    m = MargiPoseModel(CanonicalSkeletonDesc, 2, True, 'patch8', 'jsd')
+    sd = W.make_state_dict(2, 5)
+    m.load_state_dict(sd, strict=True)
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, sd[k])
+
+
+def test_geometry_tables():
+    """Tap lists of the transposed / strided forms (host logic of engine.py)."""
+    from margipose_amd.engine import _up_classes
+    cls = _up_classes(True)
+    assert [len(t) for _, _, t in cls] == [2, 2, 2, 4]          # (1 + shortcut), 2, 2, 4 taps
+    assert sum(len([x for x in t if x[3] == 0]) for _, _, t in cls) == 9
+    # each kernel tap appears exactly once across the parity classes
+    assert sorted(x[2] for _, _, t in cls for x in t if x[3] == 0) == list(range(9))

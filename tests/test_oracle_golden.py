@@ -133,6 +133,7 @@ def test_model_T2_vs_reference(golden_dir):
     sd = W.make_state_dict(T_, seed, torch.float64)
     x, target, _ = W.seeded_inputs(seed + 1000, B, dtype=torch.float64)
     mask = torch.tensor(g['mask'])
+    R.calibrate_running_stats(sd, x, T_)
     with torch.no_grad():
         xy, zy, xz = R.inner_forward(sd, x, T_, train=False)
         np.testing.assert_allclose(R.heatmaps_to_coords(xy[-1], zy[-1], xz[-1]).numpy(), g['coords_eval_f64'],

@@ -190,6 +190,16 @@ def gen_model():
         model = mm.MargiPoseModel(Skel, T, True, 'patch8', 'jsd').to(dt)
         model.load_state_dict(W.make_state_dict(T, seed, dt), strict=True)
         x, target, mask = x_t.to(dt), target_t.to(dt), torch.tensor(mask_np, dtype=dt)
+        # calibrate the synthetic running stats (momentum 1, one pass) so eval-mode logits are well conditioned
+        bns = [mod for mod in model.modules() if isinstance(mod, nn.BatchNorm2d)]
+        for mod in bns:
+            mod.momentum = 1.0
+        model.train()
+        with torch.no_grad():
+            model(x)
+        for mod in bns:
+            mod.momentum = 0.1
+            mod.num_batches_tracked.zero_()
         model.eval()
         with torch.no_grad():
             res['coords_eval_' + tag] = t2n(model(x))
