@@ -1,0 +1,209 @@
+#!/usr/bin/env python
+"""Benchmark of the MargiPose hot path on MI355X (driver contract: see the task statement).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" = one pass of the hot path over one batch of synthetic frames: forward (stem + n_stages x 3
+columns + soft-argmax) + 3D loss (JS + Euclidean) + backward + (N > 1: ONE all-reduce of the flat gradient
+buffer over RCCL) + SGD update.  Workload = BASELINE.json configs[2] ("1xMI355X training step, batch=32,
+JS-reg + pixelwise loss on"): the config the metric "images/sec fwd+bwd at 256x256, 17 joints" is quoted on,
+with the 3-stage model of configs[1].  fp32 arithmetic throughout (the reference's precision).
+
+Rank 0 prints ONE JSON line.  `roofline` describes the dominant kernel (the fp32-MFMA implicit-GEMM
+convolution; algorithmic FLOPs / HIP-event launch duration measured inside the timed region);
+`tail_roofline` is the soft-argmax kernel the metric also names (algorithmic bytes / launch duration, HBM
+bound); `cpu_baseline` times the oracle (the stock-PyTorch CPU restatement of the reference, oracle/model_ref.py)
+on the host cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
+PEAK_HBM_GBPS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=32, help='per-GPU batch (weak scaling)')
+    ap.add_argument('--stages', type=int, default=3)
+    ap.add_argument('--size', type=int, default=256)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-timing', action='store_true')
+    ap.add_argument('--cpu-batch', type=int, default=8)
+    return ap.parse_args()
+
+
+def cpu_baseline(stages, size, cpu_batch):
+    """The oracle's training step on the host CPU (bounded sample)."""
+    from collections import OrderedDict
+    from oracle import model_ref as R
+    from oracle import weights as W
+    threads = torch.get_num_threads()
+    sd = W.make_state_dict(stages, 12345)
+    params = OrderedDict((k, v.requires_grad_(True)) for k, v in sd.items() if v.is_floating_point() and 'running' not in k)
+    x, target, mask = W.seeded_inputs(12345, cpu_batch, size)
+
+    def step():
+        for p in params.values():
+            p.grad = None
+        R.train_step_reference(sd, x, target, mask, stages)
+
+    step()                                  # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        step()
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt > 10.0 or n >= 4:
+            break
+    return {'value': cpu_batch * n / dt, 'unit': 'images/sec', 'cores': threads, 'kind': 'port',
+            'sample': '%d timed fwd+loss+bwd steps of batch %d (T=%d, %dx%d, fp32) with oracle/model_ref.py on torch CPU, '
+                      '%d threads' % (n, cpu_batch, stages, size, size, threads)}
+
+
+def tail_large_microbench(device):
+    """Cache-defeating soft-argmax run (B=2048 fp32 -> 856 MB through the kernel), SURVEY.md §8d."""
+    from margipose_amd import _lib
+    B, F = 2048, 32
+    lg = [torch.randn(B, 17, F, F, device=device) * 4 for _ in range(3)]
+    hm = [torch.empty_like(l) for l in lg]
+    xyz = torch.empty(B, 17, 3, device=device)
+    L = _lib.lib()
+
+    def run():
+        _lib.check(L.mpose_softmax_dsnt_fwd(_lib.ptr_array(lg), _lib.ptr_array(hm), None, _lib.ptr(xyz), 3, B * 17, F, F, 0,
+                                            _lib.stream_ptr()), 'softmax')
+    for _ in range(3):
+        run()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    s.record()
+    for _ in range(10):
+        run()
+    e.record()
+    torch.cuda.synchronize()
+    sec = s.elapsed_time(e) * 1e-3 / 10
+    nbytes = 3 * B * 17 * F * F * 8 + B * 17 * 12
+    return {'bound': 'hbm', 'achieved': nbytes / sec / 1e9, 'peak': PEAK_HBM_GBPS, 'unit': 'GB/s',
+            'frac': nbytes / sec / 1e9 / PEAK_HBM_GBPS, 'traffic': None, 'note': 'B=2048 fp32 (856 MB/launch, exceeds the 256 MB Infinity Cache)'}
+
+
+def main():
+    args = parse()
+    from margipose_amd import dsntnn, parallel
+    from margipose_amd.engine import KernelTimer
+    from margipose_amd.models import CanonicalSkeletonDesc, MargiPoseModel
+    rank, world, local_rank = parallel.init_from_env()
+    if world != args.gpus:
+        if args.gpus != 1 or world != 1:
+            raise SystemExit('--gpus %d does not match WORLD_SIZE %d (launch with torch.distributed.run)' % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a ROCm GPU: the hot path has no CPU fallback')
+    device = torch.device('cuda', local_rank)
+    torch.cuda.set_device(device)
+
+    torch.manual_seed(12345)                # the seed the reference's eval/infer use (bin/eval_3d.py:123)
+    model = MargiPoseModel(CanonicalSkeletonDesc, args.stages, True, 'patch8', 'jsd').to(device).train()
+    parallel.broadcast_parameters(model)
+    parallel.attach(model)
+    opt = torch.optim.SGD(model.parameters(), lr=0.01, momentum=0.9)
+    g = torch.Generator(device='cpu').manual_seed(12345 + rank)
+    B = args.batch
+    x = torch.randn(B, 3, args.size, args.size, generator=g).to(device)
+    target = (torch.rand(B, 17, 3, generator=g) * 2 - 1).to(device)
+    mask = torch.ones(B, 17, device=device)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        out = model(x)
+        loss = dsntnn.average_loss(model.forward_3d_losses(out, target), mask)
+        loss.backward()
+        opt.step()
+        return loss
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        loss = step()
+    timer = None
+    if rank == 0 and not args.no_kernel_timing:
+        timer = KernelTimer()
+        model.inner.engine().timer = timer
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    model.inner.engine().timer = None
+    loss_value = float(loss)
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank != 0:
+        if world > 1:
+            torch.distributed.barrier()
+        return
+    images = world * B * args.steps
+    res = {
+        'metric': 'images/sec fwd+bwd at 256x256, 17 joints (training step: forward + JS/Euclidean loss + backward + SGD)',
+        'value': images / dt, 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'BASELINE configs[2]: training step, per-GPU batch %d, %d-stage MargiPose, %dx%d input, 17 joints, '
+                               '32x32 heatmaps, JS + Euclidean loss, SGD(momentum 0.9)' % (B, args.stages, args.size, args.size),
+                   'global_batch': world * B, 'n_stages': args.stages, 'stem': 'patch8 (in-repo deterministic stem; '
+                   'InceptionV4 stem of the reference is third-party and unpinned)', 'parallelism': 'dp%d' % world,
+                   'final_loss': loss_value},
+    }
+    if timer is not None:
+        summ = timer.summary()
+        convs = {k: v for k, v in summ.items() if k.startswith('conv:') or k.startswith('wgrad:')}
+        total_ms = sum(v['total_ms'] for v in summ.values())
+        if convs:
+            top = max(convs.items(), key=lambda kv: kv[1]['total_ms'])
+            tf = top[1]['work_per_launch'] / (top[1]['avg_us'] * 1e-6) / 1e12
+            all_flops = sum(v['work'] for v in convs.values())
+            all_ms = sum(v['total_ms'] for v in convs.values())
+            res['roofline'] = {'bound': 'mfma', 'achieved': tf, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                               'frac': tf / PEAK_FP32_MFMA_TFLOPS, 'traffic': None, 'kernel': top[0],
+                               'avg_launch_us': top[1]['avg_us'], 'launches': top[1]['n'],
+                               'flops_per_launch': top[1]['work_per_launch'],
+                               'all_conv_kernels_tflops': all_flops / (all_ms * 1e-3) / 1e12,
+                               'conv_share_of_step_gpu_time': all_ms / (1e3 * dt)}
+        tail = summ.get('tail:softmax_dsnt_fwd')
+        if tail:
+            gbps = tail['work_per_launch'] / (tail['avg_us'] * 1e-6) / 1e9
+            res['tail_roofline'] = {'bound': 'hbm', 'achieved': gbps, 'peak': PEAK_HBM_GBPS, 'unit': 'GB/s',
+                                    'frac': gbps / PEAK_HBM_GBPS, 'traffic': None, 'kernel': 'softmax_dsnt_fwd_k (3 planes, B=%d)' % B,
+                                    'avg_launch_us': tail['avg_us'], 'bytes_per_launch': tail['work_per_launch']}
+        res['kernel_time_breakdown_ms_per_step'] = {k: round(v['total_ms'] / args.steps, 3) for k, v in
+                                                    sorted(summ.items(), key=lambda kv: -kv[1]['total_ms'])[:12]}
+        res['tail_roofline_large'] = tail_large_microbench(device)
+    if world == 1 and not args.no_cpu_baseline:
+        res['cpu_baseline'] = cpu_baseline(args.stages, args.size, args.cpu_batch)
+    print(json.dumps(res))
+    if world > 1:
+        torch.distributed.barrier()
+
+
+if __name__ == '__main__':
+    main()

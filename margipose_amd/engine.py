@@ -145,6 +145,47 @@ class _Block:
         self.bns = _BN(rb.shortcut[1], cout, self.cout_s)
 
 
+class KernelTimer:
+    """HIP-event timing of individual launches on the stream they are enqueued on (torch's current stream).
+    Used by bench.py to measure per-kernel average durations inside the timed region."""
+
+    def __init__(self):
+        self.records = []          # (tag, start, end, work)
+
+    def start(self):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        return ev
+
+    def stop(self, tag, start, work):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        self.records.append((tag, start, ev, work))
+
+    def summary(self):
+        """tag -> dict(n, total_ms, avg_us, work_per_launch).  Call after torch.cuda.synchronize()."""
+        out = {}
+        for tag, a, b, work in self.records:
+            d = out.setdefault(tag, {'n': 0, 'total_ms': 0.0, 'work': 0.0})
+            d['n'] += 1
+            d['total_ms'] += a.elapsed_time(b)
+            d['work'] += work
+        for d in out.values():
+            d['avg_us'] = 1e3 * d['total_ms'] / d['n']
+            d['work_per_launch'] = d['work'] / d['n']
+        return out
+
+
+def _geom_flops(g):
+    """Algorithmic FLOPs of one group of a conv launch: 2 * slots * taps * Cin * Cout."""
+    f = 0
+    for ci in range(g.n_classes):
+        for ti in range(g.cls[ci].n_taps):
+            cout = g.Cout1 if g.cls[ci].taps[ti].acc else g.Cout0
+            f += 2 * g.B * g.GH * g.GW * g.Cin * cout
+    return f
+
+
 def _jobs_to_device(arr, device):
     return torch.from_numpy(arr.view(np.uint8).copy()).to(device)
 
@@ -182,6 +223,8 @@ class Engine:
         self._geoms = {}
         self._tables = {}
         self._arena_key = None
+        self.timer = None            # optional KernelTimer (bench.py)
+        self.dp = None               # optional (process_group, world_size): gradient all-reduce after backward
 
     # ------------------------------------------------------------------ parameters / arenas
     def param_list(self):
@@ -391,6 +434,8 @@ class Engine:
             g = _geom(B, H, 128, H, 192, 0, H, 1, 1, [(0, 0, [(0, 0, 0, 0)])], 192)
         else:
             raise KeyError(name)
+        g._name = '%s/%dx%d/%d->%d' % (name, g.IH, g.IW, g.Cin, g.Cout0)
+        g._flops = _geom_flops(g)
         self._geoms[key] = g
         return g
 
@@ -400,11 +445,17 @@ class Engine:
 
     def conv(self, g, ops, flags=0):
         arr = (ConvOperands * 3)(*ops)
+        t0 = self.timer.start() if self.timer is not None else None
         check(lib().mpose_conv_fwd(ctypes.byref(g), arr, len(ops), flags, stream_ptr()), 'mpose_conv_fwd')
+        if t0 is not None:
+            self.timer.stop('conv:' + g._name, t0, g._flops * len(ops))
 
     def wgrad(self, g, ops, n_split):
         arr = (WgradOperands * 3)(*ops)
+        t0 = self.timer.start() if self.timer is not None else None
         check(lib().mpose_conv_wgrad(ctypes.byref(g), arr, len(ops), n_split, stream_ptr()), 'mpose_conv_wgrad')
+        if t0 is not None:
+            self.timer.stop('wgrad:' + g._name, t0, g._flops * len(ops))
 
     def finalize(self, tb, first, n, train):
         base = tb['fin'].data_ptr() + first * BN_DT.itemsize
@@ -527,8 +578,11 @@ class Engine:
             want_xyz = t == self.T - 1
             if want_xyz:
                 xyz = torch.empty(B, self.J, 3, **f32)
+            t0 = self.timer.start() if self.timer is not None else None
             check(L.mpose_softmax_dsnt_fwd(ptr_array(logits), ptr_array(heat), None, ptr(xyz) if want_xyz else None, 3, B * self.J, F,
                                            F, 0, st()), 'mpose_softmax_dsnt_fwd')
+            if t0 is not None:      # algorithmic bytes: read logits once, write heatmaps once (+ coords)
+                self.timer.stop('tail:softmax_dsnt_fwd', t0, 3 * B * self.J * F * F * 8 + (B * self.J * 12 if want_xyz else 0))
             for p in range(3):
                 hms[p].append(heat[p])
             ctx['blocks'].append(stage_saved)

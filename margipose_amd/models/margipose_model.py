@@ -118,7 +118,11 @@ class _BackboneFn(torch.autograd.Function):
         g_hms = [list(grads[p * T:(p + 1) * T]) for p in range(3)]
         gflat, dx = engine.backward(ctx.ectx, hms, g_hms, ctx.needs_input_grad[2])
         ctx.ectx = None
-        out = engine.grads_from_flat(gflat.clone())
+        flat = gflat.clone()
+        if engine.dp is not None:
+            from .. import parallel
+            parallel.allreduce_mean_(flat, *engine.dp)      # ONE RCCL all-reduce of all gradients per step
+        out = engine.grads_from_flat(flat)
         return (None, None, dx) + tuple(out)
 
 
