@@ -23,6 +23,7 @@
 // LDS A tile rows are padded to 36 floats (144 B): the 16 lanes of a ds_read_b128 group then hit
 // 16 distinct 16-byte slots (9*i mod 16 is a bijection), so the reads are conflict-free.
 #include "common.h"
+#include <cstdlib>
 
 namespace mpose {
 namespace {
@@ -58,7 +59,7 @@ struct ConvArgs {
 __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
 template <int WM, int WN, int RM, int RN, bool ACC1>
-__global__ __launch_bounds__(256) void conv_igemm_k(ConvArgs a) {
+__global__ __launch_bounds__(256, 2) void conv_igemm_k(ConvArgs a) {
   constexpr int BM = 32 * WM * RM;
   constexpr int BN = 32 * WN * RN;
   constexpr int A_LOADS = BM / 32;           // float4 per thread per A tile
@@ -84,29 +85,36 @@ __global__ __launch_bounds__(256) void conv_igemm_k(ConvArgs a) {
     sTaps[tid] = (int)(unsigned char)t.dy | ((int)(unsigned char)t.dx << 8) | ((int)(unsigned char)t.widx << 16) | ((int)(unsigned char)t.acc << 24);
   }
 
-  // ---- per-thread staging coordinates (fixed for the whole K loop) ----
+  // ---- per-thread staging state, fixed for the whole K loop ----
+  // row_off[j]: element offset of the slot's anchor pixel (+ this thread's 4-channel column);
+  // row_taps[j]: bit t set when tap t of this class reads an in-bounds pixel for that row.
   const int a_col4 = tid & 7;
-  int a_iy[A_LOADS], a_ix[A_LOADS];
-  long a_img[A_LOADS];            // element offset of image b, or -1 when the slot is out of range
+  __syncthreads();   // sTaps visible
+  unsigned row_off[A_LOADS], row_taps[A_LOADS];
 #pragma unroll
   for (int j = 0; j < A_LOADS; ++j) {
     const int row = (tid >> 3) + 32 * j;
     const unsigned m = (unsigned)(m0 + row);
+    row_off[j] = 0; row_taps[j] = 0;
     if ((int)m < a.M) {
       const unsigned b = fdiv(m, a.div_ghw);
       const unsigned rem = m - b * (unsigned)(g.GH * g.GW);
       const unsigned gy = fdiv(rem, a.div_gw);
       const unsigned gx = rem - gy * (unsigned)g.GW;
-      a_iy[j] = (int)gy * g.in_mul;
-      a_ix[j] = (int)gx * g.in_mul;
-      a_img[j] = (long)b * g.IH * g.IW * g.Cin;
-    } else {
-      a_iy[j] = 0; a_ix[j] = 0; a_img[j] = -1;
+      const int iy0 = (int)gy * g.in_mul, ix0 = (int)gx * g.in_mul;
+      row_off[j] = ((b * (unsigned)g.IH + (unsigned)iy0) * (unsigned)g.IW + (unsigned)ix0) * (unsigned)g.Cin + (unsigned)(a_col4 * 4);
+      for (int t = 0; t < n_taps; ++t) {
+        const int tp = sTaps[t];
+        const int iy = iy0 + (int)(signed char)(tp & 0xff), ix = ix0 + (int)(signed char)((tp >> 8) & 0xff);
+        if (iy >= 0 && iy < g.IH && ix >= 0 && ix < g.IW) row_taps[j] |= 1u << t;
+      }
     }
   }
   const int n_chunks = g.Cin / KC;
   const int n_iter = n_chunks * n_taps;
   const int k4_total = g.Cin >> 2;
+  const unsigned w_lane0 = (unsigned)(((tid / BN) * g.Npad0 + (tid % BN)) * 4);                       // Npad0 == Npad1 when ACC1
+  const unsigned w_lane1 = (unsigned)((((tid + 256) / BN) * g.Npad0 + ((tid + 256) % BN)) * 4);
 
   f32x16 acc0[RM][RN];
   f32x16 acc1[RM][RN];
@@ -118,90 +126,99 @@ __global__ __launch_bounds__(256) void conv_igemm_k(ConvArgs a) {
       for (int r = 0; r < 16; ++r) { acc0[rm][rn][r] = 0.0f; acc1[rm][rn][r] = 0.0f; }
     }
 
-  float4 ra[A_LOADS], rw[W_LOADS];
-  __syncthreads();   // sTaps visible
+  float4 ra[A_LOADS];
+  float4 rw0 = make_float4(0.f, 0.f, 0.f, 0.f), rw1 = rw0;   // named (not an array): keeps the W staging in VGPRs
+  static_assert(W_LOADS <= 2, "W tile staging assumes at most two float4 per thread");
+  float4 rsc = make_float4(1.f, 1.f, 1.f, 1.f), rsh = make_float4(0.f, 0.f, 0.f, 0.f);
+  unsigned ra_ok = 0;                      // bit j: row j of the staged tile is a real (in-bounds) pixel
+  const bool pro = op.in_scale != nullptr;
 
+  // Branch-free issue of every global load of tile `it`: the tap contributes ONE wave-uniform element offset,
+  // per-row validity is a precomputed bit; invalid rows read element 0 and are zeroed at LDS-store time.
   auto load_regs = [&](int it) {
     const int c = it / n_taps;
-    const int tp = sTaps[it - c * n_taps];
+    const int t = it - c * n_taps;
+    const int tp = __builtin_amdgcn_readfirstlane(sTaps[t]);
     const int dy = (int)(signed char)(tp & 0xff), dx = (int)(signed char)((tp >> 8) & 0xff);
     const int widx = (tp >> 16) & 0xff;
     const bool second = ACC1 && ((tp >> 24) & 0xff);
-    const int ch = c * KC + a_col4 * 4;
-    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
-    const bool pro = op.in_scale != nullptr;
-    if (pro) {
-      sc = *reinterpret_cast<const float4*>(op.in_scale + ch);
-      sh = *reinterpret_cast<const float4*>(op.in_shift + ch);
-    }
+    const unsigned tap_off = (unsigned)((dy * g.IW + dx) * g.Cin + c * KC);
+    ra_ok = 0;
 #pragma unroll
     for (int j = 0; j < A_LOADS; ++j) {
-      const int iy = a_iy[j] + dy, ix = a_ix[j] + dx;
-      const bool ok = a_img[j] >= 0 && iy >= 0 && iy < g.IH && ix >= 0 && ix < g.IW;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (ok) {
-        v = *reinterpret_cast<const float4*>(op.in + a_img[j] + ((long)iy * g.IW + ix) * g.Cin + ch);
-        if (pro) {
-          v.x = fmaxf(fmaf(v.x, sc.x, sh.x), 0.f); v.y = fmaxf(fmaf(v.y, sc.y, sh.y), 0.f);
-          v.z = fmaxf(fmaf(v.z, sc.z, sh.z), 0.f); v.w = fmaxf(fmaf(v.w, sc.w, sh.w), 0.f);
-        }
-      }
-      ra[j] = v;
+      const bool ok = (row_taps[j] >> t) & 1u;
+      const unsigned off = ok ? row_off[j] + tap_off : (unsigned)(a_col4 * 4);
+      ra[j] = *reinterpret_cast<const float4*>(op.in + off);
+      ra_ok |= (ok ? 1u : 0u) << j;
     }
-    const float* wsrc = second ? op.w1 : op.w0;
-    const int npad = second ? g.Npad1 : g.Npad0;
-#pragma unroll
-    for (int j = 0; j < W_LOADS; ++j) {
-      const int idx = tid + 256 * j;
-      const int q = idx / BN, n = idx - q * BN;
-      rw[j] = *reinterpret_cast<const float4*>(wsrc + ((long)(widx * k4_total + c * (KC / 4) + q) * npad + n0 + n) * 4);
+    const float* wsrc = (second ? op.w1 : op.w0) + ((long)(widx * k4_total + c * (KC / 4)) * g.Npad0 + n0) * 4;
+    rw0 = *reinterpret_cast<const float4*>(wsrc + w_lane0);
+    if (W_LOADS > 1) rw1 = *reinterpret_cast<const float4*>(wsrc + w_lane1);
+    if (pro) {
+      rsc = *reinterpret_cast<const float4*>(op.in_scale + c * KC + a_col4 * 4);
+      rsh = *reinterpret_cast<const float4*>(op.in_shift + c * KC + a_col4 * 4);
     }
   };
+  // BN + ReLU of the producing layer (when requested) and the zero padding are applied here, after the
+  // MFMA phase, so the loads above are never waited for early.
   auto store_lds = [&](int buf) {
     float* dA = sA + buf * A_TILE;
     float* dW = sW + buf * W_TILE;
 #pragma unroll
     for (int j = 0; j < A_LOADS; ++j) {
       const int row = (tid >> 3) + 32 * j;
-      *reinterpret_cast<float4*>(dA + row * A_STRIDE + a_col4 * 4) = ra[j];
+      float4 v = ra[j];
+      if (pro) {
+        v.x = fmaxf(fmaf(v.x, rsc.x, rsh.x), 0.f); v.y = fmaxf(fmaf(v.y, rsc.y, rsh.y), 0.f);
+        v.z = fmaxf(fmaf(v.z, rsc.z, rsh.z), 0.f); v.w = fmaxf(fmaf(v.w, rsc.w, rsh.w), 0.f);
+      }
+      if (!((ra_ok >> j) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4*>(dA + row * A_STRIDE + a_col4 * 4) = v;
     }
-#pragma unroll
-    for (int j = 0; j < W_LOADS; ++j) *reinterpret_cast<float4*>(dW + (tid + 256 * j) * 4) = rw[j];
+    *reinterpret_cast<float4*>(dW + tid * 4) = rw0;
+    if (W_LOADS > 1) *reinterpret_cast<float4*>(dW + (tid + 256) * 4) = rw1;
   };
   // One (chunk, tap) tile = a 32-long fp32 FMA chain per output element, accumulated into a FRESH register
   // tile and then added to the running sum.  Error grows like sqrt(32) + sqrt(#tiles) ulps instead of
   // sqrt(K) for one K-long chain (K = 1152 for a 3x3 over 128 channels): ~5x closer to the fp64 result, which
   // matters because every rounding-induced ReLU-mask flip costs ~1e-3 relative error in the gradients.
+  // LDS fragments of k-group q+1 are requested before the MFMAs of group q are issued.
   auto compute = [&](int buf, bool second) {
-    const float* cA = sA + buf * A_TILE;
-    const float* cW = sW + buf * W_TILE;
+    const float* cA = sA + buf * A_TILE + (wm * RM * 32 + li) * A_STRIDE + lh * 4;
+    const float* cW = sW + buf * W_TILE + (lh * BN + wn * RN * 32 + li) * 4;
     f32x16 part[RM][RN];
+    float4 fa[2][RM], fb[2][RN];
+#pragma unroll
+    for (int rm = 0; rm < RM; ++rm) fa[0][rm] = *reinterpret_cast<const float4*>(cA + rm * 32 * A_STRIDE);
+#pragma unroll
+    for (int rn = 0; rn < RN; ++rn) fb[0][rn] = *reinterpret_cast<const float4*>(cW + rn * 32 * 4);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      float4 fa[RM], fb[RN];
+      const int cur = q & 1, nxt = cur ^ 1;
+      if (q < 3) {
 #pragma unroll
-      for (int rm = 0; rm < RM; ++rm)
-        fa[rm] = *reinterpret_cast<const float4*>(cA + ((wm * RM + rm) * 32 + li) * A_STRIDE + q * 8 + lh * 4);
+        for (int rm = 0; rm < RM; ++rm) fa[nxt][rm] = *reinterpret_cast<const float4*>(cA + rm * 32 * A_STRIDE + (q + 1) * 8);
 #pragma unroll
-      for (int rn = 0; rn < RN; ++rn)
-        fb[rn] = *reinterpret_cast<const float4*>(cW + ((q * 2 + lh) * BN + (wn * RN + rn) * 32 + li) * 4);
+        for (int rn = 0; rn < RN; ++rn) fb[nxt][rn] = *reinterpret_cast<const float4*>(cW + ((q + 1) * 2 * BN + rn * 32) * 4);
+      }
 #pragma unroll
-      for (int rm = 0; rm < RM; ++rm)
+      for (int e = 0; e < 4; ++e) {
 #pragma unroll
-        for (int rn = 0; rn < RN; ++rn) {
-          f32x16 c;
-          if (q == 0) {
+        for (int rm = 0; rm < RM; ++rm)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) c[r] = 0.0f;
-          } else {
-            c = part[rm][rn];
+          for (int rn = 0; rn < RN; ++rn) {
+            f32x16 c;
+            if (q == 0 && e == 0) {
+#pragma unroll
+              for (int r = 0; r < 16; ++r) c[r] = 0.0f;
+            } else {
+              c = part[rm][rn];
+            }
+            const float av = e == 0 ? fa[cur][rm].x : (e == 1 ? fa[cur][rm].y : (e == 2 ? fa[cur][rm].z : fa[cur][rm].w));
+            const float bv = e == 0 ? fb[cur][rn].x : (e == 1 ? fb[cur][rn].y : (e == 2 ? fb[cur][rn].z : fb[cur][rn].w));
+            part[rm][rn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, c, 0, 0, 0);
           }
-          c = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[rm].x, fb[rn].x, c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[rm].y, fb[rn].y, c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[rm].z, fb[rn].z, c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[rm].w, fb[rn].w, c, 0, 0, 0);
-          part[rm][rn] = c;
-        }
+      }
     }
 #pragma unroll
     for (int rm = 0; rm < RM; ++rm)
@@ -212,21 +229,47 @@ __global__ __launch_bounds__(256) void conv_igemm_k(ConvArgs a) {
       }
   };
 
-  // ---- main loop: register prefetch of tile it+1 over the MFMAs of tile it, one barrier per tile ----
+  // ---- main loop: the loads of tile it+1 are in flight across the MFMAs of tile it; one barrier per tile ----
   if (n_iter > 0) {
     load_regs(0);
     store_lds(0);
   }
   __syncthreads();
+#ifdef MPOSE_ABLATE
+  const int abl = a.flags >> 8;
+  if (abl & 16) {   // experiment: distinct static priorities for the blocks that share a CU
+    const unsigned flat = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const unsigned pr = (flat >> 8) % 3u;
+    if (pr == 1) __builtin_amdgcn_s_setprio(1);
+    else if (pr == 2) __builtin_amdgcn_s_setprio(2);
+  }
+  if (abl & 32) {   // experiment: one-time stagger
+    const unsigned flat = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const unsigned pr = (flat >> 8) % 3u;
+    for (unsigned k = 0; k < pr * 24; ++k) __builtin_amdgcn_s_sleep(127);
+  }
   for (int it = 0; it < n_iter; ++it) {
     const int buf = it & 1;
-    if (it + 1 < n_iter) load_regs(it + 1);
+    const int nx = it + 1 < n_iter ? it + 1 : it;
+    if (!(abl & 1)) load_regs(nx);
     const int c = it / n_taps;
-    const bool second = ACC1 && ((sTaps[it - c * n_taps] >> 24) & 0xff);
+    const bool second = ACC1 && ((__builtin_amdgcn_readfirstlane(sTaps[it - c * n_taps]) >> 24) & 0xff);
+    if (!(abl & 8)) compute(buf, second);
+    if (!(abl & 2)) store_lds(buf ^ 1);
+    if (!(abl & 4)) __syncthreads();
+  }
+#else
+  for (int it = 0; it < n_iter; ++it) {
+    const int buf = it & 1;
+    const int nx = it + 1 < n_iter ? it + 1 : it;        // always prefetch (the last one is a harmless repeat): no branch
+    load_regs(nx);
+    const int c = it / n_taps;
+    const bool second = ACC1 && ((__builtin_amdgcn_readfirstlane(sTaps[it - c * n_taps]) >> 24) & 0xff);
     compute(buf, second);
-    if (it + 1 < n_iter) store_lds(buf ^ 1);
+    store_lds(buf ^ 1);
     __syncthreads();
   }
+#endif
 
   // ---- epilogue ----
   float* sRed = smem;    // [2 sets][4 waves][RN*32][2] floats, pipeline LDS is free after the last barrier
@@ -314,7 +357,9 @@ __global__ __launch_bounds__(256) void conv_igemm_k(ConvArgs a) {
 template <int WM, int WN, int RM, int RN, bool ACC1>
 int launch_conv(const ConvArgs& a, int n_groups, hipStream_t s) {
   constexpr int BM = 32 * WM * RM, BN = 32 * WN * RN;
-  const int lds = (2 * BM * A_STRIDE + 2 * BN * KC) * 4 + MPOSE_MAX_TAPS * 4;
+  int lds = (2 * BM * A_STRIDE + 2 * BN * KC) * 4 + MPOSE_MAX_TAPS * 4;
+  static const int extra_lds = getenv("MPOSE_DEBUG_EXTRA_LDS") ? atoi(getenv("MPOSE_DEBUG_EXTRA_LDS")) : 0;   // occupancy experiments
+  lds += extra_lds;
   const int cmax = a.g.Cout1 > a.g.Cout0 ? a.g.Cout1 : a.g.Cout0;
   dim3 grid(a.n_mtiles * a.g.n_classes, (cmax + BN - 1) / BN, n_groups);
   conv_igemm_k<WM, WN, RM, RN, ACC1><<<grid, 256, lds, s>>>(a);
@@ -340,7 +385,7 @@ struct WgradArgs {
 };
 
 template <int TI>   // input-channel tile: 128 (4x1 waves, 2 acc tiles), 64 (2x2 waves) or 32 (1x2 waves, 2 idle)
-__global__ __launch_bounds__(256) void conv_wgrad_k(WgradArgs a) {
+__global__ __launch_bounds__(256, 2) void conv_wgrad_k(WgradArgs a) {
   constexpr int WM = TI == 128 ? 4 : (TI == 64 ? 2 : 1);
   constexpr int WN = TI == 128 ? 1 : 2;
   constexpr int RN = 64 / (32 * WN);
@@ -397,52 +442,59 @@ __global__ __launch_bounds__(256) void conv_wgrad_k(WgradArgs a) {
     for (int r = 0; r < 16; ++r) acc[rn][r] = 0.0f;
 
   float4 rx[X_LOADS], rg[G_LOADS];
+  unsigned rx_ok = 0, rg_ok = 0;
   auto decomp = [&](int m, unsigned& b, unsigned& gy, unsigned& gx) {
     b = fdiv((unsigned)m, a.div_ghw);
     const unsigned rem = (unsigned)m - b * (unsigned)(g.GH * g.GW);
     gy = fdiv(rem, a.div_gw);
     gx = rem - gy * (unsigned)g.GW;
   };
+  // Branch-free issue (clamped addresses, masks applied at LDS-store time): see conv_igemm_k.
   auto load_regs = [&](int step) {
     const int mb = m_begin + step * KP;
+    rx_ok = 0; rg_ok = 0;
 #pragma unroll
     for (int j = 0; j < X_LOADS; ++j) {
       const int m = mb + x_row0 + X_ROWSTEP * j;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (m < m_end) {
-        unsigned b, gy, gx;
-        decomp(m, b, gy, gx);
-        const int iy = (int)gy * g.in_mul + dy, ix = (int)gx * g.in_mul + dx;
-        if (iy >= 0 && iy < g.IH && ix >= 0 && ix < g.IW) {
-          v = *reinterpret_cast<const float4*>(op.in + (((long)b * g.IH + iy) * g.IW + ix) * g.Cin + k0 + x_col4 * 4);
-          if (pro) {
-            v.x = fmaxf(fmaf(v.x, sc.x, sh.x), 0.f); v.y = fmaxf(fmaf(v.y, sc.y, sh.y), 0.f);
-            v.z = fmaxf(fmaf(v.z, sc.z, sh.z), 0.f); v.w = fmaxf(fmaf(v.w, sc.w, sh.w), 0.f);
-          }
-        }
-      }
-      rx[j] = v;
+      const int mc = m < m_end ? m : m_begin;
+      unsigned b, gy, gx;
+      decomp(mc, b, gy, gx);
+      const int iy = (int)gy * g.in_mul + dy, ix = (int)gx * g.in_mul + dx;
+      const bool ok = m < m_end && iy >= 0 && iy < g.IH && ix >= 0 && ix < g.IW;
+      const long off = ok ? ((((long)b * g.IH + iy) * g.IW + ix) * g.Cin) : 0l;
+      rx[j] = *reinterpret_cast<const float4*>(op.in + off + k0 + x_col4 * 4);
+      rx_ok |= (ok ? 1u : 0u) << j;
     }
 #pragma unroll
     for (int j = 0; j < G_LOADS; ++j) {
       const int m = mb + g_row0 + 16 * j;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (m < m_end && g_col_ok) {
-        unsigned b, gy, gx;
-        decomp(m, b, gy, gx);
-        const long pix = ((long)b * g.OH + (gy * g.out_mul + oyc)) * g.OW + (gx * g.out_mul + oxc);
-        v = *reinterpret_cast<const float4*>(gout + pix * cout + n0 + g_col4 * 4);
-      }
-      rg[j] = v;
+      const bool ok = m < m_end && g_col_ok;
+      const int mc = m < m_end ? m : m_begin;
+      unsigned b, gy, gx;
+      decomp(mc, b, gy, gx);
+      const long pix = ((long)b * g.OH + (gy * g.out_mul + oyc)) * g.OW + (gx * g.out_mul + oxc);
+      const long off = ok ? (pix * cout + n0 + g_col4 * 4) : 0l;
+      rg[j] = *reinterpret_cast<const float4*>(gout + off);
+      rg_ok |= (ok ? 1u : 0u) << j;
     }
   };
   auto store_lds = [&](int buf) {
 #pragma unroll
-    for (int j = 0; j < X_LOADS; ++j)
-      *reinterpret_cast<float4*>(sX + buf * X_TILE + (x_row0 + X_ROWSTEP * j) * TI + x_col4 * 4) = rx[j];
+    for (int j = 0; j < X_LOADS; ++j) {
+      float4 v = rx[j];
+      if (pro) {
+        v.x = fmaxf(fmaf(v.x, sc.x, sh.x), 0.f); v.y = fmaxf(fmaf(v.y, sc.y, sh.y), 0.f);
+        v.z = fmaxf(fmaf(v.z, sc.z, sh.z), 0.f); v.w = fmaxf(fmaf(v.w, sc.w, sh.w), 0.f);
+      }
+      if (!((rx_ok >> j) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4*>(sX + buf * X_TILE + (x_row0 + X_ROWSTEP * j) * TI + x_col4 * 4) = v;
+    }
 #pragma unroll
-    for (int j = 0; j < G_LOADS; ++j)
-      *reinterpret_cast<float4*>(sG + buf * G_TILE + (g_row0 + 16 * j) * 64 + g_col4 * 4) = rg[j];
+    for (int j = 0; j < G_LOADS; ++j) {
+      float4 v = rg[j];
+      if (!((rg_ok >> j) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4*>(sG + buf * G_TILE + (g_row0 + 16 * j) * 64 + g_col4 * 4) = v;
+    }
   };
 
   if (n_steps > 0) { load_regs(0); store_lds(0); }
@@ -556,6 +608,9 @@ extern "C" int mpose_conv_fwd(const mpose_conv_geom* geom, const mpose_conv_oper
   a.div_gw = make_fastdiv((unsigned)geom->GW);
   a.div_ghw = make_fastdiv((unsigned)(geom->GH * geom->GW));
   a.flags = flags;
+#ifdef MPOSE_ABLATE
+  if (getenv("MPOSE_ABLATE")) a.flags |= atoi(getenv("MPOSE_ABLATE")) << 8;
+#endif
   hipStream_t s = (hipStream_t)stream;
   const int npad = geom->Npad0;
   // Tile selection: 128x64 when there is enough work to fill 256 CUs, else 64x64; N = 32 tiles for the

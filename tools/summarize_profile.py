@@ -1,0 +1,45 @@
+#!/usr/bin/env python
+"""Condense rocprofv3 csv output (kernel stats + PMC passes) into a small text summary for profiles/."""
+import csv
+import glob
+import os
+import re
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    name = re.sub(r'\(anonymous namespace\)::', '', name)
+    name = re.sub(r'mpose::', '', name)
+    return name[:110]
+
+
+def main(out):
+    for f in glob.glob(os.path.join(out, 'trace', '**', '*kernel_stats.csv'), recursive=True):
+        print('== kernel stats (%s)' % os.path.relpath(f, out))
+        rows = list(csv.DictReader(open(f)))
+        tot = sum(float(r['TotalDurationNs']) for r in rows)
+        print('%-112s %8s %12s %10s %6s' % ('kernel', 'calls', 'total_ms', 'avg_us', 'pct'))
+        for r in sorted(rows, key=lambda r: -float(r['TotalDurationNs']))[:25]:
+            print('%-112s %8s %12.3f %10.2f %6.2f' % (short(r['Name']), r['Calls'], float(r['TotalDurationNs']) / 1e6,
+                                                      float(r['AverageNs']) / 1e3, 100 * float(r['TotalDurationNs']) / tot))
+        print('total kernel time ms: %.3f' % (tot / 1e6))
+    for sub in ('pmc_sq', 'pmc_lds', 'pmc_fetch', 'pmc_write'):
+        files = glob.glob(os.path.join(out, sub, '**', '*counter_collection.csv'), recursive=True)
+        if not files:
+            continue
+        agg = defaultdict(lambda: defaultdict(float))
+        cnt = defaultdict(int)
+        for f in files:
+            for r in csv.DictReader(open(f)):
+                k = short(r['Kernel_Name'])
+                agg[k][r['Counter_Name']] += float(r['Counter_Value'])
+                cnt[(k, r['Counter_Name'])] += 1
+        print('== PMC pass %s (per-dispatch averages)' % sub)
+        for k in sorted(agg, key=lambda k: -sum(agg[k].values()))[:12]:
+            print(k)
+            print('    ' + '  '.join('%s=%.4g' % (c, v / max(cnt[(k, c)], 1)) for c, v in sorted(agg[k].items())))
+
+
+if __name__ == '__main__':
+    main(sys.argv[1])
