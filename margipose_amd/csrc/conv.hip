@@ -23,7 +23,6 @@
 // LDS A tile rows are padded to 36 floats (144 B): the 16 lanes of a ds_read_b128 group then hit
 // 16 distinct 16-byte slots (9*i mod 16 is a bijection), so the reads are conflict-free.
 #include "common.h"
-#include <cstdlib>
 
 namespace mpose {
 namespace {
@@ -53,30 +52,54 @@ struct ConvArgs {
   int M;                          // slots per class = B*GH*GW
   int n_mtiles;
   int flags;
+  int in_bias;                    // bytes: max negative tap shift, folded into the input buffer base
 };
 
 // Row of the 32x32 accumulator held in register r of lane-half h.
 __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
-template <int WM, int WN, int RM, int RN, bool ACC1>
+// Forward / data-gradient kernel.
+//
+// Cost model (measured, tools/ablate_conv.py + rocprofv3 PMC, r1): v_mfma_f32_32x32x2_f32 runs at 64 FLOP/clk/SIMD --
+// exactly the SIMD's 32 fp32 FMA lanes -- and every VALU instruction issued by ANY wave of the SIMD takes those
+// lanes away from it: kernel time ~= MFMA cycles + VALU cycles, independent of occupancy.  So the loop below is
+// written to issue (almost) no vector ALU work per MFMA:
+//   * all addresses are  buffer descriptor + loop-invariant per-lane VGPR offset + wave-uniform SGPR offset;
+//     the scalar unit advances the SGPR part (tap shift, channel chunk, k-group);
+//   * zero padding is done by the buffer unit: an out-of-bounds row gets voffset = 0xFFFFFFF0 and the load
+//     returns 0 (3 VALU ops per staged row and tap instead of compare/select trees);
+//   * a workgroup is 4 INDEPENDENT wavefronts (no workgroup barrier in the K loop): wave w owns output rows
+//     m0 + 32w .. +31 and 32*RN output channels (RN up to 4);
+//   * A operand: the wave stages ITS OWN 32 rows x 32 channels per (chunk, tap) through a wave-private,
+//     double-buffered LDS tile (coalesced 128-byte row reads, transposed into MFMA fragment order by the
+//     ds_read_b128).  LDS ops of one wave execute in order, so no s_barrier is needed;
+//   * B operand: packed weights are already in fragment order, so every lane fetches its float4 fragments
+//     straight from L2 into a 4-slot register ring, 3 k-groups ahead of use (pinned with sched_barrier, hipcc
+//     otherwise sinks the prefetch to its use).
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
+  const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, (int)soff, 0);
+  return make_float4(__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w));
+}
+
+constexpr unsigned kOob = 0xFFFFFFF0u;      // voffset that the buffer unit treats as out of range -> returns 0
+
+template <int RN, bool ACC1>
 __global__ __launch_bounds__(256, 2) void conv_igemm_k(ConvArgs a) {
-  constexpr int BM = 32 * WM * RM;
-  constexpr int BN = 32 * WN * RN;
-  constexpr int A_LOADS = BM / 32;           // float4 per thread per A tile
-  constexpr int W_LOADS = BN / 32;           // float4 per thread per W tile
-  constexpr int A_TILE = BM * A_STRIDE;      // floats
-  constexpr int W_TILE = BN * KC;            // floats
+  constexpr int BM = 128;
+  constexpr int BN = 32 * RN;
+  constexpr int A_TILE = 32 * A_STRIDE;      // floats per wave per buffer
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* sA = smem;                          // [2][A_TILE]
-  float* sW = smem + 2 * A_TILE;             // [2][W_TILE]
-  int* sTaps = reinterpret_cast<int*>(smem + 2 * A_TILE + 2 * W_TILE);   // [MPOSE_MAX_TAPS]
+  int* sTaps = reinterpret_cast<int*>(smem);                          // [MPOSE_MAX_TAPS] (+4 pad)
+  float* sA_all = smem + 16;                                          // [4 waves][2][A_TILE]
+  float* sRed = smem + 16 + 4 * 2 * A_TILE;                           // [2 sets][4 waves][BN][2]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / WN, wn = wave % WN;
   const int li = lane & 31, lh = lane >> 5;
   const mpose_conv_geom& g = a.g;
   const int cls = blockIdx.x / a.n_mtiles;
-  const int m0 = (blockIdx.x - cls * a.n_mtiles) * BM;
+  const int m0 = (blockIdx.x - cls * a.n_mtiles) * BM + wave * 32;     // first row of THIS wave
   const int n0 = blockIdx.y * BN;
   const mpose_conv_operands& op = a.op[blockIdx.z];
   const int n_taps = g.cls[cls].n_taps;
@@ -84,25 +107,25 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_k(ConvArgs a) {
     const mpose_tap t = g.cls[cls].taps[tid];
     sTaps[tid] = (int)(unsigned char)t.dy | ((int)(unsigned char)t.dx << 8) | ((int)(unsigned char)t.widx << 16) | ((int)(unsigned char)t.acc << 24);
   }
+  __syncthreads();   // sTaps visible (the only workgroup barrier before the epilogue)
+  float* sA = sA_all + wave * 2 * A_TILE;
 
-  // ---- per-thread staging state, fixed for the whole K loop ----
-  // row_off[j]: element offset of the slot's anchor pixel (+ this thread's 4-channel column);
-  // row_taps[j]: bit t set when tap t of this class reads an in-bounds pixel for that row.
-  const int a_col4 = tid & 7;
-  __syncthreads();   // sTaps visible
-  unsigned row_off[A_LOADS], row_taps[A_LOADS];
+  // ---- per-lane staging state (loop invariant) ----
+  // row_voff[j]: BYTE offset of the slot's anchor pixel + this lane's 16-byte channel column;
+  // row_taps[j]: bit t = tap t reads an in-bounds pixel for that row.
+  const int a_col4 = lane & 7;
+  unsigned row_voff[4], row_taps[4];
 #pragma unroll
-  for (int j = 0; j < A_LOADS; ++j) {
-    const int row = (tid >> 3) + 32 * j;
-    const unsigned m = (unsigned)(m0 + row);
-    row_off[j] = 0; row_taps[j] = 0;
+  for (int j = 0; j < 4; ++j) {
+    const unsigned m = (unsigned)(m0 + (lane >> 3) + 8 * j);
+    row_voff[j] = 0; row_taps[j] = 0;
     if ((int)m < a.M) {
       const unsigned b = fdiv(m, a.div_ghw);
       const unsigned rem = m - b * (unsigned)(g.GH * g.GW);
       const unsigned gy = fdiv(rem, a.div_gw);
       const unsigned gx = rem - gy * (unsigned)g.GW;
       const int iy0 = (int)gy * g.in_mul, ix0 = (int)gx * g.in_mul;
-      row_off[j] = ((b * (unsigned)g.IH + (unsigned)iy0) * (unsigned)g.IW + (unsigned)ix0) * (unsigned)g.Cin + (unsigned)(a_col4 * 4);
+      row_voff[j] = (((b * (unsigned)g.IH + (unsigned)iy0) * (unsigned)g.IW + (unsigned)ix0) * (unsigned)g.Cin + (unsigned)(a_col4 * 4)) * 4u;
       for (int t = 0; t < n_taps; ++t) {
         const int tp = sTaps[t];
         const int iy = iy0 + (int)(signed char)(tp & 0xff), ix = ix0 + (int)(signed char)((tp >> 8) & 0xff);
@@ -113,168 +136,136 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_k(ConvArgs a) {
   const int n_chunks = g.Cin / KC;
   const int n_iter = n_chunks * n_taps;
   const int k4_total = g.Cin >> 2;
-  const unsigned w_lane0 = (unsigned)(((tid / BN) * g.Npad0 + (tid % BN)) * 4);                       // Npad0 == Npad1 when ACC1
-  const unsigned w_lane1 = (unsigned)((((tid + 256) / BN) * g.Npad0 + ((tid + 256) % BN)) * 4);
-
-  f32x16 acc0[RM][RN];
-  f32x16 acc1[RM][RN];
-#pragma unroll
-  for (int rm = 0; rm < RM; ++rm)
-#pragma unroll
-    for (int rn = 0; rn < RN; ++rn) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { acc0[rm][rn][r] = 0.0f; acc1[rm][rn][r] = 0.0f; }
-    }
-
-  float4 ra[A_LOADS];
-  float4 rw0 = make_float4(0.f, 0.f, 0.f, 0.f), rw1 = rw0;   // named (not an array): keeps the W staging in VGPRs
-  static_assert(W_LOADS <= 2, "W tile staging assumes at most two float4 per thread");
-  float4 rsc = make_float4(1.f, 1.f, 1.f, 1.f), rsh = make_float4(0.f, 0.f, 0.f, 0.f);
-  unsigned ra_ok = 0;                      // bit j: row j of the staged tile is a real (in-bounds) pixel
+  const int npad = g.Npad0;                                       // == Npad1 when ACC1
   const bool pro = op.in_scale != nullptr;
+  // Buffer descriptors.  The input base is moved back by `a.in_bias` bytes so that the (possibly negative) tap
+  // shift becomes a non-negative SGPR offset.
+  const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char*>(reinterpret_cast<const char*>(op.in)) - a.in_bias, 0, 0xFFFFFF00, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(op.w0), 0, 0xFFFFFF00, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ACC1 ? op.w1 : op.w0), 0, 0xFFFFFF00, 0x00020000);
+  const unsigned w_voff = (unsigned)((lh * npad + n0 + li) * 16);   // this lane's fragment inside a k-group pair (bytes)
 
-  // Branch-free issue of every global load of tile `it`: the tap contributes ONE wave-uniform element offset,
-  // per-row validity is a precomputed bit; invalid rows read element 0 and are zeroed at LDS-store time.
-  auto load_regs = [&](int it) {
-    const int c = it / n_taps;
-    const int t = it - c * n_taps;
-    const int tp = __builtin_amdgcn_readfirstlane(sTaps[t]);
+  f32x16 acc0[RN], acc1[ACC1 ? RN : 1];
+#pragma unroll
+  for (int rn = 0; rn < RN; ++rn)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc0[rn][r] = 0.0f;
+#pragma unroll
+  for (int rn = 0; rn < (ACC1 ? RN : 1); ++rn)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc1[rn][r] = 0.0f;
+
+  float4 ra[4];
+  float4 rsc = make_float4(1.f, 1.f, 1.f, 1.f), rsh = make_float4(0.f, 0.f, 0.f, 0.f);
+  unsigned ra_inv[4] = {0, 0, 0, 0};      // 0xFFFFFFFF for out-of-bounds rows (only consumed when `pro`)
+  float4 fb[4][RN];                      // B-fragment ring: slot q holds k-group q of some tile
+
+  // wave-uniform (SGPR) description of tile `it`
+  struct TileInfo { unsigned a_soff; unsigned w_soff; int t; int c; bool second; };
+  auto tile_info = [&](int it) {
+    TileInfo ti;
+    ti.c = it / n_taps;
+    ti.t = it - ti.c * n_taps;
+    const int tp = __builtin_amdgcn_readfirstlane(sTaps[ti.t]);
     const int dy = (int)(signed char)(tp & 0xff), dx = (int)(signed char)((tp >> 8) & 0xff);
     const int widx = (tp >> 16) & 0xff;
-    const bool second = ACC1 && ((tp >> 24) & 0xff);
-    const unsigned tap_off = (unsigned)((dy * g.IW + dx) * g.Cin + c * KC);
-    ra_ok = 0;
+    ti.second = ACC1 && ((tp >> 24) & 0xff);
+    ti.a_soff = (unsigned)(((dy * g.IW + dx) * g.Cin + ti.c * KC) * 4 + a.in_bias);
+    ti.w_soff = (unsigned)((widx * k4_total + ti.c * (KC / 4)) * npad * 16);
+    return ti;
+  };
+  auto load_b = [&](const TileInfo& ti, int q, float4 (&dst)[RN]) {
+    const unsigned so = ti.w_soff + (unsigned)(q * 2 * npad * 16);
 #pragma unroll
-    for (int j = 0; j < A_LOADS; ++j) {
-      const bool ok = (row_taps[j] >> t) & 1u;
-      const unsigned off = ok ? row_off[j] + tap_off : (unsigned)(a_col4 * 4);
-      ra[j] = *reinterpret_cast<const float4*>(op.in + off);
-      ra_ok |= (ok ? 1u : 0u) << j;
+    for (int rn = 0; rn < RN; ++rn)
+      dst[rn] = buf_load4((ACC1 && ti.second) ? rs_w1 : rs_w0, w_voff + (unsigned)(rn * 512), so);
+  };
+  auto load_a = [&](const TileInfo& ti) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const unsigned inv = ((row_taps[j] >> ti.t) & 1u) - 1u;       // 0 = in bounds, 0xFFFFFFFF = padding
+      ra_inv[j] = inv;
+      ra[j] = buf_load4(rs_in, row_voff[j] | (inv & kOob), ti.a_soff);
     }
-    const float* wsrc = (second ? op.w1 : op.w0) + ((long)(widx * k4_total + c * (KC / 4)) * g.Npad0 + n0) * 4;
-    rw0 = *reinterpret_cast<const float4*>(wsrc + w_lane0);
-    if (W_LOADS > 1) rw1 = *reinterpret_cast<const float4*>(wsrc + w_lane1);
     if (pro) {
-      rsc = *reinterpret_cast<const float4*>(op.in_scale + c * KC + a_col4 * 4);
-      rsh = *reinterpret_cast<const float4*>(op.in_shift + c * KC + a_col4 * 4);
+      rsc = *reinterpret_cast<const float4*>(op.in_scale + ti.c * KC + a_col4 * 4);
+      rsh = *reinterpret_cast<const float4*>(op.in_shift + ti.c * KC + a_col4 * 4);
     }
   };
-  // BN + ReLU of the producing layer (when requested) and the zero padding are applied here, after the
-  // MFMA phase, so the loads above are never waited for early.
-  auto store_lds = [&](int buf) {
+  // BN + ReLU of the producing layer (only when requested) is applied at LDS-store time; padding rows are
+  // already zero from the buffer unit and are re-zeroed only on the `pro` path (relu(shift) != 0).
+  auto store_a = [&](int buf) {
     float* dA = sA + buf * A_TILE;
-    float* dW = sW + buf * W_TILE;
 #pragma unroll
-    for (int j = 0; j < A_LOADS; ++j) {
-      const int row = (tid >> 3) + 32 * j;
+    for (int j = 0; j < 4; ++j) {
       float4 v = ra[j];
       if (pro) {
         v.x = fmaxf(fmaf(v.x, rsc.x, rsh.x), 0.f); v.y = fmaxf(fmaf(v.y, rsc.y, rsh.y), 0.f);
         v.z = fmaxf(fmaf(v.z, rsc.z, rsh.z), 0.f); v.w = fmaxf(fmaf(v.w, rsc.w, rsh.w), 0.f);
+        if (ra_inv[j]) v = make_float4(0.f, 0.f, 0.f, 0.f);
       }
-      if (!((ra_ok >> j) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
-      *reinterpret_cast<float4*>(dA + row * A_STRIDE + a_col4 * 4) = v;
+      *reinterpret_cast<float4*>(dA + ((lane >> 3) + 8 * j) * A_STRIDE + a_col4 * 4) = v;
     }
-    *reinterpret_cast<float4*>(dW + tid * 4) = rw0;
-    if (W_LOADS > 1) *reinterpret_cast<float4*>(dW + (tid + 256) * 4) = rw1;
+    __builtin_amdgcn_wave_barrier();     // compiler ordering only; LDS executes one wave's ops in order
   };
-  // One (chunk, tap) tile = a 32-long fp32 FMA chain per output element, accumulated into a FRESH register
-  // tile and then added to the running sum.  Error grows like sqrt(32) + sqrt(#tiles) ulps instead of
-  // sqrt(K) for one K-long chain (K = 1152 for a 3x3 over 128 channels): ~5x closer to the fp64 result, which
-  // matters because every rounding-induced ReLU-mask flip costs ~1e-3 relative error in the gradients.
-  // LDS fragments of k-group q+1 are requested before the MFMAs of group q are issued.
-  auto compute = [&](int buf, bool second) {
-    const float* cA = sA + buf * A_TILE + (wm * RM * 32 + li) * A_STRIDE + lh * 4;
-    const float* cW = sW + buf * W_TILE + (lh * BN + wn * RN * 32 + li) * 4;
-    f32x16 part[RM][RN];
-    float4 fa[2][RM], fb[2][RN];
-#pragma unroll
-    for (int rm = 0; rm < RM; ++rm) fa[0][rm] = *reinterpret_cast<const float4*>(cA + rm * 32 * A_STRIDE);
-#pragma unroll
-    for (int rn = 0; rn < RN; ++rn) fb[0][rn] = *reinterpret_cast<const float4*>(cW + rn * 32 * 4);
+
+  if (n_iter > 0) {
+    TileInfo t0 = tile_info(0);
+    load_a(t0);
+    load_b(t0, 0, fb[0]);
+    load_b(t0, 1, fb[1]);
+    load_b(t0, 2, fb[2]);
+    store_a(0);
+  }
+  for (int it = 0; it < n_iter; ++it) {
+    const int buf = it & 1;
+    const TileInfo cur = tile_info(it);
+    const TileInfo nxt = tile_info(it + 1 < n_iter ? it + 1 : it);     // the last prefetch is a harmless repeat
+    load_a(nxt);
+    __builtin_amdgcn_sched_barrier(0);
+    const float* cA = sA + buf * A_TILE + li * A_STRIDE + lh * 4;
+    // One (chunk, tap) tile = a 32-long fp32 FMA chain per output element, accumulated into a FRESH register
+    // tile and then added to the running sum: error ~ sqrt(32)+sqrt(#tiles) ulps instead of sqrt(K).
+    f32x16 part[RN];
+    float4 fa = *reinterpret_cast<const float4*>(cA);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int cur = q & 1, nxt = cur ^ 1;
-      if (q < 3) {
-#pragma unroll
-        for (int rm = 0; rm < RM; ++rm) fa[nxt][rm] = *reinterpret_cast<const float4*>(cA + rm * 32 * A_STRIDE + (q + 1) * 8);
-#pragma unroll
-        for (int rn = 0; rn < RN; ++rn) fb[nxt][rn] = *reinterpret_cast<const float4*>(cW + ((q + 1) * 2 * BN + rn * 32) * 4);
-      }
+      // B fragments 3 k-groups ahead: slot (q+3)&3 was consumed by the previous k-group
+      if (q == 0) load_b(cur, 3, fb[3]);
+      else load_b(nxt, q - 1, fb[q - 1]);
+      float4 fa_next = fa;
+      if (q < 3) fa_next = *reinterpret_cast<const float4*>(cA + (q + 1) * 8);
+      __builtin_amdgcn_sched_barrier(0);   // keep the prefetches ABOVE this k-group's MFMAs
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
+        const float av = e == 0 ? fa.x : (e == 1 ? fa.y : (e == 2 ? fa.z : fa.w));
 #pragma unroll
-        for (int rm = 0; rm < RM; ++rm)
+        for (int rn = 0; rn < RN; ++rn) {
+          f32x16 c;
+          if (q == 0 && e == 0) {
 #pragma unroll
-          for (int rn = 0; rn < RN; ++rn) {
-            f32x16 c;
-            if (q == 0 && e == 0) {
-#pragma unroll
-              for (int r = 0; r < 16; ++r) c[r] = 0.0f;
-            } else {
-              c = part[rm][rn];
-            }
-            const float av = e == 0 ? fa[cur][rm].x : (e == 1 ? fa[cur][rm].y : (e == 2 ? fa[cur][rm].z : fa[cur][rm].w));
-            const float bv = e == 0 ? fb[cur][rn].x : (e == 1 ? fb[cur][rn].y : (e == 2 ? fb[cur][rn].z : fb[cur][rn].w));
-            part[rm][rn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, c, 0, 0, 0);
+            for (int r = 0; r < 16; ++r) c[r] = 0.0f;
+          } else {
+            c = part[rn];
           }
+          const float4 bq = fb[q][rn];
+          const float bv = e == 0 ? bq.x : (e == 1 ? bq.y : (e == 2 ? bq.z : bq.w));
+          part[rn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, c, 0, 0, 0);
+        }
       }
+      fa = fa_next;
     }
 #pragma unroll
-    for (int rm = 0; rm < RM; ++rm)
-#pragma unroll
-      for (int rn = 0; rn < RN; ++rn) {
-        if (ACC1 && second) acc1[rm][rn] += part[rm][rn];
-        else acc0[rm][rn] += part[rm][rn];
-      }
-  };
-
-  // ---- main loop: the loads of tile it+1 are in flight across the MFMAs of tile it; one barrier per tile ----
-  if (n_iter > 0) {
-    load_regs(0);
-    store_lds(0);
+    for (int rn = 0; rn < RN; ++rn) {
+      if (ACC1 && cur.second) acc1[rn] += part[rn];
+      else acc0[rn] += part[rn];
+    }
+    store_a(buf ^ 1);
   }
-  __syncthreads();
-#ifdef MPOSE_ABLATE
-  const int abl = a.flags >> 8;
-  if (abl & 16) {   // experiment: distinct static priorities for the blocks that share a CU
-    const unsigned flat = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-    const unsigned pr = (flat >> 8) % 3u;
-    if (pr == 1) __builtin_amdgcn_s_setprio(1);
-    else if (pr == 2) __builtin_amdgcn_s_setprio(2);
-  }
-  if (abl & 32) {   // experiment: one-time stagger
-    const unsigned flat = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-    const unsigned pr = (flat >> 8) % 3u;
-    for (unsigned k = 0; k < pr * 24; ++k) __builtin_amdgcn_s_sleep(127);
-  }
-  for (int it = 0; it < n_iter; ++it) {
-    const int buf = it & 1;
-    const int nx = it + 1 < n_iter ? it + 1 : it;
-    if (!(abl & 1)) load_regs(nx);
-    const int c = it / n_taps;
-    const bool second = ACC1 && ((__builtin_amdgcn_readfirstlane(sTaps[it - c * n_taps]) >> 24) & 0xff);
-    if (!(abl & 8)) compute(buf, second);
-    if (!(abl & 2)) store_lds(buf ^ 1);
-    if (!(abl & 4)) __syncthreads();
-  }
-#else
-  for (int it = 0; it < n_iter; ++it) {
-    const int buf = it & 1;
-    const int nx = it + 1 < n_iter ? it + 1 : it;        // always prefetch (the last one is a harmless repeat): no branch
-    load_regs(nx);
-    const int c = it / n_taps;
-    const bool second = ACC1 && ((__builtin_amdgcn_readfirstlane(sTaps[it - c * n_taps]) >> 24) & 0xff);
-    compute(buf, second);
-    store_lds(buf ^ 1);
-    __syncthreads();
-  }
-#endif
 
   // ---- epilogue ----
-  float* sRed = smem;    // [2 sets][4 waves][RN*32][2] floats, pipeline LDS is free after the last barrier
   const int oyc = g.cls[cls].oy, oxc = g.cls[cls].ox;
-  // output pixel offsets of this lane's 16 rows per rm
 #pragma unroll
   for (int set = 0; set < (ACC1 ? 2 : 1); ++set) {
     float* outp = set ? op.out1 : op.out0;
@@ -286,37 +277,33 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_k(ConvArgs a) {
 #pragma unroll
     for (int rn = 0; rn < RN; ++rn) { csum[rn] = 0.f; csq[rn] = 0.f; }
 #pragma unroll
-    for (int rm = 0; rm < RM; ++rm) {
+    for (int r = 0; r < 16; ++r) {
+      const unsigned m = (unsigned)(m0 + acc_row(r, lh));
+      const bool row_ok = (int)m < a.M;
+      long pix = 0;
+      if (row_ok) {
+        const unsigned b = fdiv(m, a.div_ghw);
+        const unsigned rem = m - b * (unsigned)(g.GH * g.GW);
+        const unsigned gy = fdiv(rem, a.div_gw);
+        const unsigned gx = rem - gy * (unsigned)g.GW;
+        pix = ((long)b * g.OH + (gy * g.out_mul + oyc)) * g.OW + (gx * g.out_mul + oxc);
+      }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (wm * RM + rm) * 32 + acc_row(r, lh);
-        const unsigned m = (unsigned)(m0 + row);
-        const bool row_ok = (int)m < a.M;
-        long pix = 0;
-        if (row_ok) {
-          const unsigned b = fdiv(m, a.div_ghw);
-          const unsigned rem = m - b * (unsigned)(g.GH * g.GW);
-          const unsigned gy = fdiv(rem, a.div_gw);
-          const unsigned gx = rem - gy * (unsigned)g.GW;
-          pix = ((long)b * g.OH + (gy * g.out_mul + oyc)) * g.OW + (gx * g.out_mul + oxc);
-        }
-#pragma unroll
-        for (int rn = 0; rn < RN; ++rn) {
-          const int n = n0 + (wn * RN + rn) * 32 + li;
-          float v = set ? acc1[rm][rn][r] : acc0[rm][rn][r];
-          if (row_ok && n < cout) {
-            const long o = pix * cout + n;
-            float second_factor = v;
-            if (masked) {
-              const float src = op.mask_src[o];
-              if (!(fmaf(src, op.mask_scale[n], op.mask_shift[n]) > 0.f)) v = 0.f;
-              second_factor = src;
-            }
-            if (accumulate) v += outp[o];
-            outp[o] = v;
-            csum[rn] += v;
-            csq[rn] = fmaf(v, second_factor, csq[rn]);
+      for (int rn = 0; rn < RN; ++rn) {
+        const int n = n0 + rn * 32 + li;
+        float v = (ACC1 && set) ? acc1[rn][r] : acc0[rn][r];
+        if (row_ok && n < cout) {
+          const long o = pix * cout + n;
+          float second_factor = v;
+          if (masked) {
+            const float src = op.mask_src[o];
+            if (!(fmaf(src, op.mask_scale[n], op.mask_shift[n]) > 0.f)) v = 0.f;
+            second_factor = src;
           }
+          if (accumulate) v += outp[o];
+          outp[o] = v;
+          csum[rn] += v;
+          csq[rn] = fmaf(v, second_factor, csq[rn]);
         }
       }
     }
@@ -326,7 +313,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_k(ConvArgs a) {
         csum[rn] += __shfl_xor(csum[rn], 32, 64);
         csq[rn] += __shfl_xor(csq[rn], 32, 64);
         if (lh == 0) {
-          float* d = sRed + ((set * 4 + wave) * (RN * 32) + rn * 32 + li) * 2;
+          float* d = sRed + ((set * 4 + wave) * BN + rn * 32 + li) * 2;
           d[0] = csum[rn]; d[1] = csq[rn];
         }
       }
@@ -338,11 +325,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_k(ConvArgs a) {
     double* stats = set ? op.stats1 : op.stats0;
     const int cout = set ? g.Cout1 : g.Cout0;
     if (stats != nullptr && tid < BN) {
-      const int cwn = tid / (RN * 32), cc = tid - cwn * (RN * 32);
       float s = 0.f, q = 0.f;
 #pragma unroll
-      for (int w = 0; w < WM; ++w) {
-        const float* d = sRed + ((set * 4 + (w * WN + cwn)) * (RN * 32) + cc) * 2;
+      for (int w = 0; w < 4; ++w) {
+        const float* d = sRed + ((set * 4 + w) * BN + tid) * 2;
         s += d[0]; q += d[1];
       }
       const int n = n0 + tid;
@@ -354,51 +340,49 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_k(ConvArgs a) {
   }
 }
 
-template <int WM, int WN, int RM, int RN, bool ACC1>
+template <int RN, bool ACC1>
 int launch_conv(const ConvArgs& a, int n_groups, hipStream_t s) {
-  constexpr int BM = 32 * WM * RM, BN = 32 * WN * RN;
-  int lds = (2 * BM * A_STRIDE + 2 * BN * KC) * 4 + MPOSE_MAX_TAPS * 4;
-  static const int extra_lds = getenv("MPOSE_DEBUG_EXTRA_LDS") ? atoi(getenv("MPOSE_DEBUG_EXTRA_LDS")) : 0;   // occupancy experiments
-  lds += extra_lds;
+  constexpr int BN = 32 * RN;
+  const int lds = (16 + 4 * 2 * 32 * A_STRIDE + 2 * 4 * BN * 2) * 4;
   const int cmax = a.g.Cout1 > a.g.Cout0 ? a.g.Cout1 : a.g.Cout0;
   dim3 grid(a.n_mtiles * a.g.n_classes, (cmax + BN - 1) / BN, n_groups);
-  conv_igemm_k<WM, WN, RM, RN, ACC1><<<grid, 256, lds, s>>>(a);
+  conv_igemm_k<RN, ACC1><<<grid, 256, lds, s>>>(a);
   return launch_status();
 }
 
 // ---------------------------------------------------------------------------------------------
 // Weight gradient: dWp[split][widx][k/4][n][4] = sum_{slots in split} X_tap[slot][k] * G[slot][n]
-// MFMA roles: i = k (input channel), j = n (output channel), reduction index = slot.
+// MFMA roles: i = k (input channel), j = n (output channel), reduction index = slot (pixel).
+//
+// In NHWC the MFMA operand layout IS the memory layout: lane (i, h) of v_mfma_f32_32x32x2_f32 wants
+// X[pixel 2p+h][k0 + i] and G[pixel 2p+h][n0 + i] -- 32 consecutive channels of one pixel = one coalesced
+// 128-byte line per lane half.  So there is no LDS staging and (following the cost model above conv_igemm_k)
+// almost no vector ALU work: each wave walks its slot rows with the SCALAR unit (row/tap validity, padding rows
+// and columns are skipped, all offsets are SGPRs), and streams `buffer_load_dword`s into a register ring DEPTH
+// pixel-pairs ahead of the MFMAs.  A workgroup = 4 independent waves that split the slot range; their partial
+// tiles are summed in a fixed order through LDS (deterministic), then written as split-K partials.
 // ---------------------------------------------------------------------------------------------
-constexpr int KP = 32;            // slots per K-step
-
 struct WgradArgs {
   mpose_conv_geom g;
   mpose_wgrad_operands op[MPOSE_MAX_GROUP];
-  FastDiv div_gw, div_ghw;
-  int M;
-  int n_split, slots_per_split;
+  FastDiv div_gh;
+  int n_split, rows_per_split;    // slot rows (b, gy) per split; a workgroup's 4 waves share one split
   int n_entries;                  // flat (class, tap) entries
   int entry_cls[MPOSE_MAX_CLASSES * MPOSE_MAX_TAPS];
   int entry_tap[MPOSE_MAX_CLASSES * MPOSE_MAX_TAPS];
   int n_widx0, n_widx1;
+  int in_bias;                    // bytes, as in ConvArgs
 };
 
-template <int TI>   // input-channel tile: 128 (4x1 waves, 2 acc tiles), 64 (2x2 waves) or 32 (1x2 waves, 2 idle)
-__global__ __launch_bounds__(256, 2) void conv_wgrad_k(WgradArgs a) {
-  constexpr int WM = TI == 128 ? 4 : (TI == 64 ? 2 : 1);
-  constexpr int WN = TI == 128 ? 1 : 2;
-  constexpr int RN = 64 / (32 * WN);
-  constexpr int X_LOADS = KP * TI / 4 / 256;   // 4 (TI=128) or 2 (TI=64)
-  constexpr int G_LOADS = KP * 64 / 4 / 256;   // 2
-  constexpr int X_TILE = KP * TI, G_TILE = KP * 64;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* sX = smem;                 // [2][X_TILE]
-  float* sG = smem + 2 * X_TILE;    // [2][G_TILE]
+__device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
+  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)voff, (int)soff, 0));
+}
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / WN, wn = wave % WN;
-  const bool wactive = wave < WM * WN;
+template <int RN>   // wave tile: 32 input channels x 32*RN output channels
+__global__ __launch_bounds__(256, 2) void conv_wgrad_k(WgradArgs a) {
+  constexpr int DEPTH = 8;                     // pixel pairs in flight (RN*64 MFMA cycles each)
+  extern __shared__ __attribute__((aligned(16))) float smem[];     // [3 waves][RN*16][64] reduction scratch
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lh = lane >> 5;
   const mpose_conv_geom& g = a.g;
   const int entry = blockIdx.x / a.n_split;
@@ -407,33 +391,63 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_k(WgradArgs a) {
   const mpose_tap tap = g.cls[cls].taps[a.entry_tap[entry]];
   const bool second = tap.acc != 0;
   const int npad = second ? g.Npad1 : g.Npad0;
-  const int n_ctiles = npad / 64;
+  const int cout = second ? g.Cout1 : g.Cout0;
+  const int n_ctiles = (cout + 32 * RN - 1) / (32 * RN);
   const int k_tile = blockIdx.y / n_ctiles, n_tile = blockIdx.y - k_tile * n_ctiles;
-  if (k_tile * TI >= g.Cin) return;
-  const int k0 = k_tile * TI, n0 = n_tile * 64;
+  const int k0 = k_tile * 32, n0 = n_tile * 32 * RN;
   const mpose_wgrad_operands& op = a.op[blockIdx.z];
   const float* gout = second ? op.gout1 : op.gout0;
-  const int cout = second ? g.Cout1 : g.Cout0;
   float* dw = second ? op.dw1 : op.dw0;
   const int n_widx = second ? a.n_widx1 : a.n_widx0;
   const int oyc = g.cls[cls].oy, oxc = g.cls[cls].ox;
   const int dy = tap.dy, dx = tap.dx;
 
-  const int m_begin = split * a.slots_per_split;
-  const int m_end = min(a.M, m_begin + a.slots_per_split);
-  const int n_steps = (m_end - m_begin + KP - 1) / KP;
+  // slot rows of this wave
+  const int n_rows = g.B * g.GH;
+  const int r_split0 = split * a.rows_per_split;
+  const int r_split1 = min(n_rows, r_split0 + a.rows_per_split);
+  const int rpw = (a.rows_per_split + 3) >> 2;
+  const int r_begin = min(r_split1, r_split0 + wave * rpw);
+  const int r_end = min(r_split1, r_begin + rpw);
+  // valid slot columns for this tap: 0 <= gx*in_mul + dx < IW  ->  pairs [p_lo, p_hi)
+  int gx_lo = 0, gx_hi = g.GW;
+  while (gx_lo < g.GW && gx_lo * g.in_mul + dx < 0) ++gx_lo;
+  while (gx_hi > gx_lo && (gx_hi - 1) * g.in_mul + dx >= g.IW) --gx_hi;
+  const int p_lo = gx_lo >> 1, p_hi = (gx_hi + 1) >> 1;
+  const int pairs_per_row = p_hi - p_lo;
 
-  constexpr int XC4 = TI / 4;                  // float4 per X row
-  const int x_col4 = tid % XC4, x_row0 = tid / XC4;
-  constexpr int X_ROWSTEP = 256 / XC4;
-  const int g_col4 = tid & 15, g_row0 = tid >> 4;
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char*>(reinterpret_cast<const char*>(op.in)) - a.in_bias, 0, 0xFFFFFF00, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gout), 0, 0xFFFFFF00, 0x00020000);
+  const unsigned x_voff = (unsigned)((lh * g.in_mul * g.Cin + k0 + li) * 4);
+  const unsigned g_voff = (unsigned)((lh * g.out_mul * cout + n0 + li) * 4);
+  const unsigned lane_bit = 1u << lh;
   const bool pro = op.in_scale != nullptr;
-  float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (pro) {
-    sc = *reinterpret_cast<const float4*>(op.in_scale + k0 + x_col4 * 4);
-    sh = *reinterpret_cast<const float4*>(op.in_shift + k0 + x_col4 * 4);
-  }
-  const bool g_col_ok = (n0 + g_col4 * 4) < cout;     // cout % 4 == 0
+  float psc = 1.f, psh = 0.f;
+  if (pro) { psc = op.in_scale[k0 + li]; psh = op.in_shift[k0 + li]; }
+
+  // scalar cursor over (slot row, pixel pair): only rows whose tap-shifted input row is in bounds
+  struct Cursor { int r, p; unsigned xs, gs; };
+  auto row_valid = [&](int r, unsigned& xs, unsigned& gs) {
+    const unsigned b = fdiv((unsigned)r, a.div_gh);
+    const int gy = r - (int)b * g.GH;
+    const int iy = gy * g.in_mul + dy;
+    xs = (unsigned)((((int)b * g.IH + iy) * g.IW + dx) * g.Cin * 4 + a.in_bias);
+    gs = (unsigned)((((int)b * g.OH + gy * g.out_mul + oyc) * g.OW + oxc) * cout * 4);
+    return iy >= 0 && iy < g.IH;
+  };
+  auto seek = [&](Cursor& c) {          // move to the first valid row at or after c.r
+    while (c.r < r_end) {
+      unsigned xs, gs;
+      const bool ok = row_valid(c.r, xs, gs);
+      c.xs = __builtin_amdgcn_readfirstlane(xs); c.gs = __builtin_amdgcn_readfirstlane(gs);
+      if (__builtin_amdgcn_readfirstlane((int)ok)) break;
+      ++c.r;
+    }
+  };
+  auto advance = [&](Cursor& c) {
+    if (++c.p == p_hi) { c.p = p_lo; ++c.r; seek(c); }
+  };
 
   f32x16 acc[RN];
 #pragma unroll
@@ -441,94 +455,77 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_k(WgradArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[rn][r] = 0.0f;
 
-  float4 rx[X_LOADS], rg[G_LOADS];
-  unsigned rx_ok = 0, rg_ok = 0;
-  auto decomp = [&](int m, unsigned& b, unsigned& gy, unsigned& gx) {
-    b = fdiv((unsigned)m, a.div_ghw);
-    const unsigned rem = (unsigned)m - b * (unsigned)(g.GH * g.GW);
-    gy = fdiv(rem, a.div_gw);
-    gx = rem - gy * (unsigned)g.GW;
+  float rx[DEPTH], rg[DEPTH][RN];
+  unsigned rinv[DEPTH];
+  Cursor ld; ld.r = r_begin; ld.p = p_lo; ld.xs = 0; ld.gs = 0;
+  if (pairs_per_row > 0) seek(ld); else ld.r = r_end;
+  // number of real pairs of this wave
+  int todo = 0;
+  {
+    Cursor cnt = ld;
+    while (cnt.r < r_end) { todo += pairs_per_row; ++cnt.r; seek(cnt); }
+  }
+  auto issue = [&](int slot) {
+    // lanes of an out-of-range pixel (row padding column, or cursor past the end) read zeros
+    unsigned flags = 3u;
+    unsigned xs = 0, gs = 0;
+    if (ld.r < r_end) {
+      const int gx0 = ld.p * 2;
+      flags = ((gx0 < gx_lo || gx0 >= gx_hi) ? 1u : 0u) | ((gx0 + 1 < gx_lo || gx0 + 1 >= gx_hi) ? 2u : 0u);
+      xs = ld.xs + (unsigned)(gx0 * g.in_mul * g.Cin * 4);
+      gs = ld.gs + (unsigned)(gx0 * g.out_mul * cout * 4);
+    }
+    const unsigned inv = (flags & lane_bit) ? 0xFFFFFFFFu : 0u;
+    rinv[slot] = inv;
+    rx[slot] = buf_load1(rs_x, x_voff | (inv & kOob), xs);
+#pragma unroll
+    for (int rn = 0; rn < RN; ++rn) rg[slot][rn] = buf_load1(rs_g, (g_voff + (unsigned)(rn * 128)) | (inv & kOob), gs);
+    if (ld.r < r_end) advance(ld);
   };
-  // Branch-free issue (clamped addresses, masks applied at LDS-store time): see conv_igemm_k.
-  auto load_regs = [&](int step) {
-    const int mb = m_begin + step * KP;
-    rx_ok = 0; rg_ok = 0;
 #pragma unroll
-    for (int j = 0; j < X_LOADS; ++j) {
-      const int m = mb + x_row0 + X_ROWSTEP * j;
-      const int mc = m < m_end ? m : m_begin;
-      unsigned b, gy, gx;
-      decomp(mc, b, gy, gx);
-      const int iy = (int)gy * g.in_mul + dy, ix = (int)gx * g.in_mul + dx;
-      const bool ok = m < m_end && iy >= 0 && iy < g.IH && ix >= 0 && ix < g.IW;
-      const long off = ok ? ((((long)b * g.IH + iy) * g.IW + ix) * g.Cin) : 0l;
-      rx[j] = *reinterpret_cast<const float4*>(op.in + off + k0 + x_col4 * 4);
-      rx_ok |= (ok ? 1u : 0u) << j;
-    }
+  for (int s = 0; s < DEPTH; ++s) issue(s);
+  for (int done = 0; done < todo; done += DEPTH) {
 #pragma unroll
-    for (int j = 0; j < G_LOADS; ++j) {
-      const int m = mb + g_row0 + 16 * j;
-      const bool ok = m < m_end && g_col_ok;
-      const int mc = m < m_end ? m : m_begin;
-      unsigned b, gy, gx;
-      decomp(mc, b, gy, gx);
-      const long pix = ((long)b * g.OH + (gy * g.out_mul + oyc)) * g.OW + (gx * g.out_mul + oxc);
-      const long off = ok ? (pix * cout + n0 + g_col4 * 4) : 0l;
-      rg[j] = *reinterpret_cast<const float4*>(gout + off);
-      rg_ok |= (ok ? 1u : 0u) << j;
-    }
-  };
-  auto store_lds = [&](int buf) {
+    for (int s = 0; s < DEPTH; ++s) {
+      float xv = rx[s];
+      if (pro) { xv = fmaxf(fmaf(xv, psc, psh), 0.f); if (rinv[s]) xv = 0.f; }
+      float gv[RN];
 #pragma unroll
-    for (int j = 0; j < X_LOADS; ++j) {
-      float4 v = rx[j];
-      if (pro) {
-        v.x = fmaxf(fmaf(v.x, sc.x, sh.x), 0.f); v.y = fmaxf(fmaf(v.y, sc.y, sh.y), 0.f);
-        v.z = fmaxf(fmaf(v.z, sc.z, sh.z), 0.f); v.w = fmaxf(fmaf(v.w, sc.w, sh.w), 0.f);
-      }
-      if (!((rx_ok >> j) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
-      *reinterpret_cast<float4*>(sX + buf * X_TILE + (x_row0 + X_ROWSTEP * j) * TI + x_col4 * 4) = v;
-    }
+      for (int rn = 0; rn < RN; ++rn) gv[rn] = rg[s][rn];
+      issue(s);                                   // refill this slot for the pair DEPTH ahead
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int j = 0; j < G_LOADS; ++j) {
-      float4 v = rg[j];
-      if (!((rg_ok >> j) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
-      *reinterpret_cast<float4*>(sG + buf * G_TILE + (g_row0 + 16 * j) * 64 + g_col4 * 4) = v;
+      for (int rn = 0; rn < RN; ++rn) acc[rn] = __builtin_amdgcn_mfma_f32_32x32x2f32(xv, gv[rn], acc[rn], 0, 0, 0);
     }
-  };
-
-  if (n_steps > 0) { load_regs(0); store_lds(0); }
-  __syncthreads();
-  for (int st = 0; st < n_steps; ++st) {
-    const int buf = st & 1;
-    if (st + 1 < n_steps) load_regs(st + 1);
-    const float* cX = sX + buf * X_TILE;
-    const float* cG = sG + buf * G_TILE;
-    if (wactive) {
-#pragma unroll
-    for (int kk = 0; kk < KP / 2; ++kk) {
-      const float av = cX[(kk * 2 + lh) * TI + wm * 32 + li];
-#pragma unroll
-      for (int rn = 0; rn < RN; ++rn) {
-        const float bv = cG[(kk * 2 + lh) * 64 + (wn * RN + rn) * 32 + li];
-        acc[rn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[rn], 0, 0, 0);
-      }
-    }
-    }
-    if (st + 1 < n_steps) store_lds(buf ^ 1);
-    __syncthreads();
   }
 
-  // epilogue: rows i = input channel; regs 4*rg..4*rg+3 are 4 consecutive channels -> one float4
-  if (!wactive) return;
+  // ---- deterministic cross-wave sum through LDS: wave 0 += wave 1, 2, 3 ----
+  if (wave > 0) {
+    float* d = smem + (size_t)(wave - 1) * RN * 16 * 64;
+#pragma unroll
+    for (int rn = 0; rn < RN; ++rn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) d[(rn * 16 + r) * 64 + lane] = acc[rn][r];
+  }
+  __syncthreads();
+  if (wave != 0) return;
+#pragma unroll
+  for (int w = 0; w < 3; ++w) {
+    const float* d = smem + (size_t)w * RN * 16 * 64;
+#pragma unroll
+    for (int rn = 0; rn < RN; ++rn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[rn][r] += d[(rn * 16 + r) * 64 + lane];
+  }
+  // rows i = input channel; regs 4*rg..4*rg+3 are 4 consecutive channels -> one float4 of the packed layout
   const int k4_total = g.Cin >> 2;
   float* base = dw + ((long)(split * n_widx + tap.widx) * k4_total) * npad * 4;
 #pragma unroll
   for (int rn = 0; rn < RN; ++rn) {
-    const int n = n0 + (wn * RN + rn) * 32 + li;
+    const int n = n0 + rn * 32 + li;
 #pragma unroll
     for (int rgp = 0; rgp < 4; ++rgp) {
-      const int k4 = (k0 + wm * 32) / 4 + 2 * rgp + lh;
+      const int k4 = k0 / 4 + 2 * rgp + lh;
       const float4 v = make_float4(acc[rn][4 * rgp], acc[rn][4 * rgp + 1], acc[rn][4 * rgp + 2], acc[rn][4 * rgp + 3]);
       *reinterpret_cast<float4*>(base + ((long)k4 * npad + n) * 4) = v;
     }
@@ -608,27 +605,29 @@ extern "C" int mpose_conv_fwd(const mpose_conv_geom* geom, const mpose_conv_oper
   a.div_gw = make_fastdiv((unsigned)geom->GW);
   a.div_ghw = make_fastdiv((unsigned)(geom->GH * geom->GW));
   a.flags = flags;
-#ifdef MPOSE_ABLATE
-  if (getenv("MPOSE_ABLATE")) a.flags |= atoi(getenv("MPOSE_ABLATE")) << 8;
-#endif
+  {
+    long min_shift = 0;
+    for (int c = 0; c < geom->n_classes; ++c)
+      for (int t = 0; t < geom->cls[c].n_taps; ++t) {
+        const long sft = ((long)geom->cls[c].taps[t].dy * geom->IW + geom->cls[c].taps[t].dx) * geom->Cin * 4;
+        if (sft < min_shift) min_shift = sft;
+      }
+    a.in_bias = (int)(-min_shift);
+    const long in_bytes = (long)geom->B * geom->IH * geom->IW * geom->Cin * 4;
+    if (in_bytes + a.in_bias >= 0xFFFFFF00l - (1l << 20)) return MPOSE_EINVAL;       // 32-bit buffer offsets
+  }
   hipStream_t s = (hipStream_t)stream;
   const int npad = geom->Npad0;
-  // Tile selection: 128x64 when there is enough work to fill 256 CUs, else 64x64; N = 32 tiles for the
-  // 17(->32)-channel layers.
   const int cmax = (acc1 && geom->Cout1 > geom->Cout0) ? geom->Cout1 : geom->Cout0;
   if (cmax > npad) return MPOSE_EINVAL;
-  if (cmax <= 32) {
-    a.n_mtiles = (a.M + 127) / 128;
-    return acc1 ? launch_conv<4, 1, 1, 1, true>(a, n_groups, s) : launch_conv<4, 1, 1, 1, false>(a, n_groups, s);
-  }
+  a.n_mtiles = (a.M + 127) / 128;
+  if (cmax <= 32) return acc1 ? launch_conv<1, true>(a, n_groups, s) : launch_conv<1, false>(a, n_groups, s);
   if (npad % 64) return MPOSE_EINVAL;
-  const long blocks128 = (long)((a.M + 127) / 128) * geom->n_classes * ((cmax + 63) / 64) * n_groups;
-  if (blocks128 >= 1024) {
-    a.n_mtiles = (a.M + 127) / 128;
-    return acc1 ? launch_conv<4, 1, 1, 2, true>(a, n_groups, s) : launch_conv<4, 1, 1, 2, false>(a, n_groups, s);
-  }
-  a.n_mtiles = (a.M + 63) / 64;
-  return acc1 ? launch_conv<2, 2, 1, 1, true>(a, n_groups, s) : launch_conv<2, 2, 1, 1, false>(a, n_groups, s);
+  if (acc1) return launch_conv<2, true>(a, n_groups, s);
+  // widest wave tile that divides the padded N: 128 channels (RN=4), 96 (RN=3) or 64 (RN=2)
+  if (cmax % 128 == 0) return launch_conv<4, false>(a, n_groups, s);
+  if (cmax % 96 == 0 && npad % 96 == 0) return launch_conv<3, false>(a, n_groups, s);
+  return launch_conv<2, false>(a, n_groups, s);
 }
 
 extern "C" int mpose_conv_wgrad(const mpose_conv_geom* geom, const mpose_wgrad_operands* ops, int n_groups, int n_split,
@@ -636,11 +635,12 @@ extern "C" int mpose_conv_wgrad(const mpose_conv_geom* geom, const mpose_wgrad_o
   int rc = check_geom(geom);
   if (rc) return rc;
   if (n_groups < 1 || n_groups > MPOSE_MAX_GROUP || n_split < 1) return MPOSE_EINVAL;
-  if ((geom->Npad0 % 64) || (geom->Cout0 % 4)) return MPOSE_EINVAL;
+  if ((geom->Npad0 % 64) || (geom->Cout0 % 32) || (geom->GW & 1)) return MPOSE_EINVAL;
   WgradArgs a{};
   a.g = *geom;
   bool acc1 = false;
   int max0 = -1, max1 = -1;
+  long min_shift = 0;
   for (int c = 0; c < geom->n_classes; ++c)
     for (int t = 0; t < geom->cls[c].n_taps; ++t) {
       const mpose_tap& tp = geom->cls[c].taps[t];
@@ -649,35 +649,40 @@ extern "C" int mpose_conv_wgrad(const mpose_conv_geom* geom, const mpose_wgrad_o
       ++a.n_entries;
       if (tp.acc) { acc1 = true; if (tp.widx > max1) max1 = tp.widx; }
       else if (tp.widx > max0) max0 = tp.widx;
+      const long sft = ((long)tp.dy * geom->IW + tp.dx) * geom->Cin * 4;
+      if (sft < min_shift) min_shift = sft;
     }
   a.n_widx0 = max0 + 1;
   a.n_widx1 = max1 + 1;
-  if (acc1 && ((geom->Npad1 % 64) || (geom->Cout1 % 4) || geom->Npad1 != geom->Npad0)) return MPOSE_EINVAL;
+  a.in_bias = (int)(-min_shift) + geom->Cin * 4;      // + one pixel: a pair may start one column left of the row
+  if (acc1 && ((geom->Npad1 % 64) || (geom->Cout1 % 32) || geom->Npad1 != geom->Npad0 || geom->Cout1 != geom->Cout0)) return MPOSE_EINVAL;
   for (int i = 0; i < n_groups; ++i) {
     a.op[i] = ops[i];
     if (!ops[i].in || !ops[i].gout0 || !ops[i].dw0) return MPOSE_EINVAL;
     if (acc1 && (!ops[i].gout1 || !ops[i].dw1)) return MPOSE_EINVAL;
   }
-  a.M = geom->B * geom->GH * geom->GW;
-  if (a.M == 0 || a.n_entries == 0) return 0;
-  a.div_gw = make_fastdiv((unsigned)geom->GW);
-  a.div_ghw = make_fastdiv((unsigned)(geom->GH * geom->GW));
+  const int n_rows = geom->B * geom->GH;
+  if (n_rows == 0 || a.n_entries == 0) return 0;
+  const long in_bytes = (long)geom->B * geom->IH * geom->IW * geom->Cin * 4;
+  const long g_bytes = (long)geom->B * geom->OH * geom->OW * geom->Cout0 * 4;
+  if (in_bytes + a.in_bias >= 0xFFFFFF00l - (1l << 20) || g_bytes >= 0xFFFFFF00l - (1l << 20)) return MPOSE_EINVAL;
+  a.div_gh = make_fastdiv((unsigned)geom->GH);
   a.n_split = n_split;
-  a.slots_per_split = ((a.M + n_split - 1) / n_split + KP - 1) / KP * KP;
+  a.rows_per_split = (n_rows + n_split - 1) / n_split;
   hipStream_t s = (hipStream_t)stream;
-  const int n_ctiles = geom->Npad0 / 64;
-  if (geom->Cin % 128 == 0) {
-    dim3 grid(a.n_entries * n_split, (geom->Cin / 128) * n_ctiles, n_groups);
-    const int lds = (2 * KP * 128 + 2 * KP * 64) * 4;
-    conv_wgrad_k<128><<<grid, 256, lds, s>>>(a);
-  } else if (geom->Cin % 64 == 0) {
-    dim3 grid(a.n_entries * n_split, (geom->Cin / 64) * n_ctiles, n_groups);
-    const int lds = (2 * KP * 64 + 2 * KP * 64) * 4;
-    conv_wgrad_k<64><<<grid, 256, lds, s>>>(a);
+  const int cout = geom->Cout0;
+  if (cout % 128 == 0) {
+    dim3 grid(a.n_entries * n_split, (geom->Cin / 32) * (cout / 128), n_groups);
+    conv_wgrad_k<4><<<grid, 256, 3 * 4 * 16 * 64 * 4, s>>>(a);
+  } else if (cout % 96 == 0) {
+    dim3 grid(a.n_entries * n_split, (geom->Cin / 32) * (cout / 96), n_groups);
+    conv_wgrad_k<3><<<grid, 256, 3 * 3 * 16 * 64 * 4, s>>>(a);
+  } else if (cout % 64 == 0) {
+    dim3 grid(a.n_entries * n_split, (geom->Cin / 32) * (cout / 64), n_groups);
+    conv_wgrad_k<2><<<grid, 256, 3 * 2 * 16 * 64 * 4, s>>>(a);
   } else {
-    dim3 grid(a.n_entries * n_split, (geom->Cin / 32) * n_ctiles, n_groups);
-    const int lds = (2 * KP * 32 + 2 * KP * 64) * 4;
-    conv_wgrad_k<32><<<grid, 256, lds, s>>>(a);
+    dim3 grid(a.n_entries * n_split, (geom->Cin / 32) * (cout / 32), n_groups);
+    conv_wgrad_k<1><<<grid, 256, 3 * 1 * 16 * 64 * 4, s>>>(a);
   }
   return launch_status();
 }
