@@ -83,11 +83,19 @@ __device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t rsrc, unsigne
   return make_float4(__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w));
 }
 
+__device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
+  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)voff, (int)soff, 0));
+}
+
 constexpr unsigned kOob = 0xFFFFFFF0u;      // voffset that the buffer unit treats as out of range -> returns 0
 
-template <int RN, bool ACC1>
-__global__ __launch_bounds__(256, 2) void conv_igemm_k(ConvArgs a) {
-  constexpr int BM = 128;
+// KS = 2 (split-K inside the workgroup): waves (2t, 2t+1) share output rows t and take half of the (chunk, tap)
+// tiles each; used when a launch would otherwise put fewer than ~2.5 waves on a SIMD (the 16x16 layers at
+// batch 32 give 1.5: every SIMD would wait for the ones that got two).  The halves are summed through the
+// (by then dead) A-tile LDS region in a fixed order.
+template <int RN, bool ACC1, int KS>
+__global__ __launch_bounds__(256, (RN == 4 && KS == 2) ? 1 : 2) void conv_igemm_k(ConvArgs a) {
+  constexpr int BM = 128 / KS;
   constexpr int BN = 32 * RN;
   constexpr int A_TILE = 32 * A_STRIDE;      // floats per wave per buffer
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -99,7 +107,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_k(ConvArgs a) {
   const int li = lane & 31, lh = lane >> 5;
   const mpose_conv_geom& g = a.g;
   const int cls = blockIdx.x / a.n_mtiles;
-  const int m0 = (blockIdx.x - cls * a.n_mtiles) * BM + wave * 32;     // first row of THIS wave
+  const int kh = (KS == 2) ? (wave & 1) : 0;                              // K half of this wave
+  const int m0 = (blockIdx.x - cls * a.n_mtiles) * BM + (KS == 2 ? (wave >> 1) : wave) * 32;   // first row of THIS wave
   const int n0 = blockIdx.y * BN;
   const mpose_conv_operands& op = a.op[blockIdx.z];
   const int n_taps = g.cls[cls].n_taps;
@@ -210,18 +219,20 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_k(ConvArgs a) {
     __builtin_amdgcn_wave_barrier();     // compiler ordering only; LDS executes one wave's ops in order
   };
 
-  if (n_iter > 0) {
-    TileInfo t0 = tile_info(0);
+  const int it_begin = (KS == 2 && kh) ? (n_iter >> 1) : 0;
+  const int it_end = (KS == 2 && !kh) ? (n_iter >> 1) : n_iter;
+  if (it_begin < it_end) {
+    TileInfo t0 = tile_info(it_begin);
     load_a(t0);
     load_b(t0, 0, fb[0]);
     load_b(t0, 1, fb[1]);
     load_b(t0, 2, fb[2]);
-    store_a(0);
+    store_a(it_begin & 1);
   }
-  for (int it = 0; it < n_iter; ++it) {
+  for (int it = it_begin; it < it_end; ++it) {
     const int buf = it & 1;
     const TileInfo cur = tile_info(it);
-    const TileInfo nxt = tile_info(it + 1 < n_iter ? it + 1 : it);     // the last prefetch is a harmless repeat
+    const TileInfo nxt = tile_info(it + 1 < it_end ? it + 1 : it);     // the last prefetch is a harmless repeat
     load_a(nxt);
     __builtin_amdgcn_sched_barrier(0);
     const float* cA = sA + buf * A_TILE + li * A_STRIDE + lh * 4;
@@ -264,8 +275,46 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_k(ConvArgs a) {
     store_a(buf ^ 1);
   }
 
-  // ---- epilogue ----
+  // ---- split-K exchange: odd waves hand their partial tiles to their even partner through LDS ----
+  if (KS == 2) {
+    __syncthreads();                                   // every wave is done with its A tiles
+    float* ex = sA_all + (size_t)(wave >> 1) * (ACC1 ? 2 : 1) * RN * 16 * 64;
+    if (kh) {
+#pragma unroll
+      for (int rn = 0; rn < RN; ++rn)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          ex[(rn * 16 + r) * 64 + lane] = acc0[rn][r];
+          if (ACC1) ex[((RN + rn) * 16 + r) * 64 + lane] = acc1[rn][r];
+        }
+    }
+    __syncthreads();
+    if (!kh) {
+#pragma unroll
+      for (int rn = 0; rn < RN; ++rn)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          acc0[rn][r] += ex[(rn * 16 + r) * 64 + lane];
+          if (ACC1) acc1[rn][r] += ex[((RN + rn) * 16 + r) * 64 + lane];
+        }
+    }
+  }
+  const bool writer = (KS == 1) || !kh;
+
+  // ---- epilogue (branch-free: buffer stores/loads, rows beyond M get an out-of-range offset and are dropped) ----
   const int oyc = g.cls[cls].oy, oxc = g.cls[cls].ox;
+  unsigned row_pix[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const unsigned m = (unsigned)(m0 + acc_row(r, lh));
+    const unsigned mm = (int)m < a.M ? m : 0u;
+    const unsigned b = fdiv(mm, a.div_ghw);
+    const unsigned rem = mm - b * (unsigned)(g.GH * g.GW);
+    const unsigned gy = fdiv(rem, a.div_gw);
+    const unsigned gx = rem - gy * (unsigned)g.GW;
+    const unsigned pix = (b * (unsigned)g.OH + (gy * g.out_mul + oyc)) * (unsigned)g.OW + (gx * g.out_mul + oxc);
+    row_pix[r] = ((int)m < a.M && writer) ? pix : 0xFFFFFFFFu;
+  }
 #pragma unroll
   for (int set = 0; set < (ACC1 ? 2 : 1); ++set) {
     float* outp = set ? op.out1 : op.out0;
@@ -273,48 +322,53 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_k(ConvArgs a) {
     double* stats = set ? op.stats1 : op.stats0;
     const bool masked = (set == 0) && op.mask_src != nullptr;
     const bool accumulate = (set == 0) && (a.flags & 1);
-    float csum[RN], csq[RN];
+    const unsigned out_bytes = (unsigned)((long)g.B * g.OH * g.OW * cout * 4);
+    const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(outp, 0, out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_m = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(masked ? op.mask_src : outp), 0, out_bytes, 0x00020000);
 #pragma unroll
-    for (int rn = 0; rn < RN; ++rn) { csum[rn] = 0.f; csq[rn] = 0.f; }
+    for (int rn = 0; rn < RN; ++rn) {
+      const int nb = n0 + rn * 32;                 // wave-uniform: the whole 32-column group is in or out (cout % 32 == 0)
+      float csum = 0.f, csq = 0.f;
+      if (nb < cout) {
+        const int n = nb + li;
+        unsigned voff[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const unsigned m = (unsigned)(m0 + acc_row(r, lh));
-      const bool row_ok = (int)m < a.M;
-      long pix = 0;
-      if (row_ok) {
-        const unsigned b = fdiv(m, a.div_ghw);
-        const unsigned rem = m - b * (unsigned)(g.GH * g.GW);
-        const unsigned gy = fdiv(rem, a.div_gw);
-        const unsigned gx = rem - gy * (unsigned)g.GW;
-        pix = ((long)b * g.OH + (gy * g.out_mul + oyc)) * g.OW + (gx * g.out_mul + oxc);
-      }
+        for (int r = 0; r < 16; ++r) voff[r] = row_pix[r] == 0xFFFFFFFFu ? kOob : (row_pix[r] * (unsigned)cout + (unsigned)n) * 4u;
+        float v[16];
 #pragma unroll
-      for (int rn = 0; rn < RN; ++rn) {
-        const int n = n0 + rn * 32 + li;
-        float v = (ACC1 && set) ? acc1[rn][r] : acc0[rn][r];
-        if (row_ok && n < cout) {
-          const long o = pix * cout + n;
-          float second_factor = v;
-          if (masked) {
-            const float src = op.mask_src[o];
-            if (!(fmaf(src, op.mask_scale[n], op.mask_shift[n]) > 0.f)) v = 0.f;
-            second_factor = src;
+        for (int r = 0; r < 16; ++r) v[r] = (ACC1 && set) ? acc1[rn][r] : acc0[rn][r];
+        if (masked) {
+          const float msc = op.mask_scale[n], msh = op.mask_shift[n];
+          float src[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) src[r] = buf_load1(rs_m, voff[r], 0);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            if (!(fmaf(src[r], msc, msh) > 0.f)) v[r] = 0.f;
+            csq = fmaf(v[r], src[r], csq);
           }
-          if (accumulate) v += outp[o];
-          outp[o] = v;
-          csum[rn] += v;
-          csq[rn] = fmaf(v, second_factor, csq[rn]);
+        }
+        if (accumulate) {
+          float old[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) old[r] = buf_load1(rs_o, voff[r], 0);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] += old[r];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[r]), rs_o, (int)voff[r], 0, 0);
+          const float vv = (voff[r] == kOob) ? 0.f : v[r];
+          csum += vv;
+          if (!masked) csq = fmaf(vv, vv, csq);
         }
       }
-    }
-    if (stats != nullptr) {
-#pragma unroll
-      for (int rn = 0; rn < RN; ++rn) {
-        csum[rn] += __shfl_xor(csum[rn], 32, 64);
-        csq[rn] += __shfl_xor(csq[rn], 32, 64);
+      if (stats != nullptr) {
+        csum += __shfl_xor(csum, 32, 64);
+        csq += __shfl_xor(csq, 32, 64);
         if (lh == 0) {
           float* d = sRed + ((set * 4 + wave) * BN + rn * 32 + li) * 2;
-          d[0] = csum[rn]; d[1] = csq[rn];
+          d[0] = csum; d[1] = csq;
         }
       }
     }
@@ -340,14 +394,23 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_k(ConvArgs a) {
   }
 }
 
-template <int RN, bool ACC1>
-int launch_conv(const ConvArgs& a, int n_groups, hipStream_t s) {
+template <int RN, bool ACC1, int KS>
+int launch_conv(const ConvArgs& a0, int n_groups, hipStream_t s) {
   constexpr int BN = 32 * RN;
+  ConvArgs a = a0;
+  a.n_mtiles = (a.M + 128 / KS - 1) / (128 / KS);
   const int lds = (16 + 4 * 2 * 32 * A_STRIDE + 2 * 4 * BN * 2) * 4;
   const int cmax = a.g.Cout1 > a.g.Cout0 ? a.g.Cout1 : a.g.Cout0;
   dim3 grid(a.n_mtiles * a.g.n_classes, (cmax + BN - 1) / BN, n_groups);
-  conv_igemm_k<RN, ACC1><<<grid, 256, lds, s>>>(a);
+  conv_igemm_k<RN, ACC1, KS><<<grid, 256, lds, s>>>(a);
   return launch_status();
+}
+
+// waves per SIMD of a launch without split-K (1024 SIMDs)
+template <int RN>
+inline bool want_ksplit(const ConvArgs& a, int cmax, int n_groups) {
+  const long waves = (long)((a.M + 31) / 32) * a.g.n_classes * ((cmax + 32 * RN - 1) / (32 * RN)) * n_groups;
+  return waves < 2560;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -374,14 +437,10 @@ struct WgradArgs {
   int in_bias;                    // bytes, as in ConvArgs
 };
 
-__device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
-  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)voff, (int)soff, 0));
-}
-
 template <int RN>   // wave tile: 32 input channels x 32*RN output channels
 __global__ __launch_bounds__(256, 2) void conv_wgrad_k(WgradArgs a) {
   constexpr int DEPTH = 8;                     // pixel pairs in flight (RN*64 MFMA cycles each)
-  extern __shared__ __attribute__((aligned(16))) float smem[];     // [3 waves][RN*16][64] reduction scratch
+  extern __shared__ __attribute__((aligned(16))) float smem[];     // [RN*16][64] reduction scratch
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lh = lane >> 5;
   const mpose_conv_geom& g = a.g;
@@ -499,24 +558,25 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_k(WgradArgs a) {
     }
   }
 
-  // ---- deterministic cross-wave sum through LDS: wave 0 += wave 1, 2, 3 ----
-  if (wave > 0) {
-    float* d = smem + (size_t)(wave - 1) * RN * 16 * 64;
+  // ---- deterministic cross-wave sum through LDS: wave 0 += wave 1, then 2, then 3 (one tile of scratch, so
+  //      LDS never limits residency: the register budget allows 4 workgroups per CU) ----
+  for (int w = 1; w < 4; ++w) {
+    if (wave == w) {
 #pragma unroll
-    for (int rn = 0; rn < RN; ++rn)
+      for (int rn = 0; rn < RN; ++rn)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) d[(rn * 16 + r) * 64 + lane] = acc[rn][r];
+        for (int r = 0; r < 16; ++r) smem[(rn * 16 + r) * 64 + lane] = acc[rn][r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int rn = 0; rn < RN; ++rn)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[rn][r] += smem[(rn * 16 + r) * 64 + lane];
+    }
+    __syncthreads();
   }
-  __syncthreads();
   if (wave != 0) return;
-#pragma unroll
-  for (int w = 0; w < 3; ++w) {
-    const float* d = smem + (size_t)w * RN * 16 * 64;
-#pragma unroll
-    for (int rn = 0; rn < RN; ++rn)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[rn][r] += d[(rn * 16 + r) * 64 + lane];
-  }
   // rows i = input channel; regs 4*rg..4*rg+3 are 4 consecutive channels -> one float4 of the packed layout
   const int k4_total = g.Cin >> 2;
   float* base = dw + ((long)(split * n_widx + tap.widx) * k4_total) * npad * 4;
@@ -620,14 +680,17 @@ extern "C" int mpose_conv_fwd(const mpose_conv_geom* geom, const mpose_conv_oper
   const int npad = geom->Npad0;
   const int cmax = (acc1 && geom->Cout1 > geom->Cout0) ? geom->Cout1 : geom->Cout0;
   if (cmax > npad) return MPOSE_EINVAL;
-  a.n_mtiles = (a.M + 127) / 128;
-  if (cmax <= 32) return acc1 ? launch_conv<1, true>(a, n_groups, s) : launch_conv<1, false>(a, n_groups, s);
+  if ((geom->Cout0 % 32) || (acc1 && (geom->Cout1 % 32))) return MPOSE_EINVAL;
+  if ((long)geom->B * geom->OH * geom->OW * cmax * 4 >= 0xFFFFFF00l) return MPOSE_EINVAL;
+  if (cmax <= 32) return acc1 ? launch_conv<1, true, 1>(a, n_groups, s) : launch_conv<1, false, 1>(a, n_groups, s);
   if (npad % 64) return MPOSE_EINVAL;
-  if (acc1) return launch_conv<2, true>(a, n_groups, s);
+  if (acc1) return want_ksplit<2>(a, cmax, n_groups) ? launch_conv<2, true, 2>(a, n_groups, s) : launch_conv<2, true, 1>(a, n_groups, s);
   // widest wave tile that divides the padded N: 128 channels (RN=4), 96 (RN=3) or 64 (RN=2)
-  if (cmax % 128 == 0) return launch_conv<4, false>(a, n_groups, s);
-  if (cmax % 96 == 0 && npad % 96 == 0) return launch_conv<3, false>(a, n_groups, s);
-  return launch_conv<2, false>(a, n_groups, s);
+  if (cmax % 128 == 0)
+    return want_ksplit<4>(a, cmax, n_groups) ? launch_conv<4, false, 2>(a, n_groups, s) : launch_conv<4, false, 1>(a, n_groups, s);
+  if (cmax % 96 == 0 && npad % 96 == 0)
+    return want_ksplit<3>(a, cmax, n_groups) ? launch_conv<3, false, 2>(a, n_groups, s) : launch_conv<3, false, 1>(a, n_groups, s);
+  return want_ksplit<2>(a, cmax, n_groups) ? launch_conv<2, false, 2>(a, n_groups, s) : launch_conv<2, false, 1>(a, n_groups, s);
 }
 
 extern "C" int mpose_conv_wgrad(const mpose_conv_geom* geom, const mpose_wgrad_operands* ops, int n_groups, int n_split,
@@ -673,16 +736,16 @@ extern "C" int mpose_conv_wgrad(const mpose_conv_geom* geom, const mpose_wgrad_o
   const int cout = geom->Cout0;
   if (cout % 128 == 0) {
     dim3 grid(a.n_entries * n_split, (geom->Cin / 32) * (cout / 128), n_groups);
-    conv_wgrad_k<4><<<grid, 256, 3 * 4 * 16 * 64 * 4, s>>>(a);
+    conv_wgrad_k<4><<<grid, 256, 4 * 16 * 64 * 4, s>>>(a);
   } else if (cout % 96 == 0) {
     dim3 grid(a.n_entries * n_split, (geom->Cin / 32) * (cout / 96), n_groups);
-    conv_wgrad_k<3><<<grid, 256, 3 * 3 * 16 * 64 * 4, s>>>(a);
+    conv_wgrad_k<3><<<grid, 256, 3 * 16 * 64 * 4, s>>>(a);
   } else if (cout % 64 == 0) {
     dim3 grid(a.n_entries * n_split, (geom->Cin / 32) * (cout / 64), n_groups);
-    conv_wgrad_k<2><<<grid, 256, 3 * 2 * 16 * 64 * 4, s>>>(a);
+    conv_wgrad_k<2><<<grid, 256, 2 * 16 * 64 * 4, s>>>(a);
   } else {
     dim3 grid(a.n_entries * n_split, (geom->Cin / 32) * (cout / 32), n_groups);
-    conv_wgrad_k<1><<<grid, 256, 3 * 1 * 16 * 64 * 4, s>>>(a);
+    conv_wgrad_k<1><<<grid, 256, 1 * 16 * 64 * 4, s>>>(a);
   }
   return launch_status();
 }

@@ -376,11 +376,11 @@ class Engine:
                     coef_job(cj[base + 3 + c], b.bns, b.bn2, 4, 2, 3, cnt)
                     coef_job(cj[base + 6 + c], b.bn1, b.bn1, 2, 0, 1, cnt)
                     slots_in = B * (hw_in(i) if b.kind == 'up' else hw_out(i)) ** 2
-                    unpack_job(uj[base + 3 * c], b.conv2, self._n_split(cnt))
-                    unpack_job(uj[base + 3 * c + 1], b.conv_in, self._n_split(slots_in))
-                    unpack_job(uj[base + 3 * c + 2], b.conv_sc, self._n_split(slots_in))
+                    unpack_job(uj[base + 3 * c], b.conv2, self._n_split(cnt, self._wg_tiles(b, 'conv2')))
+                    unpack_job(uj[base + 3 * c + 1], b.conv_in, self._n_split(slots_in, self._wg_tiles(b, 'in')))
+                    unpack_job(uj[base + 3 * c + 2], b.conv_sc, self._n_split(slots_in, self._wg_tiles(b, 'in')))
         coef_job(cj[self.T * 90], self.stem_bn, self.stem_bn, 4, 0, 1, B * F * F)
-        unpack_job(uj[self.T * 90], self.stem_conv, self._n_split(B * F * F))
+        unpack_job(uj[self.T * 90], self.stem_conv, self._n_split(B * F * F, 6))
         tb['partials'] = torch.empty(part_off, dtype=torch.float32, device=dev)
         pbase = tb['partials'].data_ptr()
         uj['src'] = pbase + 4 * uj['src']
@@ -675,7 +675,7 @@ class Engine:
                     wo.in_, wo.in_scale, wo.in_shift = sv['c1'][c].data_ptr(), self._bnf_ptr(b.bn1, 0), self._bnf_ptr(b.bn1, 1)
                     wo.gout0, wo.dw0 = d_c2[c].data_ptr(), tb['part_ptr'][id(b.conv2)]
                     wops.append(wo)
-                self.wgrad(self.geom('f_conv2', B, Hout, b0), wops, self._n_split(cnt))
+                self.wgrad(self.geom('f_conv2', B, Hout, b0), wops, self._n_split(cnt, self._wg_tiles(b0, 'conv2')))
                 # (4) BN1 backward
                 run_coef(jb + 6, 3)
                 d_c1 = [torch.empty(B, Hout, Hout, Cs, **f32) for _ in range(3)]
@@ -695,7 +695,7 @@ class Engine:
                     wo.gout0, wo.gout1 = d_c1[c].data_ptr(), d_sc[c].data_ptr()
                     wo.dw0, wo.dw1 = tb['part_ptr'][id(b.conv_in)], tb['part_ptr'][id(b.conv_sc)]
                     wops.append(wo)
-                self.wgrad(self.geom(gname, B, Hin, b0), wops, self._n_split(slots))
+                self.wgrad(self.geom(gname, B, Hin, b0), wops, self._n_split(slots, self._wg_tiles(b0, 'in')))
                 # (6) dgrad of conv_in, then the shortcut's dgrad accumulated on top
                 d_x = [torch.empty(B, Hin, Hin, b0.cin_s, **f32) for _ in range(3)]
                 k3 = {'regular': 'd_in3_regular', 'down': 'd_in3_down', 'up': 'd_in3_up'}[b0.kind]
@@ -749,7 +749,7 @@ class Engine:
             check(L.mpose_bn_bwd_apply((BnBwdApplyOperands * 3)(ao), 1, F * F, B, 128, 0, 0, st()), 'mpose_bn_bwd_apply')
             wo = WgradOperands()
             wo.in_, wo.gout0, wo.dw0 = ctx['s2d'].data_ptr(), d_raw.data_ptr(), tb['part_ptr'][id(self.stem_conv)]
-            self.wgrad(self.geom('f_stem', B, F), [wo], self._n_split(B * F * F))
+            self.wgrad(self.geom('f_stem', B, F), [wo], self._n_split(B * F * F, 6))
             if need_dx:
                 d_s2d = torch.empty_like(ctx['s2d'])
                 op = ConvOperands()
@@ -762,15 +762,23 @@ class Engine:
         return self.gflat, dx
 
     @staticmethod
-    def _n_split(slots):
-        """Split-K factor of the weight-gradient GEMMs: enough workgroups to fill 256 CUs."""
-        if slots >= 32768:
-            return 8
-        if slots >= 8192:
-            return 4
-        if slots >= 2048:
-            return 2
-        return 1
+    def _n_split(slots, tiles=108):
+        """Split-K factor of the weight-gradient GEMMs.  `tiles` = (tap entries) x (Cin/32) x (Cout tiles) of ONE
+        column; the launch has 3 columns.  4 workgroups of 4 waves are resident per CU (1024 slots): pick the
+        split that fills them in a single round without spilling into a second one."""
+        rows = max(1, slots // 32)
+        n = max(1, min(16, 1024 // max(1, 3 * tiles), rows // 4))
+        return n
+
+    @staticmethod
+    def _wg_tiles(blk, which):
+        """Output tiles of one column's weight-gradient launch (see conv_wgrad_k's grid)."""
+        cs = blk.cout_s
+        ctile = 128 if cs % 128 == 0 else (96 if cs % 96 == 0 else (64 if cs % 64 == 0 else 32))
+        n_ct = cs // ctile
+        if which == 'conv2':
+            return 9 * (blk.cout_s // 32) * n_ct
+        return 10 * (blk.cin_s // 32) * n_ct
 
     def grads_from_flat(self, flat):
         out = []

@@ -35,3 +35,16 @@ def test_no_cpu_fallback():
         dsntnn.flat_softmax(torch.zeros(1, 17, 32, 32))
     with pytest.raises(_lib.MposeError):
         dsntnn.dsnt(torch.zeros(1, 17, 32, 32))
+
+
+def test_no_kernel_spills_to_scratch():
+    """Policy: no gfx950 kernel may use scratch memory (a spilled instantiation of the conv kernel once produced
+    wrong results and, in the K loop, spills also force early vmcnt waits)."""
+    import subprocess
+    from margipose_amd import build
+    for src in build.sources():
+        out = subprocess.run([build._hipcc()] + build.HIPCC_FLAGS + ['-Rpass-analysis=kernel-resource-usage', '-c', src, '-o', '/dev/null'],
+                             stdout=subprocess.PIPE, stderr=subprocess.STDOUT).stdout.decode(errors='replace')
+        sizes = [int(x) for x in re.findall(r'ScratchSize \[bytes/lane\]: (\d+)', out)]
+        assert sizes, 'no resource-usage remarks for %s' % src
+        assert max(sizes) == 0, '%s: a kernel spills %d bytes/lane to scratch' % (os.path.basename(src), max(sizes))
