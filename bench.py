@@ -101,6 +101,25 @@ def tail_large_microbench(device):
             'frac': nbytes / sec / 1e9 / PEAK_HBM_GBPS, 'traffic': None, 'note': 'B=2048 fp32 (856 MB/launch, exceeds the 256 MB Infinity Cache)'}
 
 
+def inference_microbench(model, device, size):
+    """BASELINE configs[1]: batch-64 eval-mode forward (fp32), reported next to the training metric."""
+    model.eval()
+    x = torch.randn(64, 3, size, size, device=device)
+    with torch.no_grad():
+        for _ in range(2):
+            model(x)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 5
+        for _ in range(n):
+            model(x)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    model.train()
+    return {'images_per_sec': 64 * n / dt, 'batch': 64, 'ms_per_forward': 1e3 * dt / n, 'dtype': 'f32',
+            'note': 'eval-mode forward (running-stat BatchNorm), heatmaps + coordinates for all stages'}
+
+
 def main():
     args = parse()
     from margipose_amd import dsntnn, parallel
@@ -198,6 +217,8 @@ def main():
         res['kernel_time_breakdown_ms_per_step'] = {k: round(v['total_ms'] / args.steps, 3) for k, v in
                                                     sorted(summ.items(), key=lambda kv: -kv[1]['total_ms'])[:12]}
         res['tail_roofline_large'] = tail_large_microbench(device)
+    if world == 1:
+        res['inference'] = inference_microbench(model, device, args.size)
     if world == 1 and not args.no_cpu_baseline:
         res['cpu_baseline'] = cpu_baseline(args.stages, args.size, args.cpu_batch)
     print(json.dumps(res))

@@ -120,12 +120,15 @@ __global__ __launch_bounds__(64 * MPOSE_MAX_GROUP) void softmax_dsnt_fwd_k(Softm
     float s = 0.0f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      v[i].x = expf(v[i].x - m); v[i].y = expf(v[i].y - m); v[i].z = expf(v[i].z - m); v[i].w = expf(v[i].w - m);
+      // v_exp_f32 (1 ulp on 2^x): the argument scaling costs |x| * 6e-8 relative error, i.e. only probabilities
+      // that are already ~0 lose digits; the dominant entries (x - m ~ 0) are exact to fp32 rounding.
+      v[i].x = __expf(v[i].x - m); v[i].y = __expf(v[i].y - m); v[i].z = __expf(v[i].z - m); v[i].w = __expf(v[i].w - m);
       s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
     }
     s = wave_sum(s);
+    const float rs = 1.0f / s;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) { v[i].x /= s; v[i].y /= s; v[i].z /= s; v[i].w /= s; }
+    for (int i = 0; i < NV; ++i) { v[i].x *= rs; v[i].y *= rs; v[i].z *= rs; v[i].w *= rs; }
   }
   (void)inv;
 
@@ -239,6 +242,14 @@ __global__ __launch_bounds__(64 * MPOSE_MAX_GROUP) void stage_loss_fwd_k(LossArg
     plane_target(plane, t, tx, ty);
     Gauss q;
     if (a.pixelwise) q = make_gauss(g, lane, tx, ty, a.sigma);
+    // when 256 % W == 0 a lane's four columns are the same for every i: their Gaussian factors are hoisted
+    const bool fixed_cols = (256 % g.W) == 0;
+    float gx_fixed[4] = {0.f, 0.f, 0.f, 0.f};
+    if (a.pixelwise && fixed_cols) {
+      const int w0 = (lane * 4) % g.W;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { const float d = cell_coord(w0 + c, g.two_over_w, g.first_w) - q.tx; gx_fixed[c] = __expf(d * d * q.kx); }
+    }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       int h, w0;
@@ -249,14 +260,15 @@ __global__ __launch_bounds__(64 * MPOSE_MAX_GROUP) void stage_loss_fwd_k(LossArg
       const float rs = (pv[0] + pv[1]) + (pv[2] + pv[3]);
       sy = fmaf(rs, y, sy);
       float gy = 0.0f;
-      if (a.pixelwise) { const float d = y - q.ty; gy = expf(d * d * q.ky) * q.inv_norm; }
+      if (a.pixelwise) { const float d = y - q.ty; gy = __expf(d * d * q.ky) * q.inv_norm; }
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const float x = x0 + (float)c * g.two_over_w;
         sx = fmaf(pv[c], x, sx);
         if (a.pixelwise && (i * 64 + lane) < g.n4) {
-          const float d = x - q.tx;
-          js += js_term(pv[c], gy * expf(d * d * q.kx));
+          float gxv = gx_fixed[c];
+          if (!fixed_cols) { const float d = x - q.tx; gxv = __expf(d * d * q.kx); }
+          js += js_term(pv[c], gy * gxv);
         }
       }
     }
@@ -318,6 +330,13 @@ __global__ __launch_bounds__(64 * MPOSE_MAX_GROUP) void stage_loss_bwd_k(LossArg
   plane_target(plane, t, tx, ty);
   Gauss q;
   if (a.pixelwise) q = make_gauss(g, lane, tx, ty, a.sigma);
+  const bool fixed_cols = (256 % g.W) == 0;
+  float gx_fixed[4] = {0.f, 0.f, 0.f, 0.f};
+  if (a.pixelwise && fixed_cols) {
+    const int w0f = (lane * 4) % g.W;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { const float d = cell_coord(w0f + c, g.two_over_w, g.first_w) - q.tx; gx_fixed[c] = __expf(d * d * q.kx); }
+  }
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     int h, w0;
@@ -325,14 +344,18 @@ __global__ __launch_bounds__(64 * MPOSE_MAX_GROUP) void stage_loss_bwd_k(LossArg
     const float y = cell_coord(h, g.two_over_h, g.first_h);
     const float x0 = cell_coord(w0, g.two_over_w, g.first_w);
     float gy = 0.0f;
-    if (a.pixelwise) { const float d = y - q.ty; gy = expf(d * d * q.ky) * q.inv_norm; }
+    if (a.pixelwise) { const float d = y - q.ty; gy = __expf(d * d * q.ky) * q.inv_norm; }
     const float pv[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
     float r[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const float x = x0 + (float)c * g.two_over_w;
       float d = cx * x + cy * y;
-      if (a.pixelwise) { const float dd = x - q.tx; d += js_dp(pv[c], gy * expf(dd * dd * q.kx)); }
+      if (a.pixelwise) {
+        float gxv = gx_fixed[c];
+        if (!fixed_cols) { const float dd = x - q.tx; gxv = __expf(dd * dd * q.kx); }
+        d += js_dp(pv[c], gy * gxv);
+      }
       r[c] = wgt * d;
     }
     if (a.accumulate) { o[i].x += r[0]; o[i].y += r[1]; o[i].z += r[2]; o[i].w += r[3]; }

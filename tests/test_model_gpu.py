@@ -253,3 +253,47 @@ def test_full_config_shapes_and_properties():
         full = m(x[:8])
         half = m(x[:4])
     assert (full[:4] - half).abs().max() < 1e-5
+
+
+@pytest.mark.parametrize('size,T', [(384, 1), (512, 1), (128, 2)])
+def test_other_input_sizes_vs_oracle(size, T):
+    """The model is fully convolutional (384 -> 48x48 heatmaps / mid 24, 512 -> 64x64 / mid 32)."""
+    from margipose_amd import dsntnn
+    from margipose_amd.models import CanonicalSkeletonDesc, MargiPoseModel
+    seed, B = 600 + size, 1 if size > 256 else 2
+    x, target, mask = W.seeded_inputs(seed, B, size)
+    sd = R.calibrate_running_stats(W.make_state_dict(T, seed, torch.float64), x.double(), T)
+    m = MargiPoseModel(CanonicalSkeletonDesc, T, True, 'patch8', 'jsd')
+    m.load_state_dict(OrderedDict((k, v.float() if v.is_floating_point() else v) for k, v in sd.items()), strict=True)
+    m = m.cuda().train()
+    out = m(x.cuda())
+    F = size // 8
+    assert m.xy_heatmaps[-1].shape == (B, 17, F, F)
+    l3 = m.forward_3d_losses(out, target.cuda())
+    loss = dsntnn.average_loss(l3, mask.cuda())
+    loss.backward()
+    params = OrderedDict((k, v.requires_grad_(True)) for k, v in sd.items() if v.is_floating_point() and 'running' not in k)
+    xy, zy, xz = R.inner_forward(sd, x.double(), T, True)
+    ref_l3 = R.forward_3d_losses(xy, zy, xz, target.double())
+    ref_loss = R.average_loss(ref_l3, mask.double())
+    ref_loss.backward()
+    errs = {'coords': rel(out.detach().cpu(), R.heatmaps_to_coords(xy[-1], zy[-1], xz[-1]).detach()),
+            'l3': rel(l3.detach().cpu(), ref_l3.detach()), 'hm_zy': rel(m.zy_heatmaps[-1].detach().cpu(), zy[-1].detach())}
+    report('size%d' % size, errs)
+    gn = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in m.parameters())).cpu())
+    gn_ref = float(torch.sqrt(sum((p.grad ** 2).sum() for p in params.values())))
+    assert abs(gn - gn_ref) / gn_ref < 2e-3, (gn, gn_ref)      # whole-model gradient norm (see grad_noise_gate for why not 1e-4)
+
+
+def test_five_stage_model_runs():
+    """BASELINE configs[4]: 5-stage model (forward/backward plumbing at 256x256; n_stages is a free ctor arg)."""
+    from margipose_amd import dsntnn
+    from margipose_amd.models import CanonicalSkeletonDesc, MargiPoseModel
+    torch.manual_seed(5)
+    m = MargiPoseModel(CanonicalSkeletonDesc, 5, True, 'patch8', 'jsd').cuda().train()
+    x = torch.randn(4, 3, 256, 256, device='cuda')
+    out = m(x)
+    assert len(m.xy_heatmaps) == 5 and out.shape == (4, 17, 3)
+    loss = dsntnn.average_loss(m.forward_3d_losses(out, torch.rand(4, 17, 3, device='cuda') * 2 - 1), torch.ones(4, 17, device='cuda'))
+    loss.backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
