@@ -240,8 +240,43 @@ def gen_model():
     npz('model_T2.npz', seed=seed, **res)
 
 
+# ------------------------------------------------------------------ 1cycle schedule + a short training curve
+def gen_train_curve():
+    from margipose.hyperparam_scheduler import make_1cycle
+    T, seed, B, n_steps = 1, 701, 2, 5
+    x_t, target_t, _ = W.seeded_inputs(seed + 1000, B, dtype=torch.float64)
+    res = {}
+    for dt, tag in ((torch.float64, 'f64'), (torch.float32, 'f32')):
+        model = mm.MargiPoseModel(Skel, T, True, 'patch8', 'jsd').to(dt)
+        model.load_state_dict(W.make_state_dict(T, seed, dt), strict=True)
+        model.train()
+        opt = torch.optim.SGD(model.parameters(), lr=0)
+        sched = make_1cycle(opt, 10, lr_max=0.05, momentum=0.9)
+        x, target = x_t.to(dt), target_t.to(dt)
+        mask = torch.ones(B, 17, dtype=dt)
+        losses, lrs, moms = [], [], []
+        for it in range(n_steps):
+            sched.batch_step()
+            lrs.append(opt.param_groups[0]['lr']); moms.append(opt.param_groups[0]['momentum'])
+            out = model(x)
+            loss = dsntnn.average_loss(model.forward_3d_losses(out, target), mask)
+            opt.zero_grad(); loss.backward(); opt.step()
+            losses.append(float(loss))
+        res['losses_' + tag] = np.array(losses)
+        res['final_coords_' + tag] = t2n(out)
+    res['lr'] = np.array(lrs); res['momentum'] = np.array(moms)
+    # the schedule over a longer horizon (exact host arithmetic)
+    opt = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=0)
+    sched = make_1cycle(opt, 1000, lr_max=1.0, momentum=0.9)
+    lr_long, mom_long = [], []
+    for it in range(1000):
+        sched.batch_step(); lr_long.append(opt.param_groups[0]['lr']); mom_long.append(opt.param_groups[0]['momentum'])
+    res['lr_1000'] = np.array(lr_long); res['momentum_1000'] = np.array(mom_long)
+    npz('train_curve.npz', seed=seed, **res)
+
+
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ['keys', 'tail', 'perm', 'column', 'model']
+    which = sys.argv[1:] or ['keys', 'tail', 'perm', 'column', 'model', 'curve']
     for w in which:
-        {'keys': gen_keys, 'tail': gen_tail, 'perm': gen_perm, 'column': gen_column, 'model': gen_model}[w]()
+        {'keys': gen_keys, 'tail': gen_tail, 'perm': gen_perm, 'column': gen_column, 'model': gen_model, 'curve': gen_train_curve}[w]()
