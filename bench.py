@@ -43,6 +43,8 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--cpu-batch', type=int, default=8)
+    ap.add_argument('--overlap-wgrad', action='store_true', help='weight-gradient GEMMs on a side stream (+2-3 %% step rate; '
+                    'per-kernel durations then include GPU sharing, so the roofline block is less clean)')
     return ap.parse_args()
 
 
@@ -138,6 +140,7 @@ def main():
     model = MargiPoseModel(CanonicalSkeletonDesc, args.stages, True, 'patch8', 'jsd').to(device).train()
     parallel.broadcast_parameters(model)
     parallel.attach(model)
+    model.inner.engine().overlap_wgrad = args.overlap_wgrad
     opt = torch.optim.SGD(model.parameters(), lr=0.01, momentum=0.9)
     g = torch.Generator(device='cpu').manual_seed(12345 + rank)
     B = args.batch
@@ -190,7 +193,7 @@ def main():
         'config': {'workload': 'BASELINE configs[2]: training step, per-GPU batch %d, %d-stage MargiPose, %dx%d input, 17 joints, '
                                '32x32 heatmaps, JS + Euclidean loss, SGD(momentum 0.9)' % (B, args.stages, args.size, args.size),
                    'global_batch': world * B, 'n_stages': args.stages, 'stem': 'patch8 (in-repo deterministic stem; '
-                   'InceptionV4 stem of the reference is third-party and unpinned)', 'parallelism': 'dp%d' % world,
+                   'InceptionV4 stem of the reference is third-party and unpinned)', 'parallelism': 'dp%d' % world, 'overlap_wgrad': bool(args.overlap_wgrad),
                    'final_loss': loss_value},
     }
     if timer is not None:

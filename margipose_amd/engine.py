@@ -224,6 +224,8 @@ class Engine:
         self._tables = {}
         self._arena_key = None
         self.timer = None            # optional KernelTimer (bench.py)
+        self.side_stream = None      # weight-gradient GEMMs run here, off the data-gradient critical path
+        self.overlap_wgrad = False   # opt-in (+2.6 % step rate, but per-kernel timings then include GPU sharing)
         self.dp = None               # optional (process_group, world_size): gradient all-reduce after backward
 
     # ------------------------------------------------------------------ parameters / arenas
@@ -457,6 +459,23 @@ class Engine:
         if t0 is not None:
             self.timer.stop('wgrad:' + g._name, t0, g._flops * len(ops))
 
+    def wgrad_async(self, g, ops, n_split, tensors):
+        """Weight-gradient launch on the side stream: it only feeds the final unpack, so it overlaps the next
+        block's data-gradient chain and the small BatchNorm kernels.  `tensors` are the buffers it reads: their
+        memory must not be recycled by the caching allocator before the side stream is done with them."""
+        if not self.overlap_wgrad:
+            self.wgrad(g, ops, n_split)
+            return
+        main = torch.cuda.current_stream()
+        if self.side_stream is None or self.side_stream.device != main.device:
+            self.side_stream = torch.cuda.Stream(device=main.device)
+        side = self.side_stream
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            self.wgrad(g, ops, n_split)
+        for t in tensors:
+            t.record_stream(side)
+
     def finalize(self, tb, first, n, train):
         base = tb['fin'].data_ptr() + first * BN_DT.itemsize
         check(lib().mpose_bn_finalize(c_void_p(base), n, int(train), ctypes.c_float(BN_EPS), ctypes.c_float(BN_MOMENTUM),
@@ -675,7 +694,8 @@ class Engine:
                     wo.in_, wo.in_scale, wo.in_shift = sv['c1'][c].data_ptr(), self._bnf_ptr(b.bn1, 0), self._bnf_ptr(b.bn1, 1)
                     wo.gout0, wo.dw0 = d_c2[c].data_ptr(), tb['part_ptr'][id(b.conv2)]
                     wops.append(wo)
-                self.wgrad(self.geom('f_conv2', B, Hout, b0), wops, self._n_split(cnt, self._wg_tiles(b0, 'conv2')))
+                self.wgrad_async(self.geom('f_conv2', B, Hout, b0), wops, self._n_split(cnt, self._wg_tiles(b0, 'conv2')),
+                                 sv['c1'] + d_c2)
                 # (4) BN1 backward
                 run_coef(jb + 6, 3)
                 d_c1 = [torch.empty(B, Hout, Hout, Cs, **f32) for _ in range(3)]
@@ -695,7 +715,8 @@ class Engine:
                     wo.gout0, wo.gout1 = d_c1[c].data_ptr(), d_sc[c].data_ptr()
                     wo.dw0, wo.dw1 = tb['part_ptr'][id(b.conv_in)], tb['part_ptr'][id(b.conv_sc)]
                     wops.append(wo)
-                self.wgrad(self.geom(gname, B, Hin, b0), wops, self._n_split(slots, self._wg_tiles(b0, 'in')))
+                self.wgrad_async(self.geom(gname, B, Hin, b0), wops, self._n_split(slots, self._wg_tiles(b0, 'in')),
+                                 list(sv['x']) + d_c1 + d_sc)
                 # (6) dgrad of conv_in, then the shortcut's dgrad accumulated on top
                 d_x = [torch.empty(B, Hin, Hin, b0.cin_s, **f32) for _ in range(3)]
                 k3 = {'regular': 'd_in3_regular', 'down': 'd_in3_down', 'up': 'd_in3_up'}[b0.kind]
@@ -749,7 +770,7 @@ class Engine:
             check(L.mpose_bn_bwd_apply((BnBwdApplyOperands * 3)(ao), 1, F * F, B, 128, 0, 0, st()), 'mpose_bn_bwd_apply')
             wo = WgradOperands()
             wo.in_, wo.gout0, wo.dw0 = ctx['s2d'].data_ptr(), d_raw.data_ptr(), tb['part_ptr'][id(self.stem_conv)]
-            self.wgrad(self.geom('f_stem', B, F), [wo], self._n_split(B * F * F, 6))
+            self.wgrad_async(self.geom('f_stem', B, F), [wo], self._n_split(B * F * F, 6), [ctx['s2d'], d_raw])
             if need_dx:
                 d_s2d = torch.empty_like(ctx['s2d'])
                 op = ConvOperands()
@@ -758,6 +779,8 @@ class Engine:
                 dx = torch.empty(ctx['x_shape'], **f32)
                 check(L.mpose_depth_to_space8(ptr(d_s2d), ptr(dx), B, ctx['x_shape'][2], st()), 'mpose_depth_to_space8')
             # ---- ONE launch turns every packed partial sum into torch-layout gradients ----
+            if self.overlap_wgrad and self.side_stream is not None:
+                torch.cuda.current_stream().wait_stream(self.side_stream)
             check(L.mpose_unpack_wgrads(ptr(tb['unpack']), self.T * 90 + 1, tb['unpack_max'], st()), 'mpose_unpack_wgrads')
         return self.gflat, dx
 

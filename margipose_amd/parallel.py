@@ -18,10 +18,14 @@ def init_from_env(backend=None):
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         if backend is None:
-            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+            backend = os.environ.get('MPOSE_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
+        if os.environ.get('MPOSE_SINGLE_DEVICE'):        # functional testing: several ranks share GPU 0 (gloo only)
+            local_rank = 0
         if backend == 'nccl':
             torch.cuda.set_device(local_rank)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    if os.environ.get('MPOSE_SINGLE_DEVICE'):
+        local_rank = 0
     return rank, world, local_rank
 
 

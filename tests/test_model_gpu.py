@@ -297,3 +297,34 @@ def test_five_stage_model_runs():
     loss = dsntnn.average_loss(m.forward_3d_losses(out, torch.rand(4, 17, 3, device='cuda') * 2 - 1), torch.ones(4, 17, device='cuda'))
     loss.backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
+
+
+def test_overlap_wgrad_matches_serial():
+    """Side-stream weight gradients (opt-in) give bit-identical gradients to the serial schedule."""
+    from margipose_amd import dsntnn
+    T, seed, B = 1, 91, 4
+    x, target, mask = W.seeded_inputs(seed, B)
+    m = build(T, seed, x).train()
+    def run(overlap):
+        m.inner.engine().overlap_wgrad = overlap
+        m.zero_grad(set_to_none=True)
+        loss = dsntnn.average_loss(m.forward_3d_losses(m(x.cuda()), target.cuda()), mask.cuda())
+        loss.backward()
+        torch.cuda.synchronize()
+        return [p.grad.clone() for p in m.parameters()]
+    a = run(False)
+    b = run(True)
+    c = run(True)
+    assert all(torch.equal(u, v) for u, v in zip(a, b)) and all(torch.equal(u, v) for u, v in zip(b, c))
+
+
+def test_data_parallel_two_ranks_share_one_gpu():
+    """tools/dp_check.py under torch.distributed.run: 2 ranks on cuda:0 over gloo (RCCL needs distinct devices);
+    averaged gradients must equal the mean of the shards' gradients."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MPOSE_DIST_BACKEND='gloo', MPOSE_SINGLE_DEVICE='1')
+    out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+                          '127.0.0.1', '--master-port', str(29600 + os.getpid() % 300), os.path.join(root, 'tools', 'dp_check.py')],
+                         env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600).stdout.decode(errors='replace')
+    assert 'DP_CHECK_OK' in out, out[-2000:]
