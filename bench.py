@@ -40,6 +40,8 @@ def parse():
     ap.add_argument('--batch', type=int, default=32, help='per-GPU batch (weak scaling)')
     ap.add_argument('--stages', type=int, default=3)
     ap.add_argument('--size', type=int, default=256)
+    ap.add_argument('--stem', default='inceptionv4', choices=['patch8', 'inceptionv4'],
+                    help="'inceptionv4' = the reference's default feature extractor; 'patch8' = the light in-repo stem")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--cpu-batch', type=int, default=8)
@@ -48,13 +50,13 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(stages, size, cpu_batch):
+def cpu_baseline(stages, size, cpu_batch, stem='inceptionv4'):
     """The oracle's training step on the host CPU (bounded sample)."""
     from collections import OrderedDict
     from oracle import model_ref as R
     from oracle import weights as W
     threads = torch.get_num_threads()
-    sd = W.make_state_dict(stages, 12345)
+    sd = W.make_state_dict(stages, 12345, stem=stem)
     params = OrderedDict((k, v.requires_grad_(True)) for k, v in sd.items() if v.is_floating_point() and 'running' not in k)
     x, target, mask = W.seeded_inputs(12345, cpu_batch, size)
 
@@ -73,7 +75,7 @@ def cpu_baseline(stages, size, cpu_batch):
             break
     return {'value': cpu_batch * n / dt, 'unit': 'images/sec', 'cores': threads, 'kind': 'port',
             'sample': '%d timed fwd+loss+bwd steps of batch %d (T=%d, %dx%d, fp32) with oracle/model_ref.py on torch CPU, '
-                      '%d threads' % (n, cpu_batch, stages, size, size, threads)}
+                      '%d threads, %s stem' % (n, cpu_batch, stages, size, size, threads, stem)}
 
 
 def tail_large_microbench(device):
@@ -137,7 +139,7 @@ def main():
     torch.cuda.set_device(device)
 
     torch.manual_seed(12345)                # the seed the reference's eval/infer use (bin/eval_3d.py:123)
-    model = MargiPoseModel(CanonicalSkeletonDesc, args.stages, True, 'patch8', 'jsd').to(device).train()
+    model = MargiPoseModel(CanonicalSkeletonDesc, args.stages, True, args.stem, 'jsd').to(device).train()
     parallel.broadcast_parameters(model)
     parallel.attach(model)
     model.inner.engine().overlap_wgrad = args.overlap_wgrad
@@ -192,8 +194,10 @@ def main():
         'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': 'BASELINE configs[2]: training step, per-GPU batch %d, %d-stage MargiPose, %dx%d input, 17 joints, '
                                '32x32 heatmaps, JS + Euclidean loss, SGD(momentum 0.9)' % (B, args.stages, args.size, args.size),
-                   'global_batch': world * B, 'n_stages': args.stages, 'stem': 'patch8 (in-repo deterministic stem; '
-                   'InceptionV4 stem of the reference is third-party and unpinned)', 'parallelism': 'dp%d' % world, 'overlap_wgrad': bool(args.overlap_wgrad),
+                   'global_batch': world * B, 'n_stages': args.stages,
+                   'stem': ('inceptionv4 (reference default; restated from SURVEY Appendix B, third-party original unavailable: '
+                            'unpinned, random init)' if args.stem == 'inceptionv4' else
+                            'patch8 (in-repo deterministic stem; the InceptionV4 stem is available with --stem inceptionv4)'), 'parallelism': 'dp%d' % world, 'overlap_wgrad': bool(args.overlap_wgrad),
                    'final_loss': loss_value},
     }
     if timer is not None:
@@ -223,7 +227,7 @@ def main():
     if world == 1:
         res['inference'] = inference_microbench(model, device, args.size)
     if world == 1 and not args.no_cpu_baseline:
-        res['cpu_baseline'] = cpu_baseline(args.stages, args.size, args.cpu_batch)
+        res['cpu_baseline'] = cpu_baseline(args.stages, args.size, args.cpu_batch, args.stem)
     print(json.dumps(res))
     if world > 1:
         torch.distributed.barrier()

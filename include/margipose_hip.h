@@ -120,6 +120,8 @@ typedef struct {
   int in_mul, out_mul;                 /* 1 or 2 */
   int n_classes;
   int Npad0, Npad1;                    /* padded N of the packed weights for acc 0 / acc 1 */
+  int in_ld;                           /* pixel stride (floats) of the input tensor, 0 = Cin (dense); a larger value */
+  int out_ld0, out_ld1;                /*   reads/writes a channel slice of a wider (concatenated) NHWC tensor       */
   mpose_tap_class cls[MPOSE_MAX_CLASSES];
 } mpose_conv_geom;
 
@@ -197,6 +199,9 @@ typedef struct {
   float* invstd;                       /* out (train): 1/sqrt(var + eps) */
   int C;
   int count;                           /* B*H*W of the normalised tensor */
+  const float* conv_bias;              /* optional bias of the producing conv (folded: the conv kernels are bias-free) */
+  float eps;                           /* 0 = the launch-wide default */
+  int pad_;
 } mpose_bn_job;
 
 /* For every job: derive scale/shift (+ mean/invstd); train != 0 also updates the running stats. */
@@ -261,6 +266,18 @@ typedef struct {
 } mpose_bn_bwd_coef_job;
 
 int mpose_bn_bwd_coef(const mpose_bn_bwd_coef_job* jobs_dev, int n_jobs, void* stream);
+
+/* 3x3 pooling over NHWC with the producer's BN+ReLU applied on the fly (scale/shift may be NULL = identity).
+ * kind 0: max pool, stride 2, pad 1 (the reference rewrites MaxPool2d padding to k//2, models/margipose_model.py:111-117);
+ * kind 1: average pool, stride 1, pad 1, count_include_pad = False.  Output goes to a channel slice (out_ld). */
+int mpose_pool3_fwd(const float* in, const float* scale, const float* shift, float* out, int B, int IH, int IW, int C,
+                    int out_ld, int kind, void* stream);
+/* Backward: adds into d_in (gradient w.r.t. the ACTIVATED input); g is read from a channel slice (g_ld). */
+int mpose_pool3_bwd(const float* in, const float* scale, const float* shift, const float* g, float* d_in, int B, int IH,
+                    int IW, int C, int g_ld, int kind, void* stream);
+/* NCHW (B, C, H, W) -> NHWC (B, H, W, Cpad) zero padded, and the reverse gather for the input gradient. */
+int mpose_image_to_nhwc(const float* x, float* out, int B, int C, int H, int W, int Cpad, void* stream);
+int mpose_nhwc_to_image(const float* g, float* dx, int B, int C, int H, int W, int Cpad, void* stream);
 
 /* Layout / glue kernels. */
 /* NCHW image (B,3,S,S) -> NHWC space-to-depth (B, S/8, S/8, 192) for the patch8 stem, and back. */

@@ -87,6 +87,7 @@ class ConvGeom(ctypes.Structure):
                 ('OH', c_int), ('OW', c_int), ('Cout0', c_int), ('Cout1', c_int),
                 ('GH', c_int), ('GW', c_int), ('in_mul', c_int), ('out_mul', c_int),
                 ('n_classes', c_int), ('Npad0', c_int), ('Npad1', c_int),
+                ('in_ld', c_int), ('out_ld0', c_int), ('out_ld1', c_int),
                 ('cls', TapClass * MAX_CLASSES)]
 
 

@@ -17,7 +17,11 @@ namespace {
 
 __global__ __launch_bounds__(256) void bn_finalize_k(const mpose_bn_job* __restrict__ jobs, int train, float eps, float momentum) {
   const mpose_bn_job j = jobs[blockIdx.x];
+  if (j.eps > 0.f) eps = j.eps;
   for (int c = threadIdx.x; c < j.C; c += 256) {
+    // The conv kernels are bias-free; a producing conv's bias b only shifts the BN input: batch/running mean
+    // of (y + b) = mean(y) + b, and  scale*(y + b) + beta - (mean + b)*scale  ==  scale*y + beta - mean*scale.
+    const double cb = (j.conv_bias != nullptr) ? (double)j.conv_bias[c] : 0.0;
     double mean, var;
     if (train) {
       const double n = (double)j.count;
@@ -26,11 +30,11 @@ __global__ __launch_bounds__(256) void bn_finalize_k(const mpose_bn_job* __restr
       if (var < 0.0) var = 0.0;
       if (j.running_mean != nullptr) {
         const double unbiased = (j.count > 1) ? var * n / (n - 1.0) : var;
-        j.running_mean[c] = (float)((1.0 - momentum) * (double)j.running_mean[c] + momentum * mean);
+        j.running_mean[c] = (float)((1.0 - momentum) * (double)j.running_mean[c] + momentum * (mean + cb));
         j.running_var[c] = (float)((1.0 - momentum) * (double)j.running_var[c] + momentum * unbiased);
       }
     } else {
-      mean = (double)j.running_mean[c];
+      mean = (double)j.running_mean[c] - cb;
       var = (double)j.running_var[c];
     }
     const double invstd = 1.0 / sqrt(var + (double)eps);

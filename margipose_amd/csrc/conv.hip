@@ -123,6 +123,7 @@ __global__ __launch_bounds__(256, (RN == 4 && KS == 2) ? 1 : 2) void conv_igemm_
   // row_voff[j]: BYTE offset of the slot's anchor pixel + this lane's 16-byte channel column;
   // row_taps[j]: bit t = tap t reads an in-bounds pixel for that row.
   const int a_col4 = lane & 7;
+  const int in_ld = g.in_ld > 0 ? g.in_ld : g.Cin;
   unsigned row_voff[4], row_taps[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(256, (RN == 4 && KS == 2) ? 1 : 2) void conv_igemm_
       const unsigned gy = fdiv(rem, a.div_gw);
       const unsigned gx = rem - gy * (unsigned)g.GW;
       const int iy0 = (int)gy * g.in_mul, ix0 = (int)gx * g.in_mul;
-      row_voff[j] = (((b * (unsigned)g.IH + (unsigned)iy0) * (unsigned)g.IW + (unsigned)ix0) * (unsigned)g.Cin + (unsigned)(a_col4 * 4)) * 4u;
+      row_voff[j] = (((b * (unsigned)g.IH + (unsigned)iy0) * (unsigned)g.IW + (unsigned)ix0) * (unsigned)in_ld + (unsigned)(a_col4 * 4)) * 4u;
       for (int t = 0; t < n_taps; ++t) {
         const int tp = sTaps[t];
         const int iy = iy0 + (int)(signed char)(tp & 0xff), ix = ix0 + (int)(signed char)((tp >> 8) & 0xff);
@@ -180,7 +181,7 @@ __global__ __launch_bounds__(256, (RN == 4 && KS == 2) ? 1 : 2) void conv_igemm_
     const int dy = (int)(signed char)(tp & 0xff), dx = (int)(signed char)((tp >> 8) & 0xff);
     const int widx = (tp >> 16) & 0xff;
     ti.second = ACC1 && ((tp >> 24) & 0xff);
-    ti.a_soff = (unsigned)(((dy * g.IW + dx) * g.Cin + ti.c * KC) * 4 + a.in_bias);
+    ti.a_soff = (unsigned)(((dy * g.IW + dx) * in_ld + ti.c * KC) * 4 + a.in_bias);
     ti.w_soff = (unsigned)((widx * k4_total + ti.c * (KC / 4)) * npad * 16);
     return ti;
   };
@@ -322,7 +323,9 @@ __global__ __launch_bounds__(256, (RN == 4 && KS == 2) ? 1 : 2) void conv_igemm_
     double* stats = set ? op.stats1 : op.stats0;
     const bool masked = (set == 0) && op.mask_src != nullptr;
     const bool accumulate = (set == 0) && (a.flags & 1);
-    const unsigned out_bytes = (unsigned)((long)g.B * g.OH * g.OW * cout * 4);
+    const int old_ = set ? g.out_ld1 : g.out_ld0;
+    const int out_ld = old_ > 0 ? old_ : cout;
+    const unsigned out_bytes = (unsigned)((((long)g.B * g.OH * g.OW - 1) * out_ld + cout) * 4);
     const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(outp, 0, out_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_m = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(masked ? op.mask_src : outp), 0, out_bytes, 0x00020000);
 #pragma unroll
@@ -333,7 +336,7 @@ __global__ __launch_bounds__(256, (RN == 4 && KS == 2) ? 1 : 2) void conv_igemm_
         const int n = nb + li;
         unsigned voff[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) voff[r] = row_pix[r] == 0xFFFFFFFFu ? kOob : (row_pix[r] * (unsigned)cout + (unsigned)n) * 4u;
+        for (int r = 0; r < 16; ++r) voff[r] = row_pix[r] == 0xFFFFFFFFu ? kOob : (row_pix[r] * (unsigned)out_ld + (unsigned)n) * 4u;
         float v[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) v[r] = (ACC1 && set) ? acc1[rn][r] : acc0[rn][r];
@@ -478,8 +481,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_k(WgradArgs a) {
   const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<char*>(reinterpret_cast<const char*>(op.in)) - a.in_bias, 0, 0xFFFFFF00, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gout), 0, 0xFFFFFF00, 0x00020000);
-  const unsigned x_voff = (unsigned)((lh * g.in_mul * g.Cin + k0 + li) * 4);
-  const unsigned g_voff = (unsigned)((lh * g.out_mul * cout + n0 + li) * 4);
+  const int in_ld = g.in_ld > 0 ? g.in_ld : g.Cin;
+  const int gld_ = second ? g.out_ld1 : g.out_ld0;
+  const int g_ld = gld_ > 0 ? gld_ : cout;
+  const unsigned x_voff = (unsigned)((lh * g.in_mul * in_ld + k0 + li) * 4);
+  const unsigned g_voff = (unsigned)((lh * g.out_mul * g_ld + n0 + li) * 4);
   const unsigned lane_bit = 1u << lh;
   const bool pro = op.in_scale != nullptr;
   float psc = 1.f, psh = 0.f;
@@ -491,8 +497,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_k(WgradArgs a) {
     const unsigned b = fdiv((unsigned)r, a.div_gh);
     const int gy = r - (int)b * g.GH;
     const int iy = gy * g.in_mul + dy;
-    xs = (unsigned)((((int)b * g.IH + iy) * g.IW + dx) * g.Cin * 4 + a.in_bias);
-    gs = (unsigned)((((int)b * g.OH + gy * g.out_mul + oyc) * g.OW + oxc) * cout * 4);
+    xs = (unsigned)((((int)b * g.IH + iy) * g.IW + dx) * in_ld * 4 + a.in_bias);
+    gs = (unsigned)((((int)b * g.OH + gy * g.out_mul + oyc) * g.OW + oxc) * g_ld * 4);
     return iy >= 0 && iy < g.IH;
   };
   auto seek = [&](Cursor& c) {          // move to the first valid row at or after c.r
@@ -531,8 +537,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_k(WgradArgs a) {
     if (ld.r < r_end) {
       const int gx0 = ld.p * 2;
       flags = ((gx0 < gx_lo || gx0 >= gx_hi) ? 1u : 0u) | ((gx0 + 1 < gx_lo || gx0 + 1 >= gx_hi) ? 2u : 0u);
-      xs = ld.xs + (unsigned)(gx0 * g.in_mul * g.Cin * 4);
-      gs = ld.gs + (unsigned)(gx0 * g.out_mul * cout * 4);
+      xs = ld.xs + (unsigned)(gx0 * g.in_mul * in_ld * 4);
+      gs = ld.gs + (unsigned)(gx0 * g.out_mul * g_ld * 4);
     }
     const unsigned inv = (flags & lane_bit) ? 0xFFFFFFFFu : 0u;
     rinv[slot] = inv;
@@ -669,11 +675,11 @@ extern "C" int mpose_conv_fwd(const mpose_conv_geom* geom, const mpose_conv_oper
     long min_shift = 0;
     for (int c = 0; c < geom->n_classes; ++c)
       for (int t = 0; t < geom->cls[c].n_taps; ++t) {
-        const long sft = ((long)geom->cls[c].taps[t].dy * geom->IW + geom->cls[c].taps[t].dx) * geom->Cin * 4;
+        const long sft = ((long)geom->cls[c].taps[t].dy * geom->IW + geom->cls[c].taps[t].dx) * (geom->in_ld > 0 ? geom->in_ld : geom->Cin) * 4;
         if (sft < min_shift) min_shift = sft;
       }
     a.in_bias = (int)(-min_shift);
-    const long in_bytes = (long)geom->B * geom->IH * geom->IW * geom->Cin * 4;
+    const long in_bytes = (long)geom->B * geom->IH * geom->IW * (geom->in_ld > 0 ? geom->in_ld : geom->Cin) * 4;
     if (in_bytes + a.in_bias >= 0xFFFFFF00l - (1l << 20)) return MPOSE_EINVAL;       // 32-bit buffer offsets
   }
   hipStream_t s = (hipStream_t)stream;
@@ -681,7 +687,10 @@ extern "C" int mpose_conv_fwd(const mpose_conv_geom* geom, const mpose_conv_oper
   const int cmax = (acc1 && geom->Cout1 > geom->Cout0) ? geom->Cout1 : geom->Cout0;
   if (cmax > npad) return MPOSE_EINVAL;
   if ((geom->Cout0 % 32) || (acc1 && (geom->Cout1 % 32))) return MPOSE_EINVAL;
-  if ((long)geom->B * geom->OH * geom->OW * cmax * 4 >= 0xFFFFFF00l) return MPOSE_EINVAL;
+  {
+    const int ldm = geom->out_ld0 > geom->out_ld1 ? geom->out_ld0 : geom->out_ld1;
+    if ((long)geom->B * geom->OH * geom->OW * (ldm > cmax ? ldm : cmax) * 4 >= 0xFFFFFF00l) return MPOSE_EINVAL;
+  }
   if (cmax <= 32) return acc1 ? launch_conv<1, true, 1>(a, n_groups, s) : launch_conv<1, false, 1>(a, n_groups, s);
   if (npad % 64) return MPOSE_EINVAL;
   if (acc1) return want_ksplit<2>(a, cmax, n_groups) ? launch_conv<2, true, 2>(a, n_groups, s) : launch_conv<2, true, 1>(a, n_groups, s);
@@ -712,12 +721,12 @@ extern "C" int mpose_conv_wgrad(const mpose_conv_geom* geom, const mpose_wgrad_o
       ++a.n_entries;
       if (tp.acc) { acc1 = true; if (tp.widx > max1) max1 = tp.widx; }
       else if (tp.widx > max0) max0 = tp.widx;
-      const long sft = ((long)tp.dy * geom->IW + tp.dx) * geom->Cin * 4;
+      const long sft = ((long)tp.dy * geom->IW + tp.dx) * (geom->in_ld > 0 ? geom->in_ld : geom->Cin) * 4;
       if (sft < min_shift) min_shift = sft;
     }
   a.n_widx0 = max0 + 1;
   a.n_widx1 = max1 + 1;
-  a.in_bias = (int)(-min_shift) + geom->Cin * 4;      // + one pixel: a pair may start one column left of the row
+  a.in_bias = (int)(-min_shift) + (geom->in_ld > 0 ? geom->in_ld : geom->Cin) * 4;      // + one pixel: a pair may start one column left of the row
   if (acc1 && ((geom->Npad1 % 64) || (geom->Cout1 % 32) || geom->Npad1 != geom->Npad0 || geom->Cout1 != geom->Cout0)) return MPOSE_EINVAL;
   for (int i = 0; i < n_groups; ++i) {
     a.op[i] = ops[i];
@@ -726,8 +735,8 @@ extern "C" int mpose_conv_wgrad(const mpose_conv_geom* geom, const mpose_wgrad_o
   }
   const int n_rows = geom->B * geom->GH;
   if (n_rows == 0 || a.n_entries == 0) return 0;
-  const long in_bytes = (long)geom->B * geom->IH * geom->IW * geom->Cin * 4;
-  const long g_bytes = (long)geom->B * geom->OH * geom->OW * geom->Cout0 * 4;
+  const long in_bytes = (long)geom->B * geom->IH * geom->IW * (geom->in_ld > 0 ? geom->in_ld : geom->Cin) * 4;
+  const long g_bytes = (long)geom->B * geom->OH * geom->OW * (geom->out_ld0 > geom->Cout0 ? geom->out_ld0 : geom->Cout0) * 4;
   if (in_bytes + a.in_bias >= 0xFFFFFF00l - (1l << 20) || g_bytes >= 0xFFFFFF00l - (1l << 20)) return MPOSE_EINVAL;
   a.div_gh = make_fastdiv((unsigned)geom->GH);
   a.n_split = n_split;

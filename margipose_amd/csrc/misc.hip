@@ -217,6 +217,129 @@ __global__ __launch_bounds__(256) void reduce_partials_k(const float* __restrict
   }
 }
 
+
+// ---- 3x3 pooling (InceptionV4 stem: MaxPool2d(3, stride 2, pad 1) and AvgPool2d(3, 1, 1, count_include_pad=False)) ----
+struct PoolArgs {
+  const float* in; const float* scale; const float* shift; const float* g; float* out;
+  int B, IH, IW, C, OH, OW, ld, kind;
+};
+
+__device__ __forceinline__ float4 pool_act(const PoolArgs& a, long pix, int c, const float4& sc, const float4& sh) {
+  float4 v = *reinterpret_cast<const float4*>(a.in + pix * a.C + c);
+  if (a.scale != nullptr) {
+    v.x = fmaxf(fmaf(v.x, sc.x, sh.x), 0.f); v.y = fmaxf(fmaf(v.y, sc.y, sh.y), 0.f);
+    v.z = fmaxf(fmaf(v.z, sc.z, sh.z), 0.f); v.w = fmaxf(fmaf(v.w, sc.w, sh.w), 0.f);
+  }
+  return v;
+}
+
+__global__ __launch_bounds__(256) void pool3_fwd_k(PoolArgs a) {
+  const int c4n = a.C >> 2;
+  const int st = a.kind == 0 ? 2 : 1;
+  const long total = (long)a.B * a.OH * a.OW * c4n;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % c4n) * 4;
+    long r = i / c4n;
+    const int ox = (int)(r % a.OW); r /= a.OW;
+    const int oy = (int)(r % a.OH);
+    const long b = r / a.OH;
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.scale != nullptr) { sc = *reinterpret_cast<const float4*>(a.scale + c); sh = *reinterpret_cast<const float4*>(a.shift + c); }
+    float4 acc = a.kind == 0 ? make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY) : make_float4(0.f, 0.f, 0.f, 0.f);
+    int cnt = 0;
+    for (int ky = -1; ky <= 1; ++ky)
+      for (int kx = -1; kx <= 1; ++kx) {
+        const int iy = oy * st + ky, ix = ox * st + kx;
+        if (iy < 0 || iy >= a.IH || ix < 0 || ix >= a.IW) continue;
+        const float4 v = pool_act(a, (b * a.IH + iy) * a.IW + ix, c, sc, sh);
+        if (a.kind == 0) { acc.x = fmaxf(acc.x, v.x); acc.y = fmaxf(acc.y, v.y); acc.z = fmaxf(acc.z, v.z); acc.w = fmaxf(acc.w, v.w); }
+        else { acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+        ++cnt;
+      }
+    if (a.kind == 1) { const float rc = 1.0f / (float)cnt; acc.x *= rc; acc.y *= rc; acc.z *= rc; acc.w *= rc; }
+    *reinterpret_cast<float4*>(a.out + ((b * a.OH + oy) * a.OW + ox) * a.ld + c) = acc;
+  }
+}
+
+// Gather form (deterministic, no atomics): one thread per INPUT element sums what the windows containing it send back.
+__global__ __launch_bounds__(256) void pool3_bwd_k(PoolArgs a) {
+  const int c4n = a.C >> 2;
+  const long total = (long)a.B * a.IH * a.IW * c4n;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % c4n) * 4;
+    long r = i / c4n;
+    const int ix = (int)(r % a.IW); r /= a.IW;
+    const int iy = (int)(r % a.IH);
+    const long b = r / a.IH;
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.scale != nullptr) { sc = *reinterpret_cast<const float4*>(a.scale + c); sh = *reinterpret_cast<const float4*>(a.shift + c); }
+    float d[4] = {0.f, 0.f, 0.f, 0.f};
+    if (a.kind == 1) {
+      for (int oy = iy - 1; oy <= iy + 1; ++oy)
+        for (int ox = ix - 1; ox <= ix + 1; ++ox) {
+          if (oy < 0 || oy >= a.OH || ox < 0 || ox >= a.OW) continue;
+          const int ny = min(oy + 1, a.IH - 1) - max(oy - 1, 0) + 1, nx = min(ox + 1, a.IW - 1) - max(ox - 1, 0) + 1;
+          const float rc = 1.0f / (float)(ny * nx);
+          const float4 gv = *reinterpret_cast<const float4*>(a.g + ((b * a.OH + oy) * a.OW + ox) * a.ld + c);
+          d[0] += gv.x * rc; d[1] += gv.y * rc; d[2] += gv.z * rc; d[3] += gv.w * rc;
+        }
+    } else {
+      const float4 me4 = pool_act(a, (b * a.IH + iy) * a.IW + ix, c, sc, sh);
+      const float me[4] = {me4.x, me4.y, me4.z, me4.w};
+      // windows (stride 2, pad 1) that contain (iy, ix): oy with 2*oy - 1 <= iy <= 2*oy + 1
+      for (int oy = (iy + 1) / 2 - ((iy & 1) ? 0 : 0); oy >= 0 && 2 * oy + 1 >= iy; --oy) {
+        if (oy >= a.OH || 2 * oy - 1 > iy) continue;
+        for (int ox = (ix + 1) / 2; ox >= 0 && 2 * ox + 1 >= ix; --ox) {
+          if (ox >= a.OW || 2 * ox - 1 > ix) continue;
+          // first position (row-major scan, as ATen records it) holding the window maximum
+          float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+          int arg[4] = {-1, -1, -1, -1};
+          for (int ky = -1; ky <= 1; ++ky)
+            for (int kx = -1; kx <= 1; ++kx) {
+              const int yy = oy * 2 + ky, xx = ox * 2 + kx;
+              if (yy < 0 || yy >= a.IH || xx < 0 || xx >= a.IW) continue;
+              const float4 v4 = pool_act(a, (b * a.IH + yy) * a.IW + xx, c, sc, sh);
+              const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+              for (int e = 0; e < 4; ++e) if (v[e] > best[e]) { best[e] = v[e]; arg[e] = (ky + 1) * 3 + (kx + 1); }
+            }
+          const int mine = (iy - oy * 2 + 1) * 3 + (ix - ox * 2 + 1);
+          const float4 gv = *reinterpret_cast<const float4*>(a.g + ((b * a.OH + oy) * a.OW + ox) * a.ld + c);
+          const float g4[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) if (arg[e] == mine) d[e] += g4[e];
+          (void)me;
+        }
+      }
+    }
+    float4* dst = reinterpret_cast<float4*>(a.out + ((b * a.IH + iy) * a.IW + ix) * a.C + c);
+    float4 o = *dst;
+    o.x += d[0]; o.y += d[1]; o.z += d[2]; o.w += d[3];
+    *dst = o;
+  }
+}
+
+// NCHW (B,C,H,W) <-> NHWC (B,H,W,Cpad), channels >= C zero
+__global__ __launch_bounds__(256) void image_to_nhwc_k(const float* __restrict__ x, float* __restrict__ out, int B, int C, long HW, int Cpad) {
+  const long npix = (long)B * HW;
+  for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < npix; p += (long)gridDim.x * 256) {
+    const long b = p / HW, px = p - b * HW;
+    for (int c = 0; c < Cpad; c += 4) {
+      float e[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) e[t] = (c + t < C) ? x[(b * C + c + t) * HW + px] : 0.f;
+      *reinterpret_cast<float4*>(out + p * Cpad + c) = make_float4(e[0], e[1], e[2], e[3]);
+    }
+  }
+}
+__global__ __launch_bounds__(256) void nhwc_to_image_k(const float* __restrict__ g, float* __restrict__ dx, int B, int C, long HW, int Cpad) {
+  const long npix = (long)B * HW;
+  for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < npix; p += (long)gridDim.x * 256) {
+    const long b = p / HW, px = p - b * HW;
+    for (int c = 0; c < C; ++c) dx[(b * C + c) * HW + px] = g[p * Cpad + c];
+  }
+}
+
 }  // namespace
 }  // namespace mpose
 
@@ -305,5 +428,47 @@ extern "C" int mpose_reduce_partials(const float* src, float* dst, int n_partial
   if (n_partial < 1 || n < 0) return MPOSE_EINVAL;
   if (n == 0) return 0;
   reduce_partials_k<<<grid_for(n, 256), 256, 0, (hipStream_t)stream>>>(src, dst, n_partial, n, accumulate);
+  return launch_status();
+}
+
+static int pool_dims(int kind, int IH, int IW, int& OH, int& OW) {
+  if (kind == 0) { OH = (IH + 2 - 3) / 2 + 1; OW = (IW + 2 - 3) / 2 + 1; return 0; }
+  if (kind == 1) { OH = IH; OW = IW; return 0; }
+  return MPOSE_EINVAL;
+}
+
+extern "C" int mpose_pool3_fwd(const float* in, const float* scale, const float* shift, float* out, int B, int IH, int IW, int C,
+                               int out_ld, int kind, void* stream) {
+  PoolArgs a{};
+  if (pool_dims(kind, IH, IW, a.OH, a.OW) || (C & 3) || out_ld < C || (out_ld & 3)) return MPOSE_EINVAL;
+  a.in = in; a.scale = scale; a.shift = shift; a.out = out; a.B = B; a.IH = IH; a.IW = IW; a.C = C; a.ld = out_ld; a.kind = kind;
+  const long total = (long)B * a.OH * a.OW * (C / 4);
+  if (total == 0) return 0;
+  pool3_fwd_k<<<grid_for(total, 256), 256, 0, (hipStream_t)stream>>>(a);
+  return launch_status();
+}
+
+extern "C" int mpose_pool3_bwd(const float* in, const float* scale, const float* shift, const float* g, float* d_in, int B, int IH,
+                               int IW, int C, int g_ld, int kind, void* stream) {
+  PoolArgs a{};
+  if (pool_dims(kind, IH, IW, a.OH, a.OW) || (C & 3) || g_ld < C || (g_ld & 3)) return MPOSE_EINVAL;
+  a.in = in; a.scale = scale; a.shift = shift; a.g = g; a.out = d_in; a.B = B; a.IH = IH; a.IW = IW; a.C = C; a.ld = g_ld; a.kind = kind;
+  const long total = (long)B * IH * IW * (C / 4);
+  if (total == 0) return 0;
+  pool3_bwd_k<<<grid_for(total, 256), 256, 0, (hipStream_t)stream>>>(a);
+  return launch_status();
+}
+
+extern "C" int mpose_image_to_nhwc(const float* x, float* out, int B, int C, int H, int W, int Cpad, void* stream) {
+  if (C < 1 || C > Cpad || (Cpad & 3)) return MPOSE_EINVAL;
+  if ((long)B * H * W == 0) return 0;
+  image_to_nhwc_k<<<grid_for((long)B * H * W, 256), 256, 0, (hipStream_t)stream>>>(x, out, B, C, (long)H * W, Cpad);
+  return launch_status();
+}
+
+extern "C" int mpose_nhwc_to_image(const float* g, float* dx, int B, int C, int H, int W, int Cpad, void* stream) {
+  if (C < 1 || C > Cpad || (Cpad & 3)) return MPOSE_EINVAL;
+  if ((long)B * H * W == 0) return 0;
+  nhwc_to_image_k<<<grid_for((long)B * H * W, 256), 256, 0, (hipStream_t)stream>>>(g, dx, B, C, (long)H * W, Cpad);
   return launch_status();
 }

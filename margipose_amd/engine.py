@@ -39,7 +39,8 @@ PACK_DT = np.dtype([('src', 'u8'), ('dst', 'u8'), ('N', 'i4'), ('K', 'i4'), ('T'
 UNPACK_DT = np.dtype([('src', 'u8'), ('dst', 'u8'), ('N', 'i4'), ('K', 'i4'), ('T', 'i4'), ('Npad', 'i4'), ('Kpad', 'i4'),
                       ('n_split', 'i4'), ('sn', 'i8'), ('sk', 'i8'), ('st', 'i8'), ('accumulate', 'i4')], align=True)
 BN_DT = np.dtype([('stats', 'u8'), ('gamma', 'u8'), ('beta', 'u8'), ('running_mean', 'u8'), ('running_var', 'u8'),
-                  ('scale', 'u8'), ('shift', 'u8'), ('mean', 'u8'), ('invstd', 'u8'), ('C', 'i4'), ('count', 'i4')], align=True)
+                  ('scale', 'u8'), ('shift', 'u8'), ('mean', 'u8'), ('invstd', 'u8'), ('C', 'i4'), ('count', 'i4'),
+                  ('conv_bias', 'u8'), ('eps', 'f4'), ('pad_', 'i4')], align=True)
 COEF_DT = np.dtype([('sums', 'u8'), ('gamma', 'u8'), ('mean', 'u8'), ('invstd', 'u8'), ('coef', 'u8'), ('dgamma', 'u8'),
                     ('dbeta', 'u8'), ('sums_stride', 'i4'), ('which', 'i4'), ('C', 'i4'), ('c_stride', 'i4'), ('count', 'i4'),
                     ('sg_col', 'i4')], align=True)
@@ -115,7 +116,7 @@ class _Conv:
 
     def strides(self, dgrad):
         """(sn, sk, st): element strides of (n, k, tap) in the torch-layout weight."""
-        kk = self.k * self.k
+        kk = getattr(self, 'kk', self.k * self.k)
         if self.stem:                            # (128, 3, 8, 8) seen as (128, 192) 1x1
             return (192, 1, 0) if not dgrad else (1, 192, 0)
         if not self.transposed:                  # (Cout, Cin, k, k)
@@ -192,6 +193,7 @@ def _jobs_to_device(arr, device):
 
 class Engine:
     """Owns the launch plan of one MargiPoseModelInner instance."""
+    COEF_ITEMSIZE = COEF_DT.itemsize
 
     def __init__(self, inner):
         self.inner = inner
@@ -214,12 +216,22 @@ class Engine:
                     grp.append(_Block(rb, kinds[i], chans[i][0], chans[i][1]))
                 blocks.append(grp)
             self.stage_blocks.append(blocks)
-        self.stem_conv = _Conv(inner.in_cnn[0].weight, False, 1, 192, 128, 192, 128, stem=True)
-        self.stem_bn = _BN(inner.in_cnn[1], 128, 128)
         self.combiners = [m.conv.weight for m in inner.hm_combiners]
         self._all_blocks = [b for st in self.stage_blocks for grp in st for b in grp]
-        self._convs = [self.stem_conv] + [c for b in self._all_blocks for c in (b.conv_in, b.conv2, b.conv_sc)]
-        self._bns = [self.stem_bn] + [n for b in self._all_blocks for n in (b.bn1, b.bn2, b.bns)]
+        block_convs = [c for b in self._all_blocks for c in (b.conv_in, b.conv2, b.conv_sc)]
+        block_bns = [n for b in self._all_blocks for n in (b.bn1, b.bn2, b.bns)]
+        self.stem = None
+        if getattr(inner, 'feature_extractor_name', 'patch8') == 'inceptionv4':
+            from .stem import InceptionV4Stem
+            self.stem_conv = self.stem_bn = None
+            self._convs, self._bns = [], block_bns           # filled right below (the stem needs `self` first)
+            self.stem = InceptionV4Stem(self, inner.in_cnn)
+            self._convs = self.stem.convs + block_convs
+        else:
+            self.stem_conv = _Conv(inner.in_cnn[0].weight, False, 1, 192, 128, 192, 128, stem=True)
+            self.stem_bn = _BN(inner.in_cnn[1], 128, 128)
+            self._convs = [self.stem_conv] + block_convs
+            self._bns = [self.stem_bn] + block_bns
         self._geoms = {}
         self._tables = {}
         self._arena_key = None
@@ -236,6 +248,10 @@ class Engine:
             ps.append(c.param)
         for n in self._bns:
             ps += [n.m.weight, n.m.bias]
+        if self.stem is not None:
+            for m in self.stem.bn_modules:
+                ps += [m.weight, m.bias]
+            ps += self.stem.extra_params
         ps += self.combiners
         return ps
 
@@ -273,9 +289,12 @@ class Engine:
         self._grad_total = goff
         self.gflat = torch.zeros(goff, dtype=torch.float32, device=device)
         # num_batches_tracked of every BN becomes a view of one int64 vector: one increment per step
-        self._nbt = torch.stack([n.m.num_batches_tracked.to(device) for n in self._bns]).contiguous()
-        for i, n in enumerate(self._bns):
-            n.m.num_batches_tracked = self._nbt[i]
+        bn_mods = [n.m for n in self._bns] + (self.stem.bn_modules if self.stem is not None else [])
+        self._nbt = torch.stack([m.num_batches_tracked.to(device) for m in bn_mods]).contiguous()
+        for i, m in enumerate(bn_mods):
+            m.num_batches_tracked = self._nbt[i]
+        if self.stem is not None:
+            self.stem.setup(device)
         # pack job table
         jobs = np.zeros(2 * len(self._convs), dtype=PACK_DT)
         mx = 0
@@ -347,8 +366,10 @@ class Engine:
         # backward coefficient jobs: per (stage, block): bn2 x3, bns x3, bn1 x3 ; stem last
         cj = np.zeros(self.T * 90 + 1, dtype=COEF_DT)
         # wgrad partial arena + unpack jobs: per (stage, block, column): conv2, conv_in, conv_sc ; stem last
-        uj = np.zeros(self.T * 90 + 1, dtype=UNPACK_DT)
-        bn_job(fj[0], self.stem_bn, B * F * F)
+        n_stem_convs = len(self.stem.convs) if self.stem is not None else 1
+        uj = np.zeros(self.T * 90 + n_stem_convs, dtype=UNPACK_DT)
+        if self.stem is None:
+            bn_job(fj[0], self.stem_bn, B * F * F)
         part_off = 0
         part_offs = {}
         mx = 0
@@ -381,8 +402,13 @@ class Engine:
                     unpack_job(uj[base + 3 * c], b.conv2, self._n_split(cnt, self._wg_tiles(b, 'conv2')))
                     unpack_job(uj[base + 3 * c + 1], b.conv_in, self._n_split(slots_in, self._wg_tiles(b, 'in')))
                     unpack_job(uj[base + 3 * c + 2], b.conv_sc, self._n_split(slots_in, self._wg_tiles(b, 'in')))
-        coef_job(cj[self.T * 90], self.stem_bn, self.stem_bn, 4, 0, 1, B * F * F)
-        unpack_job(uj[self.T * 90], self.stem_conv, self._n_split(B * F * F, 6))
+        if self.stem is None:
+            coef_job(cj[self.T * 90], self.stem_bn, self.stem_bn, 4, 0, 1, B * F * F)
+            unpack_job(uj[self.T * 90], self.stem_conv, self._n_split(B * F * F, 6))
+        else:
+            for i, op in enumerate([o for o in self.stem.ops if hasattr(o, 'conv')]):
+                unpack_job(uj[self.T * 90 + i], op.conv, self.stem_n_split(B, 8 * F, op))
+        tb['n_unpack'] = self.T * 90 + n_stem_convs
         tb['partials'] = torch.empty(part_off, dtype=torch.float32, device=dev)
         pbase = tb['partials'].data_ptr()
         uj['src'] = pbase + 4 * uj['src']
@@ -476,6 +502,22 @@ class Engine:
         for t in tensors:
             t.record_stream(side)
 
+    def finalize_table(self, table, first, n, train):
+        base = table.data_ptr() + first * BN_DT.itemsize
+        check(lib().mpose_bn_finalize(c_void_p(base), n, int(train), ctypes.c_float(BN_EPS), ctypes.c_float(BN_MOMENTUM),
+                                      stream_ptr()), 'mpose_bn_finalize')
+
+    def part_ptr(self, B, S, conv):
+        return self._tables_for(B, S // 8)['part_ptr'][id(conv)]
+
+    def stem_n_split(self, B, S, op):
+        H = S // op.dst.div
+        ctile = 128 if op.cout % 128 == 0 else (96 if op.cout % 96 == 0 else (64 if op.cout % 64 == 0 else 32))
+        cin_s = op.conv.cin_s
+        tiles = op.kh * op.kw * (cin_s // 32) * (op.cout // ctile)
+        rows = B * H
+        return max(1, min(16, 1024 // max(1, tiles), rows // 4))
+
     def finalize(self, tb, first, n, train):
         base = tb['fin'].data_ptr() + first * BN_DT.itemsize
         check(lib().mpose_bn_finalize(c_void_p(base), n, int(train), ctypes.c_float(BN_EPS), ctypes.c_float(BN_MOMENTUM),
@@ -507,24 +549,30 @@ class Engine:
         self.pack_weights()
         if train:
             self.stat_arena.zero_()
-        else:
+        elif self.stem is None:
             self.finalize(tb, 0, 1 + self.T * 90, False)     # scale/shift from the running statistics
+        else:
+            self.finalize(tb, 1, self.T * 90, False)
 
-        # ---- stem: space-to-depth + 1x1 conv (192->128) + BN + ReLU ----
-        s2d = torch.empty(B, F, F, 192, **f32)
-        check(L.mpose_space_to_depth8(ptr(x), ptr(s2d), B, S, st()), 'mpose_space_to_depth8')
-        stem_raw = torch.empty(B, F, F, 128, **f32)
-        op = ConvOperands()
-        op.in_, op.w0, op.out0 = s2d.data_ptr(), self._wptr(self.stem_conv), stem_raw.data_ptr()
-        if train:
-            op.stats0 = self._stats_ptr(self.stem_bn)
-        self.conv(self.geom('f_stem', B, F), [op])
-        if train:
-            self.finalize(tb, 0, 1, True)
-        inp = torch.empty(B, F, F, 128, **f32)
-        check(L.mpose_bn_relu_fwd(ptr(stem_raw), c_void_p(self._bnf_ptr(self.stem_bn, 0)), c_void_p(self._bnf_ptr(self.stem_bn, 1)),
-                                  ptr(inp), c_int64(inp.numel()), 128, st()), 'mpose_bn_relu_fwd')
-        ctx['s2d'], ctx['stem_raw'], ctx['stem_out'] = s2d, stem_raw, inp
+        if self.stem is not None:
+            # ---- InceptionV4 feature extractor (stem.py) ----
+            inp, ctx['stem_ctx'] = self.stem.forward(x, train, save)
+        else:
+            # ---- patch8 stem: space-to-depth + 1x1 conv (192->128) + BN + ReLU ----
+            s2d = torch.empty(B, F, F, 192, **f32)
+            check(L.mpose_space_to_depth8(ptr(x), ptr(s2d), B, S, st()), 'mpose_space_to_depth8')
+            stem_raw = torch.empty(B, F, F, 128, **f32)
+            op = ConvOperands()
+            op.in_, op.w0, op.out0 = s2d.data_ptr(), self._wptr(self.stem_conv), stem_raw.data_ptr()
+            if train:
+                op.stats0 = self._stats_ptr(self.stem_bn)
+            self.conv(self.geom('f_stem', B, F), [op])
+            if train:
+                self.finalize(tb, 0, 1, True)
+            inp = torch.empty(B, F, F, 128, **f32)
+            check(L.mpose_bn_relu_fwd(ptr(stem_raw), c_void_p(self._bnf_ptr(self.stem_bn, 0)), c_void_p(self._bnf_ptr(self.stem_bn, 1)),
+                                      ptr(inp), c_int64(inp.numel()), 128, st()), 'mpose_bn_relu_fwd')
+            ctx['s2d'], ctx['stem_raw'], ctx['stem_out'] = s2d, stem_raw, inp
         ctx['inps'] = []
 
         hms = [[], [], []]
@@ -756,32 +804,35 @@ class Engine:
 
         dx = None
         if D is not None:
-            # ---- stem backward: ReLU mask, BN backward, wgrad (+ dgrad when the input wants a gradient) ----
-            n = self.stem_bn
-            gm = torch.empty_like(D)
-            check(L.mpose_relu_bwd(ptr(D), ptr(ctx['stem_out']), ptr(gm), c_int64(gm.numel()), st()), 'mpose_relu_bwd')
-            ro = BnBwdReduceOperands()
-            ro.g, ro.a, ro.sums = gm.data_ptr(), ctx['stem_raw'].data_ptr(), self._stats_ptr(n, True)
-            check(L.mpose_bn_bwd_reduce((BnBwdReduceOperands * 3)(ro), 1, F * F, B, 128, 0, 0, st()), 'mpose_bn_bwd_reduce')
-            run_coef(self.T * 90, 1)
-            d_raw = torch.empty_like(D)
-            ao = BnBwdApplyOperands()
-            ao.g, ao.a, ao.coef_a, ao.da = gm.data_ptr(), ctx['stem_raw'].data_ptr(), self._bnf_ptr(n, 4), d_raw.data_ptr()
-            check(L.mpose_bn_bwd_apply((BnBwdApplyOperands * 3)(ao), 1, F * F, B, 128, 0, 0, st()), 'mpose_bn_bwd_apply')
-            wo = WgradOperands()
-            wo.in_, wo.gout0, wo.dw0 = ctx['s2d'].data_ptr(), d_raw.data_ptr(), tb['part_ptr'][id(self.stem_conv)]
-            self.wgrad_async(self.geom('f_stem', B, F), [wo], self._n_split(B * F * F, 6), [ctx['s2d'], d_raw])
-            if need_dx:
-                d_s2d = torch.empty_like(ctx['s2d'])
-                op = ConvOperands()
-                op.in_, op.w0, op.out0 = d_raw.data_ptr(), self._wptr(self.stem_conv, True), d_s2d.data_ptr()
-                self.conv(self.geom('d_stem', B, F), [op])
-                dx = torch.empty(ctx['x_shape'], **f32)
-                check(L.mpose_depth_to_space8(ptr(d_s2d), ptr(dx), B, ctx['x_shape'][2], st()), 'mpose_depth_to_space8')
+            if self.stem is not None:
+                dx = self.stem.backward(ctx['stem_ctx'], D, need_dx)
+            else:
+                # ---- stem backward: ReLU mask, BN backward, wgrad (+ dgrad when the input wants a gradient) ----
+                n = self.stem_bn
+                gm = torch.empty_like(D)
+                check(L.mpose_relu_bwd(ptr(D), ptr(ctx['stem_out']), ptr(gm), c_int64(gm.numel()), st()), 'mpose_relu_bwd')
+                ro = BnBwdReduceOperands()
+                ro.g, ro.a, ro.sums = gm.data_ptr(), ctx['stem_raw'].data_ptr(), self._stats_ptr(n, True)
+                check(L.mpose_bn_bwd_reduce((BnBwdReduceOperands * 3)(ro), 1, F * F, B, 128, 0, 0, st()), 'mpose_bn_bwd_reduce')
+                run_coef(self.T * 90, 1)
+                d_raw = torch.empty_like(D)
+                ao = BnBwdApplyOperands()
+                ao.g, ao.a, ao.coef_a, ao.da = gm.data_ptr(), ctx['stem_raw'].data_ptr(), self._bnf_ptr(n, 4), d_raw.data_ptr()
+                check(L.mpose_bn_bwd_apply((BnBwdApplyOperands * 3)(ao), 1, F * F, B, 128, 0, 0, st()), 'mpose_bn_bwd_apply')
+                wo = WgradOperands()
+                wo.in_, wo.gout0, wo.dw0 = ctx['s2d'].data_ptr(), d_raw.data_ptr(), tb['part_ptr'][id(self.stem_conv)]
+                self.wgrad_async(self.geom('f_stem', B, F), [wo], self._n_split(B * F * F, 6), [ctx['s2d'], d_raw])
+                if need_dx:
+                    d_s2d = torch.empty_like(ctx['s2d'])
+                    op = ConvOperands()
+                    op.in_, op.w0, op.out0 = d_raw.data_ptr(), self._wptr(self.stem_conv, True), d_s2d.data_ptr()
+                    self.conv(self.geom('d_stem', B, F), [op])
+                    dx = torch.empty(ctx['x_shape'], **f32)
+                    check(L.mpose_depth_to_space8(ptr(d_s2d), ptr(dx), B, ctx['x_shape'][2], st()), 'mpose_depth_to_space8')
             # ---- ONE launch turns every packed partial sum into torch-layout gradients ----
             if self.overlap_wgrad and self.side_stream is not None:
                 torch.cuda.current_stream().wait_stream(self.side_stream)
-            check(L.mpose_unpack_wgrads(ptr(tb['unpack']), self.T * 90 + 1, tb['unpack_max'], st()), 'mpose_unpack_wgrads')
+            check(L.mpose_unpack_wgrads(ptr(tb['unpack']), tb['n_unpack'], tb['unpack_max'], st()), 'mpose_unpack_wgrads')
         return self.gflat, dx
 
     @staticmethod

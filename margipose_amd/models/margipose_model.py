@@ -26,7 +26,7 @@ Default_MargiPose_Desc = {
     'settings': {
         'n_stages': 4,
         'axis_permutation': True,
-        'feature_extractor': 'patch8',
+        'feature_extractor': 'inceptionv4',
         'pixelwise_loss': 'jsd',
     },
 }
@@ -96,6 +96,11 @@ class HeatmapCombiner(nn.Module):
 def make_image_feature_extractor(model_name):
     if model_name == 'patch8':
         return nn.Sequential(nn.Conv2d(3, 128, kernel_size=8, stride=8, bias=False), nn.BatchNorm2d(128), nn.Identity())
+    if model_name == 'inceptionv4':
+        # parameter holders with pretrainedmodels' key layout; PyTorch default initialisation (the reference loads
+        # ImageNet weights, which cannot be downloaded here) -- see stem.py for the "unpinned" caveat
+        from ..stem import make_inceptionv4_stem_modules
+        return make_inceptionv4_stem_modules()
     raise Exception('unsupported image feature extractor model name: ' + model_name)
 
 
@@ -132,6 +137,7 @@ class MargiPoseModelInner(nn.Module):
         self.n_stages = n_stages
         self.n_joints = n_joints
         self.in_cnn = make_image_feature_extractor(feature_extractor)
+        self.feature_extractor_name = feature_extractor
         self.xy_hm_cnns = nn.ModuleList()
         self.zy_hm_cnns = nn.ModuleList()
         self.xz_hm_cnns = nn.ModuleList()
@@ -226,7 +232,7 @@ def create_model(model_desc):
     s = model_desc['settings']
     return MargiPoseModel(skel_desc=CanonicalSkeletonDesc, n_stages=s.get('n_stages', 4),
                           axis_permutation=s.get('axis_permutation', True),
-                          feature_extractor=s.get('feature_extractor', 'patch8'),
+                          feature_extractor=s.get('feature_extractor', 'inceptionv4'),
                           pixelwise_loss=s.get('pixelwise_loss', 'jsd'))
 
 

@@ -91,6 +91,41 @@ def patch8_stem(sd, x, train):
     return F.relu(_bn(sd, 'inner.in_cnn.1', f, train))
 
 
+def _basic_conv(sd, key, x, train, stride=1):
+    """pretrainedmodels' BasicConv2d after the reference's padding rewrite (models/margipose_model.py:111-117):
+    Conv2d(bias=False, padding=k//2) -> BatchNorm2d(eps=1e-3) -> ReLU."""
+    w = sd[key + '.conv.weight']
+    y = F.conv2d(x, w, None, stride=stride, padding=(w.shape[2] // 2, w.shape[3] // 2))
+    y = F.batch_norm(y, sd[key + '.bn.running_mean'], sd[key + '.bn.running_var'], sd[key + '.bn.weight'], sd[key + '.bn.bias'],
+                     training=train, momentum=BN_MOMENTUM, eps=1e-3)
+    return F.relu(y)
+
+
+def inceptionv4_stem(sd, x, train):
+    """models/margipose_model.py:104-118 with inceptionv4().features[0:7] restated from SURVEY.md Appendix B
+    (the third-party source, pretrainedmodels==0.6.0, is not in the reference tree: parity UNPINNED)."""
+    p = 'inner.in_cnn.'
+    x = _basic_conv(sd, p + '0', x, train, 2)
+    x = _basic_conv(sd, p + '1', x, train)
+    x = _basic_conv(sd, p + '2', x, train)
+    x = torch.cat([F.max_pool2d(x, 3, stride=2, padding=1), _basic_conv(sd, p + '3.conv', x, train, 2)], 1)            # Mixed_3a
+    b0 = _basic_conv(sd, p + '4.branch0.1', _basic_conv(sd, p + '4.branch0.0', x, train), train)
+    b1 = x
+    for i in range(4):
+        b1 = _basic_conv(sd, p + '4.branch1.%d' % i, b1, train)
+    x = torch.cat([b0, b1], 1)                                                                                          # Mixed_4a
+    x = torch.cat([_basic_conv(sd, p + '5.conv', x, train, 2), F.max_pool2d(x, 3, stride=2, padding=1)], 1)             # Mixed_5a
+    b0 = _basic_conv(sd, p + '6.branch0', x, train)
+    b1 = _basic_conv(sd, p + '6.branch1.1', _basic_conv(sd, p + '6.branch1.0', x, train), train)
+    b2 = x
+    for i in range(3):
+        b2 = _basic_conv(sd, p + '6.branch2.%d' % i, b2, train)
+    b3 = _basic_conv(sd, p + '6.branch3.1', F.avg_pool2d(x, 3, stride=1, padding=1, count_include_pad=False), train)
+    x = torch.cat([b0, b1, b2, b3], 1)                                                                                  # Inception_A
+    y = F.conv2d(x, sd[p + '7.weight'], sd[p + '7.bias'])
+    return F.relu(_bn(sd, p + '8', y, train))
+
+
 def flat_softmax(x):
     """dsntnn.py:124-130."""
     return F.softmax(x.flatten(2), dim=-1).view_as(x)
@@ -98,7 +133,7 @@ def flat_softmax(x):
 
 def inner_forward(sd, x, n_stages, train, axis_permutation=True):
     """models/margipose_model.py:179-200 -- returns three lists (xy, zy, xz) of per-stage heatmaps."""
-    inp = patch8_stem(sd, x, train)
+    inp = inceptionv4_stem(sd, x, train) if 'inner.in_cnn.0.conv.weight' in sd else patch8_stem(sd, x, train)
     spaces = PLANES if axis_permutation else ('xy', 'xy', 'xy')
     outs = {p: [] for p in PLANES}
     for t in range(n_stages):

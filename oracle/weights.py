@@ -47,9 +47,33 @@ def column_entries(prefix, n_joints=17):
     return e
 
 
-def schema(n_stages, n_joints=17):
-    """Ordered key -> shape map of MargiPoseModel(n_stages) with the patch8 stem."""
-    e = [('inner.in_cnn.0.weight', (128, 3, 8, 8))] + _bn_entries('inner.in_cnn.1', 128)
+def _basic_entries(prefix, cin, cout, k):
+    k = k if isinstance(k, tuple) else (k, k)
+    return [(prefix + '.conv.weight', (cout, cin) + k)] + _bn_entries(prefix + '.bn', cout)
+
+
+def inceptionv4_stem_entries(p='inner.in_cnn.'):
+    """pretrainedmodels' InceptionV4 features[0:7] + the reference's 1x1 head (unpinned)."""
+    e = _basic_entries(p + '0', 3, 32, 3) + _basic_entries(p + '1', 32, 32, 3) + _basic_entries(p + '2', 32, 64, 3)
+    e += _basic_entries(p + '3.conv', 64, 96, 3)
+    e += _basic_entries(p + '4.branch0.0', 160, 64, 1) + _basic_entries(p + '4.branch0.1', 64, 96, 3)
+    e += _basic_entries(p + '4.branch1.0', 160, 64, 1) + _basic_entries(p + '4.branch1.1', 64, 64, (1, 7))
+    e += _basic_entries(p + '4.branch1.2', 64, 64, (7, 1)) + _basic_entries(p + '4.branch1.3', 64, 96, 3)
+    e += _basic_entries(p + '5.conv', 192, 192, 3)
+    e += _basic_entries(p + '6.branch0', 384, 96, 1)
+    e += _basic_entries(p + '6.branch1.0', 384, 64, 1) + _basic_entries(p + '6.branch1.1', 64, 96, 3)
+    e += _basic_entries(p + '6.branch2.0', 384, 64, 1) + _basic_entries(p + '6.branch2.1', 64, 96, 3) + _basic_entries(p + '6.branch2.2', 96, 96, 3)
+    e += _basic_entries(p + '6.branch3.1', 384, 96, 1)
+    e += [(p + '7.weight', (128, 384, 1, 1)), (p + '7.bias', (128,))] + _bn_entries(p + '8', 128)
+    return e
+
+
+def schema(n_stages, n_joints=17, stem='patch8'):
+    """Ordered key -> shape map of MargiPoseModel(n_stages) with the given stem."""
+    if stem == 'inceptionv4':
+        e = inceptionv4_stem_entries()
+    else:
+        e = [('inner.in_cnn.0.weight', (128, 3, 8, 8))] + _bn_entries('inner.in_cnn.1', 128)
     # nn.ModuleList registration order (models/margipose_model.py:158-162): all xy columns, then zy,
     # then xz, then the combiners.
     for p in PLANES:
@@ -85,8 +109,8 @@ def fill_like(shapes, seed, dtype=torch.float32):
     return sd
 
 
-def make_state_dict(n_stages, seed, dtype=torch.float32):
-    return fill_like(schema(n_stages), seed, dtype)
+def make_state_dict(n_stages, seed, dtype=torch.float32, stem='patch8'):
+    return fill_like(schema(n_stages, stem=stem), seed, dtype)
 
 
 def column_state_dict(prefix, seed, dtype=torch.float32):

@@ -32,6 +32,8 @@ def test_registry_and_errors():
     from margipose_amd.models import Default_MargiPose_Desc, create_model
     from margipose_amd.models.margipose_model import MargiPoseModel, CanonicalSkeletonDesc
     m = create_model({'type': 'margipose', 'version': '6.0.1', 'settings': {'n_stages': 1}})
+    assert m.inner.feature_extractor_name == 'inceptionv4'        # the reference's default (models/margipose_model.py:20)
+    assert sum(p.numel() for k, p in m.named_parameters() if k.startswith('inner.in_cnn')) == 972896
     assert m.inner.n_stages == 1 and m.data_specs.input_specs.size == 256 and m.xy_heatmaps is None
     assert Default_MargiPose_Desc['settings']['n_stages'] == 4
     with pytest.raises(Exception, match='unrecognised model'):
