@@ -166,7 +166,7 @@ int mpose_conv_wgrad(const mpose_conv_geom* geom, const mpose_wgrad_operands* op
 /* Batched weight (re)packing and gradient un-packing; jobs live in device memory. */
 typedef struct {
   const float* src;                    /* torch-layout weight */
-  float* dst;                          /* packed [T][K/4][Npad][4] */
+  float* dst;                          /* packed bf16 planes [T][Kpad/16][3 (hi,mid,lo)][Npad][2][8]: 1.5 floats per element */
   int N, K, T, Npad, Kpad;
   int64_t sn, sk, st;                  /* element strides of n, k, tap in src */
 } mpose_pack_job;

@@ -1,5 +1,6 @@
-// Implicit-GEMM convolution engine for gfx950 on the exact-fp32 matrix cores
-// (v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD, bitwise an fp32 fma chain).
+// Implicit-GEMM convolution engine for gfx950: fp32 convolutions computed on the bf16 matrix cores with
+// 3-way split operands ("bf16x6", fp32-equivalent accuracy; see conv_igemm_k) -- and, for the weight
+// gradient, on the exact-fp32 v_mfma_f32_32x32x2_f32.
 //
 // Replaces every Conv2d / ConvTranspose2d of reference src/margipose/models/margipose_model.py
 // (:33, :67-68, :73-74, :79-82), their data-gradients and their weight-gradients.  One kernel
@@ -17,11 +18,9 @@
 // input tile; the ReLU mask and the BN-backward reductions are folded into the dgrad epilogue;
 // the xy/zy/xz columns of a stage run as one grouped launch (blockIdx.z).
 //
-// Layout: activations NHWC fp32, weights pre-packed [widx][K/4][Npad][4] so that both MFMA
-// operands are fetched from LDS with one ds_read_b128 per four MFMAs:
-//   lane (i = l&31, h = l>>5) holds A[pixel i][k = q*8 + h*4 + j] and B[k][n = l&31], j = 0..3.
-// LDS A tile rows are padded to 36 floats (144 B): the 16 lanes of a ds_read_b128 group then hit
-// 16 distinct 16-byte slots (9*i mod 16 is a bijection), so the reads are conflict-free.
+// Layout: activations NHWC fp32; weights pre-split into three bf16 planes and packed
+// [widx][K/16][plane][Npad][half][8] -- one 16-byte v_mfma_f32_32x32x16_bf16 B fragment per (n, half):
+//   lane (i = l&31, h = l>>5) holds A[pixel i][k = 16 s + 8 h + 0..7] and B[k = 16 s + 8 h + 0..7][n = l&31].
 #include "common.h"
 
 namespace mpose {
@@ -42,8 +41,10 @@ inline FastDiv make_fastdiv(unsigned d) {
 }
 __device__ __forceinline__ unsigned fdiv(unsigned n, FastDiv f) { return (__umulhi(n, f.mul) + n) >> f.shift; }
 
-constexpr int KC = 32;            // channels per K-chunk
-constexpr int A_STRIDE = 36;      // padded floats per A-tile row
+constexpr int KC = 32;              // channels per K-chunk = two 16-deep MFMA k-groups
+constexpr int A_ROW_B = 80;         // LDS bytes per pixel row of one bf16 plane: 64 B of data + 16 B pad
+constexpr int A_PLANE_B = 64 * A_ROW_B;
+constexpr int A_TILE_B = 3 * A_PLANE_B;   // hi / mid / lo planes of one 64-pixel x 32-channel tile
 
 struct ConvArgs {
   mpose_conv_geom g;
@@ -58,57 +59,79 @@ struct ConvArgs {
 // Row of the 32x32 accumulator held in register r of lane-half h.
 __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
-// Forward / data-gradient kernel.
-//
-// Cost model (measured, tools/ablate_conv.py + rocprofv3 PMC, r1): v_mfma_f32_32x32x2_f32 runs at 64 FLOP/clk/SIMD --
-// exactly the SIMD's 32 fp32 FMA lanes -- and every VALU instruction issued by ANY wave of the SIMD takes those
-// lanes away from it: kernel time ~= MFMA cycles + VALU cycles, independent of occupancy.  So the loop below is
-// written to issue (almost) no vector ALU work per MFMA:
-//   * all addresses are  buffer descriptor + loop-invariant per-lane VGPR offset + wave-uniform SGPR offset;
-//     the scalar unit advances the SGPR part (tap shift, channel chunk, k-group);
-//   * zero padding is done by the buffer unit: an out-of-bounds row gets voffset = 0xFFFFFFF0 and the load
-//     returns 0 (3 VALU ops per staged row and tap instead of compare/select trees);
-//   * a workgroup is 4 INDEPENDENT wavefronts (no workgroup barrier in the K loop): wave w owns output rows
-//     m0 + 32w .. +31 and 32*RN output channels (RN up to 4);
-//   * A operand: the wave stages ITS OWN 32 rows x 32 channels per (chunk, tap) through a wave-private,
-//     double-buffered LDS tile (coalesced 128-byte row reads, transposed into MFMA fragment order by the
-//     ds_read_b128).  LDS ops of one wave execute in order, so no s_barrier is needed;
-//   * B operand: packed weights are already in fragment order, so every lane fetches its float4 fragments
-//     straight from L2 into a 4-slot register ring, 3 k-groups ahead of use (pinned with sched_barrier, hipcc
-//     otherwise sinks the prefetch to its use).
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
   const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, (int)soff, 0);
   return make_float4(__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w));
 }
-
+__device__ __forceinline__ u32x4 buf_load4u(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
+  return __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, (int)soff, 0);
+}
 __device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
   return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)voff, (int)soff, 0));
 }
 
 constexpr unsigned kOob = 0xFFFFFFF0u;      // voffset that the buffer unit treats as out of range -> returns 0
 
-// KS = 2 (split-K inside the workgroup): waves (2t, 2t+1) share output rows t and take half of the (chunk, tap)
-// tiles each; used when a launch would otherwise put fewer than ~2.5 waves on a SIMD (the 16x16 layers at
-// batch 32 give 1.5: every SIMD would wait for the ones that got two).  The halves are summed through the
-// (by then dead) A-tile LDS region in a fixed order.
-template <int RN, bool ACC1, int KS>
-__global__ __launch_bounds__(256, (RN == 4 && KS == 2) ? 1 : 2) void conv_igemm_k(ConvArgs a) {
-  constexpr int BM = 128 / KS;
-  constexpr int BN = 32 * RN;
-  constexpr int A_TILE = 32 * A_STRIDE;      // floats per wave per buffer
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  int* sTaps = reinterpret_cast<int*>(smem);                          // [MPOSE_MAX_TAPS] (+4 pad)
-  float* sA_all = smem + 16;                                          // [4 waves][2][A_TILE]
-  float* sRed = smem + 16 + 4 * 2 * A_TILE;                           // [2 sets][4 waves][BN][2]
+// fp32 -> three bf16 planes with x == hi + mid + lo up to 2^-27 |x| (round-to-nearest at every level; the two
+// subtractions are exact in fp32).  gfx950 has v_cvt_pk_bf16_f32, so a float4 costs ~20 VALU instructions.
+__device__ __forceinline__ void split4(const float4 v, bf16x4& h, bf16x4& m, bf16x4& l) {
+  const f32x4 x = {v.x, v.y, v.z, v.w};
+  h = __builtin_convertvector(x, bf16x4);
+  const f32x4 r1 = x - __builtin_convertvector(h, f32x4);
+  m = __builtin_convertvector(r1, bf16x4);
+  const f32x4 r2 = r1 - __builtin_convertvector(m, f32x4);
+  l = __builtin_convertvector(r2, bf16x4);
+}
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+__device__ __forceinline__ f32x16 mfma_bf16(const bf16x8 a, const bf16x8 b, const f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ bf16x8 as_bf16x8(const u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
+
+// Forward / data-gradient kernel: fp32 convolution on the bf16 matrix cores ("bf16x6").
+//
+// Why: gfx950's fp32 MFMA (v_mfma_f32_32x32x2_f32) runs on the SIMD's 32 fp32 FMA lanes -- measured 147 TFLOP/s
+// for the whole chip (tools/probe/mfma_probe.hip) -- while v_mfma_f32_32x32x16_bf16 sustains 1.9 PFLOP/s.  An fp32
+// value is the exact sum of three bf16 values (8 significant bits each), so  a*b = sum_ij a_i*b_j ; the three
+// smallest cross terms (mid*lo, lo*mid, lo*lo <= 2^-26 |ab|) are below fp32's own rounding and are dropped.  Six
+// bf16 MFMAs (products exact, fp32 accumulation) therefore replace eight fp32 MFMAs per 16 channels at 2.2x the
+// speed, with the same error bound as an fp32 FMA chain (tests/test_conv_gpu.py compares both against fp64).
+//
+// Cost model (measured, tools/probe/): a bf16 MFMA occupies its SIMD for ~16.5 ns whatever the occupancy, a
+// dependent accumulate chain costs nothing extra, and VALU instructions of the same SIMD do not hide under it
+// (+1..1.6 ns each).  So: ONE wave per SIMD with a fat 64-pixel x 32*RN-channel register tile (512 registers),
+// deep register prefetch instead of occupancy, and as little VALU per MFMA as possible:
+//   * all addresses are  buffer descriptor + loop-invariant per-lane VGPR offset + wave-uniform SGPR offset;
+//   * zero padding is done by the buffer unit (out-of-bounds rows get voffset 0xFFFFFFF0 and read 0);
+//   * a workgroup is 4 INDEPENDENT wavefronts (no workgroup barrier in the K loop);
+//   * A operand: the wave stages ITS OWN 64 rows x 32 channels per (chunk, tap): coalesced 128-byte row reads,
+//     optional BN+ReLU of the producer, the 3-way bf16 split, then three ds_write_b64 into a wave-private,
+//     double-buffered LDS tile whose ds_read_b128 delivers MFMA fragment order (row pitch 80 B: conflict-free);
+//   * B operand: weights are split and laid out in fragment order ONCE per step by pack_weights_k, so every lane
+//     fetches 16-byte fragments straight from L2 into a register ring a whole tile (96 MFMAs) ahead of use.
+// KS (split-K inside the workgroup): KS waves share one 64-row tile and take 1/KS of the (chunk, tap) tiles each;
+// chosen per launch so that the number of waves is close to a multiple of the 1024 SIMDs.  The parts are summed
+// through the (by then dead) A-tile LDS region in a fixed order.
+template <int RN, bool ACC1, int KS>
+__global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
+  constexpr int BM = 256 / KS;
+  constexpr int BN = 32 * RN;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  int* sTaps = reinterpret_cast<int*>(smem_raw);                                  // [MPOSE_MAX_TAPS] (+4 pad)
+  unsigned char* sA_all = smem_raw + 64;                                          // [4 waves][2][A_TILE_B]
+  float* sRed = reinterpret_cast<float*>(smem_raw + 64 + 4 * 2 * A_TILE_B);       // [2 sets][4 waves][BN][2]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lh = lane >> 5;
   const mpose_conv_geom& g = a.g;
   const int cls = blockIdx.x / a.n_mtiles;
-  const int kh = (KS == 2) ? (wave & 1) : 0;                              // K half of this wave
-  const int m0 = (blockIdx.x - cls * a.n_mtiles) * BM + (KS == 2 ? (wave >> 1) : wave) * 32;   // first row of THIS wave
+  const int kh = wave % KS;                                                       // K part of this wave
+  const int m0 = (blockIdx.x - cls * a.n_mtiles) * BM + (wave / KS) * 64;          // first row of THIS wave
   const int n0 = blockIdx.y * BN;
   const mpose_conv_operands& op = a.op[blockIdx.z];
   const int n_taps = g.cls[cls].n_taps;
@@ -117,16 +140,16 @@ __global__ __launch_bounds__(256, (RN == 4 && KS == 2) ? 1 : 2) void conv_igemm_
     sTaps[tid] = (int)(unsigned char)t.dy | ((int)(unsigned char)t.dx << 8) | ((int)(unsigned char)t.widx << 16) | ((int)(unsigned char)t.acc << 24);
   }
   __syncthreads();   // sTaps visible (the only workgroup barrier before the epilogue)
-  float* sA = sA_all + wave * 2 * A_TILE;
+  unsigned char* sA = sA_all + wave * 2 * A_TILE_B;
 
   // ---- per-lane staging state (loop invariant) ----
   // row_voff[j]: BYTE offset of the slot's anchor pixel + this lane's 16-byte channel column;
   // row_taps[j]: bit t = tap t reads an in-bounds pixel for that row.
   const int a_col4 = lane & 7;
   const int in_ld = g.in_ld > 0 ? g.in_ld : g.Cin;
-  unsigned row_voff[4], row_taps[4];
+  unsigned row_voff[8], row_taps[8];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < 8; ++j) {
     const unsigned m = (unsigned)(m0 + (lane >> 3) + 8 * j);
     row_voff[j] = 0; row_taps[j] = 0;
     if ((int)m < a.M) {
@@ -145,8 +168,9 @@ __global__ __launch_bounds__(256, (RN == 4 && KS == 2) ? 1 : 2) void conv_igemm_
   }
   const int n_chunks = g.Cin / KC;
   const int n_iter = n_chunks * n_taps;
-  const int k4_total = g.Cin >> 2;
+  const int k16_total = g.Cin >> 4;
   const int npad = g.Npad0;                                       // == Npad1 when ACC1
+  const unsigned plane_b = (unsigned)npad * 32u;                   // bytes of one (k-group, plane) slab of packed weights
   const bool pro = op.in_scale != nullptr;
   // Buffer descriptors.  The input base is moved back by `a.in_bias` bytes so that the (possibly negative) tap
   // shift becomes a non-negative SGPR offset.
@@ -154,22 +178,24 @@ __global__ __launch_bounds__(256, (RN == 4 && KS == 2) ? 1 : 2) void conv_igemm_
       const_cast<char*>(reinterpret_cast<const char*>(op.in)) - a.in_bias, 0, 0xFFFFFF00, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_w0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(op.w0), 0, 0xFFFFFF00, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_w1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ACC1 ? op.w1 : op.w0), 0, 0xFFFFFF00, 0x00020000);
-  const unsigned w_voff = (unsigned)((lh * npad + n0 + li) * 16);   // this lane's fragment inside a k-group pair (bytes)
+  const unsigned w_voff = (unsigned)(((n0 + li) * 2 + lh) * 16);     // this lane's 16-byte fragment inside a slab
 
-  f32x16 acc0[RN], acc1[ACC1 ? RN : 1];
+  f32x16 acc0[2][RN], acc1[ACC1 ? 2 : 1][ACC1 ? RN : 1];
 #pragma unroll
-  for (int rn = 0; rn < RN; ++rn)
+  for (int rm = 0; rm < 2; ++rm)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc0[rn][r] = 0.0f;
+    for (int rn = 0; rn < RN; ++rn)
 #pragma unroll
-  for (int rn = 0; rn < (ACC1 ? RN : 1); ++rn)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc1[rn][r] = 0.0f;
+      for (int r = 0; r < 16; ++r) {
+        acc0[rm][rn][r] = 0.0f;
+        if (ACC1) acc1[rm][rn][r] = 0.0f;
+      }
 
-  float4 ra[4];
+  float4 ra[8];
   float4 rsc = make_float4(1.f, 1.f, 1.f, 1.f), rsh = make_float4(0.f, 0.f, 0.f, 0.f);
-  unsigned ra_inv[4] = {0, 0, 0, 0};      // 0xFFFFFFFF for out-of-bounds rows (only consumed when `pro`)
-  float4 fb[4][RN];                      // B-fragment ring: slot q holds k-group q of some tile
+  unsigned ra_inv = 0;                   // bit j: staged row j is padding (only consumed when `pro`)
+  u32x4 fb[2][RN][3];                    // B-fragment ring: [k-group][column block][plane] of the NEXT use
+  bf16x8 afA[2][3], afB[2][3];           // A fragments [row block][plane] of k-group 0 / 1
 
   // wave-uniform (SGPR) description of tile `it`
   struct TileInfo { unsigned a_soff; unsigned w_soff; int t; int c; bool second; };
@@ -182,20 +208,21 @@ __global__ __launch_bounds__(256, (RN == 4 && KS == 2) ? 1 : 2) void conv_igemm_
     const int widx = (tp >> 16) & 0xff;
     ti.second = ACC1 && ((tp >> 24) & 0xff);
     ti.a_soff = (unsigned)(((dy * g.IW + dx) * in_ld + ti.c * KC) * 4 + a.in_bias);
-    ti.w_soff = (unsigned)((widx * k4_total + ti.c * (KC / 4)) * npad * 16);
+    ti.w_soff = (unsigned)(widx * k16_total + ti.c * (KC / 16)) * 3u * plane_b;
     return ti;
   };
-  auto load_b = [&](const TileInfo& ti, int q, float4 (&dst)[RN]) {
-    const unsigned so = ti.w_soff + (unsigned)(q * 2 * npad * 16);
+  auto load_b = [&](const TileInfo& ti, int s, int rn) {
+    const unsigned so = ti.w_soff + (unsigned)s * 3u * plane_b;
 #pragma unroll
-    for (int rn = 0; rn < RN; ++rn)
-      dst[rn] = buf_load4((ACC1 && ti.second) ? rs_w1 : rs_w0, w_voff + (unsigned)(rn * 512), so);
+    for (int pl = 0; pl < 3; ++pl)
+      fb[s][rn][pl] = buf_load4u((ACC1 && ti.second) ? rs_w1 : rs_w0, w_voff + (unsigned)(rn * 1024), so + (unsigned)pl * plane_b);
   };
   auto load_a = [&](const TileInfo& ti) {
+    ra_inv = 0;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < 8; ++j) {
       const unsigned inv = ((row_taps[j] >> ti.t) & 1u) - 1u;       // 0 = in bounds, 0xFFFFFFFF = padding
-      ra_inv[j] = inv;
+      ra_inv |= inv & (1u << j);
       ra[j] = buf_load4(rs_in, row_voff[j] | (inv & kOob), ti.a_soff);
     }
     if (pro) {
@@ -203,119 +230,128 @@ __global__ __launch_bounds__(256, (RN == 4 && KS == 2) ? 1 : 2) void conv_igemm_
       rsh = *reinterpret_cast<const float4*>(op.in_shift + ti.c * KC + a_col4 * 4);
     }
   };
-  // BN + ReLU of the producing layer (only when requested) is applied at LDS-store time; padding rows are
-  // already zero from the buffer unit and are re-zeroed only on the `pro` path (relu(shift) != 0).
+  // BN + ReLU of the producing layer (only when requested) and the bf16 split happen at LDS-store time; padding
+  // rows are already zero from the buffer unit and are re-zeroed only on the `pro` path (relu(shift) != 0).
   auto store_a = [&](int buf) {
-    float* dA = sA + buf * A_TILE;
+    unsigned char* dA = sA + buf * A_TILE_B + (lane >> 3) * A_ROW_B + a_col4 * 8;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < 8; ++j) {
       float4 v = ra[j];
       if (pro) {
         v.x = fmaxf(fmaf(v.x, rsc.x, rsh.x), 0.f); v.y = fmaxf(fmaf(v.y, rsc.y, rsh.y), 0.f);
         v.z = fmaxf(fmaf(v.z, rsc.z, rsh.z), 0.f); v.w = fmaxf(fmaf(v.w, rsc.w, rsh.w), 0.f);
-        if (ra_inv[j]) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((ra_inv >> j) & 1u) v = make_float4(0.f, 0.f, 0.f, 0.f);
       }
-      *reinterpret_cast<float4*>(dA + ((lane >> 3) + 8 * j) * A_STRIDE + a_col4 * 4) = v;
+      bf16x4 h, m, l;
+      split4(v, h, m, l);
+      *reinterpret_cast<bf16x4*>(dA + j * 8 * A_ROW_B) = h;
+      *reinterpret_cast<bf16x4*>(dA + j * 8 * A_ROW_B + A_PLANE_B) = m;
+      *reinterpret_cast<bf16x4*>(dA + j * 8 * A_ROW_B + 2 * A_PLANE_B) = l;
     }
     __builtin_amdgcn_wave_barrier();     // compiler ordering only; LDS executes one wave's ops in order
   };
+  auto read_frags = [&](int buf, int s, bf16x8 (&af)[2][3]) {
+    const unsigned char* cA = sA + buf * A_TILE_B + li * A_ROW_B + s * 32 + lh * 16;
+#pragma unroll
+    for (int rm = 0; rm < 2; ++rm)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl)
+        af[rm][pl] = *reinterpret_cast<const bf16x8*>(cA + rm * 32 * A_ROW_B + pl * A_PLANE_B);
+  };
+  // the six bf16 products of one 16-channel k-group, smallest terms first; then refill the consumed B fragments
+  // with the same k-group of the NEXT tile (a whole tile of MFMAs ahead of their use)
+  auto mfma_group_on = [&](auto& acc, int s, const bf16x8 (&af)[2][3], const TileInfo& nxt) {
+#pragma unroll
+    for (int rn = 0; rn < RN; ++rn) {
+      const bf16x8 bh = as_bf16x8(fb[s][rn][0]), bm = as_bf16x8(fb[s][rn][1]), bl = as_bf16x8(fb[s][rn][2]);
+#pragma unroll
+      for (int rm = 0; rm < 2; ++rm) {
+        f32x16 c = acc[rm][rn];
+        c = mfma_bf16(af[rm][2], bh, c);
+        c = mfma_bf16(af[rm][0], bl, c);
+        c = mfma_bf16(af[rm][1], bm, c);
+        c = mfma_bf16(af[rm][1], bh, c);
+        c = mfma_bf16(af[rm][0], bm, c);
+        c = mfma_bf16(af[rm][0], bh, c);
+        acc[rm][rn] = c;
+      }
+      load_b(nxt, s, rn);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  auto mfma_group = [&](int s, const bf16x8 (&af)[2][3], const TileInfo& cur, const TileInfo& nxt) {
+    if constexpr (ACC1) {
+      if (cur.second) mfma_group_on(acc1, s, af, nxt);      // wave-uniform branch
+      else mfma_group_on(acc0, s, af, nxt);
+    } else {
+      mfma_group_on(acc0, s, af, nxt);
+    }
+  };
 
-  const int it_begin = (KS == 2 && kh) ? (n_iter >> 1) : 0;
-  const int it_end = (KS == 2 && !kh) ? (n_iter >> 1) : n_iter;
+  const int it_begin = (KS == 1) ? 0 : (n_iter * kh) / KS;
+  const int it_end = (KS == 1) ? n_iter : (n_iter * (kh + 1)) / KS;
   if (it_begin < it_end) {
-    TileInfo t0 = tile_info(it_begin);
+    const TileInfo t0 = tile_info(it_begin);
     load_a(t0);
-    load_b(t0, 0, fb[0]);
-    load_b(t0, 1, fb[1]);
-    load_b(t0, 2, fb[2]);
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int rn = 0; rn < RN; ++rn) load_b(t0, s, rn);
     store_a(it_begin & 1);
+    read_frags(it_begin & 1, 0, afA);
   }
   for (int it = it_begin; it < it_end; ++it) {
     const int buf = it & 1;
     const TileInfo cur = tile_info(it);
     const TileInfo nxt = tile_info(it + 1 < it_end ? it + 1 : it);     // the last prefetch is a harmless repeat
     load_a(nxt);
+    read_frags(buf, 1, afB);
     __builtin_amdgcn_sched_barrier(0);
-    const float* cA = sA + buf * A_TILE + li * A_STRIDE + lh * 4;
-    // One (chunk, tap) tile = a 32-long fp32 FMA chain per output element, accumulated into a FRESH register
-    // tile and then added to the running sum: error ~ sqrt(32)+sqrt(#tiles) ulps instead of sqrt(K).
-    f32x16 part[RN];
-    float4 fa = *reinterpret_cast<const float4*>(cA);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      // B fragments 3 k-groups ahead: slot (q+3)&3 was consumed by the previous k-group
-      if (q == 0) load_b(cur, 3, fb[3]);
-      else load_b(nxt, q - 1, fb[q - 1]);
-      float4 fa_next = fa;
-      if (q < 3) fa_next = *reinterpret_cast<const float4*>(cA + (q + 1) * 8);
-      __builtin_amdgcn_sched_barrier(0);   // keep the prefetches ABOVE this k-group's MFMAs
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float av = e == 0 ? fa.x : (e == 1 ? fa.y : (e == 2 ? fa.z : fa.w));
-#pragma unroll
-        for (int rn = 0; rn < RN; ++rn) {
-          f32x16 c;
-          if (q == 0 && e == 0) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) c[r] = 0.0f;
-          } else {
-            c = part[rn];
-          }
-          const float4 bq = fb[q][rn];
-          const float bv = e == 0 ? bq.x : (e == 1 ? bq.y : (e == 2 ? bq.z : bq.w));
-          part[rn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, c, 0, 0, 0);
-        }
-      }
-      fa = fa_next;
-    }
-#pragma unroll
-    for (int rn = 0; rn < RN; ++rn) {
-      if (ACC1 && cur.second) acc1[rn] += part[rn];
-      else acc0[rn] += part[rn];
-    }
+    mfma_group(0, afA, cur, nxt);
     store_a(buf ^ 1);
+    read_frags(buf ^ 1, 0, afA);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_group(1, afB, cur, nxt);
   }
 
-  // ---- split-K exchange: odd waves hand their partial tiles to their even partner through LDS ----
-  if (KS == 2) {
+  // ---- split-K exchange: waves with kh > 0 hand their partial tiles to wave kh == 0 through LDS ----
+  if (KS > 1) {
+    constexpr int EX = (ACC1 ? 2 : 1) * 2 * RN * 16 * 64;      // floats per handed-over tile set
     __syncthreads();                                   // every wave is done with its A tiles
-    float* ex = sA_all + (size_t)(wave >> 1) * (ACC1 ? 2 : 1) * RN * 16 * 64;
+    float* ex_all = reinterpret_cast<float*>(sA_all);
     if (kh) {
+      float* ex = ex_all + (size_t)((wave / KS) * (KS - 1) + (kh - 1)) * EX;
 #pragma unroll
-      for (int rn = 0; rn < RN; ++rn)
+      for (int rm = 0; rm < 2; ++rm)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          ex[(rn * 16 + r) * 64 + lane] = acc0[rn][r];
-          if (ACC1) ex[((RN + rn) * 16 + r) * 64 + lane] = acc1[rn][r];
-        }
+        for (int rn = 0; rn < RN; ++rn)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            ex[((rm * RN + rn) * 16 + r) * 64 + lane] = acc0[rm][rn][r];
+            if (ACC1) ex[(((2 + rm) * RN + rn) * 16 + r) * 64 + lane] = acc1[ACC1 ? rm : 0][ACC1 ? rn : 0][r];
+          }
     }
     __syncthreads();
     if (!kh) {
 #pragma unroll
-      for (int rn = 0; rn < RN; ++rn)
+      for (int p = 0; p < KS - 1; ++p) {
+        const float* ex = ex_all + (size_t)((wave / KS) * (KS - 1) + p) * EX;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          acc0[rn][r] += ex[(rn * 16 + r) * 64 + lane];
-          if (ACC1) acc1[rn][r] += ex[((RN + rn) * 16 + r) * 64 + lane];
-        }
+        for (int rm = 0; rm < 2; ++rm)
+#pragma unroll
+          for (int rn = 0; rn < RN; ++rn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              acc0[rm][rn][r] += ex[((rm * RN + rn) * 16 + r) * 64 + lane];
+              if (ACC1) acc1[ACC1 ? rm : 0][ACC1 ? rn : 0][r] += ex[(((2 + rm) * RN + rn) * 16 + r) * 64 + lane];
+            }
+      }
     }
   }
   const bool writer = (KS == 1) || !kh;
 
   // ---- epilogue (branch-free: buffer stores/loads, rows beyond M get an out-of-range offset and are dropped) ----
   const int oyc = g.cls[cls].oy, oxc = g.cls[cls].ox;
-  unsigned row_pix[16];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const unsigned m = (unsigned)(m0 + acc_row(r, lh));
-    const unsigned mm = (int)m < a.M ? m : 0u;
-    const unsigned b = fdiv(mm, a.div_ghw);
-    const unsigned rem = mm - b * (unsigned)(g.GH * g.GW);
-    const unsigned gy = fdiv(rem, a.div_gw);
-    const unsigned gx = rem - gy * (unsigned)g.GW;
-    const unsigned pix = (b * (unsigned)g.OH + (gy * g.out_mul + oyc)) * (unsigned)g.OW + (gx * g.out_mul + oxc);
-    row_pix[r] = ((int)m < a.M && writer) ? pix : 0xFFFFFFFFu;
-  }
 #pragma unroll
   for (int set = 0; set < (ACC1 ? 2 : 1); ++set) {
     float* outp = set ? op.out1 : op.out0;
@@ -328,50 +364,70 @@ __global__ __launch_bounds__(256, (RN == 4 && KS == 2) ? 1 : 2) void conv_igemm_
     const unsigned out_bytes = (unsigned)((((long)g.B * g.OH * g.OW - 1) * out_ld + cout) * 4);
     const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(outp, 0, out_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_m = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(masked ? op.mask_src : outp), 0, out_bytes, 0x00020000);
+    float csum[RN], csq[RN];
 #pragma unroll
-    for (int rn = 0; rn < RN; ++rn) {
-      const int nb = n0 + rn * 32;                 // wave-uniform: the whole 32-column group is in or out (cout % 32 == 0)
-      float csum = 0.f, csq = 0.f;
-      if (nb < cout) {
-        const int n = nb + li;
-        unsigned voff[16];
+    for (int rn = 0; rn < RN; ++rn) csum[rn] = csq[rn] = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) voff[r] = row_pix[r] == 0xFFFFFFFFu ? kOob : (row_pix[r] * (unsigned)out_ld + (unsigned)n) * 4u;
-        float v[16];
+    for (int rm = 0; rm < 2; ++rm) {
+      unsigned row_pix[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = (ACC1 && set) ? acc1[rn][r] : acc0[rn][r];
-        if (masked) {
-          const float msc = op.mask_scale[n], msh = op.mask_shift[n];
-          float src[16];
+      for (int r = 0; r < 16; ++r) {
+        const unsigned m = (unsigned)(m0 + rm * 32 + acc_row(r, lh));
+        const unsigned mm = (int)m < a.M ? m : 0u;
+        const unsigned b = fdiv(mm, a.div_ghw);
+        const unsigned rem = mm - b * (unsigned)(g.GH * g.GW);
+        const unsigned gy = fdiv(rem, a.div_gw);
+        const unsigned gx = rem - gy * (unsigned)g.GW;
+        const unsigned pix = (b * (unsigned)g.OH + (gy * g.out_mul + oyc)) * (unsigned)g.OW + (gx * g.out_mul + oxc);
+        row_pix[r] = ((int)m < a.M && writer) ? pix : 0xFFFFFFFFu;
+      }
 #pragma unroll
-          for (int r = 0; r < 16; ++r) src[r] = buf_load1(rs_m, voff[r], 0);
+      for (int rn = 0; rn < RN; ++rn) {
+        const int nb = n0 + rn * 32;                 // wave-uniform: the whole 32-column group is in or out (cout % 32 == 0)
+        if (nb < cout) {
+          const int n = nb + li;
+          unsigned voff[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) voff[r] = row_pix[r] == 0xFFFFFFFFu ? kOob : (row_pix[r] * (unsigned)out_ld + (unsigned)n) * 4u;
+          float v[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] = (ACC1 && set) ? acc1[ACC1 ? rm : 0][ACC1 ? rn : 0][r] : acc0[rm][rn][r];
+          if (masked) {
+            const float msc = op.mask_scale[n], msh = op.mask_shift[n];
+            float src[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) src[r] = buf_load1(rs_m, voff[r], 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              if (!(fmaf(src[r], msc, msh) > 0.f)) v[r] = 0.f;
+              csq[rn] = fmaf(v[r], src[r], csq[rn]);
+            }
+          }
+          if (accumulate) {
+            float old[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) old[r] = buf_load1(rs_o, voff[r], 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] += old[r];
+          }
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            if (!(fmaf(src[r], msc, msh) > 0.f)) v[r] = 0.f;
-            csq = fmaf(v[r], src[r], csq);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[r]), rs_o, (int)voff[r], 0, 0);
+            const float vv = (voff[r] == kOob) ? 0.f : v[r];
+            csum[rn] += vv;
+            if (!masked) csq[rn] = fmaf(vv, vv, csq[rn]);
           }
         }
-        if (accumulate) {
-          float old[16];
-#pragma unroll
-          for (int r = 0; r < 16; ++r) old[r] = buf_load1(rs_o, voff[r], 0);
-#pragma unroll
-          for (int r = 0; r < 16; ++r) v[r] += old[r];
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[r]), rs_o, (int)voff[r], 0, 0);
-          const float vv = (voff[r] == kOob) ? 0.f : v[r];
-          csum += vv;
-          if (!masked) csq = fmaf(vv, vv, csq);
-        }
       }
-      if (stats != nullptr) {
-        csum += __shfl_xor(csum, 32, 64);
-        csq += __shfl_xor(csq, 32, 64);
+    }
+    if (stats != nullptr) {
+#pragma unroll
+      for (int rn = 0; rn < RN; ++rn) {
+        const float s_ = csum[rn] + __shfl_xor(csum[rn], 32, 64);
+        const float q_ = csq[rn] + __shfl_xor(csq[rn], 32, 64);
         if (lh == 0) {
           float* d = sRed + ((set * 4 + wave) * BN + rn * 32 + li) * 2;
-          d[0] = csum; d[1] = csq;
+          d[0] = s_; d[1] = q_;
         }
       }
     }
@@ -400,20 +456,45 @@ __global__ __launch_bounds__(256, (RN == 4 && KS == 2) ? 1 : 2) void conv_igemm_
 template <int RN, bool ACC1, int KS>
 int launch_conv(const ConvArgs& a0, int n_groups, hipStream_t s) {
   constexpr int BN = 32 * RN;
+  constexpr int lds = 64 + 4 * 2 * A_TILE_B + 2 * 4 * BN * 2 * 4;
+  static bool attr_set = false;          // > 64 KiB of dynamic LDS has to be requested once per kernel
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_k<RN, ACC1, KS>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+      return MPOSE_EINVAL;
+    attr_set = true;
+  }
   ConvArgs a = a0;
-  a.n_mtiles = (a.M + 128 / KS - 1) / (128 / KS);
-  const int lds = (16 + 4 * 2 * 32 * A_STRIDE + 2 * 4 * BN * 2) * 4;
+  a.n_mtiles = (a.M + 256 / KS - 1) / (256 / KS);
   const int cmax = a.g.Cout1 > a.g.Cout0 ? a.g.Cout1 : a.g.Cout0;
   dim3 grid(a.n_mtiles * a.g.n_classes, (cmax + BN - 1) / BN, n_groups);
   conv_igemm_k<RN, ACC1, KS><<<grid, 256, lds, s>>>(a);
   return launch_status();
 }
 
-// waves per SIMD of a launch without split-K (1024 SIMDs)
+// Split-K factor: one workgroup (4 waves, one per SIMD) owns a CU, so a launch runs in ceil(WGs / 256) rounds;
+// take the smallest KS in {1, 2, 4} whose last round is reasonably full.
 template <int RN>
-inline bool want_ksplit(const ConvArgs& a, int cmax, int n_groups) {
-  const long waves = (long)((a.M + 31) / 32) * a.g.n_classes * ((cmax + 32 * RN - 1) / (32 * RN)) * n_groups;
-  return waves < 2560;
+inline int pick_ks(const ConvArgs& a, int cmax, int n_groups) {
+  const int n_iter = (a.g.Cin / KC) * a.g.cls[0].n_taps;
+  int best = 1;
+  double best_eff = 0.0;
+  for (int ks = 1; ks <= 4; ks *= 2) {
+    if (ks > 1 && n_iter < 2 * ks) break;
+    const long wgs = (long)((a.M + 256 / ks - 1) / (256 / ks)) * a.g.n_classes * ((cmax + 32 * RN - 1) / (32 * RN)) * n_groups;
+    const long rounds = (wgs + 255) / 256;
+    const double eff = (double)wgs / (256.0 * rounds);
+    if (eff > best_eff + 0.08) { best = ks; best_eff = eff; }
+  }
+  return best;
+}
+
+template <int RN, bool ACC1>
+int launch_conv_ks(const ConvArgs& a, int cmax, int n_groups, hipStream_t s) {
+  switch (pick_ks<RN>(a, cmax, n_groups)) {
+    case 4: return launch_conv<RN, ACC1, 4>(a, n_groups, s);
+    case 2: return launch_conv<RN, ACC1, 2>(a, n_groups, s);
+    default: return launch_conv<RN, ACC1, 1>(a, n_groups, s);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -438,6 +519,11 @@ struct WgradArgs {
   int entry_tap[MPOSE_MAX_CLASSES * MPOSE_MAX_TAPS];
   int n_widx0, n_widx1;
   int in_bias;                    // bytes, as in ConvArgs
+  // XCD-aware work order: workgroup b runs on XCD b % 8 (observed, speed only), and each XCD has a private 4 MiB
+  // L2.  The work list is ordered (group, pixel split) outermost, (k/n tile, tap) innermost, and XCD c takes the
+  // contiguous chunk c of it, so all 9 taps x Cin/32 tiles that re-read one pixel split's X and dY slices run on
+  // ONE L2 at about the same time (instead of every L2 pulling every slice: measured 5-9x over-fetch before).
+  int n_ytiles, n_groups, chunk, total;
 };
 
 template <int RN>   // wave tile: 32 input channels x 32*RN output channels
@@ -447,17 +533,22 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_k(WgradArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lh = lane >> 5;
   const mpose_conv_geom& g = a.g;
-  const int entry = blockIdx.x / a.n_split;
-  const int split = blockIdx.x - entry * a.n_split;
+  const unsigned slot_id = blockIdx.x >> 3, work = (blockIdx.x & 7u) * (unsigned)a.chunk + slot_id;
+  if (slot_id >= (unsigned)a.chunk || work >= (unsigned)a.total) return;
+  unsigned wrk = work;
+  const int entry = wrk % (unsigned)a.n_entries; wrk /= (unsigned)a.n_entries;
+  const int ytile = wrk % (unsigned)a.n_ytiles; wrk /= (unsigned)a.n_ytiles;
+  const int split = wrk % (unsigned)a.n_split;
+  const int group = wrk / (unsigned)a.n_split;
   const int cls = a.entry_cls[entry];
   const mpose_tap tap = g.cls[cls].taps[a.entry_tap[entry]];
   const bool second = tap.acc != 0;
   const int npad = second ? g.Npad1 : g.Npad0;
   const int cout = second ? g.Cout1 : g.Cout0;
   const int n_ctiles = (cout + 32 * RN - 1) / (32 * RN);
-  const int k_tile = blockIdx.y / n_ctiles, n_tile = blockIdx.y - k_tile * n_ctiles;
+  const int k_tile = ytile / n_ctiles, n_tile = ytile - k_tile * n_ctiles;
   const int k0 = k_tile * 32, n0 = n_tile * 32 * RN;
-  const mpose_wgrad_operands& op = a.op[blockIdx.z];
+  const mpose_wgrad_operands& op = a.op[group];
   const float* gout = second ? op.gout1 : op.gout0;
   float* dw = second ? op.dw1 : op.dw0;
   const int n_widx = second ? a.n_widx1 : a.n_widx0;
@@ -601,19 +692,27 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_k(WgradArgs a) {
 // ---------------------------------------------------------------------------------------------
 // Weight packing / gradient unpacking (one launch for all convolutions of the model)
 // ---------------------------------------------------------------------------------------------
+// dst layout (bf16): [T][Kpad/16][plane 3][Npad][half 2][8]  -- one 16-byte MFMA B fragment per (n, half)
 __global__ __launch_bounds__(256) void pack_weights_k(const mpose_pack_job* __restrict__ jobs) {
   const mpose_pack_job j = jobs[blockIdx.y];
   const long total = (long)j.T * j.Kpad * j.Npad;
+  __bf16* dst = reinterpret_cast<__bf16*>(j.dst);
+  const long plane = (long)j.Npad * 16;
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
-    const int k_lo = (int)(e & 3);
-    long r = e >> 2;
+    const int k_lo = (int)(e & 15);              // half * 8 + j
+    long r = e >> 4;
     const int n = (int)(r % j.Npad); r /= j.Npad;
-    const int k4 = (int)(r % (j.Kpad / 4));
-    const int t = (int)(r / (j.Kpad / 4));
-    const int k = k4 * 4 + k_lo;
+    const int k16 = (int)(r % (j.Kpad / 16));
+    const int t = (int)(r / (j.Kpad / 16));
+    const int k = k16 * 16 + k_lo;
     float v = 0.f;
     if (n < j.N && k < j.K) v = j.src[n * j.sn + k * j.sk + t * j.st];
-    j.dst[e] = v;
+    const __bf16 h = (__bf16)v;
+    const float r1 = v - (float)h;
+    const __bf16 m = (__bf16)r1;
+    const __bf16 l = (__bf16)(r1 - (float)m);
+    __bf16* d = dst + ((long)(t * (j.Kpad / 16) + k16) * 3) * plane + (long)n * 16 + k_lo;
+    d[0] = h; d[plane] = m; d[2 * plane] = l;
   }
 }
 
@@ -691,15 +790,14 @@ extern "C" int mpose_conv_fwd(const mpose_conv_geom* geom, const mpose_conv_oper
     const int ldm = geom->out_ld0 > geom->out_ld1 ? geom->out_ld0 : geom->out_ld1;
     if ((long)geom->B * geom->OH * geom->OW * (ldm > cmax ? ldm : cmax) * 4 >= 0xFFFFFF00l) return MPOSE_EINVAL;
   }
-  if (cmax <= 32) return acc1 ? launch_conv<1, true, 1>(a, n_groups, s) : launch_conv<1, false, 1>(a, n_groups, s);
+  if (geom->Cin % 16) return MPOSE_EINVAL;
+  if (cmax <= 32) return acc1 ? launch_conv_ks<1, true>(a, cmax, n_groups, s) : launch_conv_ks<1, false>(a, cmax, n_groups, s);
   if (npad % 64) return MPOSE_EINVAL;
-  if (acc1) return want_ksplit<2>(a, cmax, n_groups) ? launch_conv<2, true, 2>(a, n_groups, s) : launch_conv<2, true, 1>(a, n_groups, s);
+  if (acc1) return launch_conv_ks<2, true>(a, cmax, n_groups, s);
   // widest wave tile that divides the padded N: 128 channels (RN=4), 96 (RN=3) or 64 (RN=2)
-  if (cmax % 128 == 0)
-    return want_ksplit<4>(a, cmax, n_groups) ? launch_conv<4, false, 2>(a, n_groups, s) : launch_conv<4, false, 1>(a, n_groups, s);
-  if (cmax % 96 == 0 && npad % 96 == 0)
-    return want_ksplit<3>(a, cmax, n_groups) ? launch_conv<3, false, 2>(a, n_groups, s) : launch_conv<3, false, 1>(a, n_groups, s);
-  return want_ksplit<2>(a, cmax, n_groups) ? launch_conv<2, false, 2>(a, n_groups, s) : launch_conv<2, false, 1>(a, n_groups, s);
+  if (cmax % 128 == 0) return launch_conv_ks<4, false>(a, cmax, n_groups, s);
+  if (cmax % 96 == 0 && npad % 96 == 0) return launch_conv_ks<3, false>(a, cmax, n_groups, s);
+  return launch_conv_ks<2, false>(a, cmax, n_groups, s);
 }
 
 extern "C" int mpose_conv_wgrad(const mpose_conv_geom* geom, const mpose_wgrad_operands* ops, int n_groups, int n_split,
@@ -743,19 +841,16 @@ extern "C" int mpose_conv_wgrad(const mpose_conv_geom* geom, const mpose_wgrad_o
   a.rows_per_split = (n_rows + n_split - 1) / n_split;
   hipStream_t s = (hipStream_t)stream;
   const int cout = geom->Cout0;
-  if (cout % 128 == 0) {
-    dim3 grid(a.n_entries * n_split, (geom->Cin / 32) * (cout / 128), n_groups);
-    conv_wgrad_k<4><<<grid, 256, 4 * 16 * 64 * 4, s>>>(a);
-  } else if (cout % 96 == 0) {
-    dim3 grid(a.n_entries * n_split, (geom->Cin / 32) * (cout / 96), n_groups);
-    conv_wgrad_k<3><<<grid, 256, 3 * 16 * 64 * 4, s>>>(a);
-  } else if (cout % 64 == 0) {
-    dim3 grid(a.n_entries * n_split, (geom->Cin / 32) * (cout / 64), n_groups);
-    conv_wgrad_k<2><<<grid, 256, 2 * 16 * 64 * 4, s>>>(a);
-  } else {
-    dim3 grid(a.n_entries * n_split, (geom->Cin / 32) * (cout / 32), n_groups);
-    conv_wgrad_k<1><<<grid, 256, 1 * 16 * 64 * 4, s>>>(a);
-  }
+  const int rn = cout % 128 == 0 ? 4 : (cout % 96 == 0 ? 3 : (cout % 64 == 0 ? 2 : 1));
+  a.n_ytiles = (geom->Cin / 32) * (cout / (32 * rn));
+  a.n_groups = n_groups;
+  a.total = a.n_entries * a.n_ytiles * n_split * n_groups;
+  a.chunk = (a.total + 7) / 8;
+  const dim3 grid(8 * a.chunk);
+  if (rn == 4) conv_wgrad_k<4><<<grid, 256, 4 * 16 * 64 * 4, s>>>(a);
+  else if (rn == 3) conv_wgrad_k<3><<<grid, 256, 3 * 16 * 64 * 4, s>>>(a);
+  else if (rn == 2) conv_wgrad_k<2><<<grid, 256, 2 * 16 * 64 * 4, s>>>(a);
+  else conv_wgrad_k<1><<<grid, 256, 1 * 16 * 64 * 4, s>>>(a);
   return launch_status();
 }
 

@@ -110,8 +110,10 @@ class _Conv:
         self.stem = stem
         self.npad_f = _rup(cout, 64)             # forward pack: N = cout, K = cin_s
         self.npad_d = _rup(cin, 64)              # dgrad pack:   N = cin,  K = cout_s
-        self.size_f = self.T * cin_s * self.npad_f
-        self.size_d = self.T * cout_s * self.npad_d
+        # packed as three bf16 planes (hi, mid, lo) = 6 bytes per element = 1.5 floats of arena
+        self.size_f = self.T * cin_s * self.npad_f * 3 // 2
+        self.size_d = self.T * cout_s * self.npad_d * 3 // 2
+        self.size_g = self.T * cin_s * self.npad_f          # one split-K partial of the weight gradient (fp32)
         self.off_f = self.off_d = self.off_g = -1
 
     def strides(self, dgrad):
@@ -382,7 +384,7 @@ class Engine:
             j['N'], j['K'], j['T'], j['Npad'], j['Kpad'], j['n_split'] = conv.cout, conv.cin, conv.T, conv.npad_f, conv.cin_s, nsp
             j['sn'], j['sk'], j['st'], j['accumulate'] = sn, sk, stt, 0
             part_offs[id(conv)] = part_off
-            part_off += nsp * conv.size_f
+            part_off += nsp * conv.size_g
             mx = max(mx, conv.cout * conv.cin * conv.T)
 
         k = 1

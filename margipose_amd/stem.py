@@ -151,8 +151,9 @@ class InceptionV4Stem:
                 op.conv = _Conv(op.weight, False, 1, op.cin, op.cout, cin_s, op.cout)
                 op.conv.T = op.kh * op.kw
                 op.conv.kk = op.kh * op.kw
-                op.conv.size_f = op.conv.T * cin_s * op.conv.npad_f
-                op.conv.size_d = op.conv.T * op.cout * op.conv.npad_d
+                op.conv.size_g = op.conv.T * cin_s * op.conv.npad_f
+                op.conv.size_f = op.conv.size_g * 3 // 2
+                op.conv.size_d = op.conv.T * op.cout * op.conv.npad_d * 3 // 2
                 op.conv.generic = True
             else:
                 op.dst.parts.append((op.c0, op.c0 + op.src.C, None, 0.0, None))

@@ -28,7 +28,8 @@ def run(H, C, pro):
     g = _geom(B, H, C, H, C, 0, H, 1, 1, [(0, 0, t9)], C)
     flops = _geom_flops(g) * 3
     xs = [torch.randn(B, H, H, C, device='cuda') for _ in range(3)]
-    ws = [torch.randn(9 * C * C, device='cuda') * 0.05 for _ in range(3)]
+    # packed weights: three bf16 planes per element (values only matter for speed through DVFS)
+    ws = [(torch.randn(9 * C * C * 3, device='cuda') * 0.05).to(torch.bfloat16).view(torch.float32) for _ in range(3)]
     outs = [torch.empty(B, H, H, C, device='cuda') for _ in range(3)]
     sc = torch.rand(C, device='cuda') + 0.5; sh = torch.randn(C, device='cuda') * 0.1
     ops = []
