@@ -79,13 +79,19 @@ constexpr unsigned kOob = 0xFFFFFFF0u;      // voffset that the buffer unit trea
 
 // fp32 -> three bf16 planes with x == hi + mid + lo up to 2^-27 |x| (round-to-nearest at every level; the two
 // subtractions are exact in fp32).  gfx950 has v_cvt_pk_bf16_f32, so a float4 costs ~20 VALU instructions.
-__device__ __forceinline__ void split4(const float4 v, bf16x4& h, bf16x4& m, bf16x4& l) {
-  const f32x4 x = {v.x, v.y, v.z, v.w};
-  h = __builtin_convertvector(x, bf16x4);
-  const f32x4 r1 = x - __builtin_convertvector(h, f32x4);
-  m = __builtin_convertvector(r1, bf16x4);
-  const f32x4 r2 = r1 - __builtin_convertvector(m, f32x4);
-  l = __builtin_convertvector(r2, bf16x4);
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split2(const f32x2 x, unsigned& h, unsigned& m, unsigned& l) {
+  const bf16x2 hh = __builtin_convertvector(x, bf16x2);              // v_cvt_pk_bf16_f32
+  const f32x2 r1 = x - __builtin_convertvector(hh, f32x2);           // shift / and + v_pk_add_f32
+  const bf16x2 mm = __builtin_convertvector(r1, bf16x2);
+  const f32x2 r2 = r1 - __builtin_convertvector(mm, f32x2);
+  const bf16x2 ll = __builtin_convertvector(r2, bf16x2);
+  h = __builtin_bit_cast(unsigned, hh); m = __builtin_bit_cast(unsigned, mm); l = __builtin_bit_cast(unsigned, ll);
+}
+__device__ __forceinline__ void split4(const float4 v, uint2& h, uint2& m, uint2& l) {
+  split2(f32x2{v.x, v.y}, h.x, m.x, l.x);
+  split2(f32x2{v.z, v.w}, h.y, m.y, l.y);
 }
 
 __device__ __forceinline__ f32x16 mfma_bf16(const bf16x8 a, const bf16x8 b, const f32x16 c) {
@@ -167,7 +173,6 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
     }
   }
   const int n_chunks = g.Cin / KC;
-  const int n_iter = n_chunks * n_taps;
   const int k16_total = g.Cin >> 4;
   const int npad = g.Npad0;                                       // == Npad1 when ACC1
   const unsigned plane_b = (unsigned)npad * 32u;                   // bytes of one (k-group, plane) slab of packed weights
@@ -180,180 +185,180 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
   const __amdgpu_buffer_rsrc_t rs_w1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ACC1 ? op.w1 : op.w0), 0, 0xFFFFFF00, 0x00020000);
   const unsigned w_voff = (unsigned)(((n0 + li) * 2 + lh) * 16);     // this lane's 16-byte fragment inside a slab
 
-  f32x16 acc0[2][RN], acc1[ACC1 ? 2 : 1][ACC1 ? RN : 1];
-#pragma unroll
-  for (int rm = 0; rm < 2; ++rm)
-#pragma unroll
-    for (int rn = 0; rn < RN; ++rn)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        acc0[rm][rn][r] = 0.0f;
-        if (ACC1) acc1[rm][rn][r] = 0.0f;
-      }
-
+  f32x16 acc0[2][RN];
   float4 ra[8];
   float4 rsc = make_float4(1.f, 1.f, 1.f, 1.f), rsh = make_float4(0.f, 0.f, 0.f, 0.f);
   unsigned ra_inv = 0;                   // bit j: staged row j is padding (only consumed when `pro`)
   u32x4 fb[2][RN][3];                    // B-fragment ring: [k-group][column block][plane] of the NEXT use
   bf16x8 afA[2][3], afB[2][3];           // A fragments [row block][plane] of k-group 0 / 1
+  const int oyc = g.cls[cls].oy, oxc = g.cls[cls].ox;
 
-  // wave-uniform (SGPR) description of tile `it`
-  struct TileInfo { unsigned a_soff; unsigned w_soff; int t; int c; bool second; };
-  auto tile_info = [&](int it) {
-    TileInfo ti;
-    ti.c = it / n_taps;
-    ti.t = it - ti.c * n_taps;
-    const int tp = __builtin_amdgcn_readfirstlane(sTaps[ti.t]);
-    const int dy = (int)(signed char)(tp & 0xff), dx = (int)(signed char)((tp >> 8) & 0xff);
-    const int widx = (tp >> 16) & 0xff;
-    ti.second = ACC1 && ((tp >> 24) & 0xff);
-    ti.a_soff = (unsigned)(((dy * g.IW + dx) * in_ld + ti.c * KC) * 4 + a.in_bias);
-    ti.w_soff = (unsigned)(widx * k16_total + ti.c * (KC / 16)) * 3u * plane_b;
-    return ti;
-  };
-  auto load_b = [&](const TileInfo& ti, int s, int rn) {
-    const unsigned so = ti.w_soff + (unsigned)s * 3u * plane_b;
-#pragma unroll
-    for (int pl = 0; pl < 3; ++pl)
-      fb[s][rn][pl] = buf_load4u((ACC1 && ti.second) ? rs_w1 : rs_w0, w_voff + (unsigned)(rn * 1024), so + (unsigned)pl * plane_b);
-  };
-  auto load_a = [&](const TileInfo& ti) {
-    ra_inv = 0;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const unsigned inv = ((row_taps[j] >> ti.t) & 1u) - 1u;       // 0 = in bounds, 0xFFFFFFFF = padding
-      ra_inv |= inv & (1u << j);
-      ra[j] = buf_load4(rs_in, row_voff[j] | (inv & kOob), ti.a_soff);
-    }
-    if (pro) {
-      rsc = *reinterpret_cast<const float4*>(op.in_scale + ti.c * KC + a_col4 * 4);
-      rsh = *reinterpret_cast<const float4*>(op.in_shift + ti.c * KC + a_col4 * 4);
-    }
-  };
-  // BN + ReLU of the producing layer (only when requested) and the bf16 split happen at LDS-store time; padding
-  // rows are already zero from the buffer unit and are re-zeroed only on the `pro` path (relu(shift) != 0).
-  auto store_a = [&](int buf) {
-    unsigned char* dA = sA + buf * A_TILE_B + (lane >> 3) * A_ROW_B + a_col4 * 8;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      float4 v = ra[j];
-      if (pro) {
-        v.x = fmaxf(fmaf(v.x, rsc.x, rsh.x), 0.f); v.y = fmaxf(fmaf(v.y, rsc.y, rsh.y), 0.f);
-        v.z = fmaxf(fmaf(v.z, rsc.z, rsh.z), 0.f); v.w = fmaxf(fmaf(v.w, rsc.w, rsh.w), 0.f);
-        if ((ra_inv >> j) & 1u) v = make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-      bf16x4 h, m, l;
-      split4(v, h, m, l);
-      *reinterpret_cast<bf16x4*>(dA + j * 8 * A_ROW_B) = h;
-      *reinterpret_cast<bf16x4*>(dA + j * 8 * A_ROW_B + A_PLANE_B) = m;
-      *reinterpret_cast<bf16x4*>(dA + j * 8 * A_ROW_B + 2 * A_PLANE_B) = l;
-    }
-    __builtin_amdgcn_wave_barrier();     // compiler ordering only; LDS executes one wave's ops in order
-  };
-  auto read_frags = [&](int buf, int s, bf16x8 (&af)[2][3]) {
-    const unsigned char* cA = sA + buf * A_TILE_B + li * A_ROW_B + s * 32 + lh * 16;
+  // Taps with acc == 0 (the convolution proper) come first in a class's tap list, taps with acc == 1 (the fused
+  // 1x1 shortcut of a ResidualBlock: same input, second weight set, second output) last.  The two sets run as
+  // two passes of the same pipeline with ONE accumulator tile, so the fused launch keeps the full 128-wide tile.
+  int n_taps0 = 0;
+  for (int t = 0; t < n_taps; ++t) n_taps0 += (((sTaps[t] >> 24) & 0xff) == 0) ? 1 : 0;
+  n_taps0 = __builtin_amdgcn_readfirstlane(n_taps0);
+
+#pragma unroll 1
+  for (int set = 0; set < (ACC1 ? 2 : 1); ++set) {
+    const int t_lo = set ? n_taps0 : 0;
+    const int nt = set ? n_taps - n_taps0 : (ACC1 ? n_taps0 : n_taps);
+    const int n_iter = n_chunks * nt;
+    const __amdgpu_buffer_rsrc_t rs_w = set ? rs_w1 : rs_w0;
 #pragma unroll
     for (int rm = 0; rm < 2; ++rm)
 #pragma unroll
+      for (int rn = 0; rn < RN; ++rn)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc0[rm][rn][r] = 0.0f;
+
+    // wave-uniform (SGPR) description of tile `it`
+    struct TileInfo { unsigned a_soff; unsigned w_soff; int t; int c; };
+    auto tile_info = [&](int it) {
+      TileInfo ti;
+      ti.c = it / nt;
+      ti.t = t_lo + it - ti.c * nt;
+      const int tp = __builtin_amdgcn_readfirstlane(sTaps[ti.t]);
+      const int dy = (int)(signed char)(tp & 0xff), dx = (int)(signed char)((tp >> 8) & 0xff);
+      const int widx = (tp >> 16) & 0xff;
+      ti.a_soff = (unsigned)(((dy * g.IW + dx) * in_ld + ti.c * KC) * 4 + a.in_bias);
+      ti.w_soff = (unsigned)(widx * k16_total + ti.c * (KC / 16)) * 3u * plane_b;
+      return ti;
+    };
+    auto load_b = [&](const TileInfo& ti, int s_, int rn) {
+      const unsigned so = ti.w_soff + (unsigned)s_ * 3u * plane_b;
+#pragma unroll
       for (int pl = 0; pl < 3; ++pl)
-        af[rm][pl] = *reinterpret_cast<const bf16x8*>(cA + rm * 32 * A_ROW_B + pl * A_PLANE_B);
-  };
-  // the six bf16 products of one 16-channel k-group, smallest terms first; then refill the consumed B fragments
-  // with the same k-group of the NEXT tile (a whole tile of MFMAs ahead of their use)
-  auto mfma_group_on = [&](auto& acc, int s, const bf16x8 (&af)[2][3], const TileInfo& nxt) {
+        fb[s_][rn][pl] = buf_load4u(rs_w, w_voff + (unsigned)(rn * 1024), so + (unsigned)pl * plane_b);
+    };
+    auto load_a = [&](const TileInfo& ti) {
+      ra_inv = 0;
 #pragma unroll
-    for (int rn = 0; rn < RN; ++rn) {
-      const bf16x8 bh = as_bf16x8(fb[s][rn][0]), bm = as_bf16x8(fb[s][rn][1]), bl = as_bf16x8(fb[s][rn][2]);
-#pragma unroll
-      for (int rm = 0; rm < 2; ++rm) {
-        f32x16 c = acc[rm][rn];
-        c = mfma_bf16(af[rm][2], bh, c);
-        c = mfma_bf16(af[rm][0], bl, c);
-        c = mfma_bf16(af[rm][1], bm, c);
-        c = mfma_bf16(af[rm][1], bh, c);
-        c = mfma_bf16(af[rm][0], bm, c);
-        c = mfma_bf16(af[rm][0], bh, c);
-        acc[rm][rn] = c;
+      for (int j = 0; j < 8; ++j) {
+        const unsigned inv = ((row_taps[j] >> ti.t) & 1u) - 1u;       // 0 = in bounds, 0xFFFFFFFF = padding
+        ra_inv |= inv & (1u << j);
+        ra[j] = buf_load4(rs_in, row_voff[j] | (inv & kOob), ti.a_soff);
       }
-      load_b(nxt, s, rn);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  };
-  auto mfma_group = [&](int s, const bf16x8 (&af)[2][3], const TileInfo& cur, const TileInfo& nxt) {
-    if constexpr (ACC1) {
-      if (cur.second) mfma_group_on(acc1, s, af, nxt);      // wave-uniform branch
-      else mfma_group_on(acc0, s, af, nxt);
-    } else {
-      mfma_group_on(acc0, s, af, nxt);
-    }
-  };
-
-  const int it_begin = (KS == 1) ? 0 : (n_iter * kh) / KS;
-  const int it_end = (KS == 1) ? n_iter : (n_iter * (kh + 1)) / KS;
-  if (it_begin < it_end) {
-    const TileInfo t0 = tile_info(it_begin);
-    load_a(t0);
+      if (pro) {
+        rsc = *reinterpret_cast<const float4*>(op.in_scale + ti.c * KC + a_col4 * 4);
+        rsh = *reinterpret_cast<const float4*>(op.in_shift + ti.c * KC + a_col4 * 4);
+      }
+    };
+    // BN + ReLU of the producing layer (only when requested) and the bf16 split happen at LDS-store time; padding
+    // rows are already zero from the buffer unit and are re-zeroed only on the `pro` path (relu(shift) != 0).
+    auto store_a = [&](int buf) {
+      unsigned char* dA = sA + buf * A_TILE_B + (lane >> 3) * A_ROW_B + a_col4 * 8;
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-      for (int rn = 0; rn < RN; ++rn) load_b(t0, s, rn);
-    store_a(it_begin & 1);
-    read_frags(it_begin & 1, 0, afA);
-  }
-  for (int it = it_begin; it < it_end; ++it) {
-    const int buf = it & 1;
-    const TileInfo cur = tile_info(it);
-    const TileInfo nxt = tile_info(it + 1 < it_end ? it + 1 : it);     // the last prefetch is a harmless repeat
-    load_a(nxt);
-    read_frags(buf, 1, afB);
-    __builtin_amdgcn_sched_barrier(0);
-    mfma_group(0, afA, cur, nxt);
-    store_a(buf ^ 1);
-    read_frags(buf ^ 1, 0, afA);
-    __builtin_amdgcn_sched_barrier(0);
-    mfma_group(1, afB, cur, nxt);
-  }
-
-  // ---- split-K exchange: waves with kh > 0 hand their partial tiles to wave kh == 0 through LDS ----
-  if (KS > 1) {
-    constexpr int EX = (ACC1 ? 2 : 1) * 2 * RN * 16 * 64;      // floats per handed-over tile set
-    __syncthreads();                                   // every wave is done with its A tiles
-    float* ex_all = reinterpret_cast<float*>(sA_all);
-    if (kh) {
-      float* ex = ex_all + (size_t)((wave / KS) * (KS - 1) + (kh - 1)) * EX;
+      for (int j = 0; j < 8; ++j) {
+        float4 v = ra[j];
+        if (pro) {
+          const bool pad = (ra_inv >> j) & 1u;
+          v.x = pad ? 0.f : fmaxf(fmaf(v.x, rsc.x, rsh.x), 0.f); v.y = pad ? 0.f : fmaxf(fmaf(v.y, rsc.y, rsh.y), 0.f);
+          v.z = pad ? 0.f : fmaxf(fmaf(v.z, rsc.z, rsh.z), 0.f); v.w = pad ? 0.f : fmaxf(fmaf(v.w, rsc.w, rsh.w), 0.f);
+        }
+        uint2 h, m, l;
+        split4(v, h, m, l);
+        *reinterpret_cast<uint2*>(dA + j * 8 * A_ROW_B) = h;
+        *reinterpret_cast<uint2*>(dA + j * 8 * A_ROW_B + A_PLANE_B) = m;
+        *reinterpret_cast<uint2*>(dA + j * 8 * A_ROW_B + 2 * A_PLANE_B) = l;
+      }
+      __builtin_amdgcn_wave_barrier();     // compiler ordering only; LDS executes one wave's ops in order
+    };
+    auto read_frags = [&](int buf, int s_, bf16x8 (&af)[2][3]) {
+      const unsigned char* cA = sA + buf * A_TILE_B + li * A_ROW_B + s_ * 32 + lh * 16;
 #pragma unroll
       for (int rm = 0; rm < 2; ++rm)
 #pragma unroll
-        for (int rn = 0; rn < RN; ++rn)
+        for (int pl = 0; pl < 3; ++pl)
+          af[rm][pl] = *reinterpret_cast<const bf16x8*>(cA + rm * 32 * A_ROW_B + pl * A_PLANE_B);
+    };
+    // the six bf16 products of one 16-channel k-group, smallest terms first; then refill the consumed B fragments
+    // with the same k-group of the NEXT tile (a whole tile of MFMAs ahead of their use)
+    auto mfma_group = [&](int s_, const bf16x8 (&af)[2][3], const TileInfo& nxt) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            ex[((rm * RN + rn) * 16 + r) * 64 + lane] = acc0[rm][rn][r];
-            if (ACC1) ex[(((2 + rm) * RN + rn) * 16 + r) * 64 + lane] = acc1[ACC1 ? rm : 0][ACC1 ? rn : 0][r];
-          }
+      for (int rn = 0; rn < RN; ++rn) {
+        const bf16x8 bh = as_bf16x8(fb[s_][rn][0]), bm = as_bf16x8(fb[s_][rn][1]), bl = as_bf16x8(fb[s_][rn][2]);
+#pragma unroll
+        for (int rm = 0; rm < 2; ++rm) {
+          f32x16 c = acc0[rm][rn];
+          c = mfma_bf16(af[rm][2], bh, c);
+          c = mfma_bf16(af[rm][0], bl, c);
+          c = mfma_bf16(af[rm][1], bm, c);
+          c = mfma_bf16(af[rm][1], bh, c);
+          c = mfma_bf16(af[rm][0], bm, c);
+          c = mfma_bf16(af[rm][0], bh, c);
+          acc0[rm][rn] = c;
+        }
+        load_b(nxt, s_, rn);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+
+    // Software pipeline (one wave per SIMD, so every latency has to be covered by this wave's own MFMAs):
+    //   global loads of A tile it+2  -> issued in the middle of iteration it, consumed in the middle of it+1;
+    //   B fragments of tile it+1     -> issued right after their use in iteration it;
+    //   LDS fragments of a k-group   -> read one MFMA group (48 MFMAs) before they are needed.
+    const int it_begin = (KS == 1) ? 0 : (n_iter * kh) / KS;
+    const int it_end = (KS == 1) ? n_iter : (n_iter * (kh + 1)) / KS;
+    if (it_begin < it_end) {
+      const TileInfo t0 = tile_info(it_begin);
+      load_a(t0);
+#pragma unroll
+      for (int s_ = 0; s_ < 2; ++s_)
+#pragma unroll
+        for (int rn = 0; rn < RN; ++rn) load_b(t0, s_, rn);
+      store_a(it_begin & 1);
+      load_a(tile_info(it_begin + 1 < it_end ? it_begin + 1 : it_begin));
+      read_frags(it_begin & 1, 0, afA);
+      TileInfo nxt = tile_info(it_begin + 1 < it_end ? it_begin + 1 : it_begin);
+      for (int it = it_begin; it < it_end; ++it) {
+        const int buf = it & 1;
+        const TileInfo nn = tile_info(it + 2 < it_end ? it + 2 : it);       // repeats at the tail are harmless
+        read_frags(buf, 1, afB);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_group(0, afA, nxt);
+        store_a(buf ^ 1);                    // tile it+1 (loaded one iteration ago)
+        load_a(nn);                          // tile it+2
+        read_frags(buf ^ 1, 0, afA);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_group(1, afB, nxt);
+        nxt = nn;
+      }
     }
-    __syncthreads();
-    if (!kh) {
-#pragma unroll
-      for (int p = 0; p < KS - 1; ++p) {
-        const float* ex = ex_all + (size_t)((wave / KS) * (KS - 1) + p) * EX;
+
+    // ---- split-K exchange: waves with kh > 0 hand their partial tiles to wave kh == 0 through LDS ----
+    if (KS > 1) {
+      constexpr int EX = 2 * RN * 16 * 64;               // floats per handed-over tile set
+      __syncthreads();                                   // every wave is done with its A tiles
+      float* ex_all = reinterpret_cast<float*>(sA_all);
+      if (kh) {
+        float* ex = ex_all + (size_t)((wave / KS) * (KS - 1) + (kh - 1)) * EX;
 #pragma unroll
         for (int rm = 0; rm < 2; ++rm)
 #pragma unroll
           for (int rn = 0; rn < RN; ++rn)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              acc0[rm][rn][r] += ex[((rm * RN + rn) * 16 + r) * 64 + lane];
-              if (ACC1) acc1[ACC1 ? rm : 0][ACC1 ? rn : 0][r] += ex[(((2 + rm) * RN + rn) * 16 + r) * 64 + lane];
-            }
+            for (int r = 0; r < 16; ++r) ex[((rm * RN + rn) * 16 + r) * 64 + lane] = acc0[rm][rn][r];
       }
-    }
-  }
-  const bool writer = (KS == 1) || !kh;
-
-  // ---- epilogue (branch-free: buffer stores/loads, rows beyond M get an out-of-range offset and are dropped) ----
-  const int oyc = g.cls[cls].oy, oxc = g.cls[cls].ox;
+      __syncthreads();
+      if (!kh) {
 #pragma unroll
-  for (int set = 0; set < (ACC1 ? 2 : 1); ++set) {
+        for (int p = 0; p < KS - 1; ++p) {
+          const float* ex = ex_all + (size_t)((wave / KS) * (KS - 1) + p) * EX;
+#pragma unroll
+          for (int rm = 0; rm < 2; ++rm)
+#pragma unroll
+            for (int rn = 0; rn < RN; ++rn)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) acc0[rm][rn][r] += ex[((rm * RN + rn) * 16 + r) * 64 + lane];
+        }
+      }
+      if (ACC1) __syncthreads();                         // the exchange area is the next pass's A tiles
+    }
+    const bool writer = (KS == 1) || !kh;
+
+    // ---- epilogue (branch-free: buffer stores/loads, rows beyond M get an out-of-range offset and are dropped) ----
     float* outp = set ? op.out1 : op.out0;
     const int cout = set ? g.Cout1 : g.Cout0;
     double* stats = set ? op.stats1 : op.stats0;
@@ -391,7 +396,7 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
           for (int r = 0; r < 16; ++r) voff[r] = row_pix[r] == 0xFFFFFFFFu ? kOob : (row_pix[r] * (unsigned)out_ld + (unsigned)n) * 4u;
           float v[16];
 #pragma unroll
-          for (int r = 0; r < 16; ++r) v[r] = (ACC1 && set) ? acc1[ACC1 ? rm : 0][ACC1 ? rn : 0][r] : acc0[rm][rn][r];
+          for (int r = 0; r < 16; ++r) v[r] = acc0[rm][rn][r];
           if (masked) {
             const float msc = op.mask_scale[n], msh = op.mask_shift[n];
             float src[16];
@@ -472,15 +477,18 @@ int launch_conv(const ConvArgs& a0, int n_groups, hipStream_t s) {
 }
 
 // Split-K factor: one workgroup (4 waves, one per SIMD) owns a CU, so a launch runs in ceil(WGs / 256) rounds;
-// take the smallest KS in {1, 2, 4} whose last round is reasonably full.
+// take the smallest KS in {1, 2, 4} whose last round is reasonably full.  The choice is made for a NOMINAL batch
+// of 32 images, not the actual one: the summation order of a sample then does not depend on how many other
+// samples share its launch, so a data-parallel shard reproduces the full batch's per-sample results bit for bit.
 template <int RN>
 inline int pick_ks(const ConvArgs& a, int cmax, int n_groups) {
   const int n_iter = (a.g.Cin / KC) * a.g.cls[0].n_taps;
+  const long m_nominal = 32l * a.g.GH * a.g.GW;
   int best = 1;
   double best_eff = 0.0;
   for (int ks = 1; ks <= 4; ks *= 2) {
     if (ks > 1 && n_iter < 2 * ks) break;
-    const long wgs = (long)((a.M + 256 / ks - 1) / (256 / ks)) * a.g.n_classes * ((cmax + 32 * RN - 1) / (32 * RN)) * n_groups;
+    const long wgs = ((m_nominal + 256 / ks - 1) / (256 / ks)) * a.g.n_classes * ((cmax + 32 * RN - 1) / (32 * RN)) * n_groups;
     const long rounds = (wgs + 255) / 256;
     const double eff = (double)wgs / (256.0 * rounds);
     if (eff > best_eff + 0.08) { best = ks; best_eff = eff; }
@@ -793,8 +801,12 @@ extern "C" int mpose_conv_fwd(const mpose_conv_geom* geom, const mpose_conv_oper
   if (geom->Cin % 16) return MPOSE_EINVAL;
   if (cmax <= 32) return acc1 ? launch_conv_ks<1, true>(a, cmax, n_groups, s) : launch_conv_ks<1, false>(a, cmax, n_groups, s);
   if (npad % 64) return MPOSE_EINVAL;
-  if (acc1) return launch_conv_ks<2, true>(a, cmax, n_groups, s);
   // widest wave tile that divides the padded N: 128 channels (RN=4), 96 (RN=3) or 64 (RN=2)
+  if (acc1) {
+    if (cmax % 128 == 0) return launch_conv_ks<4, true>(a, cmax, n_groups, s);
+    if (cmax % 96 == 0 && npad % 96 == 0) return launch_conv_ks<3, true>(a, cmax, n_groups, s);
+    return launch_conv_ks<2, true>(a, cmax, n_groups, s);
+  }
   if (cmax % 128 == 0) return launch_conv_ks<4, false>(a, cmax, n_groups, s);
   if (cmax % 96 == 0 && npad % 96 == 0) return launch_conv_ks<3, false>(a, cmax, n_groups, s);
   return launch_conv_ks<2, false>(a, cmax, n_groups, s);
