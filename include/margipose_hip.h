@@ -129,8 +129,9 @@ typedef struct {
 typedef struct {
   const float* in;                     /* input activations */
   const float* in_scale;               /* optional per-channel prologue a*x+b then ReLU (BN+ReLU of */
-  const float* in_shift;               /*   models/margipose_model.py:31-32,34-35); NULL = identity  */
-  const float* w0;                     /* packed weights [widx][Cin/4][Npad0][4] */
+  const float* in_shift;               /*   models/margipose_model.py:31-32,34-35); NULL = identity;
+                                        *   all groups of a launch alike; not with a fused shortcut   */
+  const float* w0;                     /* packed weights (mpose_pack_weights layout: three bf16 planes) */
   const float* w1;                     /* packed weights of the second accumulator, or NULL */
   float* out0;
   float* out1;

@@ -8,7 +8,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, 'csrc')
 LIB_PATH = os.path.join(PKG_DIR, 'libmargipose_hip.so')
 HIPCC_FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function',
-               '-Wno-unused-variable', '-Wno-unused-but-set-variable']
+               '-Wno-unused-variable', '-Wno-unused-but-set-variable', '-fno-slp-vectorize']
 
 
 def _hipcc():

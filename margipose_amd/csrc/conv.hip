@@ -81,17 +81,21 @@ constexpr unsigned kOob = 0xFFFFFFF0u;      // voffset that the buffer unit trea
 // subtractions are exact in fp32).  gfx950 has v_cvt_pk_bf16_f32, so a float4 costs ~20 VALU instructions.
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void split2(const f32x2 x, unsigned& h, unsigned& m, unsigned& l) {
-  const bf16x2 hh = __builtin_convertvector(x, bf16x2);              // v_cvt_pk_bf16_f32
-  const f32x2 r1 = x - __builtin_convertvector(hh, f32x2);           // shift / and + v_pk_add_f32
-  const bf16x2 mm = __builtin_convertvector(r1, bf16x2);
-  const f32x2 r2 = r1 - __builtin_convertvector(mm, f32x2);
-  const bf16x2 ll = __builtin_convertvector(r2, bf16x2);
-  h = __builtin_bit_cast(unsigned, hh); m = __builtin_bit_cast(unsigned, mm); l = __builtin_bit_cast(unsigned, ll);
+// Two elements at a time: v_cvt_pk_bf16_f32 rounds a pair; the residuals are computed with SCALAR v_sub_f32 --
+// packed-f32 VALU (v_pk_add_f32) beside MFMAs is an anti-lever on gfx950 (MI355X_MICROARCH.md), so the file is
+// also built with -fno-slp-vectorize.
+__device__ __forceinline__ float bf_lo(unsigned p) { return __uint_as_float(p << 16); }
+__device__ __forceinline__ float bf_hi(unsigned p) { return __uint_as_float(p & 0xFFFF0000u); }
+__device__ __forceinline__ void split2(const float x0, const float x1, unsigned& h, unsigned& m, unsigned& l) {
+  h = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{x0, x1}, bf16x2));
+  const float r0 = x0 - bf_lo(h), r1 = x1 - bf_hi(h);
+  m = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{r0, r1}, bf16x2));
+  const float q0 = r0 - bf_lo(m), q1 = r1 - bf_hi(m);
+  l = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{q0, q1}, bf16x2));
 }
 __device__ __forceinline__ void split4(const float4 v, uint2& h, uint2& m, uint2& l) {
-  split2(f32x2{v.x, v.y}, h.x, m.x, l.x);
-  split2(f32x2{v.z, v.w}, h.y, m.y, l.y);
+  split2(v.x, v.y, h.x, m.x, l.x);
+  split2(v.z, v.w, h.y, m.y, l.y);
 }
 
 __device__ __forceinline__ f32x16 mfma_bf16(const bf16x8 a, const bf16x8 b, const f32x16 c) {
@@ -123,7 +127,7 @@ __device__ __forceinline__ bf16x8 as_bf16x8(const u32x4 v) { return __builtin_bi
 // KS (split-K inside the workgroup): KS waves share one 64-row tile and take 1/KS of the (chunk, tap) tiles each;
 // chosen per launch so that the number of waves is close to a multiple of the 1024 SIMDs.  The parts are summed
 // through the (by then dead) A-tile LDS region in a fixed order.
-template <int RN, bool ACC1, int KS>
+template <int RN, bool ACC1, int KS, bool PRO>
 __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
   constexpr int BM = 256 / KS;
   constexpr int BN = 32 * RN;
@@ -176,7 +180,7 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
   const int k16_total = g.Cin >> 4;
   const int npad = g.Npad0;                                       // == Npad1 when ACC1
   const unsigned plane_b = (unsigned)npad * 32u;                   // bytes of one (k-group, plane) slab of packed weights
-  const bool pro = op.in_scale != nullptr;
+  constexpr bool pro = PRO;                                        // BN + ReLU of the producer applied while staging
   // Buffer descriptors.  The input base is moved back by `a.in_bias` bytes so that the (possibly negative) tap
   // shift becomes a non-negative SGPR offset.
   const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(
@@ -186,9 +190,9 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
   const unsigned w_voff = (unsigned)(((n0 + li) * 2 + lh) * 16);     // this lane's 16-byte fragment inside a slab
 
   f32x16 acc0[2][RN];
-  float4 ra[8];
-  float4 rsc = make_float4(1.f, 1.f, 1.f, 1.f), rsh = make_float4(0.f, 0.f, 0.f, 0.f);
-  unsigned ra_inv = 0;                   // bit j: staged row j is padding (only consumed when `pro`)
+  float4 ra[8];                          // A rows in flight: global -> registers -> (BN+ReLU, split) -> LDS
+  float4 rsc_c = make_float4(1.f, 1.f, 1.f, 1.f), rsh_c = make_float4(0.f, 0.f, 0.f, 0.f), rsc_n = rsc_c, rsh_n = rsh_c;
+  unsigned pad_c = 0, pad_n = 0;         // bit j: row j of the tile being staged / being loaded is padding (PRO only)
   u32x4 fb[2][RN][3];                    // B-fragment ring: [k-group][column block][plane] of the NEXT use
   bf16x8 afA[2][3], afB[2][3];           // A fragments [row block][plane] of k-group 0 / 1
   const int oyc = g.cls[cls].oy, oxc = g.cls[cls].ox;
@@ -232,39 +236,36 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
       for (int pl = 0; pl < 3; ++pl)
         fb[s_][rn][pl] = buf_load4u(rs_w, w_voff + (unsigned)(rn * 1024), so + (unsigned)pl * plane_b);
     };
-    auto load_a = [&](const TileInfo& ti) {
-      ra_inv = 0;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const unsigned inv = ((row_taps[j] >> ti.t) & 1u) - 1u;       // 0 = in bounds, 0xFFFFFFFF = padding
-        ra_inv |= inv & (1u << j);
-        ra[j] = buf_load4(rs_in, row_voff[j] | (inv & kOob), ti.a_soff);
-      }
+    // one row (16 bytes per lane) of the A tile described by `ti`
+    auto load_row = [&](const TileInfo& ti, int j, float4& dst, unsigned& padbits) {
+      const unsigned inv = ((row_taps[j] >> ti.t) & 1u) - 1u;       // 0 = in bounds, 0xFFFFFFFF = padding
+      if (pro) padbits = (padbits & ~(1u << j)) | (inv & (1u << j));
+      dst = buf_load4(rs_in, row_voff[j] | (inv & kOob), ti.a_soff);
+    };
+    auto load_scale = [&](const TileInfo& ti, float4& sc, float4& sh) {
       if (pro) {
-        rsc = *reinterpret_cast<const float4*>(op.in_scale + ti.c * KC + a_col4 * 4);
-        rsh = *reinterpret_cast<const float4*>(op.in_shift + ti.c * KC + a_col4 * 4);
+        sc = *reinterpret_cast<const float4*>(op.in_scale + ti.c * KC + a_col4 * 4);
+        sh = *reinterpret_cast<const float4*>(op.in_shift + ti.c * KC + a_col4 * 4);
       }
     };
-    // BN + ReLU of the producing layer (only when requested) and the bf16 split happen at LDS-store time; padding
-    // rows are already zero from the buffer unit and are re-zeroed only on the `pro` path (relu(shift) != 0).
-    auto store_a = [&](int buf) {
-      unsigned char* dA = sA + buf * A_TILE_B + (lane >> 3) * A_ROW_B + a_col4 * 8;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        float4 v = ra[j];
-        if (pro) {
-          const bool pad = (ra_inv >> j) & 1u;
-          v.x = pad ? 0.f : fmaxf(fmaf(v.x, rsc.x, rsh.x), 0.f); v.y = pad ? 0.f : fmaxf(fmaf(v.y, rsc.y, rsh.y), 0.f);
-          v.z = pad ? 0.f : fmaxf(fmaf(v.z, rsc.z, rsh.z), 0.f); v.w = pad ? 0.f : fmaxf(fmaf(v.w, rsc.w, rsh.w), 0.f);
-        }
-        uint2 h, m, l;
-        split4(v, h, m, l);
-        *reinterpret_cast<uint2*>(dA + j * 8 * A_ROW_B) = h;
-        *reinterpret_cast<uint2*>(dA + j * 8 * A_ROW_B + A_PLANE_B) = m;
-        *reinterpret_cast<uint2*>(dA + j * 8 * A_ROW_B + 2 * A_PLANE_B) = l;
+    // BN + ReLU of the producing layer (PRO) and the bf16 split happen at LDS-store time; padding rows are already
+    // zero from the buffer unit and are re-zeroed only on the PRO path (relu(shift) != 0).
+    auto stage = [&](int buf, int j, float4 v, unsigned padbits, const float4& sc, const float4& sh) {
+      if (pro) {
+        const bool pad = (padbits >> j) & 1u;
+        v.x = pad ? 0.f : fmaxf(fmaf(v.x, sc.x, sh.x), 0.f); v.y = pad ? 0.f : fmaxf(fmaf(v.y, sc.y, sh.y), 0.f);
+        v.z = pad ? 0.f : fmaxf(fmaf(v.z, sc.z, sh.z), 0.f); v.w = pad ? 0.f : fmaxf(fmaf(v.w, sc.w, sh.w), 0.f);
       }
-      __builtin_amdgcn_wave_barrier();     // compiler ordering only; LDS executes one wave's ops in order
+      uint2 h, m, l;
+      split4(v, h, m, l);
+      unsigned char* dA = sA + buf * A_TILE_B + ((lane >> 3) + 8 * j) * A_ROW_B + a_col4 * 8;
+      *reinterpret_cast<uint2*>(dA) = h;
+      *reinterpret_cast<uint2*>(dA + A_PLANE_B) = m;
+      *reinterpret_cast<uint2*>(dA + 2 * A_PLANE_B) = l;
     };
+    auto load_a_row = [&](const TileInfo& ti, int j) { load_row(ti, j, ra[j], pad_n); };
+    auto stage_row = [&](int buf, int j) { stage(buf, j, ra[j], pad_c, rsc_c, rsh_c); };
+    auto rotate_stage_state = [&]() { pad_c = pad_n; rsc_c = rsc_n; rsh_c = rsh_n; };
     auto read_frags = [&](int buf, int s_, bf16x8 (&af)[2][3]) {
       const unsigned char* cA = sA + buf * A_TILE_B + li * A_ROW_B + s_ * 32 + lh * 16;
 #pragma unroll
@@ -273,9 +274,10 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
         for (int pl = 0; pl < 3; ++pl)
           af[rm][pl] = *reinterpret_cast<const bf16x8*>(cA + rm * 32 * A_ROW_B + pl * A_PLANE_B);
     };
-    // the six bf16 products of one 16-channel k-group, smallest terms first; then refill the consumed B fragments
-    // with the same k-group of the NEXT tile (a whole tile of MFMAs ahead of their use)
-    auto mfma_group = [&](int s_, const bf16x8 (&af)[2][3], const TileInfo& nxt) {
+    // The six bf16 products of one 16-channel k-group (smallest terms first) for all 2 x RN accumulator blocks,
+    // each column block followed by the refill of its B fragments with the same k-group of tile `nb`.  `side(rn)`
+    // is the staging work the caller wants issued between the MFMAs of column block rn.
+    auto mfma_group = [&](int s_, const bf16x8 (&af)[2][3], const TileInfo& nb, auto&& side) {
 #pragma unroll
       for (int rn = 0; rn < RN; ++rn) {
         const bf16x8 bh = as_bf16x8(fb[s_][rn][0]), bm = as_bf16x8(fb[s_][rn][1]), bl = as_bf16x8(fb[s_][rn][2]);
@@ -290,41 +292,67 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
           c = mfma_bf16(af[rm][0], bh, c);
           acc0[rm][rn] = c;
         }
-        load_b(nxt, s_, rn);
-        __builtin_amdgcn_sched_barrier(0);
+        load_b(nb, s_, rn);
+        side(rn);
       }
     };
-
-    // Software pipeline (one wave per SIMD, so every latency has to be covered by this wave's own MFMAs):
-    //   global loads of A tile it+2  -> issued in the middle of iteration it, consumed in the middle of it+1;
-    //   B fragments of tile it+1     -> issued right after their use in iteration it;
-    //   LDS fragments of a k-group   -> read one MFMA group (48 MFMAs) before they are needed.
+    // Software pipeline (ONE wave per SIMD: every latency has to be covered by this wave's own MFMAs).  Time is
+    // cut in half-bodies of 12*RN MFMAs; half 2k runs k-group 0 of tile k, half 2k+1 its k-group 1:
+    //   LDS fragments of (tile k, group s)   read during the half before their use;
+    //   staging of tile k (split -> LDS)     spread over halves 2k-3, 2k-2, into the buffer tile k-2 has left;
+    //   global loads of tile k               issued row by row as staging frees the registers: one body ahead;
+    //   B fragments of (tile k, group s)     loaded right after group s of tile k-1 used the registers.
+    // A loop body is { half 2k+1, half 2k+2 } so that all of this is one basic block for the scheduler.
     const int it_begin = (KS == 1) ? 0 : (n_iter * kh) / KS;
     const int it_end = (KS == 1) ? n_iter : (n_iter * (kh + 1)) / KS;
     if (it_begin < it_end) {
-      const TileInfo t0 = tile_info(it_begin);
-      load_a(t0);
+      auto tile_at = [&](int it) { return tile_info(it < it_end ? it : it_end - 1); };   // repeats at the tail are harmless
+      const TileInfo t0 = tile_at(it_begin);
+      TileInfo t1 = tile_at(it_begin + 1), t2 = tile_at(it_begin + 2);
+      // prologue: tiles t0 and t1 are fetched together (one exposed memory latency instead of two); t1 sits in
+      // registers that the fragment arrays take over afterwards
+      {
+        float4 rb[8], sc0 = rsc_c, sh0 = rsh_c, sc1 = rsc_c, sh1 = rsh_c;
+        unsigned pad0 = 0, pad1 = 0;
+        load_scale(t0, sc0, sh0);
 #pragma unroll
-      for (int s_ = 0; s_ < 2; ++s_)
+        for (int j = 0; j < 8; ++j) load_row(t0, j, ra[j], pad0);
+        load_scale(t1, sc1, sh1);
 #pragma unroll
-        for (int rn = 0; rn < RN; ++rn) load_b(t0, s_, rn);
-      store_a(it_begin & 1);
-      load_a(tile_info(it_begin + 1 < it_end ? it_begin + 1 : it_begin));
-      read_frags(it_begin & 1, 0, afA);
-      TileInfo nxt = tile_info(it_begin + 1 < it_end ? it_begin + 1 : it_begin);
-      for (int it = it_begin; it < it_end; ++it) {
-        const int buf = it & 1;
-        const TileInfo nn = tile_info(it + 2 < it_end ? it + 2 : it);       // repeats at the tail are harmless
-        read_frags(buf, 1, afB);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_group(0, afA, nxt);
-        store_a(buf ^ 1);                    // tile it+1 (loaded one iteration ago)
-        load_a(nn);                          // tile it+2
-        read_frags(buf ^ 1, 0, afA);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_group(1, afB, nxt);
-        nxt = nn;
+        for (int j = 0; j < 8; ++j) load_row(t1, j, rb[j], pad1);
+#pragma unroll
+        for (int s_ = 0; s_ < 2; ++s_)
+#pragma unroll
+          for (int rn = 0; rn < RN; ++rn) load_b(t0, s_, rn);
+        load_scale(t2, rsc_n, rsh_n);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { stage(it_begin & 1, j, ra[j], pad0, sc0, sh0); load_row(t2, j, ra[j], pad_n); }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) stage((it_begin + 1) & 1, j, rb[j], pad1, sc1, sh1);
       }
+      __builtin_amdgcn_wave_barrier();
+      read_frags(it_begin & 1, 0, afA);
+      read_frags(it_begin & 1, 1, afB);
+      mfma_group(0, afA, t1, [&](int) {});
+      // bodies: k = it_begin .. it_end-2
+      for (int k = it_begin; k + 1 < it_end; ++k) {
+        const int bk = k & 1;                      // buffer of tile k (free: its last fragments are in afB) = tile k+2's
+        const TileInfo t3 = tile_at(k + 3);
+        rotate_stage_state();
+        load_scale(t3, rsc_n, rsh_n);
+        read_frags(bk ^ 1, 0, afA);                // tile k+1, k-group 0
+        mfma_group(1, afB, t1, [&](int rn) {       // tile k, k-group 1; refill with tile k+1
+#pragma unroll
+          for (int j = rn * 4 / RN; j < (rn + 1) * 4 / RN; ++j) { stage_row(bk, j); load_a_row(t3, j); }
+        });
+        read_frags(bk ^ 1, 1, afB);                // tile k+1, k-group 1
+        mfma_group(0, afA, t2, [&](int rn) {       // tile k+1, k-group 0; refill with tile k+2
+#pragma unroll
+          for (int j = 4 + rn * 4 / RN; j < 4 + (rn + 1) * 4 / RN; ++j) { stage_row(bk, j); load_a_row(t3, j); }
+        });
+        t1 = t2; t2 = t3;
+      }
+      mfma_group(1, afB, t1, [&](int) {});          // last tile, k-group 1
     }
 
     // ---- split-K exchange: waves with kh > 0 hand their partial tiles to wave kh == 0 through LDS ----
@@ -384,7 +412,7 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
         const unsigned gy = fdiv(rem, a.div_gw);
         const unsigned gx = rem - gy * (unsigned)g.GW;
         const unsigned pix = (b * (unsigned)g.OH + (gy * g.out_mul + oyc)) * (unsigned)g.OW + (gx * g.out_mul + oxc);
-        row_pix[r] = ((int)m < a.M && writer) ? pix : 0xFFFFFFFFu;
+        row_pix[r] = ((int)m < a.M && writer && !(a.flags & 0x100)) ? pix : 0xFFFFFFFFu;   // 0x100: debug, drop stores
       }
 #pragma unroll
       for (int rn = 0; rn < RN; ++rn) {
@@ -458,13 +486,13 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
   }
 }
 
-template <int RN, bool ACC1, int KS>
+template <int RN, bool ACC1, int KS, bool PRO>
 int launch_conv(const ConvArgs& a0, int n_groups, hipStream_t s) {
   constexpr int BN = 32 * RN;
   constexpr int lds = 64 + 4 * 2 * A_TILE_B + 2 * 4 * BN * 2 * 4;
   static bool attr_set = false;          // > 64 KiB of dynamic LDS has to be requested once per kernel
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_k<RN, ACC1, KS>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_k<RN, ACC1, KS, PRO>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
       return MPOSE_EINVAL;
     attr_set = true;
   }
@@ -472,7 +500,7 @@ int launch_conv(const ConvArgs& a0, int n_groups, hipStream_t s) {
   a.n_mtiles = (a.M + 256 / KS - 1) / (256 / KS);
   const int cmax = a.g.Cout1 > a.g.Cout0 ? a.g.Cout1 : a.g.Cout0;
   dim3 grid(a.n_mtiles * a.g.n_classes, (cmax + BN - 1) / BN, n_groups);
-  conv_igemm_k<RN, ACC1, KS><<<grid, 256, lds, s>>>(a);
+  conv_igemm_k<RN, ACC1, KS, PRO><<<grid, 256, lds, s>>>(a);
   return launch_status();
 }
 
@@ -496,13 +524,20 @@ inline int pick_ks(const ConvArgs& a, int cmax, int n_groups) {
   return best;
 }
 
+template <int RN, bool ACC1, bool PRO>
+int launch_conv_kp(const ConvArgs& a, int cmax, int n_groups, hipStream_t s) {
+  switch (pick_ks<RN>(a, cmax, n_groups)) {
+    case 4: return launch_conv<RN, ACC1, 4, PRO>(a, n_groups, s);
+    case 2: return launch_conv<RN, ACC1, 2, PRO>(a, n_groups, s);
+    default: return launch_conv<RN, ACC1, 1, PRO>(a, n_groups, s);
+  }
+}
 template <int RN, bool ACC1>
 int launch_conv_ks(const ConvArgs& a, int cmax, int n_groups, hipStream_t s) {
-  switch (pick_ks<RN>(a, cmax, n_groups)) {
-    case 4: return launch_conv<RN, ACC1, 4>(a, n_groups, s);
-    case 2: return launch_conv<RN, ACC1, 2>(a, n_groups, s);
-    default: return launch_conv<RN, ACC1, 1>(a, n_groups, s);
+  if constexpr (!ACC1) {
+    if (a.op[0].in_scale != nullptr) return launch_conv_kp<RN, false, true>(a, cmax, n_groups, s);
   }
+  return launch_conv_kp<RN, ACC1, false>(a, cmax, n_groups, s);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -771,6 +806,8 @@ extern "C" int mpose_conv_fwd(const mpose_conv_geom* geom, const mpose_conv_oper
     a.op[i] = ops[i];
     if (!ops[i].in || !ops[i].w0 || !ops[i].out0) return MPOSE_EINVAL;
     if (acc1 && (!ops[i].w1 || !ops[i].out1)) return MPOSE_EINVAL;
+    if ((ops[i].in_scale != nullptr) != (ops[0].in_scale != nullptr)) return MPOSE_EINVAL;
+    if (ops[i].in_scale && (acc1 || !ops[i].in_shift)) return MPOSE_EINVAL;
   }
   if (acc1 && geom->Npad1 != geom->Npad0) return MPOSE_EINVAL;
   a.M = geom->B * geom->GH * geom->GW;

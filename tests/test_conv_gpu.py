@@ -1,0 +1,134 @@
+"""GPU parity of the implicit-GEMM convolution kernel called directly through the C ABI
+(mpose_pack_weights + mpose_conv_fwd), against a float64 convolution of the same inputs.
+
+The kernel computes fp32 convolutions on the bf16 matrix cores with 3-way split operands ("bf16x6",
+margipose_amd/csrc/conv.hip).  The claim tested here is that this is fp32 arithmetic in everything but the
+instruction used: its error against float64 must be no larger than the error of an ordinary fp32 convolution
+(torch CPU, fp32) of the same data -- tolerance written below -- on dense random data, which is the worst case
+for the dropped 2^-26 cross terms.  Covers stride 1 / 2, the transposed stride-2 parity classes, the fused
+shortcut pass, rows that do not fill a 64-pixel tile, and every split-K factor.
+
+Reference layers: src/margipose/models/margipose_model.py:33,36,67-68,73-74 (Conv2d / ConvTranspose2d, no bias).
+"""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _pack(L, _lib, eng, w, cout, cin, T, transposed_layout=False):
+    """Pack a torch-layout (Cout, Cin, kh, kw) weight for the forward kernel; returns the packed arena."""
+    npad = (cout + 63) // 64 * 64
+    kpad = (cin + 31) // 32 * 32
+    packed = torch.zeros(T * kpad * npad * 3 // 2, dtype=torch.float32, device='cuda')
+    jobs = np.zeros(1, dtype=eng.PACK_DT)
+    j = jobs[0]
+    j['src'], j['dst'] = w.data_ptr(), packed.data_ptr()
+    j['N'], j['K'], j['T'], j['Npad'], j['Kpad'] = cout, cin, T, npad, kpad
+    if transposed_layout:            # ConvTranspose2d weight is (Cin, Cout, kh, kw)
+        j['sn'], j['sk'], j['st'] = T, cout * T, 1
+    else:
+        j['sn'], j['sk'], j['st'] = cin * T, T, 1
+    dev = eng._jobs_to_device(jobs, 'cuda')
+    _lib.check(L.mpose_pack_weights(_lib.ptr(dev), 1, T * kpad * npad, _lib.stream_ptr()), 'pack')
+    return packed, npad, kpad
+
+
+def _run(L, _lib, g, x, packed, out, packed1=None, out1=None):
+    from margipose_amd._lib import ConvOperands
+    op = ConvOperands()
+    op.in_, op.w0, op.out0 = x.data_ptr(), packed.data_ptr(), out.data_ptr()
+    if packed1 is not None:
+        op.w1, op.out1 = packed1.data_ptr(), out1.data_ptr()
+    arr = (ConvOperands * 1)(op)
+    _lib.check(L.mpose_conv_fwd(ctypes.byref(g), arr, 1, 0, _lib.stream_ptr()), 'conv')
+    torch.cuda.synchronize()
+
+
+def _errs(got_nhwc, x_nchw, w, fn):
+    """(kernel error, torch-fp32 error), both max-abs against float64 and scaled by max |ref|."""
+    ref = fn(x_nchw.double(), w.double())
+    f32 = fn(x_nchw.float(), w.float()).double()
+    scale = ref.abs().max()
+    got = got_nhwc.cpu().double().permute(0, 3, 1, 2)
+    return float((got - ref).abs().max() / scale), float((f32 - ref).abs().max() / scale)
+
+
+# tolerance: the kernel may be at most 2x as far from float64 as torch's own fp32 convolution (plus 2e-7 slack for
+# tiny cases where both are ~1 ulp); in practice it is closer (fewer, wider accumulation steps).
+def _check(e_gpu, e_f32):
+    assert e_gpu <= 2.0 * e_f32 + 2e-7, (e_gpu, e_f32)
+
+
+@pytest.mark.parametrize('B,H,cin,cout', [(2, 32, 128, 128), (8, 16, 192, 192), (1, 12, 64, 96), (32, 32, 128, 128), (3, 8, 32, 32)])
+def test_conv3x3_fp32_equivalent(B, H, cin, cout):
+    from margipose_amd import _lib, engine as eng
+    L = _lib.lib()
+    rng = np.random.default_rng(B * 1000 + H)
+    x = torch.from_numpy(rng.standard_normal((B, cin, H, H))).float()
+    w = torch.from_numpy(rng.standard_normal((cout, cin, 3, 3)) * (2.0 / (9 * cin)) ** 0.5).float()
+    xg = x.permute(0, 2, 3, 1).contiguous().cuda()
+    wg = w.cuda()
+    packed, npad, kpad = _pack(L, _lib, eng, wg, cout, cin, 9)
+    t9 = [(ky - 1, kx - 1, ky * 3 + kx, 0) for ky, kx in eng.TAPS3]
+    g = eng._geom(B, H, cin, H, cout, 0, H, 1, 1, [(0, 0, t9)], npad)
+    out = torch.full((B, H, H, cout), float('nan'), device='cuda')
+    _run(L, _lib, g, xg, packed, out)
+    e_gpu, e_f32 = _errs(out, x, w, lambda a, b: torch.nn.functional.conv2d(a, b, padding=1))
+    _check(e_gpu, e_f32)
+
+
+def test_conv_fused_shortcut_and_stride2():
+    """Down block entry: 3x3 stride 2 + fused 1x1 stride-2 shortcut from the same input (two outputs, one launch)."""
+    from margipose_amd import _lib, engine as eng
+    L = _lib.lib()
+    B, H, cin, cout = 4, 32, 128, 192
+    rng = np.random.default_rng(7)
+    x = torch.from_numpy(rng.standard_normal((B, cin, H, H))).float()
+    w = torch.from_numpy(rng.standard_normal((cout, cin, 3, 3)) * 0.03).float()
+    ws = torch.from_numpy(rng.standard_normal((cout, cin, 1, 1)) * 0.09).float()
+    xg = x.permute(0, 2, 3, 1).contiguous().cuda()
+    packed, npad, _ = _pack(L, _lib, eng, w.cuda(), cout, cin, 9)
+    packed1, _, _ = _pack(L, _lib, eng, ws.cuda(), cout, cin, 1)
+    t9 = [(ky - 1, kx - 1, ky * 3 + kx, 0) for ky, kx in eng.TAPS3]
+    g = eng._geom(B, H, cin, H // 2, cout, cout, H // 2, 2, 1, [(0, 0, t9 + [(0, 0, 0, 1)])], npad, npad)
+    out = torch.full((B, H // 2, H // 2, cout), float('nan'), device='cuda')
+    out1 = torch.full((B, H // 2, H // 2, cout), float('nan'), device='cuda')
+    _run(L, _lib, g, xg, packed, out, packed1, out1)
+    _check(*_errs(out, x, w, lambda a, b: torch.nn.functional.conv2d(a, b, stride=2, padding=1)))
+    _check(*_errs(out1, x, ws, lambda a, b: torch.nn.functional.conv2d(a, b, stride=2)))
+
+
+def test_conv_transposed_stride2_classes():
+    """Up block entry: ConvTranspose2d(3, stride 2, pad 1, output_padding 1) as four output-parity classes."""
+    from margipose_amd import _lib, engine as eng
+    L = _lib.lib()
+    B, H, cin, cout = 4, 16, 192, 128
+    rng = np.random.default_rng(11)
+    x = torch.from_numpy(rng.standard_normal((B, cin, H, H))).float()
+    w = torch.from_numpy(rng.standard_normal((cin, cout, 3, 3)) * 0.03).float()       # (Cin, Cout, k, k)
+    xg = x.permute(0, 2, 3, 1).contiguous().cuda()
+    packed, npad, _ = _pack(L, _lib, eng, w.cuda(), cout, cin, 9, transposed_layout=True)
+    g = eng._geom(B, H, cin, 2 * H, cout, 0, H, 1, 2, eng._up_classes(False), npad)
+    out = torch.full((B, 2 * H, 2 * H, cout), float('nan'), device='cuda')
+    _run(L, _lib, g, xg, packed, out)
+    _check(*_errs(out, x, w, lambda a, b: torch.nn.functional.conv_transpose2d(a, b, stride=2, padding=1, output_padding=1)))
+
+
+def test_split_planes_are_exact():
+    """pack_weights_k's three bf16 planes add back to the fp32 weight to within 2^-24 relative (x = hi + mid + lo)."""
+    from margipose_amd import _lib, engine as eng
+    L = _lib.lib()
+    cout, cin = 64, 32
+    rng = np.random.default_rng(3)
+    w = torch.from_numpy(rng.standard_normal((cout, cin, 1, 1)) * np.exp(rng.uniform(-8, 8, (cout, cin, 1, 1)))).float().cuda()
+    packed, npad, kpad = _pack(L, _lib, eng, w, cout, cin, 1)
+    torch.cuda.synchronize()
+    planes = packed.view(torch.bfloat16).view(1, kpad // 16, 3, npad, 2, 8).float()        # [T][K16][plane][n][half][8]
+    total = planes.sum(2).double()                                                           # exact in float64
+    rebuilt = total.permute(0, 2, 1, 3, 4).reshape(npad, kpad)[:cout, :cin]                  # [n][k]
+    ref = w.view(cout, cin).double()
+    assert float(((rebuilt - ref).abs() / ref.abs()).max()) <= 2.0 ** -24
