@@ -161,6 +161,11 @@ typedef struct {
   float* dw1;
 } mpose_wgrad_operands;
 
+/* Number of (tap, input-channel tile, output-channel tile) work units of one group's weight-gradient launch;
+ * the launch runs units * n_groups * n_split workgroups, one per CU at a time (the caller sizes n_split so that
+ * this is close to a multiple of 256, and the partial-sum buffer as n_split * packed-fp32 weight size). */
+int mpose_conv_wgrad_tiles(const mpose_conv_geom* geom);
+
 int mpose_conv_wgrad(const mpose_conv_geom* geom, const mpose_wgrad_operands* ops, int n_groups,
                      int n_split, void* stream);
 

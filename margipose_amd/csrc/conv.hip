@@ -542,15 +542,20 @@ int launch_conv_ks(const ConvArgs& a, int cmax, int n_groups, hipStream_t s) {
 
 // ---------------------------------------------------------------------------------------------
 // Weight gradient: dWp[split][widx][k/4][n][4] = sum_{slots in split} X_tap[slot][k] * G[slot][n]
-// MFMA roles: i = k (input channel), j = n (output channel), reduction index = slot (pixel).
+// MFMA roles: i = k (input channel), j = n (output channel), reduction index = slot (pixel); bf16x6 like the
+// forward kernel (both operands are split in registers, products exact, fp32 accumulation).
 //
-// In NHWC the MFMA operand layout IS the memory layout: lane (i, h) of v_mfma_f32_32x32x2_f32 wants
-// X[pixel 2p+h][k0 + i] and G[pixel 2p+h][n0 + i] -- 32 consecutive channels of one pixel = one coalesced
-// 128-byte line per lane half.  So there is no LDS staging and (following the cost model above conv_igemm_k)
-// almost no vector ALU work: each wave walks its slot rows with the SCALAR unit (row/tap validity, padding rows
-// and columns are skipped, all offsets are SGPRs), and streams `buffer_load_dword`s into a register ring DEPTH
-// pixel-pairs ahead of the MFMAs.  A workgroup = 4 independent waves that split the slot range; their partial
-// tiles are summed in a fixed order through LDS (deterministic), then written as split-K partials.
+// v_mfma_f32_32x32x16_bf16 wants, per lane (i, h), EIGHT consecutive reduction indices = 8 pixels of one channel.
+// In NHWC that is 8 dword loads with a pixel stride, each one a coalesced 128-byte line across the 32 lanes of
+// a half -- so the operands go straight from L2 to registers (no LDS), are split there (5.5 VALU per element)
+// and feed 6*KB*NB MFMAs per 16-pixel group.  The wave tile is as fat as the accumulator file allows
+// (32*KB input x 32*NB output channels, up to 128 x 128 = all 256 AGPRs) because the split cost per MFMA falls
+// with (KB+NB)/(KB*NB); one wave per SIMD, the next group's 8*(KB+NB) loads in flight during the current MFMAs.
+// Pixels are walked in OCTETS (8 consecutive slots of one slot row; GW % 8 == 0): lane half h of a group takes
+// octet 2q+h.  The scalar unit walks rows/octets (padding rows are skipped); columns shifted out of the image by
+// the tap are zeroed per pixel, and anything outside the tensor reads 0 through the buffer range check.
+// A workgroup = 4 waves that split the slot rows of one (tap, tile, split); their tiles are summed in a fixed
+// order through LDS (deterministic) and written as split-K partials for unpack_wgrads_k.
 // ---------------------------------------------------------------------------------------------
 struct WgradArgs {
   mpose_conv_geom g;
@@ -561,18 +566,16 @@ struct WgradArgs {
   int entry_cls[MPOSE_MAX_CLASSES * MPOSE_MAX_TAPS];
   int entry_tap[MPOSE_MAX_CLASSES * MPOSE_MAX_TAPS];
   int n_widx0, n_widx1;
-  int in_bias;                    // bytes, as in ConvArgs
   // XCD-aware work order: workgroup b runs on XCD b % 8 (observed, speed only), and each XCD has a private 4 MiB
   // L2.  The work list is ordered (group, pixel split) outermost, (k/n tile, tap) innermost, and XCD c takes the
-  // contiguous chunk c of it, so all 9 taps x Cin/32 tiles that re-read one pixel split's X and dY slices run on
-  // ONE L2 at about the same time (instead of every L2 pulling every slice: measured 5-9x over-fetch before).
+  // contiguous chunk c of it, so all taps x tiles that re-read one pixel split's X and dY slices run on ONE L2 at
+  // about the same time (instead of every L2 pulling every slice: measured 5-9x over-fetch before).
   int n_ytiles, n_groups, chunk, total;
 };
 
-template <int RN>   // wave tile: 32 input channels x 32*RN output channels
-__global__ __launch_bounds__(256, 2) void conv_wgrad_k(WgradArgs a) {
-  constexpr int DEPTH = 8;                     // pixel pairs in flight (RN*64 MFMA cycles each)
-  extern __shared__ __attribute__((aligned(16))) float smem[];     // [RN*16][64] reduction scratch
+template <int KB, int NB>   // wave tile: 32*KB input channels x 32*NB output channels
+__global__ __launch_bounds__(256, 1) void conv_wgrad_k(WgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];     // cross-wave reduction scratch
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lh = lane >> 5;
   const mpose_conv_geom& g = a.g;
@@ -588,9 +591,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_k(WgradArgs a) {
   const bool second = tap.acc != 0;
   const int npad = second ? g.Npad1 : g.Npad0;
   const int cout = second ? g.Cout1 : g.Cout0;
-  const int n_ctiles = (cout + 32 * RN - 1) / (32 * RN);
+  const int n_ctiles = cout / (32 * NB);
   const int k_tile = ytile / n_ctiles, n_tile = ytile - k_tile * n_ctiles;
-  const int k0 = k_tile * 32, n0 = n_tile * 32 * RN;
+  const int k0 = k_tile * 32 * KB, n0 = n_tile * 32 * NB;
   const mpose_wgrad_operands& op = a.op[group];
   const float* gout = second ? op.gout1 : op.gout0;
   float* dw = second ? op.dw1 : op.dw0;
@@ -605,132 +608,244 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_k(WgradArgs a) {
   const int rpw = (a.rows_per_split + 3) >> 2;
   const int r_begin = min(r_split1, r_split0 + wave * rpw);
   const int r_end = min(r_split1, r_begin + rpw);
-  // valid slot columns for this tap: 0 <= gx*in_mul + dx < IW  ->  pairs [p_lo, p_hi)
+  // valid slot columns for this tap: 0 <= gx*in_mul + dx < IW
   int gx_lo = 0, gx_hi = g.GW;
   while (gx_lo < g.GW && gx_lo * g.in_mul + dx < 0) ++gx_lo;
   while (gx_hi > gx_lo && (gx_hi - 1) * g.in_mul + dx >= g.IW) --gx_hi;
-  const int p_lo = gx_lo >> 1, p_hi = (gx_hi + 1) >> 1;
-  const int pairs_per_row = p_hi - p_lo;
+  const int n_oct = g.GW >> 3;
 
-  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<char*>(reinterpret_cast<const char*>(op.in)) - a.in_bias, 0, 0xFFFFFF00, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gout), 0, 0xFFFFFF00, 0x00020000);
   const int in_ld = g.in_ld > 0 ? g.in_ld : g.Cin;
   const int gld_ = second ? g.out_ld1 : g.out_ld0;
   const int g_ld = gld_ > 0 ? gld_ : cout;
-  const unsigned x_voff = (unsigned)((lh * g.in_mul * in_ld + k0 + li) * 4);
-  const unsigned g_voff = (unsigned)((lh * g.out_mul * g_ld + n0 + li) * 4);
-  const unsigned lane_bit = 1u << lh;
+  // exact extents: a pixel outside the tensor (a negative offset wraps to a huge unsigned one) reads 0
+  const unsigned x_bytes = (unsigned)(((long)g.B * g.IH * g.IW - 1) * in_ld * 4 + (long)g.Cin * 4);
+  const unsigned g_bytes = (unsigned)(((long)g.B * g.OH * g.OW - 1) * g_ld * 4 + (long)cout * 4);
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(op.in), 0, x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gout), 0, g_bytes, 0x00020000);
+  const int x_pix = g.in_mul * in_ld * 4, g_pix = g.out_mul * g_ld * 4;        // byte stride between consecutive slots
+  const int x_lane = (k0 + li) * 4, g_lane = (n0 + li) * 4;
   const bool pro = op.in_scale != nullptr;
-  float psc = 1.f, psh = 0.f;
-  if (pro) { psc = op.in_scale[k0 + li]; psh = op.in_shift[k0 + li]; }
+  float psc[KB], psh[KB];
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) {
+    psc[kb] = pro ? op.in_scale[k0 + kb * 32 + li] : 1.f;
+    psh[kb] = pro ? op.in_shift[k0 + kb * 32 + li] : 0.f;
+  }
 
-  // scalar cursor over (slot row, pixel pair): only rows whose tap-shifted input row is in bounds
-  struct Cursor { int r, p; unsigned xs, gs; };
-  auto row_valid = [&](int r, unsigned& xs, unsigned& gs) {
-    const unsigned b = fdiv((unsigned)r, a.div_gh);
-    const int gy = r - (int)b * g.GH;
-    const int iy = gy * g.in_mul + dy;
-    xs = (unsigned)((((int)b * g.IH + iy) * g.IW + dx) * in_ld * 4 + a.in_bias);
-    gs = (unsigned)((((int)b * g.OH + gy * g.out_mul + oyc) * g.OW + oxc) * g_ld * 4);
-    return iy >= 0 && iy < g.IH;
-  };
-  auto seek = [&](Cursor& c) {          // move to the first valid row at or after c.r
+  // ---- scalar cursor over (slot row, octet); only rows whose tap-shifted input row is in bounds ----
+  struct Cursor { int r, o; int xs, gs; };       // xs/gs: byte offsets of the row's first slot (tap shift applied to x)
+  auto seek = [&](Cursor& c) {                   // move to the first valid row at or after c.r
     while (c.r < r_end) {
-      unsigned xs, gs;
-      const bool ok = row_valid(c.r, xs, gs);
-      c.xs = __builtin_amdgcn_readfirstlane(xs); c.gs = __builtin_amdgcn_readfirstlane(gs);
-      if (__builtin_amdgcn_readfirstlane((int)ok)) break;
+      const unsigned b = fdiv((unsigned)c.r, a.div_gh);
+      const int gy = c.r - (int)b * g.GH;
+      const int iy = gy * g.in_mul + dy;
+      c.xs = __builtin_amdgcn_readfirstlane((((int)b * g.IH + iy) * g.IW + dx) * in_ld * 4);
+      c.gs = __builtin_amdgcn_readfirstlane((((int)b * g.OH + gy * g.out_mul + oyc) * g.OW + oxc) * g_ld * 4);
+      if (iy >= 0 && iy < g.IH) break;
       ++c.r;
     }
   };
-  auto advance = [&](Cursor& c) {
-    if (++c.p == p_hi) { c.p = p_lo; ++c.r; seek(c); }
+  struct Octet { int xs, gs; unsigned mask; };
+  auto take = [&](Cursor& c) {                   // current octet (or an all-masked dummy past the end), then advance
+    Octet o;
+    if (c.r < r_end) {
+      const int gx0 = c.o * 8;
+      o.xs = c.xs + gx0 * x_pix;
+      o.gs = c.gs + gx0 * g_pix;
+      const int lo = min(8, max(0, gx_lo - gx0)), hi = min(8, max(0, gx_hi - gx0));
+      o.mask = ((1u << hi) - 1u) & ~((1u << lo) - 1u);
+      if (++c.o == n_oct) { c.o = 0; ++c.r; seek(c); }
+    } else {
+      o.xs = 0; o.gs = 0; o.mask = 0;
+    }
+    return o;
   };
-
-  f32x16 acc[RN];
-#pragma unroll
-  for (int rn = 0; rn < RN; ++rn)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[rn][r] = 0.0f;
-
-  float rx[DEPTH], rg[DEPTH][RN];
-  unsigned rinv[DEPTH];
-  Cursor ld; ld.r = r_begin; ld.p = p_lo; ld.xs = 0; ld.gs = 0;
-  if (pairs_per_row > 0) seek(ld); else ld.r = r_end;
-  // number of real pairs of this wave
-  int todo = 0;
+  Cursor cur; cur.r = r_begin; cur.o = 0; cur.xs = 0; cur.gs = 0;
+  seek(cur);
+  int n_groups16 = 0;                            // 16-pixel groups of this wave
   {
-    Cursor cnt = ld;
-    while (cnt.r < r_end) { todo += pairs_per_row; ++cnt.r; seek(cnt); }
-  }
-  auto issue = [&](int slot) {
-    // lanes of an out-of-range pixel (row padding column, or cursor past the end) read zeros
-    unsigned flags = 3u;
-    unsigned xs = 0, gs = 0;
-    if (ld.r < r_end) {
-      const int gx0 = ld.p * 2;
-      flags = ((gx0 < gx_lo || gx0 >= gx_hi) ? 1u : 0u) | ((gx0 + 1 < gx_lo || gx0 + 1 >= gx_hi) ? 2u : 0u);
-      xs = ld.xs + (unsigned)(gx0 * g.in_mul * in_ld * 4);
-      gs = ld.gs + (unsigned)(gx0 * g.out_mul * g_ld * 4);
-    }
-    const unsigned inv = (flags & lane_bit) ? 0xFFFFFFFFu : 0u;
-    rinv[slot] = inv;
-    rx[slot] = buf_load1(rs_x, x_voff | (inv & kOob), xs);
-#pragma unroll
-    for (int rn = 0; rn < RN; ++rn) rg[slot][rn] = buf_load1(rs_g, (g_voff + (unsigned)(rn * 128)) | (inv & kOob), gs);
-    if (ld.r < r_end) advance(ld);
-  };
-#pragma unroll
-  for (int s = 0; s < DEPTH; ++s) issue(s);
-  for (int done = 0; done < todo; done += DEPTH) {
-#pragma unroll
-    for (int s = 0; s < DEPTH; ++s) {
-      float xv = rx[s];
-      if (pro) { xv = fmaxf(fmaf(xv, psc, psh), 0.f); if (rinv[s]) xv = 0.f; }
-      float gv[RN];
-#pragma unroll
-      for (int rn = 0; rn < RN; ++rn) gv[rn] = rg[s][rn];
-      issue(s);                                   // refill this slot for the pair DEPTH ahead
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int rn = 0; rn < RN; ++rn) acc[rn] = __builtin_amdgcn_mfma_f32_32x32x2f32(xv, gv[rn], acc[rn], 0, 0, 0);
-    }
+    Cursor cnt = cur;
+    int octs = 0;
+    while (cnt.r < r_end) { octs += n_oct; ++cnt.r; seek(cnt); }
+    n_groups16 = (octs + 1) >> 1;
   }
 
-  // ---- deterministic cross-wave sum through LDS: wave 0 += wave 1, then 2, then 3 (one tile of scratch, so
-  //      LDS never limits residency: the register budget allows 4 workgroups per CU) ----
-  for (int w = 1; w < 4; ++w) {
-    if (wave == w) {
+  f32x16 acc[KB][NB];
 #pragma unroll
-      for (int rn = 0; rn < RN; ++rn)
+  for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) smem[(rn * 16 + r) * 64 + lane] = acc[rn][r];
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[kb][nb][r] = 0.0f;
+
+  // Software pipeline (one wave per SIMD; VALU work hides only in the shadow of independent MFMAs, ~5 per MFMA).
+  // A 16-pixel group q is KB "regions" of 6*NB MFMAs; region kb multiplies A(q,kb) with all B(q,*) while the
+  // VALU (a) splits A of the NEXT region (of group q+1 after the last one) and (b) splits its share of group q+1's
+  // B blocks.  Every raw value register is re-loaded right after the split that consumed it, with the data it will
+  // deliver one whole group later: G of group q+2, X of group q+1 (block 0: q+2).
+  float rx[KB][8], rgv[NB][8];
+  struct Lane { int xv, gv; unsigned mask; };
+  auto next_lane = [&]() {                       // lane half h takes octet h of the next group
+    const Octet o0 = take(cur);
+    const Octet o1 = take(cur);
+    Lane ln;
+    ln.xv = (lh ? o1.xs : o0.xs) + x_lane;
+    ln.gv = (lh ? o1.gs : o0.gs) + g_lane;
+    ln.mask = lh ? o1.mask : o0.mask;
+    return ln;
+  };
+  auto load_x = [&](const Lane& ln, int kb) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j)                   // per pixel: may fall outside the tensor -> reads 0
+      rx[kb][j] = buf_load1(rs_x, (unsigned)(ln.xv + j * x_pix) + (unsigned)(kb * 128), 0);
+  };
+  auto load_g = [&](const Lane& ln, int nb) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) rgv[nb][j] = buf_load1(rs_g, (unsigned)ln.gv + (unsigned)(nb * 128), (unsigned)(j * g_pix));
+  };
+  struct Frag { u32x4 h, m, l; };
+  auto split8 = [&](const float (&v)[8], Frag& f) {
+    unsigned hh[4], mm[4], ll[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) split2(v[2 * q], v[2 * q + 1], hh[q], mm[q], ll[q]);
+    f.h = u32x4{hh[0], hh[1], hh[2], hh[3]}; f.m = u32x4{mm[0], mm[1], mm[2], mm[3]}; f.l = u32x4{ll[0], ll[1], ll[2], ll[3]};
+  };
+  auto split_x = [&](int kb, unsigned mask, Frag& f) {       // BN+ReLU prologue, column mask, split
+    float xv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float v = rx[kb][j];
+      if (pro) v = fmaxf(fmaf(v, psc[kb], psh[kb]), 0.f);
+      xv[j] = ((mask >> j) & 1u) ? v : 0.f;
     }
-    __syncthreads();
-    if (wave == 0) {
+    split8(xv, f);
+  };
+
+  // B fragments of the next group wait in a wave-private LDS area (48 registers less than a second register set)
+  u32x4* sB = reinterpret_cast<u32x4*>(smem) + wave * (NB * 3 * 64) + lane;      // [nb][plane][lane]
+  if (n_groups16 > 0) {
+    Frag bc[NB], aF[2];
+    Lane ln1 = next_lane();                       // group 0
+    unsigned mask_q = ln1.mask, mask_q1;
 #pragma unroll
-      for (int rn = 0; rn < RN; ++rn)
+    for (int nb = 0; nb < NB; ++nb) load_g(ln1, nb);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[rn][r] += smem[(rn * 16 + r) * 64 + lane];
+    for (int kb = 0; kb < KB; ++kb) load_x(ln1, kb);
+    ln1 = next_lane();                            // group 1
+    mask_q1 = ln1.mask;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) { split8(rgv[nb], bc[nb]); load_g(ln1, nb); }
+    split_x(0, mask_q, aF[0]);
+    load_x(ln1, 0);
+
+    for (int q = 0; q < n_groups16; ++q) {
+      const Lane ln2 = next_lane();               // group q+2 (past the end: all-masked dummy octets at offset 0)
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) {
+        const Frag& ac = aF[kb & 1];
+        Frag& an = aF[(kb + 1) & 1];
+        // VALU side of the region: this region's share of group q+1's B blocks (parked in LDS), next region's A
+#pragma unroll
+        for (int nb = kb * NB / KB; nb < (kb + 1) * NB / KB; ++nb) {
+          Frag t;
+          split8(rgv[nb], t);
+          load_g(ln2, nb);
+          sB[(nb * 3 + 0) * 64] = t.h; sB[(nb * 3 + 1) * 64] = t.m; sB[(nb * 3 + 2) * 64] = t.l;
+        }
+        if (kb + 1 < KB) { split_x(kb + 1, mask_q, an); load_x(ln1, kb + 1); }
+        else { split_x(0, mask_q1, an); load_x(ln2, 0); }
+        // matrix side
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          f32x16 c = acc[kb][nb];
+          c = mfma_bf16(as_bf16x8(ac.l), as_bf16x8(bc[nb].h), c);
+          c = mfma_bf16(as_bf16x8(ac.h), as_bf16x8(bc[nb].l), c);
+          c = mfma_bf16(as_bf16x8(ac.m), as_bf16x8(bc[nb].m), c);
+          c = mfma_bf16(as_bf16x8(ac.m), as_bf16x8(bc[nb].h), c);
+          c = mfma_bf16(as_bf16x8(ac.h), as_bf16x8(bc[nb].m), c);
+          c = mfma_bf16(as_bf16x8(ac.h), as_bf16x8(bc[nb].h), c);
+          acc[kb][nb] = c;
+          if (kb == KB - 1) {                     // last use in this group: fetch the next group's fragments
+            bc[nb].h = sB[(nb * 3 + 0) * 64]; bc[nb].m = sB[(nb * 3 + 1) * 64]; bc[nb].l = sB[(nb * 3 + 2) * 64];
+          }
+        }
+        // interleave: the region's ~6 VALU instructions per MFMA go into the MFMAs' shadows
+#pragma unroll
+        for (int i = 0; i < 6 * NB; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+          if (i % 2 == 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);        // keep each region's loads and splits inside the region
+      }
+      if (KB & 1) aF[0] = aF[1];
+      mask_q = mask_q1; mask_q1 = ln2.mask; ln1 = ln2;
     }
-    __syncthreads();
   }
-  if (wave != 0) return;
-  // rows i = input channel; regs 4*rg..4*rg+3 are 4 consecutive channels -> one float4 of the packed layout
+  __syncthreads();                                // the reduction below reuses the LDS of slower waves' B areas
+
+  // ---- deterministic cross-wave sum through LDS.  An "item" is one float4 per lane = 4 consecutive input
+  //      channels of one (kb, nb, register group): every wave parks its items in its own LDS region, then wave w
+  //      sums items w, w+4, ... over the regions in the fixed order 0,1,2,3 and writes them to the split-K partial
+  //      buffer (layout [split][widx][K/4][Npad][4]).  Tiles of more than 32 items go in two halves (LDS size). ----
+  constexpr int ITEMS = KB * NB * 4, HALVES = ITEMS > 32 ? 2 : 1, IPH = ITEMS / HALVES;
+  float4* sm4 = reinterpret_cast<float4*>(smem);                     // [4 regions][IPH][64]
   const int k4_total = g.Cin >> 2;
   float* base = dw + ((long)(split * n_widx + tap.widx) * k4_total) * npad * 4;
 #pragma unroll
-  for (int rn = 0; rn < RN; ++rn) {
-    const int n = n0 + rn * 32 + li;
+  for (int half = 0; half < HALVES; ++half) {
+    if (half) __syncthreads();
 #pragma unroll
-    for (int rgp = 0; rgp < 4; ++rgp) {
-      const int k4 = k0 / 4 + 2 * rgp + lh;
-      const float4 v = make_float4(acc[rn][4 * rgp], acc[rn][4 * rgp + 1], acc[rn][4 * rgp + 2], acc[rn][4 * rgp + 3]);
+    for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int item = (kb * NB + nb) * 4 + rg;
+          if (item >= half * IPH && item < (half + 1) * IPH)
+            sm4[(wave * IPH + (item - half * IPH)) * 64 + lane] =
+                make_float4(acc[kb][nb][4 * rg], acc[kb][nb][4 * rg + 1], acc[kb][nb][4 * rg + 2], acc[kb][nb][4 * rg + 3]);
+        }
+    __syncthreads();
+    for (int il = wave; il < IPH; il += 4) {
+      const float4 v0 = sm4[(0 * IPH + il) * 64 + lane], v1 = sm4[(1 * IPH + il) * 64 + lane];
+      const float4 v2 = sm4[(2 * IPH + il) * 64 + lane], v3 = sm4[(3 * IPH + il) * 64 + lane];
+      const float4 v = make_float4(((v0.x + v1.x) + v2.x) + v3.x, ((v0.y + v1.y) + v2.y) + v3.y,
+                                   ((v0.z + v1.z) + v2.z) + v3.z, ((v0.w + v1.w) + v2.w) + v3.w);
+      const int item = half * IPH + il;
+      const int rg = item & 3, blk = item >> 2;
+      const int kb = blk / NB, nb = blk - kb * NB;
+      const int k4 = (k0 + kb * 32) / 4 + 2 * rg + lh;
+      const int n = n0 + nb * 32 + li;
       *reinterpret_cast<float4*>(base + ((long)k4 * npad + n) * 4) = v;
     }
   }
 }
+
+template <int KB, int NB>
+int launch_wgrad(const WgradArgs& a, hipStream_t s) {
+  constexpr int items = KB * NB * 4;
+  constexpr int lds_red = 4 * (items > 32 ? items / 2 : items) * 64 * 16, lds_b = 4 * NB * 3 * 64 * 16;
+  constexpr int lds = lds_red > lds_b ? lds_red : lds_b;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_k<KB, NB>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+      return MPOSE_EINVAL;
+    attr_set = true;
+  }
+  conv_wgrad_k<KB, NB><<<dim3(8 * a.chunk), 256, lds, s>>>(a);
+  return launch_status();
+}
+template <int KB>
+int launch_wgrad_n(const WgradArgs& a, int nb, hipStream_t s) {
+  switch (nb) {
+    case 4: return launch_wgrad<KB, 4>(a, s);
+    case 3: return launch_wgrad<KB, 3>(a, s);
+    case 2: return launch_wgrad<KB, 2>(a, s);
+    default: return launch_wgrad<KB, 1>(a, s);
+  }
+}
+inline int wgrad_blocks(int c) { return c % 128 == 0 ? 4 : (c % 96 == 0 ? 3 : (c % 64 == 0 ? 2 : 1)); }
 
 // ---------------------------------------------------------------------------------------------
 // Weight packing / gradient unpacking (one launch for all convolutions of the model)
@@ -849,17 +964,23 @@ extern "C" int mpose_conv_fwd(const mpose_conv_geom* geom, const mpose_conv_oper
   return launch_conv_ks<2, false>(a, cmax, n_groups, s);
 }
 
+extern "C" int mpose_conv_wgrad_tiles(const mpose_conv_geom* geom) {
+  if (check_geom(geom)) return -1;
+  int entries = 0;
+  for (int c = 0; c < geom->n_classes; ++c) entries += geom->cls[c].n_taps;
+  return entries * (geom->Cin / (32 * wgrad_blocks(geom->Cin))) * (geom->Cout0 / (32 * wgrad_blocks(geom->Cout0)));
+}
+
 extern "C" int mpose_conv_wgrad(const mpose_conv_geom* geom, const mpose_wgrad_operands* ops, int n_groups, int n_split,
                                 void* stream) {
   int rc = check_geom(geom);
   if (rc) return rc;
   if (n_groups < 1 || n_groups > MPOSE_MAX_GROUP || n_split < 1) return MPOSE_EINVAL;
-  if ((geom->Npad0 % 64) || (geom->Cout0 % 32) || (geom->GW & 1)) return MPOSE_EINVAL;
+  if ((geom->Npad0 % 64) || (geom->Cout0 % 32) || (geom->GW & 7)) return MPOSE_EINVAL;
   WgradArgs a{};
   a.g = *geom;
   bool acc1 = false;
   int max0 = -1, max1 = -1;
-  long min_shift = 0;
   for (int c = 0; c < geom->n_classes; ++c)
     for (int t = 0; t < geom->cls[c].n_taps; ++t) {
       const mpose_tap& tp = geom->cls[c].taps[t];
@@ -868,39 +989,36 @@ extern "C" int mpose_conv_wgrad(const mpose_conv_geom* geom, const mpose_wgrad_o
       ++a.n_entries;
       if (tp.acc) { acc1 = true; if (tp.widx > max1) max1 = tp.widx; }
       else if (tp.widx > max0) max0 = tp.widx;
-      const long sft = ((long)tp.dy * geom->IW + tp.dx) * (geom->in_ld > 0 ? geom->in_ld : geom->Cin) * 4;
-      if (sft < min_shift) min_shift = sft;
     }
   a.n_widx0 = max0 + 1;
   a.n_widx1 = max1 + 1;
-  a.in_bias = (int)(-min_shift) + (geom->in_ld > 0 ? geom->in_ld : geom->Cin) * 4;      // + one pixel: a pair may start one column left of the row
   if (acc1 && ((geom->Npad1 % 64) || (geom->Cout1 % 32) || geom->Npad1 != geom->Npad0 || geom->Cout1 != geom->Cout0)) return MPOSE_EINVAL;
   for (int i = 0; i < n_groups; ++i) {
     a.op[i] = ops[i];
     if (!ops[i].in || !ops[i].gout0 || !ops[i].dw0) return MPOSE_EINVAL;
     if (acc1 && (!ops[i].gout1 || !ops[i].dw1)) return MPOSE_EINVAL;
+    if (ops[i].in_scale && !ops[i].in_shift) return MPOSE_EINVAL;
   }
   const int n_rows = geom->B * geom->GH;
   if (n_rows == 0 || a.n_entries == 0) return 0;
   const long in_bytes = (long)geom->B * geom->IH * geom->IW * (geom->in_ld > 0 ? geom->in_ld : geom->Cin) * 4;
   const long g_bytes = (long)geom->B * geom->OH * geom->OW * (geom->out_ld0 > geom->Cout0 ? geom->out_ld0 : geom->Cout0) * 4;
-  if (in_bytes + a.in_bias >= 0xFFFFFF00l - (1l << 20) || g_bytes >= 0xFFFFFF00l - (1l << 20)) return MPOSE_EINVAL;
+  if (in_bytes >= 0x7FFFFF00l || g_bytes >= 0x7FFFFF00l) return MPOSE_EINVAL;        // signed 32-bit byte offsets
   a.div_gh = make_fastdiv((unsigned)geom->GH);
   a.n_split = n_split;
   a.rows_per_split = (n_rows + n_split - 1) / n_split;
   hipStream_t s = (hipStream_t)stream;
-  const int cout = geom->Cout0;
-  const int rn = cout % 128 == 0 ? 4 : (cout % 96 == 0 ? 3 : (cout % 64 == 0 ? 2 : 1));
-  a.n_ytiles = (geom->Cin / 32) * (cout / (32 * rn));
+  const int kb = wgrad_blocks(geom->Cin), nb = wgrad_blocks(geom->Cout0);
+  a.n_ytiles = (geom->Cin / (32 * kb)) * (geom->Cout0 / (32 * nb));
   a.n_groups = n_groups;
   a.total = a.n_entries * a.n_ytiles * n_split * n_groups;
   a.chunk = (a.total + 7) / 8;
-  const dim3 grid(8 * a.chunk);
-  if (rn == 4) conv_wgrad_k<4><<<grid, 256, 4 * 16 * 64 * 4, s>>>(a);
-  else if (rn == 3) conv_wgrad_k<3><<<grid, 256, 3 * 16 * 64 * 4, s>>>(a);
-  else if (rn == 2) conv_wgrad_k<2><<<grid, 256, 2 * 16 * 64 * 4, s>>>(a);
-  else conv_wgrad_k<1><<<grid, 256, 1 * 16 * 64 * 4, s>>>(a);
-  return launch_status();
+  switch (kb) {
+    case 4: return launch_wgrad_n<4>(a, nb, s);
+    case 3: return launch_wgrad_n<3>(a, nb, s);
+    case 2: return launch_wgrad_n<2>(a, nb, s);
+    default: return launch_wgrad_n<1>(a, nb, s);
+  }
 }
 
 extern "C" int mpose_pack_weights(const mpose_pack_job* jobs_dev, int n_jobs, int max_elems_per_job, void* stream) {

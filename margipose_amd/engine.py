@@ -406,7 +406,7 @@ class Engine:
                     unpack_job(uj[base + 3 * c + 2], b.conv_sc, self._n_split(slots_in, self._wg_tiles(b, 'in')))
         if self.stem is None:
             coef_job(cj[self.T * 90], self.stem_bn, self.stem_bn, 4, 0, 1, B * F * F)
-            unpack_job(uj[self.T * 90], self.stem_conv, self._n_split(B * F * F, 6))
+            unpack_job(uj[self.T * 90], self.stem_conv, self._n_split(B * F * F, 2, 1))
         else:
             for i, op in enumerate([o for o in self.stem.ops if hasattr(o, 'conv')]):
                 unpack_job(uj[self.T * 90 + i], op.conv, self.stem_n_split(B, 8 * F, op))
@@ -514,11 +514,9 @@ class Engine:
 
     def stem_n_split(self, B, S, op):
         H = S // op.dst.div
-        ctile = 128 if op.cout % 128 == 0 else (96 if op.cout % 96 == 0 else (64 if op.cout % 64 == 0 else 32))
         cin_s = op.conv.cin_s
-        tiles = op.kh * op.kw * (cin_s // 32) * (op.cout // ctile)
-        rows = B * H
-        return max(1, min(16, 1024 // max(1, tiles), rows // 4))
+        tiles = op.kh * op.kw * (cin_s // (32 * self._wg_blocks(cin_s))) * (op.cout // (32 * self._wg_blocks(op.cout)))
+        return self._n_split(B * H * 32, tiles, 1)
 
     def finalize(self, tb, first, n, train):
         base = tb['fin'].data_ptr() + first * BN_DT.itemsize
@@ -823,7 +821,7 @@ class Engine:
                 check(L.mpose_bn_bwd_apply((BnBwdApplyOperands * 3)(ao), 1, F * F, B, 128, 0, 0, st()), 'mpose_bn_bwd_apply')
                 wo = WgradOperands()
                 wo.in_, wo.gout0, wo.dw0 = ctx['s2d'].data_ptr(), d_raw.data_ptr(), tb['part_ptr'][id(self.stem_conv)]
-                self.wgrad_async(self.geom('f_stem', B, F), [wo], self._n_split(B * F * F, 6), [ctx['s2d'], d_raw])
+                self.wgrad_async(self.geom('f_stem', B, F), [wo], self._n_split(B * F * F, 2, 1), [ctx['s2d'], d_raw])
                 if need_dx:
                     d_s2d = torch.empty_like(ctx['s2d'])
                     op = ConvOperands()
@@ -838,23 +836,36 @@ class Engine:
         return self.gflat, dx
 
     @staticmethod
-    def _n_split(slots, tiles=108):
-        """Split-K factor of the weight-gradient GEMMs.  `tiles` = (tap entries) x (Cin/32) x (Cout tiles) of ONE
-        column; the launch has 3 columns.  4 workgroups of 4 waves are resident per CU (1024 slots): pick the
-        split that fills them in a single round without spilling into a second one."""
+    def _n_split(slots, tiles=27, groups=3):
+        """Split-K factor of the weight-gradient GEMMs.  `tiles` = (tap entries) x (Cin tiles) x (Cout tiles) of ONE
+        column (mpose_conv_wgrad_tiles); the launch has `groups` columns and runs tiles*groups*n workgroups, one
+        per CU at a time.  Pick the n whose last round of 256 is fullest, discounted by the fixed per-workgroup cost
+        (LDS reduction, pipeline fill) so that short row ranges are not split further than they pay for."""
         rows = max(1, slots // 32)
-        n = max(1, min(16, 1024 // max(1, 3 * tiles), rows // 4))
-        return n
+        best, best_score = 1, -1.0
+        for n in range(1, 65):
+            if n > 1 and rows < 8 * n:
+                break
+            wgs = tiles * groups * n
+            eff = wgs / (256.0 * ((wgs + 255) // 256))
+            work = rows / (4.0 * n)
+            score = eff * work / (work + 3.0)
+            if score > best_score + 1e-9:
+                best, best_score = n, score
+        return best
+
+    @staticmethod
+    def _wg_blocks(c):
+        return 4 if c % 128 == 0 else (3 if c % 96 == 0 else (2 if c % 64 == 0 else 1))
 
     @staticmethod
     def _wg_tiles(blk, which):
-        """Output tiles of one column's weight-gradient launch (see conv_wgrad_k's grid)."""
+        """Work units of one column's weight-gradient launch (mirrors mpose_conv_wgrad_tiles)."""
         cs = blk.cout_s
-        ctile = 128 if cs % 128 == 0 else (96 if cs % 96 == 0 else (64 if cs % 64 == 0 else 32))
-        n_ct = cs // ctile
+        n_ct = cs // (32 * Engine._wg_blocks(cs))
         if which == 'conv2':
-            return 9 * (blk.cout_s // 32) * n_ct
-        return 10 * (blk.cin_s // 32) * n_ct
+            return 9 * n_ct * n_ct
+        return 10 * (blk.cin_s // (32 * Engine._wg_blocks(blk.cin_s))) * n_ct
 
     def grads_from_flat(self, flat):
         out = []

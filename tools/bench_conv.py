@@ -42,8 +42,8 @@ def run(H, C, pro):
     us = timeit(lambda: _lib.check(L.mpose_conv_fwd(ctypes.byref(g), arr, 3, 0, stream_ptr()), 'conv'))
     print('conv  %dx%d %d->%d pro=%d : %7.1f us  %6.1f TFLOP/s' % (H, H, C, C, pro, us, flops / us / 1e6))
     from margipose_amd.engine import Engine
-    ctile = 128 if C % 128 == 0 else 96
-    nsp = Engine._n_split(B * H * H, 9 * (C // 32) * (C // ctile))
+    nt = C // (32 * Engine._wg_blocks(C))
+    nsp = Engine._n_split(B * H * H, 9 * nt * nt)
     parts = [torch.empty(nsp * 9 * C * C, device='cuda') for _ in range(3)]
     wops = []
     for c in range(3):
