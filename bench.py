@@ -11,8 +11,9 @@ buffer over RCCL) + SGD update.  Workload = BASELINE.json configs[2] ("1xMI355X 
 JS-reg + pixelwise loss on"): the config the metric "images/sec fwd+bwd at 256x256, 17 joints" is quoted on,
 with the 3-stage model of configs[1].  fp32 arithmetic throughout (the reference's precision).
 
-Rank 0 prints ONE JSON line.  `roofline` describes the dominant kernel (the fp32-MFMA implicit-GEMM
-convolution; algorithmic FLOPs / HIP-event launch duration measured inside the timed region);
+Rank 0 prints ONE JSON line.  `roofline` describes the dominant kernel (an implicit-GEMM convolution or its
+weight gradient: fp32 arithmetic carried out as six bf16 MFMAs per multiply-add, so the bound is the dense bf16
+MFMA peak / 6; algorithmic fp32 FLOPs / HIP-event launch duration measured inside the timed region);
 `tail_roofline` is the soft-argmax kernel the metric also names (algorithmic bytes / launch duration, HBM
 bound); `cpu_baseline` times the oracle (the stock-PyTorch CPU restatement of the reference, oracle/model_ref.py)
 on the host cores on a bounded sample of the same workload.
@@ -28,8 +29,24 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_FP32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # /opt/skills/guides/MI355X_MICROARCH.md: dense bf16 MFMA (v_mfma_f32_32x32x16_bf16)
+PEAK_BF16X6_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0     # fp32-equivalent: 6 bf16 products per fp32 multiply-add
+PEAK_FP32_MFMA_TFLOPS = 157.3     # for comparison: v_mfma_f32_32x32x2_f32 (what a plain fp32 MFMA kernel is bound by)
 PEAK_HBM_GBPS = 8000.0
+
+
+def pmc_traffic(label):
+    """HBM-side bytes per launch of the kernel `label` from the committed rocprofv3 PMC pass (profiles/*_pmc_traffic.json,
+    written by tools/summarize_profile.py from FETCH_SIZE / WRITE_SIZE collected in their own passes), or None."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic.json')), reverse=True):
+        try:
+            d = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        if label in d:
+            return d[label]
+    return None
 
 
 def parse():
@@ -209,11 +226,16 @@ def main():
             tf = top[1]['work_per_launch'] / (top[1]['avg_us'] * 1e-6) / 1e12
             all_flops = sum(v['work'] for v in convs.values())
             all_ms = sum(v['total_ms'] for v in convs.values())
-            res['roofline'] = {'bound': 'mfma', 'achieved': tf, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                               'frac': tf / PEAK_FP32_MFMA_TFLOPS, 'traffic': None, 'kernel': top[0],
+            res['roofline'] = {'bound': 'mfma', 'achieved': tf, 'peak': PEAK_BF16X6_TFLOPS, 'unit': 'TFLOP/s',
+                               'frac': tf / PEAK_BF16X6_TFLOPS, 'traffic': pmc_traffic(top[0]), 'kernel': top[0],
                                'avg_launch_us': top[1]['avg_us'], 'launches': top[1]['n'],
                                'flops_per_launch': top[1]['work_per_launch'],
+                               'note': 'achieved = algorithmic fp32 FLOPs / launch duration; the kernel executes 6 bf16 MFMA FLOPs '
+                                       'per algorithmic FLOP (3-way split operands), so peak = dense bf16 MFMA peak 2500 / 6; '
+                                       'the plain fp32 MFMA peak is %.1f' % PEAK_FP32_MFMA_TFLOPS,
+                               'bf16_mfma_tflops_executed': 6.0 * tf,
                                'all_conv_kernels_tflops': all_flops / (all_ms * 1e-3) / 1e12,
+                               'all_conv_kernels_frac': all_flops / (all_ms * 1e-3) / 1e12 / PEAK_BF16X6_TFLOPS,
                                'conv_share_of_step_gpu_time': all_ms / (1e3 * dt)}
         tail = summ.get('tail:softmax_dsnt_fwd')
         if tail:

@@ -132,9 +132,9 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
   constexpr int BM = 256 / KS;
   constexpr int BN = 32 * RN;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  int* sTaps = reinterpret_cast<int*>(smem_raw);                                  // [MPOSE_MAX_TAPS] (+4 pad)
-  unsigned char* sA_all = smem_raw + 64;                                          // [4 waves][2][A_TILE_B]
-  float* sRed = reinterpret_cast<float*>(smem_raw + 64 + 4 * 2 * A_TILE_B);       // [2 sets][4 waves][BN][2]
+  unsigned char* sA_all = smem_raw;                                               // [4 waves][2][A_TILE_B]
+  float* sRed = reinterpret_cast<float*>(smem_raw + 4 * 2 * A_TILE_B);            // [2 sets][4 waves][BN][2]
+  unsigned* sRow = reinterpret_cast<unsigned*>(smem_raw + 4 * 2 * A_TILE_B + 2 * 4 * BN * 2 * 4);   // [4 waves][64] output row offsets
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lh = lane >> 5;
@@ -145,23 +145,21 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
   const int n0 = blockIdx.y * BN;
   const mpose_conv_operands& op = a.op[blockIdx.z];
   const int n_taps = g.cls[cls].n_taps;
-  if (tid < MPOSE_MAX_TAPS) {
-    const mpose_tap t = g.cls[cls].taps[tid];
-    sTaps[tid] = (int)(unsigned char)t.dy | ((int)(unsigned char)t.dx << 8) | ((int)(unsigned char)t.widx << 16) | ((int)(unsigned char)t.acc << 24);
-  }
-  __syncthreads();   // sTaps visible (the only workgroup barrier before the epilogue)
+  // taps are read from the kernel arguments (scalar loads): {dy, dx, widx, acc} packed in one dword
+  auto tap_word = [&](int t) { return *reinterpret_cast<const int*>(&g.cls[cls].taps[t]); };
   unsigned char* sA = sA_all + wave * 2 * A_TILE_B;
 
   // ---- per-lane staging state (loop invariant) ----
   // row_voff[j]: BYTE offset of the slot's anchor pixel + this lane's 16-byte channel column;
-  // row_taps[j]: bit t = tap t reads an in-bounds pixel for that row.
+  // row_taps[j]: bit t = tap t reads an in-bounds pixel for that row (filled in after the first loads are issued).
   const int a_col4 = lane & 7;
   const int in_ld = g.in_ld > 0 ? g.in_ld : g.Cin;
   unsigned row_voff[8], row_taps[8];
+  int row_yx[8];                           // iy0 | ix0 << 16 of the row's anchor pixel (rows beyond M: never valid)
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const unsigned m = (unsigned)(m0 + (lane >> 3) + 8 * j);
-    row_voff[j] = 0; row_taps[j] = 0;
+    row_voff[j] = 0; row_taps[j] = 0; row_yx[j] = 0x7000;
     if ((int)m < a.M) {
       const unsigned b = fdiv(m, a.div_ghw);
       const unsigned rem = m - b * (unsigned)(g.GH * g.GW);
@@ -169,13 +167,18 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
       const unsigned gx = rem - gy * (unsigned)g.GW;
       const int iy0 = (int)gy * g.in_mul, ix0 = (int)gx * g.in_mul;
       row_voff[j] = (((b * (unsigned)g.IH + (unsigned)iy0) * (unsigned)g.IW + (unsigned)ix0) * (unsigned)in_ld + (unsigned)(a_col4 * 4)) * 4u;
-      for (int t = 0; t < n_taps; ++t) {
-        const int tp = sTaps[t];
-        const int iy = iy0 + (int)(signed char)(tp & 0xff), ix = ix0 + (int)(signed char)((tp >> 8) & 0xff);
-        if (iy >= 0 && iy < g.IH && ix >= 0 && ix < g.IW) row_taps[j] |= 1u << t;
-      }
+      row_yx[j] = iy0 | (ix0 << 16);
     }
   }
+  auto mark_tap = [&](int t) {             // set bit t of row_taps where tap t stays inside the image
+    const int tp = tap_word(t);
+    const int dy = (int)(signed char)(tp & 0xff), dx = (int)(signed char)((tp >> 8) & 0xff);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int iy = (row_yx[j] & 0xffff) + dy, ix = (row_yx[j] >> 16) + dx;
+      if ((unsigned)iy < (unsigned)g.IH && (unsigned)ix < (unsigned)g.IW) row_taps[j] |= 1u << t;
+    }
+  };
   const int n_chunks = g.Cin / KC;
   const int k16_total = g.Cin >> 4;
   const int npad = g.Npad0;                                       // == Npad1 when ACC1
@@ -200,9 +203,9 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
   // Taps with acc == 0 (the convolution proper) come first in a class's tap list, taps with acc == 1 (the fused
   // 1x1 shortcut of a ResidualBlock: same input, second weight set, second output) last.  The two sets run as
   // two passes of the same pipeline with ONE accumulator tile, so the fused launch keeps the full 128-wide tile.
+  bool masks_done = false;
   int n_taps0 = 0;
-  for (int t = 0; t < n_taps; ++t) n_taps0 += (((sTaps[t] >> 24) & 0xff) == 0) ? 1 : 0;
-  n_taps0 = __builtin_amdgcn_readfirstlane(n_taps0);
+  for (int t = 0; t < n_taps; ++t) n_taps0 += (((tap_word(t) >> 24) & 0xff) == 0) ? 1 : 0;
 
 #pragma unroll 1
   for (int set = 0; set < (ACC1 ? 2 : 1); ++set) {
@@ -223,7 +226,7 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
       TileInfo ti;
       ti.c = it / nt;
       ti.t = t_lo + it - ti.c * nt;
-      const int tp = __builtin_amdgcn_readfirstlane(sTaps[ti.t]);
+      const int tp = tap_word(ti.t);
       const int dy = (int)(signed char)(tp & 0xff), dx = (int)(signed char)((tp >> 8) & 0xff);
       const int widx = (tp >> 16) & 0xff;
       ti.a_soff = (unsigned)(((dy * g.IW + dx) * in_ld + ti.c * KC) * 4 + a.in_bias);
@@ -314,16 +317,21 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
       {
         float4 rb[8], sc0 = rsc_c, sh0 = rsh_c, sc1 = rsc_c, sh1 = rsh_c;
         unsigned pad0 = 0, pad1 = 0;
+#pragma unroll
+        for (int s_ = 0; s_ < 2; ++s_)
+#pragma unroll
+          for (int rn = 0; rn < RN; ++rn) load_b(t0, s_, rn);
+        if (!masks_done) { mark_tap(t0.t); mark_tap(t1.t); }     // just enough of the tap masks to get going
         load_scale(t0, sc0, sh0);
 #pragma unroll
         for (int j = 0; j < 8; ++j) load_row(t0, j, ra[j], pad0);
         load_scale(t1, sc1, sh1);
 #pragma unroll
         for (int j = 0; j < 8; ++j) load_row(t1, j, rb[j], pad1);
-#pragma unroll
-        for (int s_ = 0; s_ < 2; ++s_)
-#pragma unroll
-          for (int rn = 0; rn < RN; ++rn) load_b(t0, s_, rn);
+        if (!masks_done) {                                       // the rest of the masks while those loads fly
+          for (int t = 0; t < n_taps; ++t) mark_tap(t);
+          masks_done = true;
+        }
         load_scale(t2, rsc_n, rsh_n);
 #pragma unroll
         for (int j = 0; j < 8; ++j) { stage(it_begin & 1, j, ra[j], pad0, sc0, sh0); load_row(t2, j, ra[j], pad_n); }
@@ -400,28 +408,36 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
     float csum[RN], csq[RN];
 #pragma unroll
     for (int rn = 0; rn < RN; ++rn) csum[rn] = csq[rn] = 0.f;
+    // Output row table: lane l works out the byte offset of output pixel m0 + l ONCE (two divisions per lane
+    // instead of two per accumulator row); rows beyond M, and every row of a non-writing wave, get an offset the
+    // buffer unit rejects (stores dropped, loads return 0).  Accumulator register group rg of lane half h holds
+    // rows 8*rg + 4*h .. +3 = one ds_read_b128 of the table.
+    {
+      const unsigned m = (unsigned)(m0 + lane);
+      const unsigned mm = (int)m < a.M ? m : 0u;
+      const unsigned b = fdiv(mm, a.div_ghw);
+      const unsigned rem = mm - b * (unsigned)(g.GH * g.GW);
+      const unsigned gy = fdiv(rem, a.div_gw);
+      const unsigned gx = rem - gy * (unsigned)g.GW;
+      const unsigned pix = (b * (unsigned)g.OH + (gy * g.out_mul + oyc)) * (unsigned)g.OW + (gx * g.out_mul + oxc);
+      const bool ok = (int)m < a.M && writer;
+      sRow[wave * 64 + lane] = ok ? pix * (unsigned)out_ld * 4u : 0xFFFFF000u;
+      __builtin_amdgcn_wave_barrier();
+    }
+    const unsigned col_off = (unsigned)((n0 + li) * 4);
 #pragma unroll
     for (int rm = 0; rm < 2; ++rm) {
-      unsigned row_pix[16];
+      unsigned voff[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const unsigned m = (unsigned)(m0 + rm * 32 + acc_row(r, lh));
-        const unsigned mm = (int)m < a.M ? m : 0u;
-        const unsigned b = fdiv(mm, a.div_ghw);
-        const unsigned rem = mm - b * (unsigned)(g.GH * g.GW);
-        const unsigned gy = fdiv(rem, a.div_gw);
-        const unsigned gx = rem - gy * (unsigned)g.GW;
-        const unsigned pix = (b * (unsigned)g.OH + (gy * g.out_mul + oyc)) * (unsigned)g.OW + (gx * g.out_mul + oxc);
-        row_pix[r] = ((int)m < a.M && writer && !(a.flags & 0x100)) ? pix : 0xFFFFFFFFu;   // 0x100: debug, drop stores
+      for (int rg = 0; rg < 4; ++rg) {
+        const u32x4 e = *reinterpret_cast<const u32x4*>(sRow + wave * 64 + rm * 32 + 8 * rg + 4 * lh);
+        voff[4 * rg] = e.x + col_off; voff[4 * rg + 1] = e.y + col_off; voff[4 * rg + 2] = e.z + col_off; voff[4 * rg + 3] = e.w + col_off;
       }
 #pragma unroll
       for (int rn = 0; rn < RN; ++rn) {
         const int nb = n0 + rn * 32;                 // wave-uniform: the whole 32-column group is in or out (cout % 32 == 0)
         if (nb < cout) {
           const int n = nb + li;
-          unsigned voff[16];
-#pragma unroll
-          for (int r = 0; r < 16; ++r) voff[r] = row_pix[r] == 0xFFFFFFFFu ? kOob : (row_pix[r] * (unsigned)out_ld + (unsigned)n) * 4u;
           float v[16];
 #pragma unroll
           for (int r = 0; r < 16; ++r) v[r] = acc0[rm][rn][r];
@@ -429,7 +445,7 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
             const float msc = op.mask_scale[n], msh = op.mask_shift[n];
             float src[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) src[r] = buf_load1(rs_m, voff[r], 0);
+            for (int r = 0; r < 16; ++r) src[r] = buf_load1(rs_m, voff[r] + (unsigned)(rn * 128), 0);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
               if (!(fmaf(src[r], msc, msh) > 0.f)) v[r] = 0.f;
@@ -439,19 +455,23 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
           if (accumulate) {
             float old[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) old[r] = buf_load1(rs_o, voff[r], 0);
+            for (int r = 0; r < 16; ++r) old[r] = buf_load1(rs_o, voff[r] + (unsigned)(rn * 128), 0);
 #pragma unroll
             for (int r = 0; r < 16; ++r) v[r] += old[r];
           }
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[r]), rs_o, (int)voff[r], 0, 0);
-            const float vv = (voff[r] == kOob) ? 0.f : v[r];
-            csum[rn] += vv;
-            if (!masked) csq[rn] = fmaf(vv, vv, csq[rn]);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[r]), rs_o, (int)(voff[r] + (unsigned)(rn * 128)), 0, 0);
+            // rows beyond M accumulated zeros (their inputs were read as 0); non-writing waves are excluded below
+            csum[rn] += v[r];
+            if (!masked) csq[rn] = fmaf(v[r], v[r], csq[rn]);
           }
         }
       }
+    }
+    if (!writer) {
+#pragma unroll
+      for (int rn = 0; rn < RN; ++rn) csum[rn] = csq[rn] = 0.f;
     }
     if (stats != nullptr) {
 #pragma unroll
@@ -489,7 +509,7 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
 template <int RN, bool ACC1, int KS, bool PRO>
 int launch_conv(const ConvArgs& a0, int n_groups, hipStream_t s) {
   constexpr int BN = 32 * RN;
-  constexpr int lds = 64 + 4 * 2 * A_TILE_B + 2 * 4 * BN * 2 * 4;
+  constexpr int lds = 4 * 2 * A_TILE_B + 2 * 4 * BN * 2 * 4 + 4 * 64 * 4;
   static bool attr_set = false;          // > 64 KiB of dynamic LDS has to be requested once per kernel
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_k<RN, ACC1, KS, PRO>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
@@ -948,7 +968,7 @@ extern "C" int mpose_conv_fwd(const mpose_conv_geom* geom, const mpose_conv_oper
   if ((geom->Cout0 % 32) || (acc1 && (geom->Cout1 % 32))) return MPOSE_EINVAL;
   {
     const int ldm = geom->out_ld0 > geom->out_ld1 ? geom->out_ld0 : geom->out_ld1;
-    if ((long)geom->B * geom->OH * geom->OW * (ldm > cmax ? ldm : cmax) * 4 >= 0xFFFFFF00l) return MPOSE_EINVAL;
+    if ((long)geom->B * geom->OH * geom->OW * (ldm > cmax ? ldm : cmax) * 4 >= 0xFFFFF000l) return MPOSE_EINVAL;
   }
   if (geom->Cin % 16) return MPOSE_EINVAL;
   if (cmax <= 32) return acc1 ? launch_conv_ks<1, true>(a, cmax, n_groups, s) : launch_conv_ks<1, false>(a, cmax, n_groups, s);

@@ -34,5 +34,5 @@ for CI in (32, 64, 128, 256, 512):
         op = ConvOperands(); op.in_, op.w0, op.out0 = xs[c].data_ptr(), ws[c].data_ptr(), outs[c].data_ptr()
         ops.append(op)
     arr = (ConvOperands * 3)(*ops)
-    us = timeit(lambda: _lib.check(L.mpose_conv_fwd(ctypes.byref(g), arr, 3, int(os.environ.get('FLAGS', '0')), stream_ptr()), 'conv'))
+    us = timeit(lambda: _lib.check(L.mpose_conv_fwd(ctypes.byref(g), arr, 3, 0, stream_ptr()), 'conv'))
     print('Cin=%4d n_iter=%3d : %7.1f us  %6.1f TFLOP/s' % (CI, 9 * CI // 32, us, flops / us / 1e6))
