@@ -140,9 +140,15 @@ typedef struct {
   const float* mask_src;               /* epilogue ReLU-mask source (pre-BN activations), or NULL */
   const float* mask_scale;
   const float* mask_shift;
+  const float* in1;                    /* MPOSE_CONV_SUM_INPUTS: input of the taps with acc == 1 (same shape as `in`) */
 } mpose_conv_operands;
 
-/* Conv forward / data-gradient.  flags: bit0 = accumulate into out0 (out0 += result);
+#define MPOSE_CONV_ACCUMULATE 1   /* out0 += result */
+#define MPOSE_CONV_SUM_INPUTS 2   /* taps with acc == 1 read `in1` through `w1` and add into out0 (one pass, one
+                                   * output): the data-gradient of a ResidualBlock's input, dX = conv_in^T(dC1) +
+                                   * shortcut^T(dSC), models/margipose_model.py:39 */
+
+/* Conv forward / data-gradient.  flags: MPOSE_CONV_* bits; bit0 = accumulate into out0 (out0 += result);
  * when mask_src != NULL the result is multiplied by [mask_scale*mask_src+mask_shift > 0] before it
  * is stored, and stats0 receives (sum d, sum d*mask_src) instead of (sum, sum of squares). */
 int mpose_conv_fwd(const mpose_conv_geom* geom, const mpose_conv_operands* ops, int n_groups,

@@ -95,7 +95,7 @@ class ConvOperands(ctypes.Structure):
     _fields_ = [('in_', c_void_p), ('in_scale', c_void_p), ('in_shift', c_void_p),
                 ('w0', c_void_p), ('w1', c_void_p), ('out0', c_void_p), ('out1', c_void_p),
                 ('stats0', c_void_p), ('stats1', c_void_p),
-                ('mask_src', c_void_p), ('mask_scale', c_void_p), ('mask_shift', c_void_p)]
+                ('mask_src', c_void_p), ('mask_scale', c_void_p), ('mask_shift', c_void_p), ('in1', c_void_p)]
 
 
 class WgradOperands(ctypes.Structure):

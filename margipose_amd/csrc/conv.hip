@@ -127,8 +127,13 @@ __device__ __forceinline__ bf16x8 as_bf16x8(const u32x4 v) { return __builtin_bi
 // KS (split-K inside the workgroup): KS waves share one 64-row tile and take 1/KS of the (chunk, tap) tiles each;
 // chosen per launch so that the number of waves is close to a multiple of the 1024 SIMDs.  The parts are summed
 // through the (by then dead) A-tile LDS region in a fixed order.
-template <int RN, bool ACC1, int KS, bool PRO>
+// MODE 0: one pass.  MODE 1: taps with acc == 1 are a second pass into a second output (fused shortcut, forward).
+// MODE 2 (MPOSE_CONV_SUM_INPUTS): they are a second pass over a second INPUT that keeps accumulating into the same
+// tile -- dX = conv_in^T(dC1) + shortcut^T(dSC) -- with one epilogue.
+template <int RN, int MODE, int KS, bool PRO>
 __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
+  constexpr bool ACC1 = MODE == 1, SUM2 = MODE == 2;
+  constexpr int NPASS = MODE ? 2 : 1;
   constexpr int BM = 256 / KS;
   constexpr int BN = 32 * RN;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -186,10 +191,12 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
   constexpr bool pro = PRO;                                        // BN + ReLU of the producer applied while staging
   // Buffer descriptors.  The input base is moved back by `a.in_bias` bytes so that the (possibly negative) tap
   // shift becomes a non-negative SGPR offset.
-  const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(
+  const __amdgpu_buffer_rsrc_t rs_in0 = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<char*>(reinterpret_cast<const char*>(op.in)) - a.in_bias, 0, 0xFFFFFF00, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_in1 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char*>(reinterpret_cast<const char*>(SUM2 ? op.in1 : op.in)) - a.in_bias, 0, 0xFFFFFF00, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_w0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(op.w0), 0, 0xFFFFFF00, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_w1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ACC1 ? op.w1 : op.w0), 0, 0xFFFFFF00, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(MODE ? op.w1 : op.w0), 0, 0xFFFFFF00, 0x00020000);
   const unsigned w_voff = (unsigned)(((n0 + li) * 2 + lh) * 16);     // this lane's 16-byte fragment inside a slab
 
   f32x16 acc0[2][RN];
@@ -208,17 +215,20 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
   for (int t = 0; t < n_taps; ++t) n_taps0 += (((tap_word(t) >> 24) & 0xff) == 0) ? 1 : 0;
 
 #pragma unroll 1
-  for (int set = 0; set < (ACC1 ? 2 : 1); ++set) {
+  for (int set = 0; set < NPASS; ++set) {
     const int t_lo = set ? n_taps0 : 0;
-    const int nt = set ? n_taps - n_taps0 : (ACC1 ? n_taps0 : n_taps);
+    const int nt = set ? n_taps - n_taps0 : (MODE ? n_taps0 : n_taps);
     const int n_iter = n_chunks * nt;
     const __amdgpu_buffer_rsrc_t rs_w = set ? rs_w1 : rs_w0;
+    const __amdgpu_buffer_rsrc_t rs_in = set ? rs_in1 : rs_in0;
+    if (!SUM2 || set == 0) {
 #pragma unroll
-    for (int rm = 0; rm < 2; ++rm)
+      for (int rm = 0; rm < 2; ++rm)
 #pragma unroll
-      for (int rn = 0; rn < RN; ++rn)
+        for (int rn = 0; rn < RN; ++rn)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc0[rm][rn][r] = 0.0f;
+          for (int r = 0; r < 16; ++r) acc0[rm][rn][r] = 0.0f;
+    }
 
     // wave-uniform (SGPR) description of tile `it`
     struct TileInfo { unsigned a_soff; unsigned w_soff; int t; int c; };
@@ -363,6 +373,7 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
       mfma_group(1, afB, t1, [&](int) {});          // last tile, k-group 1
     }
 
+    if (SUM2 && set == 0) continue;          // the second input accumulates on top; one exchange + epilogue after it
     // ---- split-K exchange: waves with kh > 0 hand their partial tiles to wave kh == 0 through LDS ----
     if (KS > 1) {
       constexpr int EX = 2 * RN * 16 * 64;               // floats per handed-over tile set
@@ -395,12 +406,13 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
     const bool writer = (KS == 1) || !kh;
 
     // ---- epilogue (branch-free: buffer stores/loads, rows beyond M get an out-of-range offset and are dropped) ----
-    float* outp = set ? op.out1 : op.out0;
-    const int cout = set ? g.Cout1 : g.Cout0;
-    double* stats = set ? op.stats1 : op.stats0;
-    const bool masked = (set == 0) && op.mask_src != nullptr;
-    const bool accumulate = (set == 0) && (a.flags & 1);
-    const int old_ = set ? g.out_ld1 : g.out_ld0;
+    const int oset = SUM2 ? 0 : set;             // which output this epilogue writes
+    float* outp = oset ? op.out1 : op.out0;
+    const int cout = oset ? g.Cout1 : g.Cout0;
+    double* stats = oset ? op.stats1 : op.stats0;
+    const bool masked = (oset == 0) && op.mask_src != nullptr;
+    const bool accumulate = (oset == 0) && (a.flags & 1);
+    const int old_ = oset ? g.out_ld1 : g.out_ld0;
     const int out_ld = old_ > 0 ? old_ : cout;
     const unsigned out_bytes = (unsigned)((((long)g.B * g.OH * g.OW - 1) * out_ld + cout) * 4);
     const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(outp, 0, out_bytes, 0x00020000);
@@ -479,7 +491,7 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
         const float s_ = csum[rn] + __shfl_xor(csum[rn], 32, 64);
         const float q_ = csq[rn] + __shfl_xor(csq[rn], 32, 64);
         if (lh == 0) {
-          float* d = sRed + ((set * 4 + wave) * BN + rn * 32 + li) * 2;
+          float* d = sRed + ((oset * 4 + wave) * BN + rn * 32 + li) * 2;
           d[0] = s_; d[1] = q_;
         }
       }
@@ -506,13 +518,13 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
   }
 }
 
-template <int RN, bool ACC1, int KS, bool PRO>
+template <int RN, int MODE, int KS, bool PRO>
 int launch_conv(const ConvArgs& a0, int n_groups, hipStream_t s) {
   constexpr int BN = 32 * RN;
   constexpr int lds = 4 * 2 * A_TILE_B + 2 * 4 * BN * 2 * 4 + 4 * 64 * 4;
   static bool attr_set = false;          // > 64 KiB of dynamic LDS has to be requested once per kernel
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_k<RN, ACC1, KS, PRO>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_k<RN, MODE, KS, PRO>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
       return MPOSE_EINVAL;
     attr_set = true;
   }
@@ -520,7 +532,7 @@ int launch_conv(const ConvArgs& a0, int n_groups, hipStream_t s) {
   a.n_mtiles = (a.M + 256 / KS - 1) / (256 / KS);
   const int cmax = a.g.Cout1 > a.g.Cout0 ? a.g.Cout1 : a.g.Cout0;
   dim3 grid(a.n_mtiles * a.g.n_classes, (cmax + BN - 1) / BN, n_groups);
-  conv_igemm_k<RN, ACC1, KS, PRO><<<grid, 256, lds, s>>>(a);
+  conv_igemm_k<RN, MODE, KS, PRO><<<grid, 256, lds, s>>>(a);
   return launch_status();
 }
 
@@ -544,20 +556,21 @@ inline int pick_ks(const ConvArgs& a, int cmax, int n_groups) {
   return best;
 }
 
-template <int RN, bool ACC1, bool PRO>
+template <int RN, int MODE, bool PRO>
 int launch_conv_kp(const ConvArgs& a, int cmax, int n_groups, hipStream_t s) {
-  switch (pick_ks<RN>(a, cmax, n_groups)) {
-    case 4: return launch_conv<RN, ACC1, 4, PRO>(a, n_groups, s);
-    case 2: return launch_conv<RN, ACC1, 2, PRO>(a, n_groups, s);
-    default: return launch_conv<RN, ACC1, 1, PRO>(a, n_groups, s);
+  const int ks = pick_ks<RN>(a, cmax, n_groups);
+  if constexpr (RN > 1) {                  // (32-wide tiles never profit from a 4-way split)
+    if (ks == 4) return launch_conv<RN, MODE, 4, PRO>(a, n_groups, s);
   }
+  if (ks >= 2) return launch_conv<RN, MODE, 2, PRO>(a, n_groups, s);
+  return launch_conv<RN, MODE, 1, PRO>(a, n_groups, s);
 }
-template <int RN, bool ACC1>
-int launch_conv_ks(const ConvArgs& a, int cmax, int n_groups, hipStream_t s) {
-  if constexpr (!ACC1) {
-    if (a.op[0].in_scale != nullptr) return launch_conv_kp<RN, false, true>(a, cmax, n_groups, s);
-  }
-  return launch_conv_kp<RN, ACC1, false>(a, cmax, n_groups, s);
+template <int RN>
+int launch_conv_ks(const ConvArgs& a, int mode, int cmax, int n_groups, hipStream_t s) {
+  if (mode == 1) return launch_conv_kp<RN, 1, false>(a, cmax, n_groups, s);
+  if (mode == 2) return launch_conv_kp<RN, 2, false>(a, cmax, n_groups, s);
+  if (a.op[0].in_scale != nullptr) return launch_conv_kp<RN, 0, true>(a, cmax, n_groups, s);
+  return launch_conv_kp<RN, 0, false>(a, cmax, n_groups, s);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -937,6 +950,13 @@ extern "C" int mpose_conv_fwd(const mpose_conv_geom* geom, const mpose_conv_oper
   bool acc1 = false;
   for (int c = 0; c < geom->n_classes; ++c)
     for (int t = 0; t < geom->cls[c].n_taps; ++t) acc1 |= geom->cls[c].taps[t].acc != 0;
+  const bool sum_inputs = (flags & MPOSE_CONV_SUM_INPUTS) != 0;
+  if (sum_inputs) {                        // acc taps feed the SAME output from a second input: a single-pass launch
+    if (!acc1) return MPOSE_EINVAL;
+    for (int i = 0; i < n_groups; ++i)
+      if (!ops[i].in1 || !ops[i].w1 || ops[i].in_scale) return MPOSE_EINVAL;
+    acc1 = false;
+  }
   for (int i = 0; i < n_groups; ++i) {
     a.op[i] = ops[i];
     if (!ops[i].in || !ops[i].w0 || !ops[i].out0) return MPOSE_EINVAL;
@@ -971,17 +991,13 @@ extern "C" int mpose_conv_fwd(const mpose_conv_geom* geom, const mpose_conv_oper
     if ((long)geom->B * geom->OH * geom->OW * (ldm > cmax ? ldm : cmax) * 4 >= 0xFFFFF000l) return MPOSE_EINVAL;
   }
   if (geom->Cin % 16) return MPOSE_EINVAL;
-  if (cmax <= 32) return acc1 ? launch_conv_ks<1, true>(a, cmax, n_groups, s) : launch_conv_ks<1, false>(a, cmax, n_groups, s);
+  const int mode = sum_inputs ? 2 : (acc1 ? 1 : 0);
+  if (cmax <= 32) return launch_conv_ks<1>(a, mode, cmax, n_groups, s);
   if (npad % 64) return MPOSE_EINVAL;
   // widest wave tile that divides the padded N: 128 channels (RN=4), 96 (RN=3) or 64 (RN=2)
-  if (acc1) {
-    if (cmax % 128 == 0) return launch_conv_ks<4, true>(a, cmax, n_groups, s);
-    if (cmax % 96 == 0 && npad % 96 == 0) return launch_conv_ks<3, true>(a, cmax, n_groups, s);
-    return launch_conv_ks<2, true>(a, cmax, n_groups, s);
-  }
-  if (cmax % 128 == 0) return launch_conv_ks<4, false>(a, cmax, n_groups, s);
-  if (cmax % 96 == 0 && npad % 96 == 0) return launch_conv_ks<3, false>(a, cmax, n_groups, s);
-  return launch_conv_ks<2, false>(a, cmax, n_groups, s);
+  if (cmax % 128 == 0) return launch_conv_ks<4>(a, mode, cmax, n_groups, s);
+  if (cmax % 96 == 0 && npad % 96 == 0) return launch_conv_ks<3>(a, mode, cmax, n_groups, s);
+  return launch_conv_ks<2>(a, mode, cmax, n_groups, s);
 }
 
 extern "C" int mpose_conv_wgrad_tiles(const mpose_conv_geom* geom) {

@@ -16,6 +16,7 @@ Data layout in HBM
     float arena holding scale / shift / mean / invstd / backward coefficients.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -448,6 +449,12 @@ class Engine:
             g = _geom(B, H, co, H, co, 0, H, 1, 1, [(0, 0, [(1 - ky, 1 - kx, ky * 3 + kx, 0) for ky, kx in TAPS3])], np_f)
         elif name == 'd_in3_regular':    # dgrad of conv_in: K = cout_s, N = cin
             g = _geom(B, H, co, H, ci, 0, H, 1, 1, [(0, 0, [(1 - ky, 1 - kx, ky * 3 + kx, 0) for ky, kx in TAPS3])], np_d)
+        elif name == 'd_in_regular':     # dX = conv_in^T(dC1) + shortcut^T(dSC) in one pass (MPOSE_CONV_SUM_INPUTS)
+            g = _geom(B, H, co, H, ci, ci, H, 1, 1, [(0, 0, [(1 - ky, 1 - kx, ky * 3 + kx, 0) for ky, kx in TAPS3] + [(0, 0, 0, 1)])], np_d, np_d)
+        elif name == 'd_in_down':
+            g = _geom(B, H, co, 2 * H, ci, ci, H, 1, 2, _up_classes(True), np_d, np_d)
+        elif name == 'd_in_up':
+            g = _geom(B, H, co, H // 2, ci, ci, H // 2, 2, 1, [(0, 0, t9 + [(0, 0, 0, 1)])], np_d, np_d)
         elif name == 'd_in1_regular':
             g = _geom(B, H, co, H, ci, 0, H, 1, 1, [(0, 0, [(0, 0, 0, 0)])], np_d)
         elif name == 'd_in3_down':       # H = size of the conv OUTPUT (gradient input); result is 2H
@@ -765,17 +772,16 @@ class Engine:
                     wops.append(wo)
                 self.wgrad_async(self.geom(gname, B, Hin, b0), wops, self._n_split(slots, self._wg_tiles(b0, 'in')),
                                  list(sv['x']) + d_c1 + d_sc)
-                # (6) dgrad of conv_in, then the shortcut's dgrad accumulated on top
+                # (6) dgrad of conv_in + the shortcut's dgrad: one launch, the shortcut as a tap on a second input
                 d_x = [torch.empty(B, Hin, Hin, b0.cin_s, **f32) for _ in range(3)]
-                k3 = {'regular': 'd_in3_regular', 'down': 'd_in3_down', 'up': 'd_in3_up'}[b0.kind]
-                k1 = {'regular': 'd_in1_regular', 'down': 'd_in1_down', 'up': 'd_in1_up'}[b0.kind]
-                for name, src, conv, flags in ((k3, d_c1, 'conv_in', 0), (k1, d_sc, 'conv_sc', 1)):
-                    ops = []
-                    for c, b in enumerate(grp):
-                        op = ConvOperands()
-                        op.in_, op.w0, op.out0 = src[c].data_ptr(), self._wptr(getattr(b, conv), True), d_x[c].data_ptr()
-                        ops.append(op)
-                    self.conv(self.geom(name, B, Hout, b0), ops, flags)
+                kd = {'regular': 'd_in_regular', 'down': 'd_in_down', 'up': 'd_in_up'}[b0.kind]
+                ops = []
+                for c, b in enumerate(grp):
+                    op = ConvOperands()
+                    op.in_, op.w0, op.out0 = d_c1[c].data_ptr(), self._wptr(b.conv_in, True), d_x[c].data_ptr()
+                    op.in1, op.w1 = d_sc[c].data_ptr(), self._wptr(b.conv_sc, True)
+                    ops.append(op)
+                self.conv(self.geom(kd, B, Hout, b0), ops, 2)
                 g = d_x
                 if i == 5 and any(sp != 0 for sp in self.spaces):     # the permutation is an involution
                     outs = [g[c] if self.spaces[c] == 0 else torch.empty_like(g[c]) for c in range(3)]

@@ -43,7 +43,7 @@ def run(H, C, pro):
     print('conv  %dx%d %d->%d pro=%d : %7.1f us  %6.1f TFLOP/s' % (H, H, C, C, pro, us, flops / us / 1e6))
     from margipose_amd.engine import Engine
     nt = C // (32 * Engine._wg_blocks(C))
-    nsp = Engine._n_split(B * H * H, 9 * nt * nt)
+    nsp = int(os.environ.get('NSPLIT', '0')) or Engine._n_split(B * H * H, 9 * nt * nt)
     parts = [torch.empty(nsp * 9 * C * C, device='cuda') for _ in range(3)]
     wops = []
     for c in range(3):

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Per-kernel register / scratch usage of one csrc file (hipcc remarks), e.g. tools/kernel_resources.sh conv
 f=${1:-conv}
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -c margipose_amd/csrc/$f.hip -o /tmp/_res_$f.o -Rpass-analysis=kernel-resource-usage 2>&1 \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -c margipose_amd/csrc/$f.hip -o /tmp/_res_$f.o -Rpass-analysis=kernel-resource-usage 2>&1 \
  | python3 -c "
 import sys,re
 cur={}
