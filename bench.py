@@ -49,6 +49,13 @@ def pmc_traffic(label):
     return None
 
 
+def traffic_fields(label):
+    t = pmc_traffic(label)
+    if t is None:
+        return None, None
+    return t.get('hbm_bytes_per_launch'), t
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -226,8 +233,9 @@ def main():
             tf = top[1]['work_per_launch'] / (top[1]['avg_us'] * 1e-6) / 1e12
             all_flops = sum(v['work'] for v in convs.values())
             all_ms = sum(v['total_ms'] for v in convs.values())
+            tr_bytes, tr_detail = traffic_fields(top[0])
             res['roofline'] = {'bound': 'mfma', 'achieved': tf, 'peak': PEAK_BF16X6_TFLOPS, 'unit': 'TFLOP/s',
-                               'frac': tf / PEAK_BF16X6_TFLOPS, 'traffic': pmc_traffic(top[0]), 'kernel': top[0],
+                               'frac': tf / PEAK_BF16X6_TFLOPS, 'traffic': tr_bytes, 'traffic_detail': tr_detail, 'kernel': top[0],
                                'avg_launch_us': top[1]['avg_us'], 'launches': top[1]['n'],
                                'flops_per_launch': top[1]['work_per_launch'],
                                'note': 'achieved = algorithmic fp32 FLOPs / launch duration; the kernel executes 6 bf16 MFMA FLOPs '

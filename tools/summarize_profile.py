@@ -41,5 +41,24 @@ def main(out):
             print('    ' + '  '.join('%s=%.4g' % (c, v / max(cnt[(k, c)], 1)) for c, v in sorted(agg[k].items())))
 
 
+def traffic_table(out):
+    """Per (kernel, grid) averages of FETCH_SIZE / WRITE_SIZE (KB per dispatch, as rocprofv3 reports them)."""
+    import json
+    tab = defaultdict(lambda: defaultdict(list))
+    for sub, ctr in (('pmc_fetch', 'FETCH_SIZE'), ('pmc_write', 'WRITE_SIZE')):
+        for f in glob.glob(os.path.join(out, sub, '**', '*counter_collection.csv'), recursive=True):
+            for r in csv.DictReader(open(f)):
+                if r['Counter_Name'] == ctr:
+                    tab[(short(r['Kernel_Name']), int(r['Grid_Size']))][ctr].append(float(r['Counter_Value']))
+    print('== HBM-side traffic per dispatch by (kernel, grid): KB as reported (FETCH_SIZE of 16-B/lane streams is 1/2 of the bytes: MI355X_MICROARCH.md)')
+    rows = []
+    for (k, gsz), d in tab.items():
+        fe = sum(d['FETCH_SIZE']) / max(1, len(d['FETCH_SIZE'])); wr = sum(d['WRITE_SIZE']) / max(1, len(d['WRITE_SIZE']))
+        rows.append((fe + wr, k, gsz, len(d['FETCH_SIZE']), fe, wr))
+    for tot, k, gsz, n, fe, wr in sorted(rows, reverse=True)[:24]:
+        print('%-80s grid %8d n=%4d  FETCH %10.0f KB  WRITE %10.0f KB' % (k[:80], gsz, n, fe, wr))
+
+
 if __name__ == '__main__':
     main(sys.argv[1])
+    traffic_table(sys.argv[1])
