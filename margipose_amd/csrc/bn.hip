@@ -111,10 +111,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_k(BnReduceArgs a) {
   if (active) {
     float4 ms = make_float4(0.f, 0.f, 0.f, 0.f), mt = ms;
     if (masked) { ms = *reinterpret_cast<const float4*>(op.a_scale + col4 * 4); mt = *reinterpret_cast<const float4*>(op.a_shift + col4 * 4); }
-    for (long p = p_begin + row0; p < p_end; p += rows_per_pass) {
-      const long o = p * c4n + col4;
-      const float4 g = reinterpret_cast<const float4*>(op.g)[o];
-      const float4 x = reinterpret_cast<const float4*>(op.a)[o];
+    auto accumulate = [&](const float4 g, const float4 x, const float4 y) {
       float4 ga = g;
       if (masked) {
         if (!(fmaf(x.x, ms.x, mt.x) > 0.f)) ga.x = 0.f;
@@ -125,10 +122,29 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_k(BnReduceArgs a) {
       sga0.x += ga.x; sga0.y += ga.y; sga0.z += ga.z; sga0.w += ga.w;
       sga1.x = fmaf(ga.x, x.x, sga1.x); sga1.y = fmaf(ga.y, x.y, sga1.y); sga1.z = fmaf(ga.z, x.z, sga1.z); sga1.w = fmaf(ga.w, x.w, sga1.w);
       if (has_b) {
-        const float4 y = reinterpret_cast<const float4*>(op.b)[o];
         sg.x += g.x; sg.y += g.y; sg.z += g.z; sg.w += g.w;
         sgb.x = fmaf(g.x, y.x, sgb.x); sgb.y = fmaf(g.y, y.y, sgb.y); sgb.z = fmaf(g.z, y.z, sgb.z); sgb.w = fmaf(g.w, y.w, sgb.w);
       }
+    };
+    const float4* pg = reinterpret_cast<const float4*>(op.g);
+    const float4* pa = reinterpret_cast<const float4*>(op.a);
+    const float4* pb = reinterpret_cast<const float4*>(has_b ? op.b : op.a);
+    long p = p_begin + row0;
+    // four pixels (12 independent 16-byte loads) in flight per thread: the pass is latency-bound otherwise
+    for (; p + 3 * rows_per_pass < p_end; p += 4 * rows_per_pass) {
+      float4 g[4], x[4], y[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long o = (p + (long)u * rows_per_pass) * c4n + col4;
+        g[u] = pg[o]; x[u] = pa[o];
+        y[u] = has_b ? pb[o] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) accumulate(g[u], x[u], y[u]);
+    }
+    for (; p < p_end; p += rows_per_pass) {
+      const long o = p * c4n + col4;
+      accumulate(pg[o], pa[o], has_b ? pb[o] : make_float4(0.f, 0.f, 0.f, 0.f));
     }
     float* d = sred + ((long)row0 * a.C + col4 * 4) * 4;
     d[0] = sga0.x; d[1] = sga1.x; d[2] = sg.x; d[3] = sgb.x;

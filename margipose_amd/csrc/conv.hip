@@ -919,7 +919,13 @@ __global__ __launch_bounds__(256) void unpack_wgrads_k(const mpose_unpack_job* _
     const int t = (int)(r / j.K);
     const long src = (((long)t * (j.Kpad / 4) + (k >> 2)) * j.Npad + n) * 4 + (k & 3);
     float s = 0.f;
-    for (int sp = 0; sp < j.n_split; ++sp) s += j.src[src + sp * split_stride];
+    int sp = 0;
+    for (; sp + 4 <= j.n_split; sp += 4) {          // four partials in flight; summed in order (deterministic)
+      const float v0 = j.src[src + (sp + 0) * split_stride], v1 = j.src[src + (sp + 1) * split_stride];
+      const float v2 = j.src[src + (sp + 2) * split_stride], v3 = j.src[src + (sp + 3) * split_stride];
+      s = (((s + v0) + v1) + v2) + v3;
+    }
+    for (; sp < j.n_split; ++sp) s += j.src[src + sp * split_stride];
     float* d = j.dst + n * j.sn + k * j.sk + t * j.st;
     *d = j.accumulate ? (*d + s) : s;
   }
