@@ -20,6 +20,7 @@ import os
 
 import numpy as np
 import torch
+import torch.distributed
 
 from . import _lib
 from ._lib import (BnAddOperands, BnBwdApplyOperands, BnBwdReduceOperands, ConvGeom, ConvOperands, WgradOperands, c_int,
@@ -284,11 +285,31 @@ class Engine:
         self.bnf = torch.zeros(foff, dtype=torch.float32, device=device)
         self.stat_arena = torch.zeros(soff, dtype=torch.float64, device=device)
         # grad layout: offsets of every parameter in the flat gradient buffer
-        goff = 0
-        self._grad_offsets = []
-        for p in self.param_list():
-            self._grad_offsets.append(goff)
+        # Buckets: the parameters of stage T-1 first (their gradients are complete first in the backward
+        # pass), ..., stage 0, then the stem: each bucket is one contiguous slice = one all-reduce that overlaps the
+        # rest of the backward pass.  `_grad_offsets` stays aligned with param_list().
+        order, self._buckets = [], []
+        for t in reversed(range(self.T)):
+            start = len(order)
+            for grp in self.stage_blocks[t]:
+                for b in grp:
+                    order += [b.conv_in.param, b.conv2.param, b.conv_sc.param]
+                    for n in (b.bn1, b.bn2, b.bns):
+                        order += [n.m.weight, n.m.bias]
+            if t > 0:
+                order.append(self.combiners[t - 1])
+            self._buckets.append((start, len(order)))
+        seen = set(id(p) for p in order)
+        start = len(order)
+        order += [p for p in self.param_list() if id(p) not in seen]          # stem (+ anything not stage-owned)
+        self._buckets.append((start, len(order)))
+        goff, off_of, bounds = 0, {}, []
+        for i, p in enumerate(order):
+            off_of[id(p)] = goff
             goff += _rup(p.numel(), 4)
+            bounds.append(goff)
+        self._buckets = [((bounds[a - 1] if a > 0 else 0), (bounds[b - 1] if b > 0 else 0)) for a, b in self._buckets]
+        self._grad_offsets = [off_of[id(p)] for p in self.param_list()]
         self._grad_total = goff
         self.gflat = torch.zeros(goff, dtype=torch.float32, device=device)
         # num_batches_tracked of every BN becomes a view of one int64 vector: one increment per step
@@ -686,6 +707,7 @@ class Engine:
         def run_coef(first, n):
             check(L.mpose_bn_bwd_coef(c_void_p(coef_base + first * COEF_DT.itemsize), n, st()), 'mpose_bn_bwd_coef')
 
+        works = []          # in-flight gradient all-reduces (data parallel), one per finished bucket
         D = None            # gradient w.r.t. the stage input, cumulative over later stages (:195 is `inp = inp + ...`)
         g_comb = None
         for t in reversed(range(self.T)):
@@ -807,6 +829,7 @@ class Engine:
                                               0, st()), 'mpose_reduce_partials')
             else:
                 g_comb = None
+            self._finish_bucket(tb, self.T - 1 - t, t * 90, 90, works)
 
         dx = None
         if D is not None:
@@ -835,11 +858,25 @@ class Engine:
                     self.conv(self.geom('d_stem', B, F), [op])
                     dx = torch.empty(ctx['x_shape'], **f32)
                     check(L.mpose_depth_to_space8(ptr(d_s2d), ptr(dx), B, ctx['x_shape'][2], st()), 'mpose_depth_to_space8')
-            # ---- ONE launch turns every packed partial sum into torch-layout gradients ----
-            if self.overlap_wgrad and self.side_stream is not None:
-                torch.cuda.current_stream().wait_stream(self.side_stream)
-            check(L.mpose_unpack_wgrads(ptr(tb['unpack']), tb['n_unpack'], tb['unpack_max'], st()), 'mpose_unpack_wgrads')
+            # ---- the stem's packed partial sums -> torch-layout gradients; last bucket ----
+            self._finish_bucket(tb, self.T, self.T * 90, tb['n_unpack'] - self.T * 90, works)
+        for w in works:
+            w.wait()                   # (stream-ordered for RCCL: the current stream waits for the collective)
         return self.gflat, dx
+
+    def _finish_bucket(self, tb, bucket, first_job, n_jobs, works):
+        """Stage `bucket`'s weight-gradient partials -> flat gradient slice (one unpack launch over its job range), then,
+        under data parallelism, one asynchronous all-reduce of that slice that overlaps the rest of the backward."""
+        if self.overlap_wgrad and self.side_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.side_stream)
+        if n_jobs > 0:
+            check(lib().mpose_unpack_wgrads(c_void_p(tb['unpack'].data_ptr() + first_job * UNPACK_DT.itemsize), n_jobs,
+                                            tb['unpack_max'], stream_ptr()), 'mpose_unpack_wgrads')
+        if self.dp is not None:
+            lo, hi = self._buckets[bucket]
+            if hi > lo:
+                works.append(torch.distributed.all_reduce(self.gflat[lo:hi], op=torch.distributed.ReduceOp.SUM,
+                                                          group=self.dp[0], async_op=True))
 
     @staticmethod
     def _n_split(slots, tiles=27, groups=3):

@@ -124,9 +124,8 @@ class _BackboneFn(torch.autograd.Function):
         gflat, dx = engine.backward(ctx.ectx, hms, g_hms, ctx.needs_input_grad[2])
         ctx.ectx = None
         flat = gflat.clone()
-        if engine.dp is not None:
-            from .. import parallel
-            parallel.allreduce_mean_(flat, *engine.dp)      # ONE RCCL all-reduce of all gradients per step
+        if engine.dp is not None:       # the per-stage buckets were summed over replicas during the backward pass
+            flat.div_(engine.dp[1])
         out = engine.grads_from_flat(flat)
         return (None, None, dx) + tuple(out)
 

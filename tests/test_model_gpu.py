@@ -328,3 +328,22 @@ def test_data_parallel_two_ranks_share_one_gpu():
                           '127.0.0.1', '--master-port', str(29600 + os.getpid() % 300), os.path.join(root, 'tools', 'dp_check.py')],
                          env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600).stdout.decode(errors='replace')
     assert 'DP_CHECK_OK' in out, out[-2000:]
+
+
+def test_unused_stage_gets_zero_grads():
+    """A loss on the first stage's heatmaps only: the later stage's parameters receive exactly zero (not the stale
+    split-K partial sums of an earlier step), the first stage's gradients match a one-stage run."""
+    from margipose_amd.models import CanonicalSkeletonDesc, MargiPoseModel
+    torch.manual_seed(7)
+    m = MargiPoseModel(CanonicalSkeletonDesc, 2, True, 'patch8', 'jsd').cuda().train()
+    x = torch.randn(2, 3, 256, 256, device='cuda')
+    tgt = torch.rand(2, 17, 3, device='cuda') * 2 - 1
+    out = m(x)                                   # step 1 fills every partial buffer
+    m.forward_3d_losses(out, tgt).mean().backward()
+    m.zero_grad(set_to_none=True)
+    out = m(x)
+    (m.xy_heatmaps[0] * torch.linspace(0, 1, 32, device='cuda')).sum().backward()
+    for k, p in m.named_parameters():
+        if '_hm_cnns.1.' in k:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+    assert float(m.inner.xy_hm_cnns[0].down_layers[0].module[0].weight.grad.abs().max()) > 0
