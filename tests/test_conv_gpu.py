@@ -132,3 +132,64 @@ def test_split_planes_are_exact():
     rebuilt = total.permute(0, 2, 1, 3, 4).reshape(npad, kpad)[:cout, :cin]                  # [n][k]
     ref = w.view(cout, cin).double()
     assert float(((rebuilt - ref).abs() / ref.abs()).max()) <= 2.0 ** -24
+
+
+@pytest.mark.parametrize('B,H,C', [(2, 32, 128), (8, 16, 192), (2, 8, 32), (1, 12, 64)])
+def test_conv_prologue_and_bn_statistics(B, H, C):
+    """conv2 of a ResidualBlock: BN+ReLU of the producer applied while staging (in_scale/in_shift), and the
+    per-channel (sum, sum of squares) of the output accumulated by the epilogue (fp64 atomics) for the next BatchNorm."""
+    from margipose_amd import _lib, engine as eng
+    from margipose_amd._lib import ConvOperands
+    L = _lib.lib()
+    rng = np.random.default_rng(100 + H)
+    x = torch.from_numpy(rng.standard_normal((B, C, H, H))).float()
+    w = torch.from_numpy(rng.standard_normal((C, C, 3, 3)) * (2.0 / (9 * C)) ** 0.5).float()
+    sc = torch.from_numpy(rng.uniform(0.5, 1.5, C)).float()
+    sh = torch.from_numpy(rng.standard_normal(C) * 0.3).float()
+    xg = x.permute(0, 2, 3, 1).contiguous().cuda()
+    packed, npad, _ = _pack(L, _lib, eng, w.cuda(), C, C, 9)
+    t9 = [(ky - 1, kx - 1, ky * 3 + kx, 0) for ky, kx in eng.TAPS3]
+    g = eng._geom(B, H, C, H, C, 0, H, 1, 1, [(0, 0, t9)], npad)
+    out = torch.full((B, H, H, C), float('nan'), device='cuda')
+    stats = torch.zeros(C, 2, dtype=torch.float64, device='cuda')
+    scg, shg = sc.cuda(), sh.cuda()
+    op = ConvOperands()
+    op.in_, op.w0, op.out0 = xg.data_ptr(), packed.data_ptr(), out.data_ptr()
+    op.in_scale, op.in_shift, op.stats0 = scg.data_ptr(), shg.data_ptr(), stats.data_ptr()
+    _lib.check(L.mpose_conv_fwd(ctypes.byref(g), (ConvOperands * 1)(op), 1, 0, _lib.stream_ptr()), 'conv')
+    torch.cuda.synchronize()
+    a = torch.relu(x.double() * sc.double().view(1, C, 1, 1) + sh.double().view(1, C, 1, 1))
+    ref = torch.nn.functional.conv2d(a, w.double(), padding=1)
+    got = out.cpu().double().permute(0, 3, 1, 2)
+    assert float((got - ref).abs().max() / ref.abs().max()) < 1e-5          # fp32 prologue + fp32-equivalent conv
+    s_ref = torch.stack([ref.sum((0, 2, 3)), (ref * ref).sum((0, 2, 3))], 1)
+    err = (stats.cpu() - s_ref).abs() / (s_ref.abs() + ref.abs().max() * (B * H * H) ** 0.5)
+    assert float(err.max()) < 1e-4, float(err.max())
+
+
+@pytest.mark.parametrize('B,H,cin,cout', [(2, 32, 128, 128), (8, 16, 192, 192), (1, 12, 64, 96), (4, 32, 32, 128)])
+def test_conv_sum_of_two_inputs(B, H, cin, cout):
+    """MPOSE_CONV_SUM_INPUTS: out = conv3x3(in, w0) + conv1x1(in1, w1) in one launch (the data-gradient of a block input)."""
+    from margipose_amd import _lib, engine as eng
+    from margipose_amd._lib import ConvOperands
+    L = _lib.lib()
+    rng = np.random.default_rng(B + H + cin)
+    x0 = torch.from_numpy(rng.standard_normal((B, cin, H, H))).float()
+    x1 = torch.from_numpy(rng.standard_normal((B, cin, H, H))).float()
+    w0 = torch.from_numpy(rng.standard_normal((cout, cin, 3, 3)) * (2.0 / (9 * cin)) ** 0.5).float()
+    w1 = torch.from_numpy(rng.standard_normal((cout, cin, 1, 1)) * (2.0 / cin) ** 0.5).float()
+    p0, npad, _ = _pack(L, _lib, eng, w0.cuda(), cout, cin, 9)
+    p1, _, _ = _pack(L, _lib, eng, w1.cuda(), cout, cin, 1)
+    t9 = [(ky - 1, kx - 1, ky * 3 + kx, 0) for ky, kx in eng.TAPS3]
+    g = eng._geom(B, H, cin, H, cout, cout, H, 1, 1, [(0, 0, t9 + [(0, 0, 0, 1)])], npad, npad)
+    x0g, x1g = (t.permute(0, 2, 3, 1).contiguous().cuda() for t in (x0, x1))
+    out = torch.full((B, H, H, cout), float('nan'), device='cuda')
+    op = ConvOperands()
+    op.in_, op.in1, op.w0, op.w1, op.out0 = x0g.data_ptr(), x1g.data_ptr(), p0.data_ptr(), p1.data_ptr(), out.data_ptr()
+    _lib.check(L.mpose_conv_fwd(ctypes.byref(g), (ConvOperands * 1)(op), 1, 2, _lib.stream_ptr()), 'conv')
+    torch.cuda.synchronize()
+    fn = lambda a0, a1, v0, v1: torch.nn.functional.conv2d(a0, v0, padding=1) + torch.nn.functional.conv2d(a1, v1)
+    ref = fn(x0.double(), x1.double(), w0.double(), w1.double())
+    f32 = fn(x0, x1, w0, w1).double()
+    got = out.cpu().double().permute(0, 3, 1, 2)
+    _check(float((got - ref).abs().max() / ref.abs().max()), float((f32 - ref).abs().max() / ref.abs().max()))
