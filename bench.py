@@ -167,7 +167,7 @@ def main():
     parallel.broadcast_parameters(model)
     parallel.attach(model)
     model.inner.engine().overlap_wgrad = args.overlap_wgrad
-    opt = torch.optim.SGD(model.parameters(), lr=0.01, momentum=0.9)
+    opt = torch.optim.SGD(model.parameters(), lr=0.01, momentum=0.9, fused=True)   # same arithmetic as bin/train_3d.py:339, one launch
     g = torch.Generator(device='cpu').manual_seed(12345 + rank)
     B = args.batch
     x = torch.randn(B, 3, args.size, args.size, generator=g).to(device)
