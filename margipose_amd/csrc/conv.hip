@@ -374,36 +374,80 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
     }
 
     if (SUM2 && set == 0) continue;          // the second input accumulates on top; one exchange + epilogue after it
-    // ---- split-K exchange: waves with kh > 0 hand their partial tiles to wave kh == 0 through LDS ----
+    // ---- split-K exchange.  The KS waves of a group hold partial sums of the same 64 x 32*RN tile.  Each of them OWNS
+    //      a share of its 2*RN accumulator blocks (KS = 2: the row block rm == kh; KS = 4: row block kh & 1, column
+    //      blocks of half kh >> 1), parks the blocks it does not own in LDS, adds the other waves' parts of the blocks
+    //      it owns (in increasing kh order: deterministic) and then runs the epilogue for those only -- the exchange
+    //      and the epilogue are shared by the group instead of being one wave's job while the others idle. ----
+    auto owns = [&](int rm, int rn) {
+      if (KS == 1) return true;
+      if (KS == 2) return rm == kh;
+      return rm == (kh & 1) && ((rn * 2) / RN) == (kh >> 1);
+    };
     if (KS > 1) {
-      constexpr int EX = 2 * RN * 16 * 64;               // floats per handed-over tile set
+      constexpr int BLK = 16 * 64;                       // floats of one accumulator block
+      constexpr int STRIDE = (KS == 2 ? RN : 2 * RN - RN / 2) * BLK;    // most blocks a wave can have to park
+      static_assert(4 * STRIDE * 4 <= 4 * 2 * A_TILE_B, "exchange area must fit in the A-tile region");
       __syncthreads();                                   // every wave is done with its A tiles
-      float* ex_all = reinterpret_cast<float*>(sA_all);
-      if (kh) {
-        float* ex = ex_all + (size_t)((wave / KS) * (KS - 1) + (kh - 1)) * EX;
+      float* ex_all = reinterpret_cast<float*>(sA_all);  // [wave][parked blocks, in (rm, rn) order][16][64]
+      auto owned_by = [&](int k, int rm, int rn) {       // ownership rule for the wave with K part k
+        return KS == 2 ? rm == k : (rm == (k & 1) && ((rn * 2) / RN) == (k >> 1));
+      };
+      if constexpr (KS == 2) {                           // parked: the other row block, slot = column block
+        float* mine = ex_all + (size_t)wave * STRIDE;
+        const float* theirs = ex_all + (size_t)(wave ^ 1) * STRIDE;
 #pragma unroll
         for (int rm = 0; rm < 2; ++rm)
+          if (rm != kh) {
 #pragma unroll
-          for (int rn = 0; rn < RN; ++rn)
+            for (int rn = 0; rn < RN; ++rn)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) ex[((rm * RN + rn) * 16 + r) * 64 + lane] = acc0[rm][rn][r];
-      }
-      __syncthreads();
-      if (!kh) {
+              for (int r = 0; r < 16; ++r) mine[(rn * 16 + r) * 64 + lane] = acc0[rm][rn][r];
+          }
+        __syncthreads();
 #pragma unroll
-        for (int p = 0; p < KS - 1; ++p) {
-          const float* ex = ex_all + (size_t)((wave / KS) * (KS - 1) + p) * EX;
+        for (int rm = 0; rm < 2; ++rm)
+          if (rm == kh) {
+#pragma unroll
+            for (int rn = 0; rn < RN; ++rn)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) acc0[rm][rn][r] += theirs[(rn * 16 + r) * 64 + lane];
+          }
+      } else {
+        {
+          float* mine = ex_all + (size_t)wave * STRIDE;
+          int slot = 0;
 #pragma unroll
           for (int rm = 0; rm < 2; ++rm)
 #pragma unroll
             for (int rn = 0; rn < RN; ++rn)
+              if (!owned_by(kh, rm, rn)) {
 #pragma unroll
-              for (int r = 0; r < 16; ++r) acc0[rm][rn][r] += ex[((rm * RN + rn) * 16 + r) * 64 + lane];
+                for (int r = 0; r < 16; ++r) mine[(slot * 16 + r) * 64 + lane] = acc0[rm][rn][r];
+                ++slot;
+              }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < KS; ++p) {
+          if (p == kh) continue;
+          const float* theirs = ex_all + (size_t)(wave - kh + p) * STRIDE;
+          int slot = 0;                                  // position among the blocks wave p parked
+#pragma unroll
+          for (int rm = 0; rm < 2; ++rm)
+#pragma unroll
+            for (int rn = 0; rn < RN; ++rn)
+              if (!owned_by(p, rm, rn)) {
+                if (owned_by(kh, rm, rn)) {
+#pragma unroll
+                  for (int r = 0; r < 16; ++r) acc0[rm][rn][r] += theirs[(slot * 16 + r) * 64 + lane];
+                }
+                ++slot;
+              }
         }
       }
       if (ACC1) __syncthreads();                         // the exchange area is the next pass's A tiles
     }
-    const bool writer = (KS == 1) || !kh;
 
     // ---- epilogue (branch-free: buffer stores/loads, rows beyond M get an out-of-range offset and are dropped) ----
     const int oset = SUM2 ? 0 : set;             // which output this epilogue writes
@@ -432,7 +476,7 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
       const unsigned gy = fdiv(rem, a.div_gw);
       const unsigned gx = rem - gy * (unsigned)g.GW;
       const unsigned pix = (b * (unsigned)g.OH + (gy * g.out_mul + oyc)) * (unsigned)g.OW + (gx * g.out_mul + oxc);
-      const bool ok = (int)m < a.M && writer;
+      const bool ok = (int)m < a.M;
       sRow[wave * 64 + lane] = ok ? pix * (unsigned)out_ld * 4u : 0xFFFFF000u;
       __builtin_amdgcn_wave_barrier();
     }
@@ -448,7 +492,7 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
 #pragma unroll
       for (int rn = 0; rn < RN; ++rn) {
         const int nb = n0 + rn * 32;                 // wave-uniform: the whole 32-column group is in or out (cout % 32 == 0)
-        if (nb < cout) {
+        if (nb < cout && owns(rm, rn)) {
           const int n = nb + li;
           float v[16];
 #pragma unroll
@@ -474,16 +518,12 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[r]), rs_o, (int)(voff[r] + (unsigned)(rn * 128)), 0, 0);
-            // rows beyond M accumulated zeros (their inputs were read as 0); non-writing waves are excluded below
+            // rows beyond M accumulated zeros (their inputs were read as 0); blocks of other owners are skipped above
             csum[rn] += v[r];
             if (!masked) csq[rn] = fmaf(v[r], v[r], csq[rn]);
           }
         }
       }
-    }
-    if (!writer) {
-#pragma unroll
-      for (int rn = 0; rn < RN; ++rn) csum[rn] = csq[rn] = 0.f;
     }
     if (stats != nullptr) {
 #pragma unroll
