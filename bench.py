@@ -192,6 +192,8 @@ def main():
     # Per-kernel HIP events (for the roofline block) bracket every conv / tail launch of EVERY FOURTH timed step:
     # an event is a barrier packet between two kernels, and ~800 of them per step cost ~5 % of the step.
     timer = KernelTimer() if (rank == 0 and not args.no_kernel_timing) else None
+    if timer is not None:
+        timer.calibrate()
     timed_steps = 0
     barrier()
     t0 = time.perf_counter()
@@ -240,6 +242,7 @@ def main():
             res['roofline'] = {'bound': 'mfma', 'achieved': tf, 'peak': PEAK_BF16X6_TFLOPS, 'unit': 'TFLOP/s',
                                'frac': tf / PEAK_BF16X6_TFLOPS, 'traffic': tr_bytes, 'traffic_detail': tr_detail, 'kernel': top[0],
                                'avg_launch_us': top[1]['avg_us'], 'launches': top[1]['n'],
+                               'event_bracket_overhead_us_subtracted': 1e3 * timer.bracket_ms,
                                'flops_per_launch': top[1]['work_per_launch'],
                                'note': 'achieved = algorithmic fp32 FLOPs / launch duration; the kernel executes 6 bf16 MFMA FLOPs '
                                        'per algorithmic FLOP (3-way split operands), so peak = dense bf16 MFMA peak 2500 / 6; '
