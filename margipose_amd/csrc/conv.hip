@@ -949,25 +949,32 @@ __global__ __launch_bounds__(256) void pack_weights_k(const mpose_pack_job* __re
 
 __global__ __launch_bounds__(256) void unpack_wgrads_k(const mpose_unpack_job* __restrict__ jobs) {
   const mpose_unpack_job j = jobs[blockIdx.y];
-  const long total = (long)j.T * j.K * j.N;
   const long split_stride = (long)j.T * j.Kpad * j.Npad;
+  const int k4n = (j.K + 3) >> 2;
+  const long total = (long)k4n * j.N * 4;
+  // One thread per (k, n), the 4 channels of a packed float4 on adjacent threads: reads of the packed layout are
+  // contiguous across the wave, and a thread writes its T taps (contiguous in the torch layout when st == 1).
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
-    // enumerate (t, k, n) with n fastest so that reads of the packed layout are contiguous in n
-    const int n = (int)(e % j.N);
-    long r = e / j.N;
-    const int k = (int)(r % j.K);
-    const int t = (int)(r / j.K);
-    const long src = (((long)t * (j.Kpad / 4) + (k >> 2)) * j.Npad + n) * 4 + (k & 3);
-    float s = 0.f;
-    int sp = 0;
-    for (; sp + 4 <= j.n_split; sp += 4) {          // four partials in flight; summed in order (deterministic)
-      const float v0 = j.src[src + (sp + 0) * split_stride], v1 = j.src[src + (sp + 1) * split_stride];
-      const float v2 = j.src[src + (sp + 2) * split_stride], v3 = j.src[src + (sp + 3) * split_stride];
-      s = (((s + v0) + v1) + v2) + v3;
+    const int k_lo = (int)(e & 3);
+    const long r = e >> 2;
+    const int n = (int)(r % j.N);
+    const int k4 = (int)(r / j.N);
+    const int k = k4 * 4 + k_lo;
+    if (k >= j.K) continue;
+    float* d = j.dst + n * j.sn + k * j.sk;
+    for (int t = 0; t < j.T; ++t) {
+      const long src = (((long)t * (j.Kpad / 4) + k4) * j.Npad + n) * 4 + k_lo;
+      float s = 0.f;
+      int sp = 0;
+      for (; sp + 4 <= j.n_split; sp += 4) {        // four partials in flight; summed in order (deterministic)
+        const float v0 = j.src[src + (sp + 0) * split_stride], v1 = j.src[src + (sp + 1) * split_stride];
+        const float v2 = j.src[src + (sp + 2) * split_stride], v3 = j.src[src + (sp + 3) * split_stride];
+        s = (((s + v0) + v1) + v2) + v3;
+      }
+      for (; sp < j.n_split; ++sp) s += j.src[src + sp * split_stride];
+      float* dt = d + t * j.st;
+      *dt = j.accumulate ? (*dt + s) : s;
     }
-    for (; sp < j.n_split; ++sp) s += j.src[src + sp * split_stride];
-    float* d = j.dst + n * j.sn + k * j.sk + t * j.st;
-    *d = j.accumulate ? (*d + s) : s;
   }
 }
 
@@ -1114,7 +1121,7 @@ extern "C" int mpose_pack_weights(const mpose_pack_job* jobs_dev, int n_jobs, in
 
 extern "C" int mpose_unpack_wgrads(const mpose_unpack_job* jobs_dev, int n_jobs, int max_elems_per_job, void* stream) {
   if (n_jobs <= 0) return 0;
-  int bx = (max_elems_per_job + 256 * 8 - 1) / (256 * 8);
+  int bx = (max_elems_per_job / 9 + 256 * 2 - 1) / (256 * 2);      // ~ (k, n) pairs of the largest job / 512
   if (bx < 1) bx = 1;
   if (bx > 256) bx = 256;
   unpack_wgrads_k<<<dim3(bx, n_jobs), 256, 0, (hipStream_t)stream>>>(jobs_dev);
