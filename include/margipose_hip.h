@@ -290,6 +290,11 @@ int mpose_pool3_bwd(const float* in, const float* scale, const float* shift, con
 /* NCHW (B, C, H, W) -> NHWC (B, H, W, Cpad) zero padded, and the reverse gather for the input gradient. */
 int mpose_image_to_nhwc(const float* x, float* out, int B, int C, int H, int W, int Cpad, void* stream);
 int mpose_nhwc_to_image(const float* g, float* dx, int B, int C, int H, int W, int Cpad, void* stream);
+/* uint8 RGB frames (B,3,H,W) -> (x/255 - mean[c]) / std[c] in fp32 (`ImageSpecs.convert`, data_specs.py:6-13,38-39; mean3 /
+ * std3 are HOST arrays of 3 floats): NHWC zero-padded to Cpad channels (Cpad % 4 == 0, the InceptionV4 stem's first load),
+ * or NCHW when Cpad == 0. */
+int mpose_frames_u8(const unsigned char* frames, const float* mean3, const float* std3, float* out, int B, int H, int W,
+                    int Cpad, void* stream);
 
 /* Layout / glue kernels. */
 /* NCHW image (B,3,S,S) -> NHWC space-to-depth (B, S/8, S/8, 192) for the patch8 stem, and back. */

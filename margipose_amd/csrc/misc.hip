@@ -332,6 +332,25 @@ __global__ __launch_bounds__(256) void image_to_nhwc_k(const float* __restrict__
     }
   }
 }
+// uint8 RGB frames (B, 3, H, W) -> normalised fp32: (x/255 - mean[c]) / std[c]  (reference data_specs.py:6-13,38-39:
+// `ImageSpecs.convert` = torchvision `to_tensor` + `normalize_pixels`), written either NHWC zero-padded to Cpad channels
+// (the InceptionV4 stem's first load) or NCHW (Cpad == 0; input of the patch8 stem's space-to-depth).
+__global__ __launch_bounds__(256) void frames_u8_k(const unsigned char* __restrict__ x, float* __restrict__ out, int B, long HW, int Cpad,
+                                                  float s0, float s1, float s2, float t0, float t1, float t2) {
+  const long npix = (long)B * HW;
+  for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < npix; p += (long)gridDim.x * 256) {
+    const long b = p / HW, px = p - b * HW;
+    const float r = fmaf((float)x[(b * 3 + 0) * HW + px], s0, t0);
+    const float g = fmaf((float)x[(b * 3 + 1) * HW + px], s1, t1);
+    const float bl = fmaf((float)x[(b * 3 + 2) * HW + px], s2, t2);
+    if (Cpad == 0) {
+      out[(b * 3 + 0) * HW + px] = r; out[(b * 3 + 1) * HW + px] = g; out[(b * 3 + 2) * HW + px] = bl;
+    } else {
+      *reinterpret_cast<float4*>(out + p * Cpad) = make_float4(r, g, bl, 0.f);
+      for (int c = 4; c < Cpad; c += 4) *reinterpret_cast<float4*>(out + p * Cpad + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+}
 __global__ __launch_bounds__(256) void nhwc_to_image_k(const float* __restrict__ g, float* __restrict__ dx, int B, int C, long HW, int Cpad) {
   const long npix = (long)B * HW;
   for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < npix; p += (long)gridDim.x * 256) {
@@ -463,6 +482,21 @@ extern "C" int mpose_image_to_nhwc(const float* x, float* out, int B, int C, int
   if (C < 1 || C > Cpad || (Cpad & 3)) return MPOSE_EINVAL;
   if ((long)B * H * W == 0) return 0;
   image_to_nhwc_k<<<grid_for((long)B * H * W, 256), 256, 0, (hipStream_t)stream>>>(x, out, B, C, (long)H * W, Cpad);
+  return launch_status();
+}
+
+extern "C" int mpose_frames_u8(const unsigned char* frames, const float* mean3, const float* std3, float* out, int B, int H, int W,
+                               int Cpad, void* stream) {
+  if (!frames || !out || !mean3 || !std3 || (Cpad & 3) || Cpad < 0) return MPOSE_EINVAL;
+  if ((long)B * H * W == 0) return 0;
+  float sc[3], sh[3];
+  for (int c = 0; c < 3; ++c) {
+    if (!(std3[c] > 0.f)) return MPOSE_EINVAL;
+    sc[c] = 1.0f / (255.0f * std3[c]);
+    sh[c] = -mean3[c] / std3[c];
+  }
+  frames_u8_k<<<grid_for((long)B * H * W, 256), 256, 0, (hipStream_t)stream>>>(frames, out, B, (long)H * W, Cpad, sc[0], sc[1], sc[2],
+                                                                                 sh[0], sh[1], sh[2]);
   return launch_status();
 }
 

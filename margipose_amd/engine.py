@@ -259,6 +259,7 @@ class Engine:
         self.side_stream = None      # weight-gradient GEMMs run here, off the data-gradient critical path
         self.overlap_wgrad = False   # opt-in (+2.6 % step rate, but per-kernel timings then include GPU sharing)
         self.dp = None               # optional (process_group, world_size): gradient all-reduce after backward
+        self.input_norm = ([0.485, 0.456, 0.406], [0.229, 0.224, 0.225])    # uint8 frames: ImageSpecs mean / stddev
 
     # ------------------------------------------------------------------ parameters / arenas
     def param_list(self):
@@ -575,7 +576,10 @@ class Engine:
     def forward(self, x, train, save):
         """x: (B, 3, S, S) NCHW device tensor.  Returns (heatmap lists [3][T], xyz of last stage, ctx)."""
         L = lib()
-        x = _lib.dev_f32(x.contiguous(), 'input')
+        if isinstance(x, torch.Tensor) and x.dtype == torch.uint8 and x.is_cuda:
+            x = x.contiguous()         # raw RGB frames: normalised on the fly by the stem's first load (mpose_frames_u8)
+        else:
+            x = _lib.dev_f32(x.contiguous(), 'input')
         B, C3, S, S2 = x.shape
         if C3 != 3 or S != S2 or S % 16 != 0:
             raise _lib.MposeError('expected a (B, 3, S, S) input with S %% 16 == 0, got %s' % (tuple(x.shape),))
@@ -603,6 +607,11 @@ class Engine:
             inp, ctx['stem_ctx'] = self.stem.forward(x, train, save)
         else:
             # ---- patch8 stem: space-to-depth + 1x1 conv (192->128) + BN + ReLU ----
+            if x.dtype == torch.uint8:
+                xf = torch.empty(B, 3, S, S, **f32)
+                check(L.mpose_frames_u8(c_void_p(x.data_ptr()), (ctypes.c_float * 3)(*self.input_norm[0]), (ctypes.c_float * 3)(*self.input_norm[1]),
+                                        ptr(xf), B, S, S, 0, st()), 'mpose_frames_u8')
+                x = xf
             s2d = torch.empty(B, F, F, 192, **f32)
             check(L.mpose_space_to_depth8(ptr(x), ptr(s2d), B, S, st()), 'mpose_space_to_depth8')
             stem_raw = torch.empty(B, F, F, 128, **f32)

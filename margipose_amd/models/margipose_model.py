@@ -154,6 +154,8 @@ class MargiPoseModelInner(nn.Module):
     def engine(self):
         if self._engine is None:
             object.__setattr__(self, '_engine', Engine(self))
+            if getattr(self, '_input_norm', None) is not None:
+                self._engine.input_norm = self._input_norm
         return self._engine
 
     def _apply(self, fn, *args, **kwargs):
@@ -181,6 +183,9 @@ class MargiPoseModel(nn.Module):
                                     JointsSpecs(skel_desc, n_dims=3))
         self.pixelwise_loss = pixelwise_loss
         self.inner = MargiPoseModelInner(skel_desc.n_joints, n_stages, axis_permutation, feature_extractor)
+        # uint8 (B,3,H,W) frames are accepted too: `ImageSpecs.convert` (to_tensor + normalisation) then happens on
+        # the device, fused into the stem's first load
+        object.__setattr__(self.inner, '_input_norm', (list(IMAGENET_MEAN), list(IMAGENET_STDDEV)))
         self.xy_heatmaps = self.zy_heatmaps = self.xz_heatmaps = None
 
     def _pixelwise_flag(self):

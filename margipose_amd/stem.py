@@ -271,7 +271,12 @@ class InceptionV4Stem:
         raw = {}
         img = self.nodes[0]
         raw[img.name] = torch.empty(B, S, S, self.IMG_C, **f32)
-        check(L.mpose_image_to_nhwc(ptr(x), ptr(raw[img.name]), B, 3, S, S, self.IMG_C, st()), 'mpose_image_to_nhwc')
+        if x.dtype == torch.uint8:     # raw RGB frames: to_tensor + normalisation fused into the first load
+            mean, std = eng.input_norm
+            check(L.mpose_frames_u8(ctypes.c_void_p(x.data_ptr()), (ctypes.c_float * 3)(*mean), (ctypes.c_float * 3)(*std), ptr(raw[img.name]),
+                                    B, S, S, self.IMG_C, st()), 'mpose_frames_u8')
+        else:
+            check(L.mpose_image_to_nhwc(ptr(x), ptr(raw[img.name]), B, 3, S, S, self.IMG_C, st()), 'mpose_image_to_nhwc')
         done = set()
         for op in self.ops:
             n = op.dst

@@ -347,3 +347,31 @@ def test_unused_stage_gets_zero_grads():
         if '_hm_cnns.1.' in k:
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
     assert float(m.inner.xy_hm_cnns[0].down_layers[0].module[0].weight.grad.abs().max()) > 0
+
+
+@pytest.mark.parametrize('stem', ['patch8', 'inceptionv4'])
+def test_uint8_frames_are_normalised_on_device(stem):
+    """uint8 RGB frames in -> same result as `ImageSpecs.convert` (to_tensor + (x - mean) / std, reference
+    data_specs.py:6-13,38-39) done on the host and fed as float32 (normalisation fused into the first load)."""
+    from margipose_amd import dsntnn
+    from margipose_amd.models import CanonicalSkeletonDesc, MargiPoseModel
+    torch.manual_seed(11)
+    m = MargiPoseModel(CanonicalSkeletonDesc, 1, True, stem, 'jsd').cuda().train()
+    frames = torch.randint(0, 256, (2, 3, 256, 256), dtype=torch.uint8)
+    mean = torch.tensor(m.data_specs.input_specs.mean).view(1, 3, 1, 1)
+    std = torch.tensor(m.data_specs.input_specs.stddev).view(1, 3, 1, 1)
+    x = ((frames.float() / 255.0 - mean) / std).cuda()
+    tgt = torch.rand(2, 17, 3, device='cuda') * 2 - 1
+    state = {k: v.clone() for k, v in m.state_dict().items()}
+    out_f = m(x)
+    loss_f = dsntnn.average_loss(m.forward_3d_losses(out_f, tgt), torch.ones(2, 17, device='cuda'))
+    loss_f.backward()
+    g_f = m.inner.xy_hm_cnns[0].down_layers[0].module[0].weight.grad.clone()
+    m.load_state_dict(state)                     # same BN running statistics for the second pass
+    m.zero_grad(set_to_none=True)
+    out_u = m(frames.cuda())
+    loss_u = dsntnn.average_loss(m.forward_3d_losses(out_u, tgt), torch.ones(2, 17, device='cuda'))
+    loss_u.backward()
+    g_u = m.inner.xy_hm_cnns[0].down_layers[0].module[0].weight.grad
+    assert float((out_u - out_f).abs().max()) < 2e-5, float((out_u - out_f).abs().max())     # (x/255 - mean)/std vs fma form: 1 ulp inputs
+    assert float((g_u - g_f).norm() / g_f.norm()) < 5e-3
