@@ -126,7 +126,7 @@ def grad_noise_gate(name, gpu, ref64, ref32):
     assert stats['zero_grad_abs_max'] < 1e-4, stats
 
 
-@pytest.mark.parametrize('T,B', [(1, 2), (2, 2), (1, 8)])
+@pytest.mark.parametrize('T,B', [(1, 2), (2, 2), (1, 8), (1, 3)])
 def test_train_step_vs_oracle(T, B):
     seed = 500 + T
     x, target, mask = W.seeded_inputs(seed + 1000, B)
