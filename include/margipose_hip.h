@@ -295,6 +295,13 @@ int mpose_nhwc_to_image(const float* g, float* dx, int B, int C, int H, int W, i
  * or NCHW when Cpad == 0. */
 int mpose_frames_u8(const unsigned char* frames, const float* mean3, const float* std3, float* out, int B, int H, int W,
                     int Cpad, void* stream);
+/* First layer of the InceptionV4 stem (Conv2d(3, 32, 3, stride 2, padding 1), pretrainedmodels InceptionV4 features[0] with
+ * the reference's forced k//2 padding, models/margipose_model.py:111-117) as a gather + 1x1 convolution: patches
+ * (B, H/2, W/2, 32) with channel q = c*9 + ky*3 + kx (27..31 zero) from an fp32 NCHW image or (is_u8) uint8 frames
+ * normalised as in mpose_frames_u8; and the gradient of the gather, patches-gradient -> image gradient (B, 3, H, W). */
+int mpose_im2col_k3s2(const void* img, int is_u8, const float* mean3, const float* std3, float* out, int B, int H, int W,
+                      void* stream);
+int mpose_col2im_k3s2(const float* dpatches, float* dx, int B, int H, int W, void* stream);
 
 /* Layout / glue kernels. */
 /* NCHW image (B,3,S,S) -> NHWC space-to-depth (B, S/8, S/8, 192) for the patch8 stem, and back. */

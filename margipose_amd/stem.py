@@ -95,6 +95,16 @@ class _ConvOp:
         self.conv = None                                  # engine._Conv (packing slots)
 
 
+class _FirstConvOp(_ConvOp):
+    """Conv2d(3, 32, 3, stride 2, padding 1) on the image, run as a 1x1 convolution over gathered 3x3x3 patches
+    (mpose_im2col_k3s2): K = 27 (+5 zero) instead of 9 taps x 32 padded channels."""
+
+    def __init__(self, src, dst, c0, basic):
+        super().__init__(src, dst, c0, basic, 1)
+        assert tuple(self.weight.shape[1:]) == (3, 3, 3)
+        self.cin, self.kh, self.kw = 27, 1, 1
+
+
 class _PoolOp:
     def __init__(self, src, dst, c0, kind):
         self.src, self.dst, self.c0, self.kind = src, dst, c0, kind
@@ -103,7 +113,7 @@ class _PoolOp:
 class InceptionV4Stem:
     """Owns the stem's graph, arenas and job tables; driven by engine.Engine."""
 
-    IMG_C = 32          # the RGB image is stored NHWC with 32 channels (zero padded): conv kernels take Cin % 32 == 0
+    IMG_C = 32          # the image enters as gathered 3x3x3 patches, 27 values zero padded to 32 (Cin % 32 == 0)
 
     def __init__(self, engine, seq):
         from .engine import _Conv
@@ -114,7 +124,7 @@ class InceptionV4Stem:
         def node(name, C, div):
             N[name] = _Node(name, C, div)
             return N[name]
-        img = node('img', self.IMG_C, 1); img.is_image = True
+        img = node('img', self.IMG_C, 2); img.is_image = True         # 3x3x3 patches of the image at half resolution
         n0, n1, n2 = node('n0', 32, 2), node('n1', 32, 2), node('n2', 64, 2)
         n3 = node('n3', 160, 4)
         a4, b4, c4, d4, n4 = node('a4', 64, 4), node('b4', 64, 4), node('c4', 64, 4), node('d4', 64, 4), node('n4', 192, 4)
@@ -123,7 +133,7 @@ class InceptionV4Stem:
         n7 = node('n7', 128, 8)
         m3, m4, m5, m6 = seq[3], seq[4], seq[5], seq[6]
         ops = [
-            _ConvOp(img, n0, 0, seq[0], 2), _ConvOp(n0, n1, 0, seq[1]), _ConvOp(n1, n2, 0, seq[2]),
+            _FirstConvOp(img, n0, 0, seq[0]), _ConvOp(n0, n1, 0, seq[1]), _ConvOp(n1, n2, 0, seq[2]),
             _PoolOp(n2, n3, 0, 0), _ConvOp(n2, n3, 64, m3.conv, 2),
             _ConvOp(n3, a4, 0, m4.branch0[0]), _ConvOp(a4, n4, 0, m4.branch0[1]),
             _ConvOp(n3, b4, 0, m4.branch1[0]), _ConvOp(b4, c4, 0, m4.branch1[1]), _ConvOp(c4, d4, 0, m4.branch1[2]),
@@ -270,13 +280,13 @@ class InceptionV4Stem:
             eng.finalize_table(tb['fin'], 0, tb['n_fin'], False)
         raw = {}
         img = self.nodes[0]
-        raw[img.name] = torch.empty(B, S, S, self.IMG_C, **f32)
-        if x.dtype == torch.uint8:     # raw RGB frames: to_tensor + normalisation fused into the first load
+        raw[img.name] = torch.empty(B, S // 2, S // 2, self.IMG_C, **f32)
+        if x.dtype == torch.uint8:     # raw RGB frames: to_tensor + normalisation fused into the gather
             mean, std = eng.input_norm
-            check(L.mpose_frames_u8(ctypes.c_void_p(x.data_ptr()), (ctypes.c_float * 3)(*mean), (ctypes.c_float * 3)(*std), ptr(raw[img.name]),
-                                    B, S, S, self.IMG_C, st()), 'mpose_frames_u8')
+            check(L.mpose_im2col_k3s2(ctypes.c_void_p(x.data_ptr()), 1, (ctypes.c_float * 3)(*mean), (ctypes.c_float * 3)(*std),
+                                      ptr(raw[img.name]), B, S, S, st()), 'mpose_im2col_k3s2')
         else:
-            check(L.mpose_image_to_nhwc(ptr(x), ptr(raw[img.name]), B, 3, S, S, self.IMG_C, st()), 'mpose_image_to_nhwc')
+            check(L.mpose_im2col_k3s2(ctypes.c_void_p(x.data_ptr()), 0, None, None, ptr(raw[img.name]), B, S, S, st()), 'mpose_im2col_k3s2')
         done = set()
         for op in self.ops:
             n = op.dst
@@ -363,6 +373,6 @@ class InceptionV4Stem:
                                             ptr(dact[src.name]), B, Hs, Hs, src.C, n.C, op.kind, st()), 'mpose_pool3_bwd')
         if need_dx:
             dx = torch.empty(B, 3, S, S, **f32)
-            check(L.mpose_nhwc_to_image(ptr(dact['img']), ptr(dx), B, 3, S, S, self.IMG_C, st()), 'mpose_nhwc_to_image')
+            check(L.mpose_col2im_k3s2(ptr(dact['img']), ptr(dx), B, S, S, st()), 'mpose_col2im_k3s2')
             return dx
         return None
