@@ -324,9 +324,11 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
       TileInfo t1 = tile_at(it_begin + 1), t2 = tile_at(it_begin + 2);
       // prologue: tiles t0 and t1 are fetched together (one exposed memory latency instead of two); t1 sits in
       // registers that the fragment arrays take over afterwards
+      float4 rb[8], sc1 = rsc_c, sh1 = rsh_c;
+      unsigned pad1 = 0;
       {
-        float4 rb[8], sc0 = rsc_c, sh0 = rsh_c, sc1 = rsc_c, sh1 = rsh_c;
-        unsigned pad0 = 0, pad1 = 0;
+        float4 sc0 = rsc_c, sh0 = rsh_c;
+        unsigned pad0 = 0;
 #pragma unroll
         for (int s_ = 0; s_ < 2; ++s_)
 #pragma unroll
@@ -345,13 +347,15 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
         load_scale(t2, rsc_n, rsh_n);
 #pragma unroll
         for (int j = 0; j < 8; ++j) { stage(it_begin & 1, j, ra[j], pad0, sc0, sh0); load_row(t2, j, ra[j], pad_n); }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) stage((it_begin + 1) & 1, j, rb[j], pad1, sc1, sh1);
       }
       __builtin_amdgcn_wave_barrier();
       read_frags(it_begin & 1, 0, afA);
       read_frags(it_begin & 1, 1, afB);
-      mfma_group(0, afA, t1, [&](int) {});
+      mfma_group(0, afA, t1, [&](int rn) {        // the second tile is staged in the shadow of the first MFMAs
+#pragma unroll
+        for (int j = rn * 8 / RN; j < (rn + 1) * 8 / RN; ++j) stage((it_begin + 1) & 1, j, rb[j], pad1, sc1, sh1);
+      });
+      __builtin_amdgcn_wave_barrier();
       // bodies: k = it_begin .. it_end-2
       for (int k = it_begin; k + 1 < it_end; ++k) {
         const int bk = k & 1;                      // buffer of tile k (free: its last fragments are in afB) = tile k+2's
