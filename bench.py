@@ -241,6 +241,7 @@ def main():
             tr_bytes, tr_detail = traffic_fields(top[0])
             res['roofline'] = {'bound': 'mfma', 'achieved': tf, 'peak': PEAK_BF16X6_TFLOPS, 'unit': 'TFLOP/s',
                                'frac': tf / PEAK_BF16X6_TFLOPS, 'traffic': tr_bytes, 'traffic_detail': tr_detail, 'kernel': top[0],
+                               'mfma_busy_frac_pmc': (tr_detail or {}).get('mfma_busy_frac'),
                                'avg_launch_us': top[1]['avg_us'], 'launches': top[1]['n'],
                                'event_bracket_overhead_us_subtracted': 1e3 * timer.bracket_ms,
                                'flops_per_launch': top[1]['work_per_launch'],
