@@ -151,7 +151,11 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
   const mpose_conv_operands& op = a.op[blockIdx.z];
   const int n_taps = g.cls[cls].n_taps;
   // taps are read from the kernel arguments (scalar loads): {dy, dx, widx, acc} packed in one dword
-  auto tap_word = [&](int t) { return *reinterpret_cast<const int*>(&g.cls[cls].taps[t]); };
+  // ... once: lane t keeps tap t in a VGPR and v_readlane hands it to the scalar unit whenever a tile needs it (no
+  // scalar-memory load, whose lgkmcnt(0) would also drain the LDS reads in flight, inside the K loop)
+  const int lane_tap = (int)(threadIdx.x & 63) < MPOSE_MAX_TAPS
+      ? *reinterpret_cast<const int*>(&g.cls[cls].taps[(threadIdx.x & 63) < MPOSE_MAX_TAPS ? (threadIdx.x & 63) : 0]) : 0;
+  auto tap_word = [&](int t) { return __builtin_amdgcn_readlane(lane_tap, t); };
   unsigned char* sA = sA_all + wave * 2 * A_TILE_B;
 
   // ---- per-lane staging state (loop invariant) ----
