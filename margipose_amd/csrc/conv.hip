@@ -236,10 +236,10 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
 
     // wave-uniform (SGPR) description of tile `it`
     struct TileInfo { unsigned a_soff; unsigned w_soff; int t; int c; };
-    auto tile_info = [&](int it) {
+    auto tile_ct = [&](int c, int t) {           // tile = (channel chunk c, tap position t inside this pass's tap range)
       TileInfo ti;
-      ti.c = it / nt;
-      ti.t = t_lo + it - ti.c * nt;
+      ti.c = c;
+      ti.t = t_lo + t;
       const int tp = tap_word(ti.t);
       const int dy = (int)(signed char)(tp & 0xff), dx = (int)(signed char)((tp >> 8) & 0xff);
       const int widx = (tp >> 16) & 0xff;
@@ -247,6 +247,7 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
       ti.w_soff = (unsigned)(widx * k16_total + ti.c * (KC / 16)) * 3u * plane_b;
       return ti;
     };
+    auto tile_info = [&](int it) { const int c = it / nt; return tile_ct(c, it - c * nt); };
     auto load_b = [&](const TileInfo& ti, int s_, int rn) {
       const unsigned so = ti.w_soff + (unsigned)s_ * 3u * plane_b;
 #pragma unroll
@@ -326,6 +327,9 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
       auto tile_at = [&](int it) { return tile_info(it < it_end ? it : it_end - 1); };   // repeats at the tail are harmless
       const TileInfo t0 = tile_at(it_begin);
       TileInfo t1 = tile_at(it_begin + 1), t2 = tile_at(it_begin + 2);
+      // (chunk, tap) of the tile three ahead, advanced incrementally (a division per tile is ~18 scalar instructions)
+      int idx3 = it_begin + 3 < it_end ? it_begin + 3 : it_end - 1;
+      int c3 = idx3 / nt, tt3 = idx3 - c3 * nt;
       // prologue: tiles t0 and t1 are fetched together (one exposed memory latency instead of two); t1 sits in
       // registers that the fragment arrays take over afterwards
       float4 rb[8], sc1 = rsc_c, sh1 = rsh_c;
@@ -363,7 +367,8 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
       // bodies: k = it_begin .. it_end-2
       for (int k = it_begin; k + 1 < it_end; ++k) {
         const int bk = k & 1;                      // buffer of tile k (free: its last fragments are in afB) = tile k+2's
-        const TileInfo t3 = tile_at(k + 3);
+        const TileInfo t3 = tile_ct(c3, tt3);
+        if (idx3 + 1 < it_end) { ++idx3; if (++tt3 == nt) { tt3 = 0; ++c3; } }
         rotate_stage_state();
         load_scale(t3, rsc_n, rsh_n);
         read_frags(bk ^ 1, 0, afA);                // tile k+1, k-group 0
