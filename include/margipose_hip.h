@@ -222,7 +222,8 @@ int mpose_bn_finalize(const mpose_bn_job* jobs_dev, int n_jobs, int train, float
 
 /* out = relu(a_scale*a + a_shift) + (b_scale*b + b_shift): the tail of ResidualBlock.forward
  * (models/margipose_model.py:34-40 -- second BN + ReLU of the main branch, BN of the shortcut, add).  layout: 0 = NHWC out with C channels, 1 = NCHW out keeping
- * the first `c_keep` channels (the column's logits). */
+ * the first `c_keep` channels (the column's logits), 2 = NHWC without the ReLU on branch a (both branches plain BatchNorm:
+ * a torchvision ResNet block with a downsample path, before its post-add ReLU). */
 typedef struct {
   const float* a; const float* a_scale; const float* a_shift;
   const float* b; const float* b_scale; const float* b_shift;
@@ -302,6 +303,12 @@ int mpose_frames_u8(const unsigned char* frames, const float* mean3, const float
 int mpose_im2col_k3s2(const void* img, int is_u8, const float* mean3, const float* std3, float* out, int B, int H, int W,
                       void* stream);
 int mpose_col2im_k3s2(const float* dpatches, float* dx, int B, int H, int W, void* stream);
+/* The same gather for any odd k (stride 2, padding k/2) into Cpad >= 3*k*k channels (Cpad % 4 == 0), q = (c*k + ky)*k + kx:
+ * torchvision ResNet's conv1 = Conv2d(3, 64, 7, stride 2, padding 3) (models/margipose_model.py:119-137) as a 1x1
+ * convolution with K = 147 (+13 zero). */
+int mpose_im2col_s2(const void* img, int is_u8, const float* mean3, const float* std3, float* out, int B, int H, int W,
+                    int k, int Cpad, void* stream);
+int mpose_col2im_s2(const float* dpatches, float* dx, int B, int H, int W, int k, int Cpad, void* stream);
 
 /* Layout / glue kernels. */
 /* NCHW image (B,3,S,S) -> NHWC space-to-depth (B, S/8, S/8, 192) for the patch8 stem, and back. */

@@ -35,7 +35,7 @@ def lib():
                              'there is no CPU/PyTorch fallback for the MargiPose hot path.' % path)
         _LIB = ctypes.CDLL(path)
         _LIB.mpose_abi_version.restype = c_int
-        if _LIB.mpose_abi_version() != 2:
+        if _LIB.mpose_abi_version() != 3:
             raise MposeError('libmargipose_hip.so ABI version mismatch')
     return _LIB
 

@@ -51,6 +51,7 @@ struct BnAddArgs {
   int C, P, c_keep;
 };
 
+template <bool RELU_A>
 __global__ __launch_bounds__(256) void bn_add_nhwc_k(BnAddArgs a) {
   const mpose_bn_add_operands& op = a.op[blockIdx.y];
   const int c4n = a.C >> 2;
@@ -61,10 +62,10 @@ __global__ __launch_bounds__(256) void bn_add_nhwc_k(BnAddArgs a) {
     const float4 sa = *reinterpret_cast<const float4*>(op.a_scale + c), ta = *reinterpret_cast<const float4*>(op.a_shift + c);
     const float4 sb = *reinterpret_cast<const float4*>(op.b_scale + c), tb = *reinterpret_cast<const float4*>(op.b_shift + c);
     float4 o;
-    o.x = fmaxf(fmaf(x.x, sa.x, ta.x), 0.f) + fmaf(y.x, sb.x, tb.x);
-    o.y = fmaxf(fmaf(x.y, sa.y, ta.y), 0.f) + fmaf(y.y, sb.y, tb.y);
-    o.z = fmaxf(fmaf(x.z, sa.z, ta.z), 0.f) + fmaf(y.z, sb.z, tb.z);
-    o.w = fmaxf(fmaf(x.w, sa.w, ta.w), 0.f) + fmaf(y.w, sb.w, tb.w);
+    o.x = (RELU_A ? fmaxf(fmaf(x.x, sa.x, ta.x), 0.f) : fmaf(x.x, sa.x, ta.x)) + fmaf(y.x, sb.x, tb.x);
+    o.y = (RELU_A ? fmaxf(fmaf(x.y, sa.y, ta.y), 0.f) : fmaf(x.y, sa.y, ta.y)) + fmaf(y.y, sb.y, tb.y);
+    o.z = (RELU_A ? fmaxf(fmaf(x.z, sa.z, ta.z), 0.f) : fmaf(x.z, sa.z, ta.z)) + fmaf(y.z, sb.z, tb.z);
+    o.w = (RELU_A ? fmaxf(fmaf(x.w, sa.w, ta.w), 0.f) : fmaf(x.w, sa.w, ta.w)) + fmaf(y.w, sb.w, tb.w);
     reinterpret_cast<float4*>(op.out)[i] = o;
   }
 }
@@ -291,7 +292,9 @@ extern "C" int mpose_bn_add_fwd(const mpose_bn_add_operands* ops, int n_groups, 
   if (a.total4 == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   if (layout == 0) {
-    bn_add_nhwc_k<<<dim3(grid_for(a.total4, 256), n_groups), 256, 0, s>>>(a);
+    bn_add_nhwc_k<true><<<dim3(grid_for(a.total4, 256), n_groups), 256, 0, s>>>(a);
+  } else if (layout == 2) {             // no ReLU on branch a: bn2(x) + bn_d(shortcut) of a ResNet downsample block
+    bn_add_nhwc_k<false><<<dim3(grid_for(a.total4, 256), n_groups), 256, 0, s>>>(a);
   } else {
     if (c_keep < 1 || c_keep > C) return MPOSE_EINVAL;
     bn_add_nchw_k<<<dim3(grid_for((long)B * pixels_per_image, 256), n_groups), 256, 0, s>>>(a, B);

@@ -415,6 +415,64 @@ __global__ __launch_bounds__(256) void col2im_k3s2_k(const float* __restrict__ d
     dx[i] = s;
   }
 }
+// Generic k x k / stride 2 / pad k/2 gather (ResNet's 7x7 first layer: K = 147 -> Cpad = 160) and its gradient.
+template <bool U8>
+__global__ __launch_bounds__(256) void im2col_s2_k(const void* __restrict__ xin, float* __restrict__ out, int B, int H, int W, int k,
+                                                  int Cpad, float s0, float s1, float s2, float t0, float t1, float t2) {
+  const int OH = H >> 1, OW = W >> 1, kk2 = k * k, pad = k >> 1, c4n = Cpad >> 2;
+  const long total = (long)B * OH * OW * c4n;
+  const long HW = (long)H * W;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int q4 = (int)(i % c4n);
+    long r = i / c4n;
+    const int ox = (int)(r % OW); r /= OW;
+    const int oy = (int)(r % OH);
+    const long b = r / OH;
+    float e[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int q = q4 * 4 + u;
+      float v = 0.f;
+      if (q < 3 * kk2) {
+        const int c = q / kk2, kk = q - c * kk2, ky = kk / k, kx = kk - ky * k;
+        const int iy = 2 * oy - pad + ky, ix = 2 * ox - pad + kx;
+        if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
+          const long o = (b * 3 + c) * HW + (long)iy * W + ix;
+          if (U8) {
+            const float sc = c == 0 ? s0 : (c == 1 ? s1 : s2), sh = c == 0 ? t0 : (c == 1 ? t1 : t2);
+            v = fmaf((float)static_cast<const unsigned char*>(xin)[o], sc, sh);
+          } else {
+            v = static_cast<const float*>(xin)[o];
+          }
+        }
+      }
+      e[u] = v;
+    }
+    reinterpret_cast<float4*>(out)[i] = make_float4(e[0], e[1], e[2], e[3]);
+  }
+}
+__global__ __launch_bounds__(256) void col2im_s2_k(const float* __restrict__ dp, float* __restrict__ dx, int B, int H, int W, int k, int Cpad) {
+  const int OH = H >> 1, OW = W >> 1, pad = k >> 1;
+  const long total = (long)B * 3 * H * W;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int x = (int)(i % W);
+    long r = i / W;
+    const int y = (int)(r % H); r /= H;
+    const int c = (int)(r % 3);
+    const long b = r / 3;
+    float s = 0.f;
+    for (int ky = 0; ky < k; ++ky) {
+      const int ty = y + pad - ky;
+      if (ty < 0 || (ty & 1) || (ty >> 1) >= OH) continue;
+      for (int kx = 0; kx < k; ++kx) {
+        const int tx = x + pad - kx;
+        if (tx < 0 || (tx & 1) || (tx >> 1) >= OW) continue;
+        s += dp[((b * OH + (ty >> 1)) * OW + (tx >> 1)) * Cpad + (c * k + ky) * k + kx];
+      }
+    }
+    dx[i] = s;
+  }
+}
 __global__ __launch_bounds__(256) void nhwc_to_image_k(const float* __restrict__ g, float* __restrict__ dx, int B, int C, long HW, int Cpad) {
   const long npix = (long)B * HW;
   for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < npix; p += (long)gridDim.x * 256) {
@@ -580,6 +638,32 @@ extern "C" int mpose_im2col_k3s2(const void* img, int is_u8, const float* mean3,
   const long total = (long)B * (H / 2) * (W / 2) * 8;
   if (is_u8) im2col_k3s2_k<true><<<grid_for(total, 256), 256, 0, (hipStream_t)stream>>>(img, out, B, H, W, sc[0], sc[1], sc[2], sh[0], sh[1], sh[2]);
   else im2col_k3s2_k<false><<<grid_for(total, 256), 256, 0, (hipStream_t)stream>>>(img, out, B, H, W, 1.f, 1.f, 1.f, 0.f, 0.f, 0.f);
+  return launch_status();
+}
+
+extern "C" int mpose_im2col_s2(const void* img, int is_u8, const float* mean3, const float* std3, float* out, int B, int H, int W,
+                               int k, int Cpad, void* stream) {
+  if (!img || !out || (H & 1) || (W & 1) || H <= 0 || W <= 0 || k < 1 || !(k & 1) || (Cpad & 3) || Cpad < 3 * k * k) return MPOSE_EINVAL;
+  if (B == 0) return 0;
+  float sc[3] = {1.f, 1.f, 1.f}, sh[3] = {0.f, 0.f, 0.f};
+  if (is_u8) {
+    if (!mean3 || !std3) return MPOSE_EINVAL;
+    for (int c = 0; c < 3; ++c) {
+      if (!(std3[c] > 0.f)) return MPOSE_EINVAL;
+      sc[c] = 1.0f / (255.0f * std3[c]);
+      sh[c] = -mean3[c] / std3[c];
+    }
+  }
+  const long total = (long)B * (H / 2) * (W / 2) * (Cpad / 4);
+  if (is_u8) im2col_s2_k<true><<<grid_for(total, 256), 256, 0, (hipStream_t)stream>>>(img, out, B, H, W, k, Cpad, sc[0], sc[1], sc[2], sh[0], sh[1], sh[2]);
+  else im2col_s2_k<false><<<grid_for(total, 256), 256, 0, (hipStream_t)stream>>>(img, out, B, H, W, k, Cpad, 1.f, 1.f, 1.f, 0.f, 0.f, 0.f);
+  return launch_status();
+}
+
+extern "C" int mpose_col2im_s2(const float* dpatches, float* dx, int B, int H, int W, int k, int Cpad, void* stream) {
+  if (!dpatches || !dx || (H & 1) || (W & 1) || H <= 0 || W <= 0 || k < 1 || !(k & 1) || Cpad < 3 * k * k) return MPOSE_EINVAL;
+  if (B == 0) return 0;
+  col2im_s2_k<<<grid_for((long)B * 3 * H * W, 256), 256, 0, (hipStream_t)stream>>>(dpatches, dx, B, H, W, k, Cpad);
   return launch_status();
 }
 

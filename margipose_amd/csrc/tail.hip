@@ -515,7 +515,7 @@ using namespace mpose;
     default: return MPOSE_EINVAL;              \
   }
 
-extern "C" int mpose_abi_version(void) { return 2; }   // 2: bf16-plane packed weights, mpose_conv_operands.in1, wgrad tiles, frames/im2col entry points
+extern "C" int mpose_abi_version(void) { return 3; }   // 2: bf16-plane packed weights, mpose_conv_operands.in1, wgrad tiles, frames/im2col entry points; 3: im2col/col2im_s2, bn_add layout 2
 
 extern "C" int mpose_softmax_dsnt_fwd(const void* const* logits, void* const* heatmaps, float* plane_coords, float* xyz,
                                       int n_planes, int rows, int H, int W, int io_dtype, void* stream) {

@@ -241,11 +241,12 @@ class Engine:
         block_convs = [c for b in self._all_blocks for c in (b.conv_in, b.conv2, b.conv_sc)]
         block_bns = [n for b in self._all_blocks for n in (b.bn1, b.bn2, b.bns)]
         self.stem = None
-        if getattr(inner, 'feature_extractor_name', 'patch8') == 'inceptionv4':
-            from .stem import InceptionV4Stem
+        fe_name = getattr(inner, 'feature_extractor_name', 'patch8')
+        if fe_name != 'patch8':
+            from .stem import InceptionV4Stem, ResNetStem
             self.stem_conv = self.stem_bn = None
             self._convs, self._bns = [], block_bns           # filled right below (the stem needs `self` first)
-            self.stem = InceptionV4Stem(self, inner.in_cnn)
+            self.stem = (InceptionV4Stem if fe_name == 'inceptionv4' else ResNetStem)(self, inner.in_cnn)
             self._convs = self.stem.convs + block_convs
         else:
             self.stem_conv = _Conv(inner.in_cnn[0].weight, False, 1, 192, 128, 192, 128, stem=True)

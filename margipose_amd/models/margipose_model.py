@@ -7,9 +7,11 @@ The nn.Module tree below exists ONLY to own parameters/buffers under the referen
 `inner.hm_combiners.<t>.conv.weight`); none of the torch.nn layers is ever called.  The compute is
 one autograd Function around margipose_amd.engine.Engine.
 
-Stem: `feature_extractor='patch8'` is the in-repo deterministic stem (8x8/stride-8 conv + BN + ReLU).
-The reference's 'inceptionv4' / 'resnet*' stems depend on pretrainedmodels / torchvision ImageNet
-weights that are not in the reference tree: they raise the reference's exception text.
+Stems: the reference's 'inceptionv4' (default) and 'resnet18/34/50' feature extractors (stem.py; their layer
+definitions come from pretrainedmodels / torchvision, which are not in the reference tree: SURVEY.md §8c, parity
+unpinned; ImageNet weights cannot be downloaded, so they start from those packages' initialisation), plus
+`feature_extractor='patch8'`, an in-repo deterministic stem (8x8/stride-8 conv + BN + ReLU) used by fixtures.
+Any other name raises the reference's exception text.
 """
 from collections import namedtuple
 
@@ -101,6 +103,9 @@ def make_image_feature_extractor(model_name):
         # ImageNet weights, which cannot be downloaded here) -- see stem.py for the "unpinned" caveat
         from ..stem import make_inceptionv4_stem_modules
         return make_inceptionv4_stem_modules()
+    if model_name in {'resnet18', 'resnet34', 'resnet50'}:      # reference :119-138 (torchvision layers, see stem.py)
+        from ..stem import make_resnet_stem_modules
+        return make_resnet_stem_modules(model_name)
     raise Exception('unsupported image feature extractor model name: ' + model_name)
 
 

@@ -1,6 +1,9 @@
-"""InceptionV4 feature extractor of the reference's default model (reference models/margipose_model.py:103-118:
-`inceptionv4().features[0:7]` with every Conv2d / MaxPool2d padding rewritten to k//2, then Conv2d(384,128,1) +
-BatchNorm2d + ReLU), executed with the same gfx950 kernels as the columns.
+"""Image feature extractors of the reference (models/margipose_model.py:103-139), executed with the same gfx950
+kernels as the columns:
+  * 'inceptionv4' (the default, :104-118): `inceptionv4().features[0:7]` with every Conv2d / MaxPool2d padding
+    rewritten to k//2, then Conv2d(384,128,1) + BatchNorm2d + ReLU;
+  * 'resnet18' / 'resnet34' / 'resnet50' (:119-137): torchvision's conv1, bn1, relu, maxpool, layer1, layer2, plus
+    Conv2d(512,128,1) + BatchNorm2d + ReLU for resnet50 (layer2 of the BasicBlock nets already has 128 channels).
 
 The layer definitions come from the third-party package pretrainedmodels==0.6.0, which is NOT in the reference
 tree: they are restated from SURVEY.md Appendix B (shape-checked there: 972,896 parameters, 2.18 GMAC/image) and
@@ -13,6 +16,13 @@ per-channel (scale, shift) vectors; consumers apply relu(scale*x+shift) while st
 reading it (pools).  Concatenations are channel slices of one wider node (convs write with a leading dimension).
 Max/avg-pool outputs are "identity" channel ranges (scale 1, shift 0).  Backward walks the graph in reverse:
 masked BatchNorm backward over a whole node, then data-/weight-gradients of the producing convs.
+ResNet's residual sums are identity nodes too: s_raw = bn2(c2) + relu(prev) (or + bn_d(downsample)) is materialised
+by mpose_bn_add_fwd, and the block's post-add ReLU is the consumers' relu(1*s_raw + 0); the conv outputs feeding the
+sum (BatchNorm WITHOUT ReLU) are nodes with relu=False, whose BatchNorm backward runs unmasked.
+
+torchvision (0.3.0, requirements.txt:7) is not in the reference tree either: the ResNet layer definitions are
+restated from the published architecture (He et al. 2015; torchvision's v1.5 Bottleneck with the stride on the 3x3),
+and, like the InceptionV4 stem, can only be checked against this repo's oracle restatement (parity unpinned).
 """
 import ctypes
 
@@ -21,7 +31,7 @@ import torch
 from torch import nn
 
 from . import _lib
-from ._lib import (BnBwdApplyOperands, BnBwdReduceOperands, ConvOperands, WgradOperands, c_int64, c_void_p, check, lib, ptr,
+from ._lib import (BnAddOperands, BnBwdApplyOperands, BnBwdReduceOperands, ConvOperands, WgradOperands, c_int64, c_void_p, check, lib, ptr,
                    stream_ptr)
 
 BN_EPS_STEM = 1e-3        # BasicConv2d's BatchNorm2d(eps=0.001)
@@ -75,12 +85,65 @@ def make_inceptionv4_stem_modules():
                          Mixed_5a(), Inception_A(), nn.Conv2d(384, 128, 1), nn.BatchNorm2d(128), nn.Identity())
 
 
+class BasicBlock(nn.Module):
+    """torchvision.models.resnet.BasicBlock's parameters (conv1, bn1, conv2, bn2, downsample.{0,1})."""
+    expansion = 1
+
+    def __init__(self, cin, planes, stride):
+        super().__init__()
+        self.conv1 = nn.Conv2d(cin, planes, 3, stride, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.stride = stride
+        if stride != 1 or cin != planes:
+            self.downsample = nn.Sequential(nn.Conv2d(cin, planes, 1, stride, bias=False), nn.BatchNorm2d(planes))
+
+
+class Bottleneck(nn.Module):
+    """torchvision.models.resnet.Bottleneck's parameters (stride on conv2, "v1.5")."""
+    expansion = 4
+
+    def __init__(self, cin, planes, stride):
+        super().__init__()
+        self.conv1 = nn.Conv2d(cin, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.stride = stride
+        if stride != 1 or cin != planes * 4:
+            self.downsample = nn.Sequential(nn.Conv2d(cin, planes * 4, 1, stride, bias=False), nn.BatchNorm2d(planes * 4))
+
+
+RESNETS = {'resnet18': (BasicBlock, (2, 2)), 'resnet34': (BasicBlock, (3, 4)), 'resnet50': (Bottleneck, (3, 4))}
+
+
+def make_resnet_stem_modules(name):
+    """nn.Sequential(conv1, bn1, relu, maxpool, layer1, layer2[, conv, bn, relu]) with torchvision's module names and
+    initialisation (kaiming_normal_ fan_out for convs, BN weight 1 / bias 0); the reference loads ImageNet weights
+    (pretrained=True, :120), which cannot be downloaded here."""
+    block, (n1, n2) = RESNETS[name]
+    e = block.expansion
+    layer1 = nn.Sequential(*[block(64 if i == 0 else 64 * e, 64, 1) for i in range(n1)])
+    layer2 = nn.Sequential(*[block(64 * e if i == 0 else 128 * e, 128, 2 if i == 0 else 1) for i in range(n2)])
+    mods = [nn.Conv2d(3, 64, 7, 2, 3, bias=False), nn.BatchNorm2d(64), nn.Identity(), nn.Identity(), layer1, layer2]
+    for m in mods[:1] + list(layer1.modules()) + list(layer2.modules()):
+        if isinstance(m, nn.Conv2d):
+            nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+    if 128 * e != 128:
+        mods += [nn.Conv2d(128 * e, 128, 1), nn.BatchNorm2d(128), nn.Identity()]
+    return nn.Sequential(*mods)
+
+
 # ---------------------------------------------------------------------------------------------
 # graph description
 # ---------------------------------------------------------------------------------------------
 class _Node:
-    def __init__(self, name, C, div):
+    def __init__(self, name, C, div, relu=True):
         self.name, self.C, self.div = name, C, div      # spatial size = input size // div
+        self.relu = relu                                 # consumers see relu(scale*x+shift) (False: scale*x+shift)
         self.parts = []                                  # (c0, c1, bn_module or None, eps, conv_bias)
         self.producers = []
         self.f_off = self.s_off = -1
@@ -88,21 +151,33 @@ class _Node:
 
 
 class _ConvOp:
-    def __init__(self, src, dst, c0, basic, stride=1):
+    def __init__(self, src, dst, c0, basic, stride=1, bn=None, eps=None, bias=None):
         self.src, self.dst, self.c0, self.stride = src, dst, c0, stride
-        self.weight = basic.weight if isinstance(basic, nn.Conv2d) else basic.conv.weight
+        if isinstance(basic, nn.Conv2d):                  # plain Conv2d: the BatchNorm that follows is given explicitly
+            self.weight, self.bn, self.eps, self.bias = basic.weight, bn, (0.0 if eps is None else eps), bias
+        else:                                             # pretrainedmodels' BasicConv2d
+            self.weight, self.bn, self.eps, self.bias = basic.conv.weight, basic.bn, BN_EPS_STEM, None
         self.cout, self.cin, self.kh, self.kw = self.weight.shape
         self.conv = None                                  # engine._Conv (packing slots)
 
 
 class _FirstConvOp(_ConvOp):
-    """Conv2d(3, 32, 3, stride 2, padding 1) on the image, run as a 1x1 convolution over gathered 3x3x3 patches
-    (mpose_im2col_k3s2): K = 27 (+5 zero) instead of 9 taps x 32 padded channels."""
+    """Conv2d(3, C, k, stride 2, padding k//2) on the image, run as a 1x1 convolution over gathered k x k x 3 patches
+    (mpose_im2col_k3s2 / mpose_im2col_s2): K = 27 (+5 zero) or 147 (+13 zero) instead of k*k taps x 32 padded channels."""
 
-    def __init__(self, src, dst, c0, basic):
-        super().__init__(src, dst, c0, basic, 1)
-        assert tuple(self.weight.shape[1:]) == (3, 3, 3)
-        self.cin, self.kh, self.kw = 27, 1, 1
+    def __init__(self, src, dst, c0, basic, **kw):
+        super().__init__(src, dst, c0, basic, 1, **kw)
+        k = self.weight.shape[2]
+        assert tuple(self.weight.shape[1:]) == (3, k, k)
+        self.cin, self.kh, self.kw = 3 * k * k, 1, 1
+
+
+class _AddOp:
+    """dst_raw = [relu](affine(a)) + affine(b): the residual sum of a ResNet block (post-add ReLU is the consumers')."""
+
+    def __init__(self, a, b, dst, relu_a):
+        self.a, self.b, self.dst, self.relu_a = a, b, dst, relu_a
+        self.src, self.c0 = b, 0
 
 
 class _PoolOp:
@@ -110,53 +185,20 @@ class _PoolOp:
         self.src, self.dst, self.c0, self.kind = src, dst, c0, kind
 
 
-class InceptionV4Stem:
-    """Owns the stem's graph, arenas and job tables; driven by engine.Engine."""
+class _GraphStem:
+    """Owns a stem's graph, arenas and job tables; driven by engine.Engine.  Subclasses build `ops` / `nodes`."""
 
-    IMG_C = 32          # the image enters as gathered 3x3x3 patches, 27 values zero padded to 32 (Cin % 32 == 0)
+    IMG_C = 32          # the image enters as gathered k x k x 3 patches zero padded to IMG_C channels (Cin % 32 == 0)
+    IMG_K = 3
 
-    def __init__(self, engine, seq):
+    def _finish(self, engine, seq, ops, nodes, out_node, extra_params):
         from .engine import _Conv
-        self.engine = engine
-        self.seq = seq
-        N = {}
-
-        def node(name, C, div):
-            N[name] = _Node(name, C, div)
-            return N[name]
-        img = node('img', self.IMG_C, 2); img.is_image = True         # 3x3x3 patches of the image at half resolution
-        n0, n1, n2 = node('n0', 32, 2), node('n1', 32, 2), node('n2', 64, 2)
-        n3 = node('n3', 160, 4)
-        a4, b4, c4, d4, n4 = node('a4', 64, 4), node('b4', 64, 4), node('c4', 64, 4), node('d4', 64, 4), node('n4', 192, 4)
-        n5 = node('n5', 384, 8)
-        e6, f6, g6, p6, n6 = node('e6', 64, 8), node('f6', 64, 8), node('g6', 96, 8), node('p6', 384, 8), node('n6', 384, 8)
-        n7 = node('n7', 128, 8)
-        m3, m4, m5, m6 = seq[3], seq[4], seq[5], seq[6]
-        ops = [
-            _FirstConvOp(img, n0, 0, seq[0]), _ConvOp(n0, n1, 0, seq[1]), _ConvOp(n1, n2, 0, seq[2]),
-            _PoolOp(n2, n3, 0, 0), _ConvOp(n2, n3, 64, m3.conv, 2),
-            _ConvOp(n3, a4, 0, m4.branch0[0]), _ConvOp(a4, n4, 0, m4.branch0[1]),
-            _ConvOp(n3, b4, 0, m4.branch1[0]), _ConvOp(b4, c4, 0, m4.branch1[1]), _ConvOp(c4, d4, 0, m4.branch1[2]),
-            _ConvOp(d4, n4, 96, m4.branch1[3]),
-            _ConvOp(n4, n5, 0, m5.conv, 2), _PoolOp(n4, n5, 192, 0),
-            _ConvOp(n5, n6, 0, m6.branch0),
-            _ConvOp(n5, e6, 0, m6.branch1[0]), _ConvOp(e6, n6, 96, m6.branch1[1]),
-            _ConvOp(n5, f6, 0, m6.branch2[0]), _ConvOp(f6, g6, 0, m6.branch2[1]), _ConvOp(g6, n6, 192, m6.branch2[2]),
-            _PoolOp(n5, p6, 0, 1), _ConvOp(p6, n6, 288, m6.branch3[1]),
-            _ConvOp(n6, n7, 0, seq[7]),
-        ]
-        self.ops = ops
-        self.nodes = [img, n0, n1, n2, n3, a4, b4, c4, d4, n4, n5, e6, f6, g6, p6, n6, n7]
-        self.out_node = n7
-        bn_of = {}
+        self.engine, self.seq = engine, seq
+        self.ops, self.nodes, self.out_node = ops, nodes, out_node
         for op in ops:
             op.dst.producers.append(op)
             if isinstance(op, _ConvOp):
-                if op.weight is seq[7].weight:
-                    op.dst.parts.append((0, 128, seq[8], 0.0, seq[7].bias))
-                else:
-                    owner = [m for m in seq.modules() if isinstance(m, BasicConv2d) and m.conv.weight is op.weight][0]
-                    op.dst.parts.append((op.c0, op.c0 + op.cout, owner.bn, BN_EPS_STEM, None))
+                op.dst.parts.append((op.c0, op.c0 + op.cout, op.bn, op.eps, op.bias))
                 cin_s = self.IMG_C if op.src.is_image else op.cin
                 op.conv = _Conv(op.weight, False, 1, op.cin, op.cout, cin_s, op.cout)
                 op.conv.T = op.kh * op.kw
@@ -165,13 +207,24 @@ class InceptionV4Stem:
                 op.conv.size_f = op.conv.size_g * 3 // 2
                 op.conv.size_d = op.conv.T * op.cout * op.conv.npad_d * 3 // 2
                 op.conv.generic = True
+            elif isinstance(op, _AddOp):
+                op.dst.parts.append((0, op.dst.C, None, 0.0, None))
             else:
                 op.dst.parts.append((op.c0, op.c0 + op.src.C, None, 0.0, None))
         self.convs = [op.conv for op in ops if isinstance(op, _ConvOp)]
         self.bn_modules = [p[2] for n in self.nodes for p in n.parts if p[2] is not None]
-        self.extra_params = [seq[7].bias]
+        self.extra_params = extra_params
         self._tables = {}
         self._geoms = {}
+
+    @staticmethod
+    def _node_factory():
+        N = []
+
+        def node(name, C, div, relu=True):
+            N.append(_Node(name, C, div, relu))
+            return N[-1]
+        return N, node
 
     # ------------------------------------------------------------------ arenas
     def setup(self, device):
@@ -256,9 +309,9 @@ class InceptionV4Stem:
             if op.stride == 1:
                 g = _geom(B, Hout, op.cout, Hin, cin_s, 0, Hin, 1, 1, [(0, 0, [(-dy, -dx, w, 0) for dy, dx, w in taps])],
                           op.conv.npad_d)
-            else:       # gradient of a stride-2 3x3 (pad 1): the transposed-conv parity classes
-                assert (op.kh, op.kw, op.stride) == (3, 3, 2)
-                g = _geom(B, Hout, op.cout, Hin, cin_s, 0, Hout, 1, 2, _up_classes(False), op.conv.npad_d)
+            else:       # gradient of a stride-2 3x3 (pad 1) / 1x1: the transposed-conv parity classes
+                assert (op.kh, op.kw, op.stride) in ((3, 3, 2), (1, 1, 2))
+                g = _geom(B, Hout, op.cout, Hin, cin_s, 0, Hout, 1, 2, _up_classes(False, single_tap=op.kh == 1), op.conv.npad_d)
             g.in_ld, g.out_ld0 = op.dst.C, op.src.C
         g._name = 'stem_%s/%s->%s/%dx%d' % (kind, op.src.name, op.dst.name, op.kh, op.kw)
         from .engine import _geom_flops
@@ -281,12 +334,15 @@ class InceptionV4Stem:
         raw = {}
         img = self.nodes[0]
         raw[img.name] = torch.empty(B, S // 2, S // 2, self.IMG_C, **f32)
-        if x.dtype == torch.uint8:     # raw RGB frames: to_tensor + normalisation fused into the gather
-            mean, std = eng.input_norm
-            check(L.mpose_im2col_k3s2(ctypes.c_void_p(x.data_ptr()), 1, (ctypes.c_float * 3)(*mean), (ctypes.c_float * 3)(*std),
-                                      ptr(raw[img.name]), B, S, S, st()), 'mpose_im2col_k3s2')
+        is_u8 = x.dtype == torch.uint8     # raw RGB frames: to_tensor + normalisation fused into the gather
+        mean3 = (ctypes.c_float * 3)(*eng.input_norm[0]) if is_u8 else None
+        std3 = (ctypes.c_float * 3)(*eng.input_norm[1]) if is_u8 else None
+        if self.IMG_K == 3:
+            check(L.mpose_im2col_k3s2(ctypes.c_void_p(x.data_ptr()), int(is_u8), mean3, std3, ptr(raw[img.name]), B, S, S, st()),
+                  'mpose_im2col_k3s2')
         else:
-            check(L.mpose_im2col_k3s2(ctypes.c_void_p(x.data_ptr()), 0, None, None, ptr(raw[img.name]), B, S, S, st()), 'mpose_im2col_k3s2')
+            check(L.mpose_im2col_s2(ctypes.c_void_p(x.data_ptr()), int(is_u8), mean3, std3, ptr(raw[img.name]), B, S, S, self.IMG_K,
+                                    self.IMG_C, st()), 'mpose_im2col_s2')
         done = set()
         for op in self.ops:
             n = op.dst
@@ -304,6 +360,13 @@ class InceptionV4Stem:
                 if train:
                     o.stats0 = self.sptr(n, False, op.c0)
                 eng.conv(self.geom(op, B, S, 'f'), [o])
+            elif isinstance(op, _AddOp):
+                ao = BnAddOperands()
+                ao.a, ao.a_scale, ao.a_shift = raw[op.a.name].data_ptr(), self.fptr(op.a, 0), self.fptr(op.a, 1)
+                ao.b, ao.b_scale, ao.b_shift = raw[op.b.name].data_ptr(), self.fptr(op.b, 0), self.fptr(op.b, 1)
+                ao.out = raw[n.name].data_ptr()
+                H = S // n.div
+                check(L.mpose_bn_add_fwd((BnAddOperands * 3)(ao), 1, H * H, B, n.C, 0 if op.relu_a else 2, 0, st()), 'mpose_bn_add_fwd')
             else:
                 Hs = S // src.div
                 check(L.mpose_pool3_fwd(ptr(raw[src.name]), c_void_p(sc), c_void_p(sh), c_void_p(raw[n.name].data_ptr() + 4 * op.c0),
@@ -313,10 +376,10 @@ class InceptionV4Stem:
                 f0, nf = tb['fin_range'][n.name]
                 if nf:
                     eng.finalize_table(tb['fin'], f0, nf, True)
-        out = torch.empty(B, S // 8, S // 8, 128, **f32)
         n7 = self.out_node
+        out = torch.empty(B, S // n7.div, S // n7.div, n7.C, **f32)
         check(L.mpose_bn_relu_fwd(ptr(raw[n7.name]), c_void_p(self.fptr(n7, 0)), c_void_p(self.fptr(n7, 1)), ptr(out),
-                                  c_int64(out.numel()), 128, st()), 'mpose_bn_relu_fwd')
+                                  c_int64(out.numel()), n7.C, st()), 'mpose_bn_relu_fwd')
         ctx = {'raw': raw, 'B': B, 'S': S} if save else None
         return out, ctx
 
@@ -339,7 +402,8 @@ class InceptionV4Stem:
             # masked BatchNorm backward over the whole node (identity channel ranges: plain ReLU mask)
             ro = BnBwdReduceOperands()
             ro.g, ro.a, ro.sums = g.data_ptr(), raw[n.name].data_ptr(), self.sptr(n, True)
-            ro.a_scale, ro.a_shift = self.fptr(n, 0), self.fptr(n, 1)
+            if n.relu:
+                ro.a_scale, ro.a_shift = self.fptr(n, 0), self.fptr(n, 1)
             check(L.mpose_bn_bwd_reduce((BnBwdReduceOperands * 3)(ro), 1, H * H, B, n.C, 0, 0, st()), 'mpose_bn_bwd_reduce')
             c0_, nc = tb['coef_range'][n.name]
             if nc:
@@ -347,9 +411,18 @@ class InceptionV4Stem:
             d_raw = torch.empty(B, H, H, n.C, **f32)
             ao = BnBwdApplyOperands()
             ao.g, ao.a, ao.coef_a, ao.da = g.data_ptr(), raw[n.name].data_ptr(), self.fptr(n, 4), d_raw.data_ptr()
-            ao.a_scale, ao.a_shift = self.fptr(n, 0), self.fptr(n, 1)
+            if n.relu:
+                ao.a_scale, ao.a_shift = self.fptr(n, 0), self.fptr(n, 1)
             check(L.mpose_bn_bwd_apply((BnBwdApplyOperands * 3)(ao), 1, H * H, B, n.C, 0, 0, st()), 'mpose_bn_bwd_apply')
             for op in n.producers:
+                if isinstance(op, _AddOp):     # both addends receive d_raw (w.r.t. their affine / activated values)
+                    for t in (op.a, op.b):
+                        if t.name not in dact:       # (the identity path has other consumers that accumulate into it later)
+                            dact[t.name] = d_raw.clone() if (t is op.a and op.relu_a) else d_raw
+                        else:
+                            acc = dact[t.name]
+                            check(L.mpose_add(ptr(acc), ptr(d_raw), ptr(acc), c_int64(acc.numel()), st()), 'mpose_add')
+                    continue
                 src = op.src
                 Hs = S // src.div
                 want_dsrc = (not src.is_image) or need_dx
@@ -373,6 +446,86 @@ class InceptionV4Stem:
                                             ptr(dact[src.name]), B, Hs, Hs, src.C, n.C, op.kind, st()), 'mpose_pool3_bwd')
         if need_dx:
             dx = torch.empty(B, 3, S, S, **f32)
-            check(L.mpose_col2im_k3s2(ptr(dact['img']), ptr(dx), B, S, S, st()), 'mpose_col2im_k3s2')
+            if self.IMG_K == 3:
+                check(L.mpose_col2im_k3s2(ptr(dact['img']), ptr(dx), B, S, S, st()), 'mpose_col2im_k3s2')
+            else:
+                check(L.mpose_col2im_s2(ptr(dact['img']), ptr(dx), B, S, S, self.IMG_K, self.IMG_C, st()), 'mpose_col2im_s2')
             return dx
         return None
+
+
+class InceptionV4Stem(_GraphStem):
+    def __init__(self, engine, seq):
+        nodes, node = self._node_factory()
+        img = node('img', self.IMG_C, 2); img.is_image = True         # 3x3x3 patches of the image at half resolution
+        n0, n1, n2 = node('n0', 32, 2), node('n1', 32, 2), node('n2', 64, 2)
+        n3 = node('n3', 160, 4)
+        a4, b4, c4, d4, n4 = node('a4', 64, 4), node('b4', 64, 4), node('c4', 64, 4), node('d4', 64, 4), node('n4', 192, 4)
+        n5 = node('n5', 384, 8)
+        e6, f6, g6, p6, n6 = node('e6', 64, 8), node('f6', 64, 8), node('g6', 96, 8), node('p6', 384, 8), node('n6', 384, 8)
+        n7 = node('n7', 128, 8)
+        m3, m4, m5, m6 = seq[3], seq[4], seq[5], seq[6]
+        ops = [
+            _FirstConvOp(img, n0, 0, seq[0]), _ConvOp(n0, n1, 0, seq[1]), _ConvOp(n1, n2, 0, seq[2]),
+            _PoolOp(n2, n3, 0, 0), _ConvOp(n2, n3, 64, m3.conv, 2),
+            _ConvOp(n3, a4, 0, m4.branch0[0]), _ConvOp(a4, n4, 0, m4.branch0[1]),
+            _ConvOp(n3, b4, 0, m4.branch1[0]), _ConvOp(b4, c4, 0, m4.branch1[1]), _ConvOp(c4, d4, 0, m4.branch1[2]),
+            _ConvOp(d4, n4, 96, m4.branch1[3]),
+            _ConvOp(n4, n5, 0, m5.conv, 2), _PoolOp(n4, n5, 192, 0),
+            _ConvOp(n5, n6, 0, m6.branch0),
+            _ConvOp(n5, e6, 0, m6.branch1[0]), _ConvOp(e6, n6, 96, m6.branch1[1]),
+            _ConvOp(n5, f6, 0, m6.branch2[0]), _ConvOp(f6, g6, 0, m6.branch2[1]), _ConvOp(g6, n6, 192, m6.branch2[2]),
+            _PoolOp(n5, p6, 0, 1), _ConvOp(p6, n6, 288, m6.branch3[1]),
+            _ConvOp(n6, n7, 0, seq[7], bn=seq[8], bias=seq[7].bias),
+        ]
+        self._finish(engine, seq, ops, nodes, n7, [seq[7].bias])
+
+
+class ResNetStem(_GraphStem):
+    """conv1 (7x7/2 as a 1x1 over gathered patches) - bn1 - relu - maxpool(3, 2, 1) - layer1 - layer2 [- conv1x1+bn+relu]."""
+
+    IMG_C = 160         # 7*7*3 = 147 patch values zero padded to 160
+    IMG_K = 7
+
+    def __init__(self, engine, seq):
+        nodes, node = self._node_factory()
+        img = node('img', self.IMG_C, 2); img.is_image = True
+        c1 = node('c1', 64, 2)
+        ops = [_FirstConvOp(img, c1, 0, seq[0], bn=seq[1])]
+        cur = node('p1', 64, 4)
+        ops.append(_PoolOp(c1, cur, 0, 0))
+        div = 4
+        for li, layer in ((1, seq[4]), (2, seq[5])):
+            for bi, blk in enumerate(layer):
+                tag = 'l%db%d' % (li, bi)
+                odiv = div * blk.stride
+                if isinstance(blk, BasicBlock):
+                    planes = blk.conv1.weight.shape[0]
+                    a = node(tag + '_c1', planes, odiv)
+                    b = node(tag + '_c2', planes, odiv, relu=False)
+                    ops += [_ConvOp(cur, a, 0, blk.conv1, blk.stride, bn=blk.bn1), _ConvOp(a, b, 0, blk.conv2, 1, bn=blk.bn2)]
+                    cout = planes
+                else:
+                    planes = blk.conv1.weight.shape[0]
+                    a = node(tag + '_c1', planes, div)
+                    a2 = node(tag + '_c2', planes, odiv)
+                    b = node(tag + '_c3', planes * 4, odiv, relu=False)
+                    ops += [_ConvOp(cur, a, 0, blk.conv1, 1, bn=blk.bn1), _ConvOp(a, a2, 0, blk.conv2, blk.stride, bn=blk.bn2),
+                            _ConvOp(a2, b, 0, blk.conv3, 1, bn=blk.bn3)]
+                    cout = planes * 4
+                if hasattr(blk, 'downsample'):
+                    d = node(tag + '_d', cout, odiv, relu=False)
+                    ops.append(_ConvOp(cur, d, 0, blk.downsample[0], blk.stride, bn=blk.downsample[1]))
+                    s_ = node(tag + '_s', cout, odiv)
+                    ops.append(_AddOp(d, b, s_, False))
+                else:
+                    s_ = node(tag + '_s', cout, odiv)
+                    ops.append(_AddOp(cur, b, s_, True))
+                cur, div = s_, odiv
+        extra = []
+        if len(seq) > 6:
+            out = node('out', 128, div)
+            ops.append(_ConvOp(cur, out, 0, seq[6], bn=seq[7], bias=seq[6].bias))
+            extra = [seq[6].bias]
+            cur = out
+        self._finish(engine, seq, ops, nodes, cur, extra)

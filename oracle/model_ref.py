@@ -126,6 +126,42 @@ def inceptionv4_stem(sd, x, train):
     return F.relu(_bn(sd, p + '8', y, train))
 
 
+def resnet_stem(sd, x, train):
+    """models/margipose_model.py:119-137: torchvision resnet{18,34,50} conv1, bn1, relu, maxpool, layer1, layer2 (+ the 1x1
+    head when layer2 has more than 128 channels).  torchvision==0.3.0 is not in the reference tree: the blocks are restated
+    from the published architecture (BasicBlock: 3x3-3x3; Bottleneck: 1x1-3x3(stride)-1x1, expansion 4) -- parity UNPINNED."""
+    p = 'inner.in_cnn.'
+    x = F.relu(_bn(sd, p + '1', F.conv2d(x, sd[p + '0.weight'], None, stride=2, padding=3), train))
+    x = F.max_pool2d(x, 3, stride=2, padding=1)
+    for idx, stride in ((4, 1), (5, 2)):
+        b = 0
+        while '%s%d.%d.conv1.weight' % (p, idx, b) in sd:
+            q = '%s%d.%d.' % (p, idx, b)
+            st = stride if b == 0 else 1
+            if q + 'conv3.weight' in sd:          # Bottleneck
+                y = F.relu(_bn(sd, q + 'bn1', F.conv2d(x, sd[q + 'conv1.weight']), train))
+                y = F.relu(_bn(sd, q + 'bn2', F.conv2d(y, sd[q + 'conv2.weight'], None, stride=st, padding=1), train))
+                y = _bn(sd, q + 'bn3', F.conv2d(y, sd[q + 'conv3.weight']), train)
+            else:                                  # BasicBlock
+                y = F.relu(_bn(sd, q + 'bn1', F.conv2d(x, sd[q + 'conv1.weight'], None, stride=st, padding=1), train))
+                y = _bn(sd, q + 'bn2', F.conv2d(y, sd[q + 'conv2.weight'], None, padding=1), train)
+            if q + 'downsample.0.weight' in sd:
+                x = _bn(sd, q + 'downsample.1', F.conv2d(x, sd[q + 'downsample.0.weight'], None, stride=st), train)
+            x = F.relu(y + x)
+            b += 1
+    if p + '6.weight' in sd:
+        x = F.relu(_bn(sd, p + '7', F.conv2d(x, sd[p + '6.weight'], sd[p + '6.bias']), train))
+    return x
+
+
+def stem_forward(sd, x, train):
+    if 'inner.in_cnn.0.conv.weight' in sd:
+        return inceptionv4_stem(sd, x, train)
+    if 'inner.in_cnn.4.0.conv1.weight' in sd:
+        return resnet_stem(sd, x, train)
+    return patch8_stem(sd, x, train)
+
+
 def flat_softmax(x):
     """dsntnn.py:124-130."""
     return F.softmax(x.flatten(2), dim=-1).view_as(x)
@@ -133,7 +169,7 @@ def flat_softmax(x):
 
 def inner_forward(sd, x, n_stages, train, axis_permutation=True):
     """models/margipose_model.py:179-200 -- returns three lists (xy, zy, xz) of per-stage heatmaps."""
-    inp = inceptionv4_stem(sd, x, train) if 'inner.in_cnn.0.conv.weight' in sd else patch8_stem(sd, x, train)
+    inp = stem_forward(sd, x, train)
     spaces = PLANES if axis_permutation else ('xy', 'xy', 'xy')
     outs = {p: [] for p in PLANES}
     for t in range(n_stages):

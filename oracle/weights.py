@@ -68,10 +68,41 @@ def inceptionv4_stem_entries(p='inner.in_cnn.'):
     return e
 
 
+RESNET_LAYERS = {'resnet18': ('basic', 2, 2), 'resnet34': ('basic', 3, 4), 'resnet50': ('bottleneck', 3, 4)}
+
+
+def resnet_stem_entries(name, p='inner.in_cnn.'):
+    """torchvision ResNet conv1/bn1/layer1/layer2 as nn.Sequential children 0,1,4,5 (models/margipose_model.py:128-136)
+    + the reference's 1x1 head for resnet50 (:122-127).  torchvision is not in the reference tree: unpinned."""
+    kind, n1, n2 = RESNET_LAYERS[name]
+    ex = 1 if kind == 'basic' else 4
+    e = [(p + '0.weight', (64, 3, 7, 7))] + _bn_entries(p + '1', 64)
+    cin = 64
+    for li, (idx, planes, n, stride) in enumerate(((4, 64, n1, 1), (5, 128, n2, 2))):
+        for b in range(n):
+            q = '%s%d.%d.' % (p, idx, b)
+            st = stride if b == 0 else 1
+            if kind == 'basic':
+                e += [(q + 'conv1.weight', (planes, cin, 3, 3))] + _bn_entries(q + 'bn1', planes)
+                e += [(q + 'conv2.weight', (planes, planes, 3, 3))] + _bn_entries(q + 'bn2', planes)
+            else:
+                e += [(q + 'conv1.weight', (planes, cin, 1, 1))] + _bn_entries(q + 'bn1', planes)
+                e += [(q + 'conv2.weight', (planes, planes, 3, 3))] + _bn_entries(q + 'bn2', planes)
+                e += [(q + 'conv3.weight', (planes * 4, planes, 1, 1))] + _bn_entries(q + 'bn3', planes * 4)
+            if st != 1 or cin != planes * ex:
+                e += [(q + 'downsample.0.weight', (planes * ex, cin, 1, 1))] + _bn_entries(q + 'downsample.1', planes * ex)
+            cin = planes * ex
+    if cin != 128:
+        e += [(p + '6.weight', (128, cin, 1, 1)), (p + '6.bias', (128,))] + _bn_entries(p + '7', 128)
+    return e
+
+
 def schema(n_stages, n_joints=17, stem='patch8'):
     """Ordered key -> shape map of MargiPoseModel(n_stages) with the given stem."""
     if stem == 'inceptionv4':
         e = inceptionv4_stem_entries()
+    elif stem in RESNET_LAYERS:
+        e = resnet_stem_entries(stem)
     else:
         e = [('inner.in_cnn.0.weight', (128, 3, 8, 8))] + _bn_entries('inner.in_cnn.1', 128)
     # nn.ModuleList registration order (models/margipose_model.py:158-162): all xy columns, then zy,

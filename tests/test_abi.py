@@ -24,7 +24,7 @@ def test_library_builds_and_exports_everything():
     missing = [n for n in declared_symbols() if not hasattr(lib, n)]
     assert not missing, 'symbols declared in include/margipose_hip.h but not exported: %s' % missing
     lib.mpose_abi_version.restype = ctypes.c_int
-    assert lib.mpose_abi_version() == 2
+    assert lib.mpose_abi_version() == 3
 
 
 def test_no_cpu_fallback():

@@ -1,6 +1,7 @@
-"""GPU parity of the InceptionV4 feature extractor (margipose_amd/stem.py) against the oracle's restatement
-(oracle/model_ref.py::inceptionv4_stem).  NOTE: both restate pretrainedmodels==0.6.0 from SURVEY.md Appendix B;
-the third-party original is not available, so this pins the HIP path to the oracle, not to the original."""
+"""GPU parity of the InceptionV4 and ResNet feature extractors (margipose_amd/stem.py) against the oracle's restatements
+(oracle/model_ref.py::inceptionv4_stem / resnet_stem).  NOTE: both sides restate pretrainedmodels==0.6.0 (SURVEY.md
+Appendix B) and torchvision's ResNet blocks; the third-party originals are not available, so this pins the HIP path to
+the oracle, not to the originals."""
 from collections import OrderedDict
 
 import numpy as np
@@ -23,17 +24,18 @@ def rel_l2(a, b):
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
 
 
-def setup(T, seed, B):
+def setup(T, seed, B, stem='inceptionv4'):
     from margipose_amd.models import CanonicalSkeletonDesc, MargiPoseModel
     x, target, mask = W.seeded_inputs(seed + 1000, B)
-    sd = R.calibrate_running_stats(W.make_state_dict(T, seed, torch.float64, stem='inceptionv4'), x.double(), T)
-    m = MargiPoseModel(CanonicalSkeletonDesc, T, True, 'inceptionv4', 'jsd')
+    sd = R.calibrate_running_stats(W.make_state_dict(T, seed, torch.float64, stem=stem), x.double(), T)
+    m = MargiPoseModel(CanonicalSkeletonDesc, T, True, stem, 'jsd')
     m.load_state_dict(OrderedDict((k, v.float() if v.is_floating_point() else v) for k, v in sd.items()), strict=True)
     return m.cuda(), sd, x, target, mask
 
 
-def test_inception_stem_eval_forward():
-    m, sd, x, target, mask = setup(1, 801, 2)
+@pytest.mark.parametrize('stem', ['inceptionv4', 'resnet18', 'resnet34', 'resnet50'])
+def test_stem_eval_forward(stem):
+    m, sd, x, target, mask = setup(1, 801, 2, stem)
     m.eval()
     with torch.no_grad():
         out = m(x.cuda())
@@ -42,9 +44,10 @@ def test_inception_stem_eval_forward():
     assert rel(m.xz_heatmaps[-1].cpu(), xz[-1]) < 1e-4
 
 
-def test_inception_stem_train_step():
+@pytest.mark.parametrize('stem', ['inceptionv4', 'resnet18', 'resnet50'])
+def test_stem_train_step(stem):
     from margipose_amd import dsntnn
-    m, sd, x, target, mask = setup(1, 802, 2)
+    m, sd, x, target, mask = setup(1, 802, 2, stem)
     m.train()
     xg = x.cuda().requires_grad_(True)
     out = m(xg)
@@ -57,7 +60,7 @@ def test_inception_stem_train_step():
     ref_l3 = R.forward_3d_losses(xy, zy, xz, target.double())
     ref_loss = R.average_loss(ref_l3, mask.double())
     ref_loss.backward()
-    print('FWD coords err %.2e l3 err %.2e hm err %.2e loss %.10f ref %.10f' % (rel(out.detach().cpu(), R.heatmaps_to_coords(xy[-1], zy[-1], xz[-1]).detach()), rel(l3.detach().cpu(), ref_l3.detach()), rel(m.xy_heatmaps[-1].detach().cpu(), xy[-1].detach()), float(loss), float(ref_loss)))
+    print('FWD coords err %.2e l3 err %.2e hm err %.2e loss %.10f ref %.10f' % (rel(out.detach().cpu(), R.heatmaps_to_coords(xy[-1], zy[-1], xz[-1]).detach()), rel(l3.detach().cpu(), ref_l3.detach()), rel(m.xy_heatmaps[-1].detach().cpu(), xy[-1].detach()), float(loss.detach()), float(ref_loss.detach())))
     assert rel(out.detach().cpu(), R.heatmaps_to_coords(xy[-1], zy[-1], xz[-1]).detach()) < 1e-4
     assert rel(l3.detach().cpu(), ref_l3.detach()) < 1e-4
     # running statistics of every stem BatchNorm (incl. the conv-bias fold of in_cnn.8)
@@ -69,7 +72,7 @@ def test_inception_stem_train_step():
     # measured in this run with the fp32 oracle)
     from tests.test_model_gpu import grad_noise_gate
     sd32 = OrderedDict((k, v.float() if v.is_floating_point() else v) for k, v in
-                       R.calibrate_running_stats(W.make_state_dict(1, 802, torch.float64, stem='inceptionv4'), x.double(), 1).items())
+                       R.calibrate_running_stats(W.make_state_dict(1, 802, torch.float64, stem=stem), x.double(), 1).items())
     p32 = OrderedDict((k, v.requires_grad_(True)) for k, v in sd32.items() if v.is_floating_point() and 'running' not in k)
     x32 = x.clone().requires_grad_(True)
     a32, b32, c32 = R.inner_forward(sd32, x32, 1, True)
@@ -78,4 +81,4 @@ def test_inception_stem_train_step():
     gpu['__dx__'] = xg.grad.cpu()
     r64 = OrderedDict((k, p.grad) for k, p in params.items()); r64['__dx__'] = xr.grad
     r32 = OrderedDict((k, p.grad) for k, p in p32.items()); r32['__dx__'] = x32.grad
-    grad_noise_gate('inception_T1_B2', gpu, r64, r32)
+    grad_noise_gate('%s_T1_B2' % stem, gpu, r64, r32)
