@@ -64,8 +64,8 @@ def parse():
     ap.add_argument('--batch', type=int, default=32, help='per-GPU batch (weak scaling)')
     ap.add_argument('--stages', type=int, default=3)
     ap.add_argument('--size', type=int, default=256)
-    ap.add_argument('--stem', default='inceptionv4', choices=['patch8', 'inceptionv4'],
-                    help="'inceptionv4' = the reference's default feature extractor; 'patch8' = the light in-repo stem")
+    ap.add_argument('--stem', default='inceptionv4', choices=['patch8', 'inceptionv4', 'resnet18', 'resnet34', 'resnet50'],
+                    help="'inceptionv4' = the reference's default feature extractor; 'resnet*' = its other options; 'patch8' = the light in-repo stem")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--cpu-batch', type=int, default=8)
@@ -226,6 +226,8 @@ def main():
                    'global_batch': world * B, 'n_stages': args.stages,
                    'stem': ('inceptionv4 (reference default; restated from SURVEY Appendix B, third-party original unavailable: '
                             'unpinned, random init)' if args.stem == 'inceptionv4' else
+                            '%s (reference option, models/margipose_model.py:119-137; torchvision layers restated, unpinned, '
+                            'random init)' % args.stem if args.stem.startswith('resnet') else
                             'patch8 (in-repo deterministic stem; the InceptionV4 stem is available with --stem inceptionv4)'), 'parallelism': 'dp%d' % world, 'overlap_wgrad': bool(args.overlap_wgrad),
                    'final_loss': loss_value},
     }

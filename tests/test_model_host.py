@@ -46,6 +46,22 @@ def test_registry_and_errors():
         bad.forward_3d_losses(None, torch.zeros(1, 17, 3))
 
 
+@pytest.mark.parametrize('stem,n_params', [('resnet18', 683072), ('resnet34', 1347904), ('resnet50', 1510848)])
+def test_resnet_stems_have_torchvision_key_schema(stem, n_params):
+    """models/margipose_model.py:119-137: nn.Sequential(conv1, bn1, relu, maxpool, layer1, layer2[, conv, bn, relu]) -- keys
+    `inner.in_cnn.{0,1}`, `inner.in_cnn.{4,5}.<block>.{conv1,bn1,conv2,bn2[,conv3,bn3],downsample.{0,1}}`, `inner.in_cnn.{6,7}`
+    and torchvision's parameter counts up to layer2 (resnet18: 683,072) plus the 512->128 head of resnet50 (65,920)."""
+    from oracle import weights as W
+    from margipose_amd.models import CanonicalSkeletonDesc, MargiPoseModel
+    m = MargiPoseModel(CanonicalSkeletonDesc, 1, True, stem, 'jsd')
+    want = [k for k in W.schema(1, stem=stem) if k.startswith('inner.in_cnn')]
+    got = [k for k in m.state_dict() if k.startswith('inner.in_cnn')]
+    assert got == want
+    assert sum(p.numel() for k, p in m.named_parameters() if k.startswith('inner.in_cnn')) == n_params
+    assert ('inner.in_cnn.6.bias' in got) == (stem == 'resnet50')
+    assert 'inner.in_cnn.5.0.downsample.0.weight' in got and ('inner.in_cnn.4.0.downsample.0.weight' in got) == (stem == 'resnet50')
+
+
 def test_state_dict_roundtrip_with_oracle_weights():
     from oracle import weights as W
     from margipose_amd.models import CanonicalSkeletonDesc, MargiPoseModel
