@@ -4,6 +4,9 @@ import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from margipose_amd import _lib
+import margipose_amd.build as _b
+if os.environ.get('MPOSE_LIB'):      # ablation builds (tools/experiments/ablate_conv.py)
+    _b.LIB_PATH = os.path.abspath(os.environ['MPOSE_LIB'])
 from margipose_amd.engine import _geom, TAPS3, _geom_flops
 from margipose_amd._lib import ConvOperands, WgradOperands, stream_ptr
 

@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Ablation builds of the igemm K loop: which ingredient of a tile step costs what?  Generates variants of csrc/conv.hip
+by text substitution (results are numerically WRONG -- timing only), builds margipose_amd/_abl/lib_<variant>.so, and
+`tools/bench_conv.py` picks one with MPOSE_LIB=<path>.  Not part of the product.
+  usage: python tools/experiments/ablate_conv.py            (build all, here, no GPU needed)
+         MPOSE_LIB=margipose_amd/_abl/lib_no_b.so python tools/bench_conv.py   (on the GPU box)"""
+import os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from margipose_amd import build as B
+
+BODY = '{ stage_row(bk, j); load_a_row(t3, j); }'
+SUBS = {
+    'base': [],
+    'no_b': [('        load_b(nb, s_, rn);\n        side(rn);', '        side(rn);')],
+    'no_frag': [('        read_frags(bk ^ 1, 0, afA);                // tile k+1, k-group 0\n', ''),
+                ('        read_frags(bk ^ 1, 1, afB);                // tile k+1, k-group 1\n', '')],
+    'no_apath': [(BODY, '{ }')],
+    'no_aload': [(BODY, '{ stage_row(bk, j); }')],
+    'no_split': [('      split4(v, h, m, l);\n      unsigned char* dA = sA + buf',
+                  '      h = make_uint2(__float_as_uint(v.x), __float_as_uint(v.y)); m = make_uint2(__float_as_uint(v.z), __float_as_uint(v.w)); l = h;\n      unsigned char* dA = sA + buf')],
+}
+SUBS['mfma_only'] = SUBS['no_b'] + SUBS['no_frag'] + SUBS['no_apath']
+SUBS['b_only'] = SUBS['no_frag'] + SUBS['no_apath']
+SUBS['frag_only'] = SUBS['no_b'] + SUBS['no_apath']
+
+src = open(os.path.join(B.CSRC, 'conv.hip')).read()
+out_dir = os.path.join(B.PKG_DIR, '_abl')
+os.makedirs(out_dir, exist_ok=True)
+others = [os.path.splitext(s)[0] + '.o' for s in B.sources() if not s.endswith('conv.hip')]
+procs = []
+for name, subs in SUBS.items():
+    s = src
+    for a, b in subs:
+        assert s.count(a) >= 1, (name, a)
+        s = s.replace(a, b)
+    f = os.path.join(B.CSRC, '_abl_%s.hip' % name)         # next to conv.hip so that "common.h" resolves
+    open(f, 'w').write(s)
+    obj = os.path.join(out_dir, 'conv_%s.o' % name)
+    procs.append((name, f, obj, subprocess.Popen([B._hipcc()] + B.HIPCC_FLAGS + ['-c', f, '-o', obj], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+for name, f, obj, p in procs:
+    o, _ = p.communicate()
+    os.remove(f)
+    if p.returncode:
+        print(name, 'FAILED\n', o.decode()[-2000:]); continue
+    lib = os.path.join(out_dir, 'lib_%s.so' % name)
+    subprocess.run([B._hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', lib, obj] + others, check=True)
+    print('built', lib)
