@@ -20,6 +20,16 @@ SUBS = {
     'no_split': [('      split4(v, h, m, l);\n      unsigned char* dA = sA + buf',
                   '      h = make_uint2(__float_as_uint(v.x), __float_as_uint(v.y)); m = make_uint2(__float_as_uint(v.z), __float_as_uint(v.w)); l = h;\n      unsigned char* dA = sA + buf')],
 }
+RT_FALSE = '(a.flags & 0x40000000)'          # a condition the compiler cannot fold; always false at run time
+SUBS['fix_no_loop'] = [('for (int k = it_begin; k + 1 < it_end; ++k) {', 'for (int k = it_begin; k + 1 < it_end && %s; ++k) {' % RT_FALSE)]
+SUBS['fix_tap_const'] = [('''  const int lane_tap = (int)(threadIdx.x & 63) < MPOSE_MAX_TAPS
+      ? *reinterpret_cast<const int*>(&g.cls[cls].taps[(threadIdx.x & 63) < MPOSE_MAX_TAPS ? (threadIdx.x & 63) : 0]) : 0;''',
+                          '''  const int lane_tap = (int)(threadIdx.x & 63) < 9
+      ? ((((int)(threadIdx.x & 63) / 3 - 1) & 0xff) | ((((int)(threadIdx.x & 63) % 3 - 1) & 0xff) << 8) | ((int)(threadIdx.x & 63) << 16)) : 0;''')]
+SUBS['fix_no_masks'] = [('      if ((unsigned)iy < (unsigned)g.IH && (unsigned)ix < (unsigned)g.IW) row_taps[j] |= 1u << t;', '      row_taps[j] |= 1u << t;')]
+SUBS['fix_no_store'] = [('            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[r]), rs_o, (int)(voff[r] + (unsigned)(rn * 128)), 0, 0);',
+                         '            if (%s) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[r]), rs_o, (int)(voff[r] + (unsigned)(rn * 128)), 0, 0);' % RT_FALSE)]
+SUBS['fix_no_exchange'] = [('    if (KS > 1) {\n      constexpr int BLK = 16 * 64;', '    if (KS > 1 && %s) {\n      constexpr int BLK = 16 * 64;' % RT_FALSE)]
 SUBS['mfma_only'] = SUBS['no_b'] + SUBS['no_frag'] + SUBS['no_apath']
 SUBS['b_only'] = SUBS['no_frag'] + SUBS['no_apath']
 SUBS['frag_only'] = SUBS['no_b'] + SUBS['no_apath']
@@ -29,7 +39,10 @@ out_dir = os.path.join(B.PKG_DIR, '_abl')
 os.makedirs(out_dir, exist_ok=True)
 others = [os.path.splitext(s)[0] + '.o' for s in B.sources() if not s.endswith('conv.hip')]
 procs = []
+only = sys.argv[1:]
 for name, subs in SUBS.items():
+    if only and not any(name.startswith(o) for o in only):
+        continue
     s = src
     for a, b in subs:
         assert s.count(a) >= 1, (name, a)
