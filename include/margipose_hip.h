@@ -288,6 +288,11 @@ int mpose_pool3_fwd(const float* in, const float* scale, const float* shift, flo
 /* Backward: adds into d_in (gradient w.r.t. the ACTIVATED input); g is read from a channel slice (g_ld). */
 int mpose_pool3_bwd(const float* in, const float* scale, const float* shift, const float* g, float* d_in, int B, int IH,
                     int IW, int C, int g_ld, int kind, void* stream);
+/* The max-pool case (kind 0) of the above in two passes through a caller-provided workspace of >= B*OH*OW*C bytes
+ * (OH = (IH-1)/2+1): window arg-max positions are computed once per output element instead of up to four times per
+ * input element.  Same result bit for bit. */
+int mpose_maxpool3_bwd_ws(const float* in, const float* scale, const float* shift, const float* g, float* d_in,
+                          void* workspace, long workspace_bytes, int B, int IH, int IW, int C, int g_ld, void* stream);
 /* NCHW (B, C, H, W) -> NHWC (B, H, W, Cpad) zero padded, and the reverse gather for the input gradient. */
 int mpose_image_to_nhwc(const float* x, float* out, int B, int C, int H, int W, int Cpad, void* stream);
 int mpose_nhwc_to_image(const float* g, float* dx, int B, int C, int H, int W, int Cpad, void* stream);

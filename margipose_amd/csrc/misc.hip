@@ -319,6 +319,74 @@ __global__ __launch_bounds__(256) void pool3_bwd_k(PoolArgs a) {
   }
 }
 
+// Max-pool backward in two passes (the single-pass gather above re-derives up to four 9-element argmaxes per input
+// element): pass 1, one thread per OUTPUT window x 4 channels, records the window position (0..8, first maximum in
+// row-major order, as ATen does) in a byte; pass 2, one thread per INPUT element x 4 channels, reads the bytes and the
+// gradients of the <= 4 windows that contain it.  Deterministic, no atomics.
+__global__ __launch_bounds__(256) void maxpool3_argmax_k(PoolArgs a, unsigned char* __restrict__ arg_out) {
+  const int c4n = a.C >> 2;
+  const long total = (long)a.B * a.OH * a.OW * c4n;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % c4n) * 4;
+    long r = i / c4n;
+    const int ox = (int)(r % a.OW); r /= a.OW;
+    const int oy = (int)(r % a.OH);
+    const long b = r / a.OH;
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.scale != nullptr) { sc = *reinterpret_cast<const float4*>(a.scale + c); sh = *reinterpret_cast<const float4*>(a.shift + c); }
+    float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    unsigned arg[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int ky = -1; ky <= 1; ++ky)
+#pragma unroll
+      for (int kx = -1; kx <= 1; ++kx) {
+        const int yy = oy * 2 + ky, xx = ox * 2 + kx;
+        if (yy < 0 || yy >= a.IH || xx < 0 || xx >= a.IW) continue;
+        const float4 v4 = pool_act(a, (b * a.IH + yy) * a.IW + xx, c, sc, sh);
+        const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (v[e] > best[e]) { best[e] = v[e]; arg[e] = (unsigned)((ky + 1) * 3 + (kx + 1)); }
+      }
+    *reinterpret_cast<unsigned*>(arg_out + i * 4) = arg[0] | (arg[1] << 8) | (arg[2] << 16) | (arg[3] << 24);
+  }
+}
+__global__ __launch_bounds__(256) void maxpool3_bwd_arg_k(PoolArgs a, const unsigned char* __restrict__ arg_in) {
+  const int c4n = a.C >> 2;
+  const long total = (long)a.B * a.IH * a.IW * c4n;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c4 = (int)(i % c4n);
+    long r = i / c4n;
+    const int ix = (int)(r % a.IW); r /= a.IW;
+    const int iy = (int)(r % a.IH);
+    const long b = r / a.IH;
+    float d[4] = {0.f, 0.f, 0.f, 0.f};
+    // windows (stride 2, pad 1) containing (iy, ix): 2*oy - 1 <= iy <= 2*oy + 1
+    const int oy1 = (iy + 1) >> 1, ox1 = (ix + 1) >> 1;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int oy = oy1 - u;
+      if (oy < 0 || oy >= a.OH || 2 * oy + 1 < iy) continue;
+#pragma unroll
+      for (int w = 0; w < 2; ++w) {
+        const int ox = ox1 - w;
+        if (ox < 0 || ox >= a.OW || 2 * ox + 1 < ix) continue;
+        const long op = (b * a.OH + oy) * a.OW + ox;
+        const unsigned ar = *reinterpret_cast<const unsigned*>(arg_in + (op * c4n + c4) * 4);
+        const float4 gv = *reinterpret_cast<const float4*>(a.g + op * a.ld + c4 * 4);
+        const unsigned mine = (unsigned)((iy - oy * 2 + 1) * 3 + (ix - ox * 2 + 1));
+        d[0] += (ar & 0xff) == mine ? gv.x : 0.f;
+        d[1] += ((ar >> 8) & 0xff) == mine ? gv.y : 0.f;
+        d[2] += ((ar >> 16) & 0xff) == mine ? gv.z : 0.f;
+        d[3] += (ar >> 24) == mine ? gv.w : 0.f;
+      }
+    }
+    float4* dst = reinterpret_cast<float4*>(a.out + i * 4);
+    float4 o = *dst;
+    o.x += d[0]; o.y += d[1]; o.z += d[2]; o.w += d[3];
+    *dst = o;
+  }
+}
+
 // NCHW (B,C,H,W) <-> NHWC (B,H,W,Cpad), channels >= C zero
 __global__ __launch_bounds__(256) void image_to_nhwc_k(const float* __restrict__ x, float* __restrict__ out, int B, int C, long HW, int Cpad) {
   const long npix = (long)B * HW;
@@ -597,6 +665,19 @@ extern "C" int mpose_pool3_bwd(const float* in, const float* scale, const float*
   const long total = (long)B * IH * IW * (C / 4);
   if (total == 0) return 0;
   pool3_bwd_k<<<grid_for(total, 256), 256, 0, (hipStream_t)stream>>>(a);
+  return launch_status();
+}
+
+extern "C" int mpose_maxpool3_bwd_ws(const float* in, const float* scale, const float* shift, const float* g, float* d_in,
+                                    void* workspace, long workspace_bytes, int B, int IH, int IW, int C, int g_ld, void* stream) {
+  PoolArgs a{};
+  if (pool_dims(0, IH, IW, a.OH, a.OW) || (C & 3) || g_ld < C || (g_ld & 3)) return MPOSE_EINVAL;
+  if (!workspace || workspace_bytes < (long)B * a.OH * a.OW * C) return MPOSE_EINVAL;
+  a.in = in; a.scale = scale; a.shift = shift; a.g = g; a.out = d_in; a.B = B; a.IH = IH; a.IW = IW; a.C = C; a.ld = g_ld; a.kind = 0;
+  const long total_o = (long)B * a.OH * a.OW * (C / 4), total_i = (long)B * IH * IW * (C / 4);
+  if (total_i == 0) return 0;
+  maxpool3_argmax_k<<<grid_for(total_o, 256), 256, 0, (hipStream_t)stream>>>(a, static_cast<unsigned char*>(workspace));
+  maxpool3_bwd_arg_k<<<grid_for(total_i, 256), 256, 0, (hipStream_t)stream>>>(a, static_cast<const unsigned char*>(workspace));
   return launch_status();
 }
 

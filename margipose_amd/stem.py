@@ -441,6 +441,11 @@ class _GraphStem:
                         o.in_, o.w0 = d_raw.data_ptr() + 4 * op.c0, eng._wptr(op.conv, True)
                         o.out0 = dact[src.name].data_ptr()
                         eng.conv(self.geom(op, B, S, 'd'), [o], 1)       # accumulate
+                elif want_dsrc and op.kind == 0:
+                    ws = torch.empty(B * H * H * src.C, dtype=torch.uint8, device=dev)       # window arg-max positions
+                    check(L.mpose_maxpool3_bwd_ws(ptr(raw[src.name]), c_void_p(sc), c_void_p(sh), c_void_p(d_raw.data_ptr() + 4 * op.c0),
+                                                  ptr(dact[src.name]), ptr(ws), ctypes.c_long(ws.numel()), B, Hs, Hs, src.C, n.C, st()),
+                          'mpose_maxpool3_bwd_ws')
                 elif want_dsrc:
                     check(L.mpose_pool3_bwd(ptr(raw[src.name]), c_void_p(sc), c_void_p(sh), c_void_p(d_raw.data_ptr() + 4 * op.c0),
                                             ptr(dact[src.name]), B, Hs, Hs, src.C, n.C, op.kind, st()), 'mpose_pool3_bwd')

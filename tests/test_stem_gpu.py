@@ -82,3 +82,37 @@ def test_stem_train_step(stem):
     r64 = OrderedDict((k, p.grad) for k, p in params.items()); r64['__dx__'] = xr.grad
     r32 = OrderedDict((k, p.grad) for k, p in p32.items()); r32['__dx__'] = x32.grad
     grad_noise_gate('%s_T1_B2' % stem, gpu, r64, r32)
+
+
+@pytest.mark.parametrize('H,C', [(16, 64), (10, 8)])
+def test_maxpool_backward_two_pass_matches_single_pass_and_torch(H, C):
+    """mpose_pool3_fwd / mpose_pool3_bwd / mpose_maxpool3_bwd_ws against F.max_pool2d(relu(s*x+t), 3, 2, 1) autograd
+    (MaxPool2d with the reference's padding rewrite, models/margipose_model.py:111-117); the two backward forms must
+    agree bit for bit."""
+    import ctypes
+    import torch.nn.functional as F
+    from margipose_amd._lib import c_void_p, check, lib, ptr, stream_ptr
+    L = lib()
+    B = 3
+    g0 = torch.Generator().manual_seed(5)
+    x = torch.randn(B, H, H, C, generator=g0)
+    sc, sh = torch.rand(C, generator=g0) + 0.5, torch.randn(C, generator=g0) * 0.2
+    OH = (H - 1) // 2 + 1
+    g = torch.randn(B, OH, OH, C, generator=g0)
+    xr = x.double().requires_grad_(True)
+    act = F.relu(xr * sc.double() + sh.double())
+    act.retain_grad()
+    y = F.max_pool2d(act.permute(0, 3, 1, 2), 3, 2, 1)
+    y.backward(g.double().permute(0, 3, 1, 2))
+    xd, scd, shd, gd = x.cuda(), sc.cuda(), sh.cuda(), g.cuda()
+    out = torch.empty(B, OH, OH, C, device='cuda')
+    check(L.mpose_pool3_fwd(ptr(xd), ptr(scd), ptr(shd), ptr(out), B, H, H, C, C, 0, stream_ptr()), 'fwd')
+    assert rel(out.cpu(), y.detach().permute(0, 2, 3, 1)) < 1e-6
+    d1 = torch.zeros(B, H, H, C, device='cuda'); d2 = torch.zeros(B, H, H, C, device='cuda')
+    check(L.mpose_pool3_bwd(ptr(xd), ptr(scd), ptr(shd), ptr(gd), ptr(d1), B, H, H, C, C, 0, stream_ptr()), 'bwd')
+    ws = torch.empty(B * OH * OH * C, dtype=torch.uint8, device='cuda')
+    check(L.mpose_maxpool3_bwd_ws(ptr(xd), ptr(scd), ptr(shd), ptr(gd), ptr(d2), ptr(ws), ctypes.c_long(ws.numel()), B, H, H, C, C,
+                                  stream_ptr()), 'bwd_ws')
+    assert torch.equal(d1, d2)
+    assert rel(d2.cpu(), act.grad) < 1e-6          # gradient w.r.t. the ACTIVATED input
+    assert L.mpose_maxpool3_bwd_ws(ptr(xd), ptr(scd), ptr(shd), ptr(gd), ptr(d2), ptr(ws), ctypes.c_long(8), B, H, H, C, C, stream_ptr()) != 0
