@@ -48,7 +48,8 @@ int mpose_sizeof(int which);
  *   logits[p], heatmaps[p]: (rows, H, W) for plane p (heatmaps[p] may be NULL: coordinates only)
  *   plane_coords: (n_planes, rows, 2) = (mu_x, mu_y) per plane, may be NULL
  *   xyz: (rows, 3), only written when n_planes == 3, may be NULL
- *   io_dtype: 0 = fp32 logits/heatmaps, 1 = bf16 logits/heatmaps (arithmetic is fp32 either way) */
+ *   io_dtype: 0 = fp32 logits/heatmaps, 1 = bf16 logits/heatmaps, 2 = fp32 logits -> bf16 heatmaps (arithmetic and the
+ *   coordinates are fp32 in every mode: BASELINE configs[1], "bf16 heatmaps + fp32 soft-argmax") */
 int mpose_softmax_dsnt_fwd(const void* const* logits, void* const* heatmaps, float* plane_coords,
                            float* xyz, int n_planes, int rows, int H, int W, int io_dtype,
                            void* stream);
@@ -329,6 +330,9 @@ int mpose_axis_permute(const float* const* in, float* const* out, const int* spa
  *   out[b,y,x,c] = inp[b,y,x,c] + sum_{p,j} W[c, p*J+j] * hm[p][b,j,y,x]   (hm NCHW, inp/out NHWC) */
 int mpose_combiner_fwd(const float* const* hm, const float* w, const float* inp, float* out, int B,
                        int J, int HW, int C, void* stream);
+/* The same with bf16 heatmaps (inference storage mode, mpose_softmax_dsnt_fwd io_dtype 2). */
+int mpose_combiner_fwd_bf16(const void* const* hm, const float* w, const float* inp, float* out, int B,
+                            int J, int HW, int C, void* stream);
 /* d_hm[p][b,j,y,x] = sum_c W[c,p*J+j] * g[b,y,x,c];  dw partial sums (n_blocks, C, 3J). */
 int mpose_combiner_bwd(const float* const* hm, const float* w, const float* g, float* const* d_hm,
                        float* dw_partial, int n_partial, int B, int J, int HW, int C, void* stream);

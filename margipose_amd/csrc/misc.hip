@@ -86,6 +86,7 @@ struct CombArgs {
   const float* g;
   float* dw_partial;
   int B, J, HW, Q;            // Q = 3J
+  int hm_bf16;                // forward only: heatmaps are bf16 (inference storage mode)
 };
 
 __global__ __launch_bounds__(256) void combiner_fwd_k(CombArgs a) {
@@ -99,7 +100,8 @@ __global__ __launch_bounds__(256) void combiner_fwd_k(CombArgs a) {
   for (int i = tid; i < a.Q * CT; i += 256) {
     const int q = i / CT, px = i - q * CT;
     const int pl = q / a.J, j = q - pl * a.J;
-    sH[i] = a.hm[pl][((long)b * a.J + j) * a.HW + p0 + px];
+    const long ho = ((long)b * a.J + j) * a.HW + p0 + px;
+    sH[i] = a.hm_bf16 ? __uint_as_float((unsigned)reinterpret_cast<const unsigned short*>(a.hm[pl])[ho] << 16) : a.hm[pl][ho];
   }
   __syncthreads();
   const int c4 = tid & 31, pr = tid >> 5;
@@ -147,7 +149,8 @@ __global__ __launch_bounds__(256) void combiner_bwd_k(CombArgs a) {
     for (int i = tid; i < a.Q * CT; i += 256) {
       const int q = i / CT, px = i - q * CT;
       const int pl = q / a.J, j = q - pl * a.J;
-      sH[i] = a.hm[pl][((long)b * a.J + j) * a.HW + p0 + px];
+      const long ho = ((long)b * a.J + j) * a.HW + p0 + px;
+    sH[i] = a.hm_bf16 ? __uint_as_float((unsigned)reinterpret_cast<const unsigned short*>(a.hm[pl])[ho] << 16) : a.hm[pl][ho];
     }
     for (int i = tid; i < CT * (CC / 4); i += 256) {
       const int px = i / (CC / 4), c4 = i - px * (CC / 4);
@@ -585,12 +588,23 @@ extern "C" int mpose_axis_permute(const float* const* in, float* const* out, con
   return launch_status();
 }
 
+static int combiner_fwd_impl(const void* const* hm, int hm_bf16, const float* w, const float* inp, float* out, int B, int J, int HW,
+                             int C, void* stream);
 extern "C" int mpose_combiner_fwd(const float* const* hm, const float* w, const float* inp, float* out, int B, int J, int HW, int C,
                                   void* stream) {
+  return combiner_fwd_impl(reinterpret_cast<const void* const*>(hm), 0, w, inp, out, B, J, HW, C, stream);
+}
+extern "C" int mpose_combiner_fwd_bf16(const void* const* hm, const float* w, const float* inp, float* out, int B, int J, int HW,
+                                       int C, void* stream) {
+  return combiner_fwd_impl(hm, 1, w, inp, out, B, J, HW, C, stream);
+}
+static int combiner_fwd_impl(const void* const* hm, int hm_bf16, const float* w, const float* inp, float* out, int B, int J, int HW,
+                             int C, void* stream) {
   if (C != CC || (HW % CT) || J < 1 || 3 * J > 2 * QH_MAX) return MPOSE_EINVAL;
   if (B == 0) return 0;
   CombArgs a{};
-  for (int p = 0; p < 3; ++p) a.hm[p] = hm[p];
+  a.hm_bf16 = hm_bf16;
+  for (int p = 0; p < 3; ++p) a.hm[p] = static_cast<const float*>(hm[p]);
   a.w = w; a.inp = inp; a.out = out; a.B = B; a.J = J; a.HW = HW; a.Q = 3 * J;
   const int lds = (a.Q * CC + a.Q * CT) * 4;
   combiner_fwd_k<<<B * (HW / CT), 256, lds, (hipStream_t)stream>>>(a);

@@ -99,7 +99,7 @@ struct SoftmaxArgs {
   int n_planes, rows, H, W;
 };
 
-template <int NV, bool BF16, bool EXP>
+template <int NV, bool BF_IN, bool BF_OUT, bool EXP>
 __global__ __launch_bounds__(64 * MPOSE_MAX_GROUP) void softmax_dsnt_fwd_k(SoftmaxArgs a) {
   __shared__ float s_mu[MPOSE_MAX_GROUP][2];
   const int plane = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(64 * MPOSE_MAX_GROUP) void softmax_dsnt_fwd_k(Softm
   const size_t off = (size_t)row * (size_t)(a.H * a.W);
 
   float4 v[NV];
-  if (BF16) load_row_bf16<NV>(reinterpret_cast<const unsigned short*>(a.logits[plane]) + off, lane, g.n4, v, EXP ? -INFINITY : 0.0f);
+  if (BF_IN) load_row_bf16<NV>(reinterpret_cast<const unsigned short*>(a.logits[plane]) + off, lane, g.n4, v, EXP ? -INFINITY : 0.0f);
   else load_row<NV>(reinterpret_cast<const float*>(a.logits[plane]) + off, lane, g.n4, v, EXP ? -INFINITY : 0.0f);
 
   float inv = 1.0f;
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(64 * MPOSE_MAX_GROUP) void softmax_dsnt_fwd_k(Softm
   sy = wave_sum(sy);
 
   if (EXP && a.heatmaps[plane] != nullptr) {
-    if (BF16) store_row_bf16<NV>(reinterpret_cast<unsigned short*>(a.heatmaps[plane]) + off, lane, g.n4, v);
+    if (BF_OUT) store_row_bf16<NV>(reinterpret_cast<unsigned short*>(a.heatmaps[plane]) + off, lane, g.n4, v);
     else store_row<NV>(reinterpret_cast<float*>(a.heatmaps[plane]) + off, lane, g.n4, v);
   }
   if (lane == 0) {
@@ -527,9 +527,11 @@ extern "C" int mpose_softmax_dsnt_fwd(const void* const* logits, void* const* he
   a.plane_coords = plane_coords; a.xyz = xyz; a.n_planes = n_planes; a.rows = rows; a.H = H; a.W = W;
   hipStream_t s = (hipStream_t)stream;
   if (io_dtype == 0) {
-    MPOSE_DISPATCH_NV(nv, (softmax_dsnt_fwd_k<NV, false, true><<<rows, 64 * n_planes, 0, s>>>(a)));
+    MPOSE_DISPATCH_NV(nv, (softmax_dsnt_fwd_k<NV, false, false, true><<<rows, 64 * n_planes, 0, s>>>(a)));
   } else if (io_dtype == 1) {
-    MPOSE_DISPATCH_NV(nv, (softmax_dsnt_fwd_k<NV, true, true><<<rows, 64 * n_planes, 0, s>>>(a)));
+    MPOSE_DISPATCH_NV(nv, (softmax_dsnt_fwd_k<NV, true, true, true><<<rows, 64 * n_planes, 0, s>>>(a)));
+  } else if (io_dtype == 2) {
+    MPOSE_DISPATCH_NV(nv, (softmax_dsnt_fwd_k<NV, false, true, true><<<rows, 64 * n_planes, 0, s>>>(a)));
   } else {
     return MPOSE_EINVAL;
   }
@@ -544,7 +546,7 @@ extern "C" int mpose_dsnt_fwd(const float* const* heatmaps, float* plane_coords,
   SoftmaxArgs a{};
   for (int p = 0; p < n_planes; ++p) { a.logits[p] = heatmaps[p]; a.heatmaps[p] = nullptr; }
   a.plane_coords = plane_coords; a.xyz = xyz; a.n_planes = n_planes; a.rows = rows; a.H = H; a.W = W;
-  MPOSE_DISPATCH_NV(nv, (softmax_dsnt_fwd_k<NV, false, false><<<rows, 64 * n_planes, 0, (hipStream_t)stream>>>(a)));
+  MPOSE_DISPATCH_NV(nv, (softmax_dsnt_fwd_k<NV, false, false, false><<<rows, 64 * n_planes, 0, (hipStream_t)stream>>>(a)));
   return launch_status();
 }
 

@@ -574,8 +574,11 @@ class Engine:
               'mpose_pack_weights')
 
     # ------------------------------------------------------------------ forward
-    def forward(self, x, train, save):
-        """x: (B, 3, S, S) NCHW device tensor.  Returns (heatmap lists [3][T], xyz of last stage, ctx)."""
+    def forward(self, x, train, save, hm_bf16=False):
+        """x: (B, 3, S, S) NCHW device tensor.  Returns (heatmap lists [3][T], xyz of last stage, ctx).
+        hm_bf16 (inference only): heatmaps are stored as bf16; the soft-argmax coordinates stay fp32."""
+        if hm_bf16 and (train or save):
+            raise _lib.MposeError('bf16 heatmaps are an inference storage mode (eval, no autograd)')
         L = lib()
         if isinstance(x, torch.Tensor) and x.dtype == torch.uint8 and x.is_cuda:
             x = x.contiguous()         # raw RGB frames: normalised on the fly by the stem's first load (mpose_frames_u8)
@@ -634,8 +637,9 @@ class Engine:
         for t in range(self.T):
             if t > 0:
                 new_inp = torch.empty_like(inp)
-                check(L.mpose_combiner_fwd(ptr_array([hms[p][t - 1] for p in range(3)]), ptr(self.combiners[t - 1]), ptr(inp),
-                                           ptr(new_inp), B, self.J, F * F, 128, st()), 'mpose_combiner_fwd')
+                check((L.mpose_combiner_fwd_bf16 if hm_bf16 else L.mpose_combiner_fwd)(
+                    ptr_array([hms[p][t - 1] for p in range(3)]), ptr(self.combiners[t - 1]), ptr(inp), ptr(new_inp), B, self.J, F * F, 128,
+                    st()), 'mpose_combiner_fwd')
                 inp = new_inp
             ctx['inps'].append(inp)
             cur = [inp, inp, inp]
@@ -695,15 +699,15 @@ class Engine:
                     stage_saved.append({'x': cur, 'c1': c1, 'sc': sc, 'c2': c2})
                 cur = outs
             logits = cur
-            heat = [torch.empty_like(l) for l in logits]
+            heat = [torch.empty_like(l, dtype=torch.bfloat16 if hm_bf16 else torch.float32) for l in logits]
             want_xyz = t == self.T - 1
             if want_xyz:
                 xyz = torch.empty(B, self.J, 3, **f32)
             t0 = self.timer.start() if self.timer is not None else None
             check(L.mpose_softmax_dsnt_fwd(ptr_array(logits), ptr_array(heat), None, ptr(xyz) if want_xyz else None, 3, B * self.J, F,
-                                           F, 0, st()), 'mpose_softmax_dsnt_fwd')
+                                           F, 2 if hm_bf16 else 0, st()), 'mpose_softmax_dsnt_fwd')
             if t0 is not None:      # algorithmic bytes: read logits once, write heatmaps once (+ coords)
-                self.timer.stop('tail:softmax_dsnt_fwd', t0, 3 * B * self.J * F * F * 8 + (B * self.J * 12 if want_xyz else 0))
+                self.timer.stop('tail:softmax_dsnt_fwd', t0, 3 * B * self.J * F * F * (6 if hm_bf16 else 8) + (B * self.J * 12 if want_xyz else 0))
             for p in range(3):
                 hms[p].append(heat[p])
             ctx['blocks'].append(stage_saved)

@@ -175,9 +175,13 @@ class MargiPoseModelInner(nn.Module):
         params = eng.param_list()
         T = self.n_stages
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params)):
+            if getattr(self, 'heatmap_dtype', torch.float32) != torch.float32:
+                raise _lib.MposeError('heatmap_dtype=bfloat16 is an inference storage mode: use model.eval() under torch.no_grad()')
             flat = _BackboneFn.apply(eng, self.training, x, *params)
             return list(flat[0:T]), list(flat[T:2 * T]), list(flat[2 * T:3 * T])
-        hms, _, _ = eng.forward(x, self.training, save=False)
+        bf16 = getattr(self, 'heatmap_dtype', torch.float32) == torch.bfloat16
+        hms, xyz, _ = eng.forward(x, self.training, save=False, hm_bf16=bf16)
+        object.__setattr__(self, '_last_xyz', xyz)
         return hms[0], hms[1], hms[2]
 
 
@@ -228,8 +232,22 @@ class MargiPoseModel(nn.Module):
     def heatmaps_to_coords(xy_hm, zy_hm, xz_hm):
         return dsntnn.heatmaps_to_coords(xy_hm, zy_hm, xz_hm)
 
+    @property
+    def heatmap_dtype(self):
+        """torch.float32 (the reference's) or torch.bfloat16: inference-only storage mode of BASELINE configs[1] -- heatmaps are
+        written (and read by the next stage's combiner) as bf16, the soft-argmax runs in fp32 on the unrounded softmax."""
+        return getattr(self.inner, 'heatmap_dtype', torch.float32)
+
+    @heatmap_dtype.setter
+    def heatmap_dtype(self, dtype):
+        if dtype not in (torch.float32, torch.bfloat16):
+            raise _lib.MposeError('heatmap_dtype must be torch.float32 or torch.bfloat16')
+        object.__setattr__(self.inner, 'heatmap_dtype', dtype)
+
     def forward(self, *inputs):
         self.xy_heatmaps, self.zy_heatmaps, self.xz_heatmaps = self.inner(*inputs)
+        if self.xy_heatmaps[-1].dtype == torch.bfloat16:        # coordinates of the fp32 soft-argmax (same kernel, before rounding)
+            return self.inner._last_xyz
         return self.heatmaps_to_coords(self.xy_heatmaps[-1], self.zy_heatmaps[-1], self.xz_heatmaps[-1])
 
 

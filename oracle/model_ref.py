@@ -167,8 +167,11 @@ def flat_softmax(x):
     return F.softmax(x.flatten(2), dim=-1).view_as(x)
 
 
-def inner_forward(sd, x, n_stages, train, axis_permutation=True):
-    """models/margipose_model.py:179-200 -- returns three lists (xy, zy, xz) of per-stage heatmaps."""
+def inner_forward(sd, x, n_stages, train, axis_permutation=True, heatmap_dtype=None, unrounded=None):
+    """models/margipose_model.py:179-200 -- returns three lists (xy, zy, xz) of per-stage heatmaps.
+    heatmap_dtype=torch.bfloat16 restates BASELINE configs[1] ("bf16 heatmaps + fp32 soft-argmax"): every stage's heatmaps
+    are rounded to bf16 where they are stored (what the next combiner reads); `unrounded` (a dict) receives the last
+    stage's softmax before rounding, from which the fp32 soft-argmax coordinates are taken."""
     inp = stem_forward(sd, x, train)
     spaces = PLANES if axis_permutation else ('xy', 'xy', 'xy')
     outs = {p: [] for p in PLANES}
@@ -178,7 +181,10 @@ def inner_forward(sd, x, n_stages, train, axis_permutation=True):
             inp = inp + F.conv2d(cat, sd['inner.hm_combiners.%d.conv.weight' % (t - 1)])   # :145-150,:195
         for p, space in zip(PLANES, spaces):
             logits = heatmap_column(sd, 'inner.%s_hm_cnns.%d' % (p, t), inp, space, train)
-            outs[p].append(flat_softmax(logits))
+            hm = flat_softmax(logits)
+            if unrounded is not None:
+                unrounded[p] = hm
+            outs[p].append(hm if heatmap_dtype is None else hm.to(heatmap_dtype).to(hm.dtype))
     return outs['xy'], outs['zy'], outs['xz']
 
 

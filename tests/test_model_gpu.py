@@ -384,3 +384,40 @@ def test_uint8_frames_are_normalised_on_device(stem):
     g_u = m.inner.xy_hm_cnns[0].down_layers[0].module[0].weight.grad
     assert float((out_u - out_f).abs().max()) < 2e-5, float((out_u - out_f).abs().max())     # (x/255 - mean)/std vs fma form: 1 ulp inputs
     assert float((g_u - g_f).norm() / g_f.norm()) < 5e-3
+
+
+def test_bf16_heatmap_inference_mode():
+    """BASELINE configs[1]: eval forward with bf16 heatmap storage + fp32 soft-argmax, against the oracle with the same
+    rounding points (heatmaps rounded to bf16 where stored / read by the next combiner, coordinates from the unrounded
+    softmax).  Tolerances: coordinates 1e-4 relative (the bar of the fp32 path: rounding happens at identical points, a
+    1-ulp disagreement of a single bf16 heatmap value moves the next stage's input by < 1e-6); heatmaps one bf16 ulp
+    (2^-8 relative) where the fp32 values straddle a rounding boundary."""
+    T, B, seed = 2, 2, 640
+    x, target, mask = W.seeded_inputs(seed + 1000, B)
+    m = build(T, seed, x, True).eval()
+    m.heatmap_dtype = torch.bfloat16
+    with torch.no_grad():
+        out = m(x.cuda())
+    assert out.dtype == torch.float32 and m.xy_heatmaps[0].dtype == torch.bfloat16 and len(m.zy_heatmaps) == T
+    sd = weights(T, seed, x, True)
+    sd = OrderedDict((k, v.double() if v.is_floating_point() else v) for k, v in sd.items())
+    un = {}
+    xy, zy, xz = R.inner_forward(sd, x.double(), T, False, True, heatmap_dtype=torch.bfloat16, unrounded=un)
+    ref = R.heatmaps_to_coords(un['xy'], un['zy'], un['xz'])
+    errs = {'coords': rel(out.cpu(), ref)}
+    for name, got, want in (('xy', m.xy_heatmaps, xy), ('zy', m.zy_heatmaps, zy), ('xz', m.xz_heatmaps, xz)):
+        for t in range(T):
+            g, w = got[t].float().cpu().double(), want[t]
+            ulp = float(((g - w).abs() / w.abs().clamp_min(1e-30)).max())
+            frac_diff = float((g != w).double().mean())
+            errs['hm_%s%d_ulp' % (name, t)] = ulp
+            assert ulp <= 2.0 ** -7 and frac_diff < 5e-3, (name, t, ulp, frac_diff)
+    print(errs)
+    assert errs['coords'] < TOL, errs
+    # the storage mode is inference-only
+    m.train()
+    with pytest.raises(Exception, match='inference'):
+        m(x.cuda())
+    m.heatmap_dtype = torch.float32
+    with pytest.raises(Exception):
+        m.heatmap_dtype = torch.float16
