@@ -34,19 +34,35 @@ SUBS['mfma_only'] = SUBS['no_b'] + SUBS['no_frag'] + SUBS['no_apath']
 SUBS['b_only'] = SUBS['no_frag'] + SUBS['no_apath']
 SUBS['frag_only'] = SUBS['no_b'] + SUBS['no_apath']
 
-src = open(os.path.join(B.CSRC, 'conv.hip')).read()
+SRC = os.environ.get('CONV_SRC', os.path.join(B.CSRC, 'conv.hip'))      # e.g. a worktree with the row-group patch applied
+PREFIX = os.environ.get('ABL_PREFIX', '')
+src = open(SRC).read()
+if PREFIX == 'rowg_':                       # the same ablations for the row-group K loop of the experiment patch
+    side = 'if (j < 9) { stage_piece(bnxt, j, sc_n, sh_n); load_piece(g2, j); }'
+    import re
+    frag_lines = [(l + '\n', '') for l in dict.fromkeys(re.findall(r'            (?:frag_addr\(b(?:cur|nxt), g[cn]\.t(?: \+ \d)?, fa\);|read_frags_g\([01], fa, af[AB]\);)[^\n]*', src))]
+    SUBS = {
+        'base': [],
+        'no_b': SUBS['no_b'],
+        'no_apath': [(side, '{ }')],
+        'no_aload': [(side, 'if (j < 9) { stage_piece(bnxt, j, sc_n, sh_n); }')],
+        'no_frag': frag_lines,
+        'no_loop': [('for (int G = g_begin; G < g_end; ++G) {', 'for (int G = g_begin; G < g_end && %s; ++G) {' % RT_FALSE)],
+    }
+    SUBS['mfma_only'] = SUBS['no_b'] + SUBS['no_apath'] + SUBS['no_frag']
 out_dir = os.path.join(B.PKG_DIR, '_abl')
 os.makedirs(out_dir, exist_ok=True)
 others = [os.path.splitext(s)[0] + '.o' for s in B.sources() if not s.endswith('conv.hip')]
 procs = []
 only = sys.argv[1:]
 for name, subs in SUBS.items():
-    if only and not any(name.startswith(o) for o in only):
+    if only and not any((PREFIX + name).startswith(o) for o in only):
         continue
     s = src
     for a, b in subs:
         assert s.count(a) >= 1, (name, a)
         s = s.replace(a, b)
+    name = PREFIX + name
     f = os.path.join(B.CSRC, '_abl_%s.hip' % name)         # next to conv.hip so that "common.h" resolves
     open(f, 'w').write(s)
     obj = os.path.join(out_dir, 'conv_%s.o' % name)
