@@ -1,0 +1,7 @@
+#!/bin/bash
+# Round-end check on one GPU box: full GPU test suite, smoke, default bench line, rocprofv3 profile of the same command.
+set -x
+timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -5
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('SMOKE OK')" 2>&1 | tail -3
+timeout 900 python bench.py > gpurun_out/bench_final.json 2> gpurun_out/bench_final.err; tail -c 600 gpurun_out/bench_final.json
+bash tools/profile.sh r1i > gpurun_out/profile_r1i.log 2>&1; tail -5 gpurun_out/profile_r1i.log
