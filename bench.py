@@ -217,7 +217,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     model.inner.engine().timer = None
-    loss_value = float(loss)
+    loss_value = float(loss.detach())
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
