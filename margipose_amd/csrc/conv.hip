@@ -589,22 +589,27 @@ int launch_conv(const ConvArgs& a0, int n_groups, hipStream_t s) {
   return launch_status();
 }
 
-// Split-K factor: one workgroup (4 waves, one per SIMD) owns a CU, so a launch runs in ceil(WGs / 256) rounds;
-// take the smallest KS in {1, 2, 4} whose last round is reasonably full.  The choice is made for a NOMINAL batch
-// of 32 images, not the actual one: the summation order of a sample then does not depend on how many other
-// samples share its launch, so a data-parallel shard reproduces the full batch's per-sample results bit for bit.
+// Split-K factor: one workgroup (4 waves, one per SIMD) owns a CU, so a launch runs in ceil(WGs / 256) rounds, and
+// every round pays a fixed cost (prologue burst, exchange, epilogue, workgroup turnover) next to its share of the K
+// loop.  Cost model in microseconds, constants from the round-1 ablations (tools/experiments/):
+//     rounds * (9.5 + exchange(ks) + ceil(n_iter / ks) * (0.65 + 0.49 * RN))
+// -- e.g. 128->128 @32^2: KS 1/2/4 = 207/174/213 predicted, 195/175/202 measured; 192->192 @16^2: 124/136/125
+// predicted, 98/108/103 measured (same order).  The choice is made for a NOMINAL batch of 32 images, not the actual
+// one: the summation order of a sample then does not depend on how many other samples share its launch, so a
+// data-parallel shard reproduces the full batch's per-sample results bit for bit.
 template <int RN>
 inline int pick_ks(const ConvArgs& a, int cmax, int n_groups) {
   const int n_iter = (a.g.Cin / KC) * a.g.cls[0].n_taps;
   const long m_nominal = 32l * a.g.GH * a.g.GW;
   int best = 1;
-  double best_eff = 0.0;
-  for (int ks = 1; ks <= 4; ks *= 2) {
+  double best_cost = 0.0;
+  for (int ks = 1; ks <= (RN > 1 ? 4 : 2); ks *= 2) {
     if (ks > 1 && n_iter < 2 * ks) break;
     const long wgs = ((m_nominal + 256 / ks - 1) / (256 / ks)) * a.g.n_classes * ((cmax + 32 * RN - 1) / (32 * RN)) * n_groups;
     const long rounds = (wgs + 255) / 256;
-    const double eff = (double)wgs / (256.0 * rounds);
-    if (eff > best_eff + 0.08) { best = ks; best_eff = eff; }
+    const double exchange = ks == 1 ? 0.0 : (ks == 2 ? 1.5 : 2.5);
+    const double cost = (double)rounds * (9.5 + exchange + (double)((n_iter + ks - 1) / ks) * (0.65 + 0.49 * RN));
+    if (ks == 1 || cost < 0.97 * best_cost) { best = ks; best_cost = cost; }     // ties go to the smaller split
   }
   return best;
 }

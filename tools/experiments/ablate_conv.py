@@ -31,6 +31,8 @@ SUBS['fix_no_store'] = [('            __builtin_amdgcn_raw_buffer_store_b32(__fl
                          '            if (%s) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[r]), rs_o, (int)(voff[r] + (unsigned)(rn * 128)), 0, 0);' % RT_FALSE)]
 SUBS['fix_no_exchange'] = [('    if (KS > 1) {\n      constexpr int BLK = 16 * 64;', '    if (KS > 1 && %s) {\n      constexpr int BLK = 16 * 64;' % RT_FALSE)]
 SUBS['mfma_only'] = SUBS['no_b'] + SUBS['no_frag'] + SUBS['no_apath']
+for _k in (1, 2, 4):                            # forced split-K factor (timing of the heuristic's alternatives)
+    SUBS['ks%d' % _k] = [('  return best;\n}', '  return %d;\n}' % _k)]
 SUBS['b_only'] = SUBS['no_frag'] + SUBS['no_apath']
 SUBS['frag_only'] = SUBS['no_b'] + SUBS['no_apath']
 
