@@ -193,3 +193,92 @@ def test_conv_sum_of_two_inputs(B, H, cin, cout):
     f32 = fn(x0, x1, w0, w1).double()
     got = out.cpu().double().permute(0, 3, 1, 2)
     _check(float((got - ref).abs().max() / ref.abs().max()), float((f32 - ref).abs().max() / ref.abs().max()))
+
+
+def _wgrad(L, _lib, eng, g, x_nhwc, gout_nhwc, cout, cin, T, npad, n_split, scale=None, shift=None, gout1=None, cout1=0):
+    """mpose_conv_wgrad into n_split partial buffers + mpose_unpack_wgrads -> torch-layout (Cout, Cin, kh*kw) gradient(s)."""
+    from margipose_amd._lib import WgradOperands
+    kpad = (cin + 31) // 32 * 32
+    part = torch.full((n_split * T * kpad * npad,), float('nan'), device='cuda')
+    wo = WgradOperands()
+    wo.in_, wo.gout0, wo.dw0 = x_nhwc.data_ptr(), gout_nhwc.data_ptr(), part.data_ptr()
+    if scale is not None:
+        wo.in_scale, wo.in_shift = scale.data_ptr(), shift.data_ptr()
+    part1 = None
+    if gout1 is not None:
+        part1 = torch.full((n_split * kpad * npad,), float('nan'), device='cuda')
+        wo.gout1, wo.dw1 = gout1.data_ptr(), part1.data_ptr()
+    _lib.check(L.mpose_conv_wgrad(ctypes.byref(g), (WgradOperands * 1)(wo), 1, n_split, _lib.stream_ptr()), 'wgrad')
+    outs = []
+    for p, co, t in ((part, cout, T), (part1, cout1, 1)):
+        if p is None:
+            continue
+        dw = torch.full((co, cin, t), float('nan'), device='cuda')
+        jobs = np.zeros(1, dtype=eng.UNPACK_DT)
+        j = jobs[0]
+        j['src'], j['dst'] = p.data_ptr(), dw.data_ptr()
+        j['N'], j['K'], j['T'], j['Npad'], j['Kpad'], j['n_split'] = co, cin, t, npad, kpad, n_split
+        j['sn'], j['sk'], j['st'], j['accumulate'] = cin * t, t, 1, 0
+        dev = eng._jobs_to_device(jobs, 'cuda')
+        _lib.check(L.mpose_unpack_wgrads(_lib.ptr(dev), 1, co * cin * t, _lib.stream_ptr()), 'unpack')
+        outs.append(dw)
+    torch.cuda.synchronize()
+    return outs
+
+
+def _wgrad_errs(dw, x, go, fn, shape):
+    """(kernel error, torch-fp32 error) of a weight gradient against float64 autograd, max-abs scaled by max |ref|."""
+    def grad(dtype):
+        w = torch.zeros(shape, dtype=dtype, requires_grad=True)
+        fn(x.to(dtype), w).backward(go.to(dtype))
+        return w.grad.double()
+    ref, f32 = grad(torch.float64), grad(torch.float32)
+    scale = ref.abs().max()
+    return float((dw.cpu().double().reshape(shape) - ref).abs().max() / scale), float((f32 - ref).abs().max() / scale)
+
+
+@pytest.mark.parametrize('B,H,cin,cout,n_split,pro', [(2, 32, 128, 128, 3, False), (4, 16, 192, 192, 2, True), (1, 16, 64, 96, 1, False),
+                                                   (3, 8, 32, 32, 4, True), (2, 24, 128, 64, 5, False)])
+def test_weight_gradient_fp32_equivalent(B, H, cin, cout, n_split, pro):
+    """conv_wgrad_k through mpose_conv_wgrad + mpose_unpack_wgrads: the weight gradient of a 3x3 convolution (optionally
+    of relu(scale*x+shift), the BN+ReLU prologue) must be as close to float64 autograd as torch's fp32 gradient is (same
+    2x gate as the forward kernel), for every tile shape, rows that do not fill a split, and several split-K factors."""
+    import torch.nn.functional as F
+    from margipose_amd import _lib, engine as eng
+    L = _lib.lib()
+    rng = np.random.default_rng(B * 100 + H + cin)
+    x = torch.from_numpy(rng.standard_normal((B, cin, H, H))).float()
+    go = torch.from_numpy(rng.standard_normal((B, cout, H, H))).float()
+    sc = torch.from_numpy(rng.uniform(0.5, 1.5, cin)).float()
+    sh = torch.from_numpy(rng.standard_normal(cin) * 0.3).float()
+    npad = (cout + 63) // 64 * 64
+    t9 = [(ky - 1, kx - 1, ky * 3 + kx, 0) for ky, kx in eng.TAPS3]
+    g = eng._geom(B, H, cin, H, cout, 0, H, 1, 1, [(0, 0, t9)], npad)
+    xg, gg = x.permute(0, 2, 3, 1).contiguous().cuda(), go.permute(0, 2, 3, 1).contiguous().cuda()
+    dw, = _wgrad(L, _lib, eng, g, xg, gg, cout, cin, 9, npad, n_split, sc.cuda() if pro else None, sh.cuda() if pro else None)
+
+    def fn(a, w):
+        if pro:
+            a = F.relu(a * sc.to(a.dtype).view(1, -1, 1, 1) + sh.to(a.dtype).view(1, -1, 1, 1))
+        return F.conv2d(a, w, padding=1)
+    e_gpu, e_f32 = _wgrad_errs(dw, x, go, fn, (cout, cin, 3, 3))
+    _check(e_gpu, e_f32)
+
+
+def test_weight_gradient_stride2_with_fused_shortcut():
+    """The down block's geometry: 3x3 stride 2 + 1x1 stride-2 shortcut in one launch (acc-1 tap -> second gradient)."""
+    import torch.nn.functional as F
+    from margipose_amd import _lib, engine as eng
+    L = _lib.lib()
+    B, H, cin, cout = 2, 32, 128, 192
+    rng = np.random.default_rng(77)
+    x = torch.from_numpy(rng.standard_normal((B, cin, H, H))).float()
+    go = torch.from_numpy(rng.standard_normal((B, cout, H // 2, H // 2))).float()
+    go1 = torch.from_numpy(rng.standard_normal((B, cout, H // 2, H // 2))).float()
+    npad = (cout + 63) // 64 * 64
+    t9 = [(ky - 1, kx - 1, ky * 3 + kx, 0) for ky, kx in eng.TAPS3]
+    g = eng._geom(B, H, cin, H // 2, cout, cout, H // 2, 2, 1, [(0, 0, t9 + [(0, 0, 0, 1)])], npad, npad)
+    to = lambda t: t.permute(0, 2, 3, 1).contiguous().cuda()
+    dw, dw1 = _wgrad(L, _lib, eng, g, to(x), to(go), cout, cin, 9, npad, 2, gout1=to(go1), cout1=cout)
+    _check(*_wgrad_errs(dw, x, go, lambda a, w: F.conv2d(a, w, stride=2, padding=1), (cout, cin, 3, 3)))
+    _check(*_wgrad_errs(dw1, x, go1, lambda a, w: F.conv2d(a, w, stride=2), (cout, cin, 1, 1)))
