@@ -17,6 +17,7 @@ c_int = ctypes.c_int
 c_float = ctypes.c_float
 c_int64 = ctypes.c_int64
 
+ABI_VERSION = 3          # must equal mpose_abi_version() of the library (csrc/tail.hip)
 MAX_GROUP = 3
 MAX_TAPS = 12
 MAX_CLASSES = 4
@@ -35,7 +36,7 @@ def lib():
                              'there is no CPU/PyTorch fallback for the MargiPose hot path.' % path)
         _LIB = ctypes.CDLL(path)
         _LIB.mpose_abi_version.restype = c_int
-        if _LIB.mpose_abi_version() != 3:
+        if _LIB.mpose_abi_version() != ABI_VERSION:
             raise MposeError('libmargipose_hip.so ABI version mismatch')
     return _LIB
 
