@@ -31,6 +31,17 @@ SUBS['fix_no_store'] = [('            __builtin_amdgcn_raw_buffer_store_b32(__fl
                          '            if (%s) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[r]), rs_o, (int)(voff[r] + (unsigned)(rn * 128)), 0, 0);' % RT_FALSE)]
 SUBS['fix_no_exchange'] = [('    if (KS > 1) {\n      constexpr int BLK = 16 * 64;', '    if (KS > 1 && %s) {\n      constexpr int BLK = 16 * 64;' % RT_FALSE)]
 SUBS['mfma_only'] = SUBS['no_b'] + SUBS['no_frag'] + SUBS['no_apath']
+# ---- weight-gradient kernel (conv_wgrad_k): what do the in-register splits and the operand loads cost?
+SUBS['wg_no_split'] = [('''#pragma unroll
+    for (int q = 0; q < 4; ++q) split2(v[2 * q], v[2 * q + 1], hh[q], mm[q], ll[q]);''',
+                        '''#pragma unroll
+    for (int q = 0; q < 4; ++q) { hh[q] = __float_as_uint(v[2 * q]); mm[q] = __float_as_uint(v[2 * q + 1]); ll[q] = hh[q]; }''')]
+SUBS['wg_no_loads'] = [('          load_g(ln2, nb);\n', ''),
+                        ('        if (kb + 1 < KB) { split_x(kb + 1, mask_q, an); load_x(ln1, kb + 1); }\n        else { split_x(0, mask_q1, an); load_x(ln2, 0); }',
+                         '        if (kb + 1 < KB) { split_x(kb + 1, mask_q, an); }\n        else { split_x(0, mask_q1, an); }')]
+SUBS['wg_mfma_only'] = SUBS['wg_no_split'] + SUBS['wg_no_loads']
+SUBS['wg_no_loop'] = [('    for (int q = 0; q < n_groups16; ++q) {\n      const Lane ln2 = next_lane();', '    for (int q = 0; q < n_groups16 && (a.n_split & 0x40000000); ++q) {\n      const Lane ln2 = next_lane();')]
+SUBS['wg_no_sched'] = [('        __builtin_amdgcn_sched_barrier(0);        // keep each region', '        // (ablation: no region fence)        // keep each region')]
 for _k in (1, 2, 4):                            # forced split-K factor (timing of the heuristic's alternatives)
     SUBS['ks%d' % _k] = [('  return best;\n}', '  return %d;\n}' % _k)]
 SUBS['b_only'] = SUBS['no_frag'] + SUBS['no_apath']
