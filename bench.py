@@ -69,8 +69,9 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--cpu-batch', type=int, default=8)
-    ap.add_argument('--overlap-wgrad', action='store_true', help='weight-gradient GEMMs on a side stream (+2-3 %% step rate; '
-                    'per-kernel durations then include GPU sharing, so the roofline block is less clean)')
+    ap.add_argument('--no-overlap-wgrad', action='store_true', help='keep the weight-gradient GEMMs on the main stream (the default '
+                    'runs them on a side stream, +2.3 %% step rate; the steps whose kernels are bracketed by HIP events for the '
+                    'roofline block always run serially, so per-kernel durations are clean)')
     return ap.parse_args()
 
 
@@ -178,7 +179,7 @@ def main():
     model = MargiPoseModel(CanonicalSkeletonDesc, args.stages, True, args.stem, 'jsd').to(device).train()
     parallel.broadcast_parameters(model)
     parallel.attach(model)
-    model.inner.engine().overlap_wgrad = args.overlap_wgrad
+    model.inner.engine().overlap_wgrad = not args.no_overlap_wgrad
     opt = torch.optim.SGD(model.parameters(), lr=0.01, momentum=0.9, fused=True)   # same arithmetic as bin/train_3d.py:339, one launch
     g = torch.Generator(device='cpu').manual_seed(12345 + rank)
     B = args.batch
@@ -201,7 +202,7 @@ def main():
 
     for _ in range(args.warmup):
         loss = step()
-    # Per-kernel HIP events (for the roofline block) bracket every conv / tail launch of EVERY FOURTH timed step:
+    # Per-kernel HIP events (for the roofline block) bracket every conv / tail launch of EVERY FIFTH timed step:
     # an event is a barrier packet between two kernels, and ~800 of them per step cost ~5 % of the step.
     timer = KernelTimer() if (rank == 0 and not args.no_kernel_timing) else None
     if timer is not None:
@@ -210,7 +211,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        on = timer is not None and i % 4 == 0
+        on = timer is not None and i % 5 == 0
         model.inner.engine().timer = timer if on else None
         timed_steps += int(on)
         loss = step()
@@ -240,7 +241,7 @@ def main():
                             'unpinned, random init)' if args.stem == 'inceptionv4' else
                             '%s (reference option, models/margipose_model.py:119-137; torchvision layers restated, unpinned, '
                             'random init)' % args.stem if args.stem.startswith('resnet') else
-                            'patch8 (in-repo deterministic stem; the InceptionV4 stem is available with --stem inceptionv4)'), 'parallelism': 'dp%d' % world, 'overlap_wgrad': bool(args.overlap_wgrad),
+                            'patch8 (in-repo deterministic stem; the InceptionV4 stem is available with --stem inceptionv4)'), 'parallelism': 'dp%d' % world, 'overlap_wgrad': (not args.no_overlap_wgrad) and world == 1,
                    'final_loss': loss_value},
     }
     if timer is not None:

@@ -435,7 +435,7 @@ class _GraphStem:
                     wo.in_, wo.in_scale, wo.in_shift = raw[src.name].data_ptr(), sc, sh
                     wo.gout0 = d_raw.data_ptr() + 4 * op.c0
                     wo.dw0 = eng.part_ptr(B, S, op.conv)
-                    eng.wgrad(self.geom(op, B, S, 'f'), [wo], eng.stem_n_split(B, S, op))
+                    eng.wgrad_async(self.geom(op, B, S, 'f'), [wo], eng.stem_n_split(B, S, op), [raw[src.name], d_raw])
                     if want_dsrc:
                         o = ConvOperands()
                         o.in_, o.w0 = d_raw.data_ptr() + 4 * op.c0, eng._wptr(op.conv, True)

@@ -309,7 +309,7 @@ def test_five_stage_model_runs():
 
 
 def test_overlap_wgrad_matches_serial():
-    """Side-stream weight gradients (opt-in) give bit-identical gradients to the serial schedule."""
+    """Side-stream weight gradients (the default schedule) give bit-identical gradients to the serial schedule."""
     from margipose_amd import dsntnn
     T, seed, B = 1, 91, 4
     x, target, mask = W.seeded_inputs(seed, B)
