@@ -539,9 +539,9 @@ class Engine:
         block's data-gradient chain and the small BatchNorm kernels.  `tensors` are the buffers it reads: their
         memory must not be recycled by the caching allocator before the side stream is done with them."""
         # Serial when a KernelTimer brackets the launches (clean durations) and under data parallelism: with a gloo process
-        # group on a shared GPU the side stream made the step 6x slower (568 vs 95 ms), and the RCCL path cannot be tried on
-        # the single-GPU boxes of this round -- enable it there once it has been measured on a multi-GPU node.
-        if not self.overlap_wgrad or self.timer is not None or self.dp is not None:
+        # group on a shared GPU the side stream made the step 2-6x slower (188-568 vs 95 ms), and the RCCL path cannot be tried
+        # on the single-GPU boxes of this round -- MPOSE_DP_OVERLAP=1 enables it for a measurement on a multi-GPU node.
+        if not self.overlap_wgrad or self.timer is not None or (self.dp is not None and not os.environ.get('MPOSE_DP_OVERLAP')):
             self.wgrad(g, ops, n_split)
             return
         main = torch.cuda.current_stream()
