@@ -1,12 +1,15 @@
 """Single-node data parallelism for the MargiPose hot path (net-new: the reference is single-device,
 SURVEY.md §8e): one process per GPU, a full replica each, LOCAL BatchNorm (each replica is exactly the
-reference computation on its shard), and ONE all-reduce (RCCL over xGMI; `nccl` backend on ROCm) of the flat
-fp32 gradient buffer per step.  No activation is ever exchanged.
+reference computation on its shard), and per-stage buckets of the flat fp32 gradient buffer, each
+summed by one asynchronous all-reduce (RCCL over xGMI; `nccl` backend on ROCm) that overlaps the rest of the backward pass
+(engine.Engine._finish_bucket).  No activation is ever exchanged.
 """
 import os
 
-import torch
-import torch.distributed as dist
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')     # dmabuf IPC (the only mode the host driver supports); before HIP starts
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 
 def init_from_env(backend=None):
