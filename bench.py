@@ -205,7 +205,7 @@ def main():
 
     for _ in range(args.warmup):
         loss = step()
-    # Per-kernel HIP events (for the roofline block) bracket every conv / tail launch of EVERY FIFTH timed step:
+    # Per-kernel HIP events (for the roofline block) bracket every conv / tail launch of EVERY TENTH timed step (steps 0, 10, ...):
     # an event is a barrier packet between two kernels, and ~800 of them per step cost ~5 % of the step.
     timer = KernelTimer() if (rank == 0 and not args.no_kernel_timing) else None
     if timer is not None:
@@ -214,7 +214,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        on = timer is not None and i % 5 == 0
+        on = timer is not None and i % 10 == 0
         model.inner.engine().timer = timer if on else None
         timed_steps += int(on)
         loss = step()
