@@ -29,6 +29,8 @@ SUBS['fix_tap_const'] = [('''  const int lane_tap = (int)(threadIdx.x & 63) < MP
 SUBS['fix_no_masks'] = [('      if ((unsigned)iy < (unsigned)g.IH && (unsigned)ix < (unsigned)g.IW) row_taps[j] |= 1u << t;', '      row_taps[j] |= 1u << t;')]
 SUBS['fix_no_store'] = [('            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[r]), rs_o, (int)(voff[r] + (unsigned)(rn * 128)), 0, 0);',
                          '            if (%s) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[r]), rs_o, (int)(voff[r] + (unsigned)(rn * 128)), 0, 0);' % RT_FALSE)]
+SUBS['fix_few_masks'] = [('          for (int t = 0; t < n_taps; ++t) mark_tap(t);\n', '')]      # only the first two taps get masks (others read as padding)
+SUBS['fix_double_masks'] = [('          for (int t = 0; t < n_taps; ++t) mark_tap(t);\n', '          for (int t = 0; t < n_taps; ++t) mark_tap(t);\n          for (int t = n_taps - 1; t >= 0; --t) mark_tap(t);\n          for (int t = 0; t < n_taps; t += 1) mark_tap((t * 7) % n_taps);\n')]      # the mask loop three times (idempotent): its cost x2 on top
 SUBS['fix_no_exchange'] = [('    if (KS > 1) {\n      constexpr int BLK = 16 * 64;', '    if (KS > 1 && %s) {\n      constexpr int BLK = 16 * 64;' % RT_FALSE)]
 SUBS['mfma_only'] = SUBS['no_b'] + SUBS['no_frag'] + SUBS['no_apath']
 # ---- weight-gradient kernel (conv_wgrad_k): what do the in-register splits and the operand loads cost?
