@@ -34,7 +34,7 @@ extern "C" {
 
 int mpose_abi_version(void);
 /* sizeof() of the ABI structs, for binding self-checks: which = 0 geom, 1 conv operands, 2 wgrad
- * operands, 3 pack job, 4 unpack job, 5 bn job, 6 bn coef job, 7 bn_add ops, 8 reduce ops, 9 apply ops. */
+ * operands, 3 pack job, 4 unpack job, 5 bn job, 6 bn coef job, 7 bn_add ops, 8 reduce ops, 9 apply ops, 10 split ops. */
 int mpose_sizeof(int which);
 
 /* ------------------------------------------------------------------------------------------
@@ -145,6 +145,13 @@ typedef struct {
 } mpose_conv_operands;
 
 #define MPOSE_CONV_ACCUMULATE 1   /* out0 += result */
+#define MPOSE_CONV_PLANES_IN 4    /* `in` / `in1` are pre-split activations: three bf16 planes (hi, mid, lo) in the blocked
+                                   * layout P8[Cin/8][plane][B*IH*IW][8] (mpose_split_planes and the *_planes outputs of the
+                                   * BatchNorm kernels write it), `w0` / `w1` are packed with layout 1; in_scale must be NULL
+                                   * (the producer already applied BatchNorm + ReLU) and in_ld 0.  Runs conv_p.hip's engine:
+                                   * both operands reach LDS by DMA, two workgroups per CU. */
+#define MPOSE_CONV_BF16 8         /* with MPOSE_CONV_PLANES_IN: multiply the hi planes only (bf16 x bf16 -> fp32, one MFMA per
+                                   * fragment pair): the reduced-precision mode of BASELINE configs[4], NOT fp32-equivalent */
 #define MPOSE_CONV_SUM_INPUTS 2   /* taps with acc == 1 read `in1` through `w1` and add into out0 (one pass, one
                                    * output): the data-gradient of a ResidualBlock's input, dX = conv_in^T(dC1) +
                                    * shortcut^T(dSC), models/margipose_model.py:39 */
@@ -179,9 +186,12 @@ int mpose_conv_wgrad(const mpose_conv_geom* geom, const mpose_wgrad_operands* op
 /* Batched weight (re)packing and gradient un-packing; jobs live in device memory. */
 typedef struct {
   const float* src;                    /* torch-layout weight */
-  float* dst;                          /* packed bf16 planes [T][Kpad/16][3 (hi,mid,lo)][Npad][2][8]: 1.5 floats per element */
+  float* dst;                          /* packed bf16 planes, 1.5 floats per element:
+                                        *   layout 0: [T][Kpad/16][3 (hi,mid,lo)][Npad][2][8]   (conv.hip: fragments from L2)
+                                        *   layout 1: [T][Kpad/16][3][2 (k half)][Npad][8]      (conv_p.hip: B tiles by DMA) */
   int N, K, T, Npad, Kpad;
   int64_t sn, sk, st;                  /* element strides of n, k, tap in src */
+  int layout;
 } mpose_pack_job;
 
 int mpose_pack_weights(const mpose_pack_job* jobs_dev, int n_jobs, int max_elems_per_job,
@@ -197,6 +207,22 @@ typedef struct {
 
 int mpose_unpack_wgrads(const mpose_unpack_job* jobs_dev, int n_jobs, int max_elems_per_job,
                         void* stream);
+
+/* Pre-split activations for MPOSE_CONV_PLANES_IN (csrc/split.hip): three bf16 planes hi/mid/lo with x = hi + mid + lo
+ * (to 2^-27 |x|) in the blocked layout P8[C/8][plane][npix][8]; mpose_planes_bytes gives the buffer size.  Every
+ * elementwise pass that feeds a convolution has a variant that writes this layout directly:
+ *   mpose_split_planes         planes = split([relu](scale*src + shift)), scale NULL = identity (src NHWC fp32, C % 8 == 0):
+ *                              the BatchNorm + ReLU between a ResidualBlock's convolutions (models/margipose_model.py:31-33)
+ *   mpose_bn_add_planes        mpose_bn_add_fwd (layout 0) with the sum also (ops[i].out may be NULL: only) written as planes
+ *   mpose_bn_bwd_apply_planes  mpose_bn_bwd_apply with da / db also (ops[i].da / .db may be NULL: only) written as planes */
+typedef struct {
+  const float* src;
+  const float* scale;
+  const float* shift;
+  void* planes;
+} mpose_split_operands;
+int64_t mpose_planes_bytes(int64_t npix, int C);
+int mpose_split_planes(const mpose_split_operands* ops, int n_groups, int64_t npix, int C, int relu, void* stream);
 
 /* BatchNorm pieces (models/margipose_model.py:31,34,37; train = batch statistics, biased variance,
  * eps 1e-5; running update momentum 0.1 with unbiased variance). */
@@ -233,6 +259,8 @@ typedef struct {
 
 int mpose_bn_add_fwd(const mpose_bn_add_operands* ops, int n_groups, int pixels_per_image, int B,
                      int C, int layout, int c_keep, void* stream);
+int mpose_bn_add_planes(const mpose_bn_add_operands* ops, void* const* planes, int n_groups, int64_t npix, int C,
+                        void* stream);
 
 /* out = relu(x*scale + shift) over an NHWC tensor of n elements with C channels (the stem's BN+ReLU,
  * materialised because every column of every stage reads it), and the ReLU backward gm = g*[y>0]. */
@@ -265,6 +293,8 @@ typedef struct {
 
 int mpose_bn_bwd_apply(const mpose_bn_bwd_apply_operands* ops, int n_groups, int pixels_per_image,
                        int B, int C, int layout, int c_keep, void* stream);
+int mpose_bn_bwd_apply_planes(const mpose_bn_bwd_apply_operands* ops, void* const* da_planes, void* const* db_planes,
+                              int n_groups, int64_t npix, int C, void* stream);
 
 typedef struct {
   const double* sums;                  /* (Cs, 3) from mpose_bn_bwd_reduce, or (Cs, 2) from a conv epilogue */
@@ -277,9 +307,11 @@ typedef struct {
   int c_stride;                        /* storage channels (row length of coef) */
   int count;
   int sg_col;                          /* column of `sums` holding sum g for this BN */
+  float* dconv_bias;                   /* optional: gradient of the producing conv's bias (zero in train mode, where the
+                                        * batch mean removes the bias; gamma*invstd*sum g with frozen statistics) */
 } mpose_bn_bwd_coef_job;
 
-int mpose_bn_bwd_coef(const mpose_bn_bwd_coef_job* jobs_dev, int n_jobs, void* stream);
+int mpose_bn_bwd_coef(const mpose_bn_bwd_coef_job* jobs_dev, int n_jobs, int eval_mode, void* stream);
 
 /* 3x3 pooling over NHWC with the producer's BN+ReLU applied on the fly (scale/shift may be NULL = identity).
  * kind 0: max pool, stride 2, pad 1 (the reference rewrites MaxPool2d padding to k//2, models/margipose_model.py:111-117);

@@ -17,7 +17,7 @@ c_int = ctypes.c_int
 c_float = ctypes.c_float
 c_int64 = ctypes.c_int64
 
-ABI_VERSION = 3          # must equal mpose_abi_version() of the library (csrc/tail.hip)
+ABI_VERSION = 5          # must equal mpose_abi_version() of the library (csrc/tail.hip)
 MAX_GROUP = 3
 MAX_TAPS = 12
 MAX_CLASSES = 4
@@ -38,6 +38,8 @@ def lib():
         _LIB.mpose_abi_version.restype = c_int
         if _LIB.mpose_abi_version() != ABI_VERSION:
             raise MposeError('libmargipose_hip.so ABI version mismatch')
+        _LIB.mpose_planes_bytes.restype = c_int64
+        _LIB.mpose_planes_bytes.argtypes = [c_int64, c_int]
     return _LIB
 
 
@@ -107,6 +109,10 @@ class WgradOperands(ctypes.Structure):
 class BnAddOperands(ctypes.Structure):
     _fields_ = [('a', c_void_p), ('a_scale', c_void_p), ('a_shift', c_void_p),
                 ('b', c_void_p), ('b_scale', c_void_p), ('b_shift', c_void_p), ('out', c_void_p)]
+
+
+class SplitOperands(ctypes.Structure):
+    _fields_ = [('src', c_void_p), ('scale', c_void_p), ('shift', c_void_p), ('planes', c_void_p)]
 
 
 class BnBwdReduceOperands(ctypes.Structure):

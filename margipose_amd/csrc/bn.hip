@@ -98,7 +98,7 @@ struct BnReduceArgs {
 };
 
 __global__ __launch_bounds__(256) void bn_bwd_reduce_k(BnReduceArgs a) {
-  extern __shared__ float sred[];      // [rows_per_pass][C][4]
+  extern __shared__ double sred[];     // [rows_per_pass][C][4]
   const mpose_bn_bwd_reduce_operands& op = a.op[blockIdx.y];
   const int c4n = a.C >> 2;
   const int rows_per_pass = 256 / c4n;
@@ -106,25 +106,28 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_k(BnReduceArgs a) {
   const bool active = row0 < rows_per_pass;
   const bool has_b = op.b != nullptr;
   const bool masked = op.a_scale != nullptr;
-  float4 sga0 = make_float4(0.f, 0.f, 0.f, 0.f), sga1 = sga0, sg = sga0, sgb = sga0;
+  // fp64 accumulators (products exact): dbeta = sum g and the shortcut's sum g*b are sums with heavy cancellation -- g is a
+  // transposed convolution of zero-mean maps -- and fp32 partial sums showed up as a 2.4x excess over the fp32 reference on
+  // exactly those gradients in the round-2 parity bisect.  The pass is HBM-bound; the fp64 adds are free.
+  double sga0[4] = {0., 0., 0., 0.}, sga1[4] = {0., 0., 0., 0.}, sg[4] = {0., 0., 0., 0.}, sgb[4] = {0., 0., 0., 0.};
   const long p_begin = (long)blockIdx.x * a.pix_per_block;
   const long p_end = min(a.npix, p_begin + a.pix_per_block);
   if (active) {
     float4 ms = make_float4(0.f, 0.f, 0.f, 0.f), mt = ms;
     if (masked) { ms = *reinterpret_cast<const float4*>(op.a_scale + col4 * 4); mt = *reinterpret_cast<const float4*>(op.a_shift + col4 * 4); }
     auto accumulate = [&](const float4 g, const float4 x, const float4 y) {
-      float4 ga = g;
-      if (masked) {
-        if (!(fmaf(x.x, ms.x, mt.x) > 0.f)) ga.x = 0.f;
-        if (!(fmaf(x.y, ms.y, mt.y) > 0.f)) ga.y = 0.f;
-        if (!(fmaf(x.z, ms.z, mt.z) > 0.f)) ga.z = 0.f;
-        if (!(fmaf(x.w, ms.w, mt.w) > 0.f)) ga.w = 0.f;
-      }
-      sga0.x += ga.x; sga0.y += ga.y; sga0.z += ga.z; sga0.w += ga.w;
-      sga1.x = fmaf(ga.x, x.x, sga1.x); sga1.y = fmaf(ga.y, x.y, sga1.y); sga1.z = fmaf(ga.z, x.z, sga1.z); sga1.w = fmaf(ga.w, x.w, sga1.w);
-      if (has_b) {
-        sg.x += g.x; sg.y += g.y; sg.z += g.z; sg.w += g.w;
-        sgb.x = fmaf(g.x, y.x, sgb.x); sgb.y = fmaf(g.y, y.y, sgb.y); sgb.z = fmaf(g.z, y.z, sgb.z); sgb.w = fmaf(g.w, y.w, sgb.w);
+      const float gv[4] = {g.x, g.y, g.z, g.w}, xv[4] = {x.x, x.y, x.z, x.w}, yv[4] = {y.x, y.y, y.z, y.w};
+      const float msv[4] = {ms.x, ms.y, ms.z, ms.w}, mtv[4] = {mt.x, mt.y, mt.z, mt.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const double gd = (double)gv[e];
+        const double ga = (masked && !(fmaf(xv[e], msv[e], mtv[e]) > 0.f)) ? 0.0 : gd;
+        sga0[e] += ga;
+        sga1[e] = fma(ga, (double)xv[e], sga1[e]);
+        if (has_b) {
+          sg[e] += gd;
+          sgb[e] = fma(gd, (double)yv[e], sgb[e]);
+        }
       }
     };
     const float4* pg = reinterpret_cast<const float4*>(op.g);
@@ -147,17 +150,15 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_k(BnReduceArgs a) {
       const long o = p * c4n + col4;
       accumulate(pg[o], pa[o], has_b ? pb[o] : make_float4(0.f, 0.f, 0.f, 0.f));
     }
-    float* d = sred + ((long)row0 * a.C + col4 * 4) * 4;
-    d[0] = sga0.x; d[1] = sga1.x; d[2] = sg.x; d[3] = sgb.x;
-    d[4] = sga0.y; d[5] = sga1.y; d[6] = sg.y; d[7] = sgb.y;
-    d[8] = sga0.z; d[9] = sga1.z; d[10] = sg.z; d[11] = sgb.z;
-    d[12] = sga0.w; d[13] = sga1.w; d[14] = sg.w; d[15] = sgb.w;
+    double* d = sred + ((long)row0 * a.C + col4 * 4) * 4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { d[4 * e] = sga0[e]; d[4 * e + 1] = sga1[e]; d[4 * e + 2] = sg[e]; d[4 * e + 3] = sgb[e]; }
   }
   __syncthreads();
   for (int c = threadIdx.x; c < a.C; c += 256) {
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
     for (int r = 0; r < rows_per_pass; ++r) {
-      const float* d = sred + ((long)r * a.C + c) * 4;
+      const double* d = sred + ((long)r * a.C + c) * 4;
       s0 += d[0]; s1 += d[1]; s2 += d[2]; s3 += d[3];
     }
     atomicAdd(op.sums + (size_t)c * 4, s0);
@@ -166,7 +167,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_k(BnReduceArgs a) {
   }
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_coef_k(const mpose_bn_bwd_coef_job* __restrict__ jobs) {
+// eval_mode: the forward normalised with the RUNNING statistics (constants), so dx = gamma*invstd*g (c1 = c2 = 0);
+// dgamma / dbeta keep their formulas with mean / invstd = the running ones (bn_finalize_k stores them in eval mode too).
+__global__ __launch_bounds__(256) void bn_bwd_coef_k(const mpose_bn_bwd_coef_job* __restrict__ jobs, int eval_mode) {
   const mpose_bn_bwd_coef_job j = jobs[blockIdx.x];
   const double n = (double)j.count;
   for (int c = threadIdx.x; c < j.C; c += 256) {
@@ -175,12 +178,13 @@ __global__ __launch_bounds__(256) void bn_bwd_coef_k(const mpose_bn_bwd_coef_job
     const double mean = (double)j.mean[c], invstd = (double)j.invstd[c], gamma = (double)j.gamma[c];
     const double sgxhat = invstd * (sgx - mean * sg);
     const double c0 = gamma * invstd;
-    const double c1 = -c0 * invstd * (sgxhat / n);
-    const double c2 = -c0 * (sg / n) - c1 * mean;
+    const double c1 = eval_mode ? 0.0 : -c0 * invstd * (sgxhat / n);
+    const double c2 = eval_mode ? 0.0 : -c0 * (sg / n) - c1 * mean;
     j.coef[c] = (float)c0;
     j.coef[j.c_stride + c] = (float)c1;
     j.coef[2 * j.c_stride + c] = (float)c2;
     if (j.dgamma != nullptr) { j.dgamma[c] = (float)sgxhat; j.dbeta[c] = (float)sg; }
+    if (j.dconv_bias != nullptr) j.dconv_bias[c] = eval_mode ? (float)(c0 * sg) : 0.f;
   }
 }
 
@@ -272,6 +276,7 @@ extern "C" int mpose_sizeof(int which) {
     case 7: return (int)sizeof(mpose_bn_add_operands);
     case 8: return (int)sizeof(mpose_bn_bwd_reduce_operands);
     case 9: return (int)sizeof(mpose_bn_bwd_apply_operands);
+    case 10: return (int)sizeof(mpose_split_operands);
     default: return -1;
   }
 }
@@ -314,14 +319,14 @@ extern "C" int mpose_bn_bwd_reduce(const mpose_bn_bwd_reduce_operands* ops, int 
   int blocks = grid_for(a.npix, rows_per_pass * 16);
   if (blocks > 512) blocks = 512;
   a.pix_per_block = (int)((a.npix + blocks - 1) / blocks);
-  const int lds = rows_per_pass * C * 4 * 4;
+  const int lds = rows_per_pass * C * 4 * 8;
   bn_bwd_reduce_k<<<dim3(blocks, n_groups), 256, lds, (hipStream_t)stream>>>(a);
   return launch_status();
 }
 
-extern "C" int mpose_bn_bwd_coef(const mpose_bn_bwd_coef_job* jobs_dev, int n_jobs, void* stream) {
+extern "C" int mpose_bn_bwd_coef(const mpose_bn_bwd_coef_job* jobs_dev, int n_jobs, int eval_mode, void* stream) {
   if (n_jobs <= 0) return 0;
-  bn_bwd_coef_k<<<n_jobs, 256, 0, (hipStream_t)stream>>>(jobs_dev);
+  bn_bwd_coef_k<<<n_jobs, 256, 0, (hipStream_t)stream>>>(jobs_dev, eval_mode);
   return launch_status();
 }
 

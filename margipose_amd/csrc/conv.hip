@@ -1,6 +1,6 @@
 // Implicit-GEMM convolution engine for gfx950: fp32 convolutions computed on the bf16 matrix cores with
-// 3-way split operands ("bf16x6", fp32-equivalent accuracy; see conv_igemm_k) -- and, for the weight
-// gradient, on the exact-fp32 v_mfma_f32_32x32x2_f32.
+// 3-way split operands ("bf16x6", fp32-equivalent accuracy; see conv_igemm_k), forward, data-gradient and
+// weight-gradient alike.  (conv_p.hip holds the round-2 engine that reads PRE-SPLIT activations.)
 //
 // Replaces every Conv2d / ConvTranspose2d of reference src/margipose/models/margipose_model.py
 // (:33, :67-68, :73-74, :79-82), their data-gradients and their weight-gradients.  One kernel
@@ -941,7 +941,8 @@ inline int wgrad_blocks(int c) { return c % 128 == 0 ? 4 : (c % 96 == 0 ? 3 : (c
 // ---------------------------------------------------------------------------------------------
 // Weight packing / gradient unpacking (one launch for all convolutions of the model)
 // ---------------------------------------------------------------------------------------------
-// dst layout (bf16): [T][Kpad/16][plane 3][Npad][half 2][8]  -- one 16-byte MFMA B fragment per (n, half)
+// dst layout (bf16): [T][Kpad/16][plane 3][Npad][half 2][8]  -- one 16-byte MFMA B fragment per (n, half);
+// layout 1 (conv_p.hip): [T][Kpad/16][plane 3][half 2][Npad][8] -- 64 consecutive columns of a half = one 1 KiB DMA
 __global__ __launch_bounds__(256) void pack_weights_k(const mpose_pack_job* __restrict__ jobs) {
   const mpose_pack_job j = jobs[blockIdx.y];
   const long total = (long)j.T * j.Kpad * j.Npad;
@@ -960,7 +961,8 @@ __global__ __launch_bounds__(256) void pack_weights_k(const mpose_pack_job* __re
     const float r1 = v - (float)h;
     const __bf16 m = (__bf16)r1;
     const __bf16 l = (__bf16)(r1 - (float)m);
-    __bf16* d = dst + ((long)(t * (j.Kpad / 16) + k16) * 3) * plane + (long)n * 16 + k_lo;
+    __bf16* d = dst + ((long)(t * (j.Kpad / 16) + k16) * 3) * plane +
+                (j.layout == 1 ? ((long)(k_lo >> 3) * j.Npad + n) * 8 + (k_lo & 7) : (long)n * 16 + k_lo);
     d[0] = h; d[plane] = m; d[2 * plane] = l;
   }
 }
@@ -1001,6 +1003,9 @@ __global__ __launch_bounds__(256) void unpack_wgrads_k(const mpose_unpack_job* _
 
 using namespace mpose;
 
+int mpose_conv_planes_launch(const mpose_conv_geom* geom, const mpose_conv_operands* ops, int n_groups, int flags, int mode,
+                             int cmax, void* stream);      // conv_p.hip
+
 static int check_geom(const mpose_conv_geom* g) {
   if (!g || g->Cin <= 0 || (g->Cin % KC) || g->n_classes < 1 || g->n_classes > MPOSE_MAX_CLASSES) return MPOSE_EINVAL;
   if (g->Npad0 <= 0 || (g->Npad0 % 32)) return MPOSE_EINVAL;
@@ -1038,6 +1043,15 @@ extern "C" int mpose_conv_fwd(const mpose_conv_geom* geom, const mpose_conv_oper
   if (acc1 && geom->Npad1 != geom->Npad0) return MPOSE_EINVAL;
   a.M = geom->B * geom->GH * geom->GW;
   if (a.M == 0) return 0;
+  if (flags & MPOSE_CONV_PLANES_IN) {      // pre-split activations: conv_p.hip
+    if (ops[0].in_scale || (geom->Cout0 % 32) || (acc1 && (geom->Cout1 % 32)) || (geom->Npad0 % 64)) return MPOSE_EINVAL;
+    const int cm = (acc1 && geom->Cout1 > geom->Cout0) ? geom->Cout1 : geom->Cout0;
+    if (cm > geom->Npad0) return MPOSE_EINVAL;
+    const int ldm = geom->out_ld0 > geom->out_ld1 ? geom->out_ld0 : geom->out_ld1;
+    if ((long)geom->B * geom->OH * geom->OW * (ldm > cm ? ldm : cm) * 4 >= 0xFFFFF000l) return MPOSE_EINVAL;
+    return mpose_conv_planes_launch(geom, ops, n_groups, flags, sum_inputs ? 2 : (acc1 ? 1 : 0), cm, stream);
+  }
+  if (flags & MPOSE_CONV_BF16) return MPOSE_EINVAL;
   a.div_gw = make_fastdiv((unsigned)geom->GW);
   a.div_ghw = make_fastdiv((unsigned)(geom->GH * geom->GW));
   a.flags = flags;

@@ -120,9 +120,7 @@ __global__ __launch_bounds__(64 * MPOSE_MAX_GROUP) void softmax_dsnt_fwd_k(Softm
     float s = 0.0f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      // v_exp_f32 (1 ulp on 2^x): the argument scaling costs |x| * 6e-8 relative error, i.e. only probabilities
-      // that are already ~0 lose digits; the dominant entries (x - m ~ 0) are exact to fp32 rounding.
-      v[i].x = __expf(v[i].x - m); v[i].y = __expf(v[i].y - m); v[i].z = __expf(v[i].z - m); v[i].w = __expf(v[i].w - m);
+      v[i].x = expf(v[i].x - m); v[i].y = expf(v[i].y - m); v[i].z = expf(v[i].z - m); v[i].w = expf(v[i].w - m);
       s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
     }
     s = wave_sum(s);
@@ -191,18 +189,19 @@ __device__ __forceinline__ Gauss make_gauss(const RowGeom& g, int lane, float tx
 }
 
 // JS integrand for one element (dsntnn.py:198-207) and its derivative w.r.t. p (SURVEY §8 a-T).
+// IEEE division and logf (not v_rcp / v_log): the log RATIOS are O(0.1..1) whenever p is close to the target, so the
+// ~1e-7 ABSOLUTE error of the fast forms was a ~4e-6 relative error on the loss gradient that every layer below then
+// inherited (round-2 gradient-parity bisect, tests/test_grad_parity_gpu.py); these kernels are latency-bound anyway.
 __device__ __forceinline__ float js_term(float p, float gq) {
   const float m = 0.5f * (p + gq);
-  const float rm = __frcp_rn(m + kEps);
-  const float lp = __logf((p + kEps) * rm);
-  const float lg = __logf((gq + kEps) * rm);
+  const float lp = logf((p + kEps) / (m + kEps));
+  const float lg = logf((gq + kEps) / (m + kEps));
   return 0.5f * (p * lp + gq * lg);
 }
 __device__ __forceinline__ float js_dp(float p, float gq) {
   const float m = 0.5f * (p + gq);
-  const float rm = __frcp_rn(m + kEps);
-  const float lp = __logf((p + kEps) * rm);
-  return 0.5f * (lp + p * __frcp_rn(p + kEps) - m * rm);
+  const float lp = logf((p + kEps) / (m + kEps));
+  return 0.5f * (lp + p / (p + kEps) - m / (m + kEps));
 }
 
 struct LossArgs {
@@ -248,7 +247,7 @@ __global__ __launch_bounds__(64 * MPOSE_MAX_GROUP) void stage_loss_fwd_k(LossArg
     if (a.pixelwise && fixed_cols) {
       const int w0 = (lane * 4) % g.W;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) { const float d = cell_coord(w0 + c, g.two_over_w, g.first_w) - q.tx; gx_fixed[c] = __expf(d * d * q.kx); }
+      for (int c = 0; c < 4; ++c) { const float d = cell_coord(w0 + c, g.two_over_w, g.first_w) - q.tx; gx_fixed[c] = expf(d * d * q.kx); }
     }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -260,14 +259,14 @@ __global__ __launch_bounds__(64 * MPOSE_MAX_GROUP) void stage_loss_fwd_k(LossArg
       const float rs = (pv[0] + pv[1]) + (pv[2] + pv[3]);
       sy = fmaf(rs, y, sy);
       float gy = 0.0f;
-      if (a.pixelwise) { const float d = y - q.ty; gy = __expf(d * d * q.ky) * q.inv_norm; }
+      if (a.pixelwise) { const float d = y - q.ty; gy = expf(d * d * q.ky) * q.inv_norm; }
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const float x = x0 + (float)c * g.two_over_w;
         sx = fmaf(pv[c], x, sx);
         if (a.pixelwise && (i * 64 + lane) < g.n4) {
           float gxv = gx_fixed[c];
-          if (!fixed_cols) { const float d = x - q.tx; gxv = __expf(d * d * q.kx); }
+          if (!fixed_cols) { const float d = x - q.tx; gxv = expf(d * d * q.kx); }
           js += js_term(pv[c], gy * gxv);
         }
       }
@@ -335,7 +334,7 @@ __global__ __launch_bounds__(64 * MPOSE_MAX_GROUP) void stage_loss_bwd_k(LossArg
   if (a.pixelwise && fixed_cols) {
     const int w0f = (lane * 4) % g.W;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) { const float d = cell_coord(w0f + c, g.two_over_w, g.first_w) - q.tx; gx_fixed[c] = __expf(d * d * q.kx); }
+    for (int c = 0; c < 4; ++c) { const float d = cell_coord(w0f + c, g.two_over_w, g.first_w) - q.tx; gx_fixed[c] = expf(d * d * q.kx); }
   }
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
@@ -344,7 +343,7 @@ __global__ __launch_bounds__(64 * MPOSE_MAX_GROUP) void stage_loss_bwd_k(LossArg
     const float y = cell_coord(h, g.two_over_h, g.first_h);
     const float x0 = cell_coord(w0, g.two_over_w, g.first_w);
     float gy = 0.0f;
-    if (a.pixelwise) { const float d = y - q.ty; gy = __expf(d * d * q.ky) * q.inv_norm; }
+    if (a.pixelwise) { const float d = y - q.ty; gy = expf(d * d * q.ky) * q.inv_norm; }
     const float pv[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
     float r[4];
 #pragma unroll
@@ -353,7 +352,7 @@ __global__ __launch_bounds__(64 * MPOSE_MAX_GROUP) void stage_loss_bwd_k(LossArg
       float d = cx * x + cy * y;
       if (a.pixelwise) {
         float gxv = gx_fixed[c];
-        if (!fixed_cols) { const float dd = x - q.tx; gxv = __expf(dd * dd * q.kx); }
+        if (!fixed_cols) { const float dd = x - q.tx; gxv = expf(dd * dd * q.kx); }
         d += js_dp(pv[c], gy * gxv);
       }
       r[c] = wgt * d;
@@ -515,7 +514,7 @@ using namespace mpose;
     default: return MPOSE_EINVAL;              \
   }
 
-extern "C" int mpose_abi_version(void) { return 3; }   // 2: bf16-plane packed weights, mpose_conv_operands.in1, wgrad tiles, frames/im2col entry points; 3: im2col/col2im_s2, bn_add layout 2
+extern "C" int mpose_abi_version(void) { return 5; }   // 2: bf16-plane packed weights, mpose_conv_operands.in1, wgrad tiles, frames/im2col entry points; 3: im2col/col2im_s2, bn_add layout 2; 4: mpose_bn_bwd_coef(eval_mode); 5: plane engine (conv_p.hip, split.hip), pack job layout
 
 extern "C" int mpose_softmax_dsnt_fwd(const void* const* logits, void* const* heatmaps, float* plane_coords, float* xyz,
                                       int n_planes, int rows, int H, int W, int io_dtype, void* stream) {

@@ -17,13 +17,14 @@ Data layout in HBM
 """
 import ctypes
 import os
+import weakref
 
 import numpy as np
 import torch
 import torch.distributed
 
 from . import _lib
-from ._lib import (BnAddOperands, BnBwdApplyOperands, BnBwdReduceOperands, ConvGeom, ConvOperands, WgradOperands, c_int,
+from ._lib import (BnAddOperands, BnBwdApplyOperands, BnBwdReduceOperands, ConvGeom, ConvOperands, SplitOperands, WgradOperands, c_int,
                    c_int64, c_void_p, check, lib, ptr, ptr_array, stream_ptr)
 
 BN_EPS = 1e-5
@@ -37,7 +38,7 @@ def _rup(a, b):
 
 # numpy mirrors of the device-resident job structs (checked against mpose_sizeof at start-up)
 PACK_DT = np.dtype([('src', 'u8'), ('dst', 'u8'), ('N', 'i4'), ('K', 'i4'), ('T', 'i4'), ('Npad', 'i4'), ('Kpad', 'i4'),
-                    ('sn', 'i8'), ('sk', 'i8'), ('st', 'i8')], align=True)
+                    ('sn', 'i8'), ('sk', 'i8'), ('st', 'i8'), ('layout', 'i4')], align=True)
 UNPACK_DT = np.dtype([('src', 'u8'), ('dst', 'u8'), ('N', 'i4'), ('K', 'i4'), ('T', 'i4'), ('Npad', 'i4'), ('Kpad', 'i4'),
                       ('n_split', 'i4'), ('sn', 'i8'), ('sk', 'i8'), ('st', 'i8'), ('accumulate', 'i4')], align=True)
 BN_DT = np.dtype([('stats', 'u8'), ('gamma', 'u8'), ('beta', 'u8'), ('running_mean', 'u8'), ('running_var', 'u8'),
@@ -45,7 +46,7 @@ BN_DT = np.dtype([('stats', 'u8'), ('gamma', 'u8'), ('beta', 'u8'), ('running_me
                   ('conv_bias', 'u8'), ('eps', 'f4'), ('pad_', 'i4')], align=True)
 COEF_DT = np.dtype([('sums', 'u8'), ('gamma', 'u8'), ('mean', 'u8'), ('invstd', 'u8'), ('coef', 'u8'), ('dgamma', 'u8'),
                     ('dbeta', 'u8'), ('sums_stride', 'i4'), ('which', 'i4'), ('C', 'i4'), ('c_stride', 'i4'), ('count', 'i4'),
-                    ('sg_col', 'i4')], align=True)
+                    ('sg_col', 'i4'), ('dconv_bias', 'u8')], align=True)
 
 _SIZES_CHECKED = False
 
@@ -57,7 +58,8 @@ def _check_struct_sizes():
     L = lib()
     expect = {0: ctypes.sizeof(ConvGeom), 1: ctypes.sizeof(ConvOperands), 2: ctypes.sizeof(WgradOperands),
               3: PACK_DT.itemsize, 4: UNPACK_DT.itemsize, 5: BN_DT.itemsize, 6: COEF_DT.itemsize,
-              7: ctypes.sizeof(BnAddOperands), 8: ctypes.sizeof(BnBwdReduceOperands), 9: ctypes.sizeof(BnBwdApplyOperands)}
+              7: ctypes.sizeof(BnAddOperands), 8: ctypes.sizeof(BnBwdReduceOperands), 9: ctypes.sizeof(BnBwdApplyOperands),
+              10: ctypes.sizeof(SplitOperands)}
     for which, size in expect.items():
         got = L.mpose_sizeof(which)
         if got != size:
@@ -207,6 +209,11 @@ def _geom_flops(g):
     return f
 
 
+class _Ctx(dict):
+    """Per-forward context handed to the autograd node (a dict that can be weakly referenced)."""
+    __slots__ = ('__weakref__',)
+
+
 def _jobs_to_device(arr, device):
     return torch.from_numpy(arr.view(np.uint8).copy()).to(device)
 
@@ -262,6 +269,13 @@ class Engine:
         self.overlap_wgrad = True    # +2.3 % step rate, bit-identical results; launches bracketed by a KernelTimer stay serial
         self.dp = None               # optional (process_group, world_size): gradient all-reduce after backward
         self.input_norm = ([0.485, 0.456, 0.406], [0.229, 0.224, 0.225])    # uint8 frames: ImageSpecs mean / stddev
+        # Several forwards may be alive before their backwards run (plain autograd allows it): the BatchNorm float
+        # arenas (scale / shift / mean / invstd) belong to ONE forward at a time.  `_gen` counts forwards, `_arena_gen`
+        # says whose values the arenas hold; a forward that is about to overwrite them first snapshots them into the
+        # still-pending context, and that context's backward restores them (see _snapshot_pending / _restore_arenas).
+        self._gen = 0
+        self._arena_gen = 0
+        self._pending = None         # weakref to the newest context that saved activations and has not run backward
 
     # ------------------------------------------------------------------ parameters / arenas
     def param_list(self):
@@ -282,8 +296,14 @@ class Engine:
         self._arena_key = None
         self._tables = {}
 
+    def _bn_buffers(self):
+        mods = [n.m for n in self._bns] + (self.stem.bn_modules if self.stem is not None else [])
+        return [t for m in mods for t in (m.running_mean, m.running_var)]
+
     def _ensure_arenas(self, device):
-        key = (str(device),) + tuple(p.data_ptr() for p in self.param_list()[:4])
+        # every address baked into the device-resident job tables takes part in the key: a parameter or buffer that was
+        # re-bound outside Module._apply (load_state_dict(assign=True), p.data = ..., swap_tensors) rebuilds the tables
+        key = (str(device), hash(tuple(t.data_ptr() for t in self.param_list() + self._bn_buffers())))
         if self._arena_key == key:
             return
         _check_struct_sizes()
@@ -596,12 +616,21 @@ class Engine:
         Sm = F // 2
         if 192 % Sm != 0 or (Sm % 4) != 0 or (F * F) % 64 != 0 or F * F > 4096:
             raise _lib.MposeError('unsupported input size %d (mid size %d must divide 192 and be a multiple of 4)' % (S, Sm))
+        if save and Sm % 8 != 0:       # the weight-gradient kernel walks slot rows in octets (mpose_conv_wgrad: GW % 8 == 0)
+            raise _lib.MposeError('input size %d is inference-only: training needs a mid size (%d = S/16) that is a multiple of 8, '
+                                  'e.g. 128, 256, 384' % (S, Sm))
         dev = x.device
         self._ensure_arenas(dev)
         tb = self._tables_for(B, F)
         st = stream_ptr
         f32 = dict(dtype=torch.float32, device=dev)
-        ctx = {'B': B, 'F': F, 'train': train, 'blocks': [], 'x_shape': tuple(x.shape)}
+        ctx = _Ctx({'B': B, 'F': F, 'train': train, 'blocks': [], 'x_shape': tuple(x.shape)})
+        self._snapshot_pending()       # an earlier forward whose backward is still to come keeps its BatchNorm vectors
+        self._gen += 1
+        self._arena_gen = ctx['gen'] = self._gen
+        if save:
+            self._pending = weakref.ref(ctx)
+            ctx['param_versions'] = [p._version for p in self.param_list()]
 
         self.pack_weights()
         if train:
@@ -720,13 +749,40 @@ class Engine:
             self._nbt.add_(1)
         return hms, xyz, ctx
 
+    # ------------------------------------------------------------------ several forwards in flight
+    def _arena_tensors(self):
+        return [self.bnf] + ([self.stem.f_arena] if self.stem is not None else [])
+
+    def _snapshot_pending(self):
+        """Called before a forward overwrites the BatchNorm arenas: if the previous saved forward has not run its backward
+        yet, it gets a private copy of them (no cost in the ordinary forward-backward-forward-backward loop)."""
+        prev = self._pending() if self._pending is not None else None
+        if prev is not None and not prev.get('done') and 'arena_snap' not in prev and prev['gen'] == self._arena_gen:
+            prev['arena_snap'] = [t.clone() for t in self._arena_tensors()]
+
+    def _restore_arenas(self, ctx):
+        if ctx['gen'] == self._arena_gen:
+            return
+        self._snapshot_pending()                 # the newer forward may still want its own values back
+        snap = ctx.get('arena_snap')
+        if snap is None:
+            raise _lib.MposeError('the BatchNorm state of this forward pass is gone (internal error: no snapshot was taken)')
+        for dst, src in zip(self._arena_tensors(), snap):
+            dst.copy_(src)
+        self._arena_gen = ctx['gen']
+
     # ------------------------------------------------------------------ backward
     def backward(self, ctx, hms, g_hms, need_dx):
         """hms[p][t]: heatmaps of the forward; g_hms[p][t]: gradient w.r.t. them (or None).
-        Returns (persistent flat gradient buffer, dx or None)."""
+        Returns (persistent flat gradient buffer, dx or None).
+        Eval-mode forwards are differentiable too (running statistics are constants: dx = gamma*invstd*g)."""
         L = lib()
-        if not ctx['train']:
-            raise _lib.MposeError('backward through eval-mode BatchNorm is not implemented: call model.train()')
+        for p, v in zip(self.param_list(), ctx['param_versions']):
+            if p._version != v:      # the packed weights follow the parameters: same rule (and wording) as autograd's own check
+                raise RuntimeError('one of the variables needed for gradient computation has been modified by an inplace '
+                                   'operation: a parameter of MargiPoseModel changed between forward and backward')
+        self._restore_arenas(ctx)
+        eval_bn = 0 if ctx['train'] else 1
         B, F = ctx['B'], ctx['F']
         Sm = F // 2
         dev = self.device
@@ -740,7 +796,7 @@ class Engine:
         coef_base = tb['coef'].data_ptr()
 
         def run_coef(first, n):
-            check(L.mpose_bn_bwd_coef(c_void_p(coef_base + first * COEF_DT.itemsize), n, st()), 'mpose_bn_bwd_coef')
+            check(L.mpose_bn_bwd_coef(c_void_p(coef_base + first * COEF_DT.itemsize), n, eval_bn, st()), 'mpose_bn_bwd_coef')
 
         works = []          # in-flight gradient all-reduces (data parallel), one per finished bucket
         D = None            # gradient w.r.t. the stage input, cumulative over later stages (:195 is `inp = inp + ...`)
@@ -897,6 +953,7 @@ class Engine:
             self._finish_bucket(tb, self.T, self.T * 90, tb['n_unpack'] - self.T * 90, works)
         for w in works:
             w.wait()                   # (stream-ordered for RCCL: the current stream waits for the collective)
+        ctx['done'] = True
         return self.gflat, dx
 
     def _finish_bucket(self, tb, bucket, first_job, n_jobs, works):

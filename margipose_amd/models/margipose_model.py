@@ -126,8 +126,8 @@ class _BackboneFn(torch.autograd.Function):
         saved = ctx.saved_tensors
         hms = [list(saved[p * T:(p + 1) * T]) for p in range(3)]
         g_hms = [list(grads[p * T:(p + 1) * T]) for p in range(3)]
+        # (ctx.ectx stays: with retain_graph=True the node may run again; the saved activations go when the graph does)
         gflat, dx = engine.backward(ctx.ectx, hms, g_hms, ctx.needs_input_grad[2])
-        ctx.ectx = None
         flat = gflat.clone()
         if engine.dp is not None:       # the per-stage buckets were summed over replicas during the backward pass
             flat.div_(engine.dp[1])

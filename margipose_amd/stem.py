@@ -281,6 +281,7 @@ class _GraphStem:
                 k['coef'] = self.fptr(n, 4, a)
                 k['dgamma'] = gbase + 4 * goff[id(bn.weight)]; k['dbeta'] = gbase + 4 * goff[id(bn.bias)]
                 k['sums_stride'], k['which'], k['C'], k['c_stride'], k['count'], k['sg_col'] = 4, 1, b - a, n.C, B * H * H, 0
+                k['dconv_bias'] = gbase + 4 * goff[id(bias)] if bias is not None else 0
                 coef.append(k)
             tb['fin_range'][n.name] = (f0, len(fin) - f0)
             tb['coef_range'][n.name] = (c0_, len(coef) - c0_)
@@ -380,7 +381,7 @@ class _GraphStem:
         out = torch.empty(B, S // n7.div, S // n7.div, n7.C, **f32)
         check(L.mpose_bn_relu_fwd(ptr(raw[n7.name]), c_void_p(self.fptr(n7, 0)), c_void_p(self.fptr(n7, 1)), ptr(out),
                                   c_int64(out.numel()), n7.C, st()), 'mpose_bn_relu_fwd')
-        ctx = {'raw': raw, 'B': B, 'S': S} if save else None
+        ctx = {'raw': raw, 'B': B, 'S': S, 'train': train} if save else None
         return out, ctx
 
     # ------------------------------------------------------------------ backward
@@ -407,7 +408,7 @@ class _GraphStem:
             check(L.mpose_bn_bwd_reduce((BnBwdReduceOperands * 3)(ro), 1, H * H, B, n.C, 0, 0, st()), 'mpose_bn_bwd_reduce')
             c0_, nc = tb['coef_range'][n.name]
             if nc:
-                check(L.mpose_bn_bwd_coef(c_void_p(tb['coef'].data_ptr() + c0_ * eng.COEF_ITEMSIZE), nc, st()), 'mpose_bn_bwd_coef')
+                check(L.mpose_bn_bwd_coef(c_void_p(tb['coef'].data_ptr() + c0_ * eng.COEF_ITEMSIZE), nc, 0 if ctx.get('train', True) else 1, st()), 'mpose_bn_bwd_coef')
             d_raw = torch.empty(B, H, H, n.C, **f32)
             ao = BnBwdApplyOperands()
             ao.g, ao.a, ao.coef_a, ao.da = g.data_ptr(), raw[n.name].data_ptr(), self.fptr(n, 4), d_raw.data_ptr()

@@ -25,6 +25,23 @@ BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
 PLANES = ('xy', 'zy', 'xz')
 
+# Mask control for gradient-parity experiments (tests/test_grad_parity_gpu.py).  ReLU makes the network piecewise
+# linear; two correct fp32 implementations that disagree in the last bit of a pre-activation sitting at ~0 choose
+# different pieces, and the gradients of the two pieces differ by O(1e-3), not O(1e-7).  With RELU_MASKS set to
+# {site: 0/1 tensor} the oracle evaluates relu(x) as x * mask, i.e. it is forced onto the piece another
+# implementation chose, which separates "different piece" from "arithmetic error".  RELU_RECORD (a dict) receives
+# the oracle's own masks.  Sites are named '<block prefix>.relu1' / '.relu2' and 'inner.in_cnn.relu' (patch8 stem).
+RELU_MASKS = None
+RELU_RECORD = None
+
+
+def _relu(x, site):
+    if RELU_RECORD is not None:
+        RELU_RECORD[site] = (x > 0).detach()
+    if RELU_MASKS is not None and site in RELU_MASKS:
+        return x * RELU_MASKS[site].to(x.dtype)
+    return F.relu(x)
+
 
 def _bn(sd, key, x, train):
     """nn.BatchNorm2d defaults (models/margipose_model.py:31,34,37): batch stats + running update in
@@ -49,9 +66,9 @@ def _conv_in(sd, key, x, kind, k):
 def residual_block(sd, prefix, x, kind, train):
     """models/margipose_model.py:25-40 -- [conv_in,BN,ReLU,conv3x3,BN,ReLU](x) + [conv_sc,BN](x)."""
     m = _conv_in(sd, prefix + '.module.0', x, kind, 3)
-    m = F.relu(_bn(sd, prefix + '.module.1', m, train))
+    m = _relu(_bn(sd, prefix + '.module.1', m, train), prefix + '.relu1')
     m = F.conv2d(m, sd[prefix + '.module.3.weight'], None, stride=1, padding=1)
-    m = F.relu(_bn(sd, prefix + '.module.4', m, train))
+    m = _relu(_bn(sd, prefix + '.module.4', m, train), prefix + '.relu2')
     s = _conv_in(sd, prefix + '.shortcut.0', x, kind, 1)
     s = _bn(sd, prefix + '.shortcut.1', s, train)
     return m + s
@@ -88,7 +105,7 @@ def heatmap_column(sd, prefix, x, space, train):
 def patch8_stem(sd, x, train):
     """In-repo deterministic stem (NOT the reference's InceptionV4 stem; parity unpinned)."""
     f = F.conv2d(x, sd['inner.in_cnn.0.weight'], None, stride=8)
-    return F.relu(_bn(sd, 'inner.in_cnn.1', f, train))
+    return _relu(_bn(sd, 'inner.in_cnn.1', f, train), 'inner.in_cnn.relu')
 
 
 def _basic_conv(sd, key, x, train, stride=1):

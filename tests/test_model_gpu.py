@@ -421,3 +421,108 @@ def test_bf16_heatmap_inference_mode():
     m.heatmap_dtype = torch.float32
     with pytest.raises(Exception):
         m.heatmap_dtype = torch.float16
+
+
+def _loss_of(m, x, target, mask):
+    from margipose_amd import dsntnn
+    return dsntnn.average_loss(m.forward_3d_losses(m(x.cuda()), target.cuda()), mask.cuda())
+
+
+def test_two_forwards_in_flight_then_both_backwards():
+    """Plain autograd lets several forwards be alive before their backwards run (an eval pass in between included); the
+    engine's BatchNorm arenas belong to one forward at a time, so the pending forward is given a snapshot."""
+    T, seed, B = 1, 31, 2
+    x1, target, mask = W.seeded_inputs(seed, B)
+    x2, _, _ = W.seeded_inputs(seed + 1, B)
+    m = build(T, seed, x1).train()
+
+    def alone(x):
+        m.zero_grad(set_to_none=True)
+        _loss_of(m, x, target, mask).backward()
+        return [p.grad.clone() for p in m.parameters()]
+    g1, g2 = alone(x1), alone(x2)
+    m.zero_grad(set_to_none=True)
+    l1 = _loss_of(m, x1, target, mask)
+    l2 = _loss_of(m, x2, target, mask)           # overwrites the arenas of the first forward
+    with torch.no_grad():
+        m.eval(); m(x2.cuda()); m.train()        # ... and so does an inference pass
+    l1.backward()
+    got1 = [p.grad.clone() for p in m.parameters()]
+    m.zero_grad(set_to_none=True)
+    l2.backward()
+    got2 = [p.grad.clone() for p in m.parameters()]
+    assert all(torch.equal(a, b) for a, b in zip(g1, got1))
+    assert all(torch.equal(a, b) for a, b in zip(g2, got2))
+
+
+def test_backward_twice_with_retain_graph():
+    T, seed, B = 1, 33, 2
+    x, target, mask = W.seeded_inputs(seed, B)
+    m = build(T, seed, x).train()
+    loss = _loss_of(m, x, target, mask)
+    loss.backward(retain_graph=True)
+    g = [p.grad.clone() for p in m.parameters()]
+    loss.backward()
+    assert all(torch.equal(p.grad, 2 * a) for a, p in zip(g, m.parameters()))
+    with pytest.raises(RuntimeError):
+        loss.backward()                          # the graph is gone now, like any autograd graph
+
+
+def test_parameter_update_between_forward_and_backward_is_an_error():
+    T, seed, B = 1, 35, 2
+    x, target, mask = W.seeded_inputs(seed, B)
+    m = build(T, seed, x).train()
+    loss = _loss_of(m, x, target, mask)
+    with torch.no_grad():
+        m.inner.xy_hm_cnns[0].down_layers[0].module[0].weight.mul_(1.01)
+    with pytest.raises(RuntimeError, match='modified by an inplace operation'):
+        loss.backward()
+
+
+@pytest.mark.parametrize('stem', ['patch8', 'inceptionv4'])
+def test_backward_through_eval_mode_batchnorm(stem):
+    """model.eval() + loss.backward() (reference bin/eval_3d.py:63 computes losses in eval mode; fine-tuning with frozen
+    statistics): running statistics are constants, dx = gamma*invstd*g, and the bias of a convolution in front of a
+    BatchNorm gets a real gradient.  patch8: against the fp64 oracle on the GPU's ReLU piece (tests/test_grad_parity_gpu.py);
+    inceptionv4 (ReLU / max-pool pieces of the stem are free): against fp64 with the fp32 oracle's own deviation as the bar."""
+    from tests import test_grad_parity_gpu as GP
+    from margipose_amd import dsntnn
+    T, seed, B = 1, 37, 2
+    x, target, mask = W.seeded_inputs(seed, B)
+    m, sd = GP.build(T, seed, x, stem)
+    m.eval()
+    xg = x.cuda().requires_grad_(True)
+    out = m(xg)
+    masks = GP.gpu_relu_masks(m.inner.engine(), m.xy_heatmaps[0].grad_fn.ectx)
+    loss = dsntnn.average_loss(m.forward_3d_losses(out, target.cuda()), mask.cuda())
+    loss.backward()
+    gpu = OrderedDict((k, p.grad.detach().cpu()) for k, p in m.named_parameters())
+    gpu['__dx__'] = xg.grad.cpu()
+
+    def oracle(dtype, use_masks):
+        s = OrderedDict((k, v.detach().clone().to(dtype) if v.is_floating_point() else v.clone()) for k, v in sd.items())
+        params = OrderedDict((k, v.requires_grad_(True)) for k, v in s.items() if v.is_floating_point() and 'running' not in k)
+        xr = x.detach().to(dtype).clone().requires_grad_(True)
+        R.RELU_MASKS = masks if use_masks else None
+        try:
+            xy, zy, xz = R.inner_forward(s, xr, T, False)
+            l = R.average_loss(R.forward_3d_losses(xy, zy, xz, target.to(dtype)), mask.to(dtype))
+            l.backward()
+        finally:
+            R.RELU_MASKS = None
+        g = OrderedDict((k, p.grad) for k, p in params.items())
+        g['__dx__'] = xr.grad
+        return g, float(l.detach())
+    r64, l64 = oracle(torch.float64, True)
+    r32, _ = oracle(torch.float32, True)
+    assert abs(float(loss.detach()) - l64) <= 1e-4 * abs(l64)
+    st = GP.compare('eval_%s' % stem, gpu, r64, r32)
+    if stem == 'patch8':
+        assert st['gpu_max'] <= 5e-5 and st['gpu_median'] <= max(1.5 * st['ref32_median'], 2e-6), st
+    else:
+        assert st['gpu_median'] <= max(1e-4, 1.5 * st['ref32_median']) and st['gpu_p99'] <= max(1e-4, 1.5 * st['ref32_p99']), st
+        kb = 'inner.in_cnn.7.bias'
+        assert rel_l2(gpu[kb], r64[kb]) < 2e-2, rel_l2(gpu[kb], r64[kb])       # the conv bias in front of the last stem BatchNorm
+    for k, b in m.named_buffers():               # eval mode must not touch the running statistics
+        if 'running' in k:
+            assert torch.equal(b.cpu(), sd[k].float()), k
