@@ -75,6 +75,11 @@ def parse():
     ap.add_argument('--no-overlap-wgrad', action='store_true', help='keep the weight-gradient GEMMs on the main stream (the default '
                     'runs them on a side stream, +2.3 %% step rate; the steps whose kernels are bracketed by HIP events for the '
                     'roofline block always run serially, so per-kernel durations are clean)')
+    ap.add_argument('--eager', action='store_true', help='enqueue every step from Python (about 1000 launches) instead of replaying '
+                    'the captured HIP graph of the iteration (train_helpers.GraphedTrainStep); multi-GPU runs are eager unless '
+                    'MPOSE_DP_GRAPH=1')
+    ap.add_argument('--conv-dtype', default='f32', choices=['f32', 'bf16'], help="'bf16' = BASELINE configs[4]'s reduced-precision "
+                    'convolutions (model.conv_dtype = torch.bfloat16): a DIFFERENT workload, reported with dtype bf16, never the headline')
     return ap.parse_args()
 
 
@@ -95,42 +100,46 @@ def cpu_baseline(stages, size, cpu_batch, stem='inceptionv4'):
 
     step()                                  # warm-up
     n, t0 = 0, time.perf_counter()
-    while True:
+    while True:                             # at least 3 timed steps, then until ~12 s of CPU work or 6 steps
         step()
         n += 1
         dt = time.perf_counter() - t0
-        if dt > 10.0 or n >= 4:
+        if n >= 3 and (dt > 12.0 or n >= 6):
             break
     return {'value': cpu_batch * n / dt, 'unit': 'images/sec', 'cores': threads, 'kind': 'port',
             'sample': '%d timed fwd+loss+bwd steps of batch %d (T=%d, %dx%d, fp32) with oracle/model_ref.py on torch CPU, '
                       '%d threads, %s stem' % (n, cpu_batch, stages, size, size, threads, stem)}
 
 
-def tail_large_microbench(device):
-    """Cache-defeating soft-argmax run (B=2048 fp32 -> 856 MB through the kernel), SURVEY.md §8d."""
+def tail_microbench(device, B, bf16_out=False, launches=200):
+    """The soft-argmax kernel (flat_softmax + dsnt + heatmaps_to_coords, 3 planes per launch) on its own: `launches`
+    back-to-back launches between two HIP events on the launch stream, no calibration term subtracted -- the quotient is what
+    rocprofv3 reports as the kernel's average duration plus the ~1.5 us dependent-launch boundary (profiles/ holds the trace
+    of tools/prof_tail.py, the same loop).  Algorithmic bytes: logits read once + heatmaps written once + coords."""
     from margipose_amd import _lib
-    B, F = 2048, 32
+    F = 32
     lg = [torch.randn(B, 17, F, F, device=device) * 4 for _ in range(3)]
-    hm = [torch.empty_like(l) for l in lg]
+    hm = [torch.empty(B, 17, F, F, device=device, dtype=torch.bfloat16 if bf16_out else torch.float32) for _ in range(3)]
     xyz = torch.empty(B, 17, 3, device=device)
     L = _lib.lib()
 
     def run():
-        _lib.check(L.mpose_softmax_dsnt_fwd(_lib.ptr_array(lg), _lib.ptr_array(hm), None, _lib.ptr(xyz), 3, B * 17, F, F, 0,
-                                            _lib.stream_ptr()), 'softmax')
-    for _ in range(3):
+        _lib.check(L.mpose_softmax_dsnt_fwd(_lib.ptr_array(lg), _lib.ptr_array(hm), None, _lib.ptr(xyz), 3, B * 17, F, F,
+                                            2 if bf16_out else 0, _lib.stream_ptr()), 'softmax')
+    for _ in range(5):
         run()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     s.record()
-    for _ in range(10):
+    for _ in range(launches):
         run()
     e.record()
     torch.cuda.synchronize()
-    sec = s.elapsed_time(e) * 1e-3 / 10
-    nbytes = 3 * B * 17 * F * F * 8 + B * 17 * 12
-    return {'bound': 'hbm', 'achieved': nbytes / sec / 1e9, 'peak': PEAK_HBM_GBPS, 'unit': 'GB/s',
-            'frac': nbytes / sec / 1e9 / PEAK_HBM_GBPS, 'traffic': None, 'note': 'B=2048 fp32 (856 MB/launch, exceeds the 256 MB Infinity Cache)'}
+    sec = s.elapsed_time(e) * 1e-3 / launches
+    nbytes = 3 * B * 17 * F * F * (6 if bf16_out else 8) + B * 17 * 12
+    return {'bound': 'hbm', 'achieved': nbytes / sec / 1e9, 'peak': PEAK_HBM_GBPS, 'unit': 'GB/s', 'frac': nbytes / sec / 1e9 / PEAK_HBM_GBPS,
+            'traffic': None, 'us_per_launch': sec * 1e6, 'bytes_per_launch': nbytes, 'launches': launches,
+            'kernel': 'softmax_dsnt_fwd_k (3 planes, B=%d, %s heatmaps)' % (B, 'bf16' if bf16_out else 'fp32')}
 
 
 def inference_microbench(model, device, size):
@@ -168,6 +177,7 @@ def main():
     args = parse()
     from margipose_amd import dsntnn, parallel
     from margipose_amd.engine import KernelTimer
+    from margipose_amd.train_helpers import DeviceSGD, GraphedTrainStep
     from margipose_amd.models import CanonicalSkeletonDesc, MargiPoseModel
     rank, world, local_rank = parallel.init_from_env()
     if world != args.gpus:
@@ -183,17 +193,20 @@ def main():
     parallel.broadcast_parameters(model)
     parallel.attach(model)
     model.inner.engine().overlap_wgrad = not args.no_overlap_wgrad
-    opt = torch.optim.SGD(model.parameters(), lr=0.01, momentum=0.9, fused=True)   # same arithmetic as bin/train_3d.py:339, one launch
+    if args.conv_dtype == 'bf16':
+        model.conv_dtype = torch.bfloat16
+    # the reference's optimiser, SGD(lr, momentum) (bin/train_3d.py:339), as one launch with device-resident hyper-parameters
+    opt = DeviceSGD(model.parameters(), lr=0.01, momentum=0.9)
     g = torch.Generator(device='cpu').manual_seed(12345 + rank)
     B = args.batch
     x = torch.randn(B, 3, args.size, args.size, generator=g).to(device)
     target = (torch.rand(B, 17, 3, generator=g) * 2 - 1).to(device)
     mask = torch.ones(B, 17, device=device)
 
-    def step():
-        opt.zero_grad(set_to_none=True)
+    def eager_step():
         out = model(x)
         loss = dsntnn.average_loss(model.forward_3d_losses(out, target), mask)
+        opt.zero_grad(set_to_none=True)
         loss.backward()
         opt.step()
         return loss
@@ -203,10 +216,20 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    # The iteration is captured once as a HIP graph and replayed (every buffer of a step has a fixed address); eager mode costs
+    # ~1000 launches of host time per step.  Under data parallelism the graph would have to contain the RCCL all-reduces: opt-in.
+    use_graph = not args.eager and (world == 1 or os.environ.get('MPOSE_DP_GRAPH') == '1')
+    graphed = GraphedTrainStep(model, opt, x, target, mask, warmup=2) if use_graph else None
+
+    def step():
+        if graphed is not None:
+            return graphed()[1]
+        return eager_step()
+
     for _ in range(args.warmup):
         loss = step()
-    # Per-kernel HIP events (for the roofline block) bracket every conv / tail launch of EVERY TENTH timed step (steps 0, 10, ...):
-    # an event is a barrier packet between two kernels, and ~800 of them per step cost ~5 % of the step.
+    # Per-kernel HIP events (for the roofline block) bracket every conv / tail launch of EVERY TENTH timed step (steps 0, 10, ...),
+    # which runs eagerly: an event is a barrier packet between two kernels, and ~800 of them per step cost ~5 % of the step.
     timer = KernelTimer() if (rank == 0 and not args.no_kernel_timing) else None
     if timer is not None:
         timer.calibrate()
@@ -215,12 +238,15 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         on = timer is not None and i % 10 == 0
-        model.inner.engine().timer = timer if on else None
-        timed_steps += int(on)
-        loss = step()
+        if on:
+            model.inner.engine().timer = timer
+            timed_steps += 1
+            loss = eager_step()
+            model.inner.engine().timer = None
+        else:
+            loss = step()
     barrier()
     dt = time.perf_counter() - t0
-    model.inner.engine().timer = None
     loss_value = float(loss.detach())
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
@@ -236,7 +262,7 @@ def main():
         'metric': 'images/sec fwd+bwd at 256x256, 17 joints (training step: forward + JS/Euclidean loss + backward + SGD)',
         'value': images / dt, 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': 'f32', 'data': 'synthetic',
+        'dtype': 'f32' if args.conv_dtype == 'f32' else 'bf16', 'data': 'synthetic',
         'config': {'workload': 'BASELINE configs[2]: training step, per-GPU batch %d, %d-stage MargiPose, %dx%d input, 17 joints, '
                                '32x32 heatmaps, JS + Euclidean loss, SGD(momentum 0.9)' % (B, args.stages, args.size, args.size),
                    'global_batch': world * B, 'n_stages': args.stages,
@@ -245,6 +271,8 @@ def main():
                             '%s (reference option, models/margipose_model.py:119-137; torchvision layers restated, unpinned, '
                             'random init)' % args.stem if args.stem.startswith('resnet') else
                             'patch8 (in-repo deterministic stem; the InceptionV4 stem is available with --stem inceptionv4)'), 'parallelism': 'dp%d' % world, 'overlap_wgrad': (not args.no_overlap_wgrad) and world == 1,
+                   'step_dispatch': 'hip graph replay (train_helpers.GraphedTrainStep)' if use_graph else 'eager launches',
+                   'conv_engine': 'planes (conv_p.hip)' if model.inner.engine().use_planes else 'round-1 igemm (conv.hip)',
                    'final_loss': loss_value},
     }
     if timer is not None:
@@ -271,15 +299,17 @@ def main():
                                'all_conv_kernels_frac': all_flops / (all_ms * 1e-3) / 1e12 / PEAK_BF16X6_TFLOPS,
                                'conv_share_of_step_gpu_time': (all_ms / max(1, timed_steps)) / (1e3 * dt / args.steps),
                                'kernel_timed_steps': timed_steps}
-        tail = summ.get('tail:softmax_dsnt_fwd')
-        if tail:
-            gbps = tail['work_per_launch'] / (tail['avg_us'] * 1e-6) / 1e9
-            res['tail_roofline'] = {'bound': 'hbm', 'achieved': gbps, 'peak': PEAK_HBM_GBPS, 'unit': 'GB/s',
-                                    'frac': gbps / PEAK_HBM_GBPS, 'traffic': None, 'kernel': 'softmax_dsnt_fwd_k (3 planes, B=%d)' % B,
-                                    'avg_launch_us': tail['avg_us'], 'bytes_per_launch': tail['work_per_launch']}
         res['kernel_time_breakdown_ms_per_step'] = {k: round(v['total_ms'] / max(1, timed_steps), 3) for k, v in
                                                     sorted(summ.items(), key=lambda kv: -kv[1]['total_ms'])[:12]}
-        res['tail_roofline_large'] = tail_large_microbench(device)
+    if rank == 0 and not args.no_kernel_timing:
+        # The soft-argmax path the metric also names.  No subtraction of a calibration term: N back-to-back launches / N.
+        # At the configuration sizes the whole working set (13-27 MB) lives in the 256 MB Infinity Cache and a launch is a few
+        # microseconds: latency-bound, the GB/s there say little; the cache-defeating size is the HBM-roofline point.
+        res['tail_roofline'] = dict(tail_microbench(device, 2048), note='B=2048 fp32: 856 MB per launch, exceeds the 256 MB Infinity Cache '
+                                                                        '(the HBM-roofline point of the metric)')
+        res['tail_config_sizes'] = {
+            'configs[2] training, B=%d fp32' % B: dict(tail_microbench(device, B), note='latency-bound: working set in Infinity Cache'),
+            'configs[1] inference, B=64 bf16 heatmaps': dict(tail_microbench(device, 64, bf16_out=True), note='latency-bound: working set in Infinity Cache')}
     if world == 1:
         res['inference'] = inference_microbench(model, device, args.size)
     if world == 1 and not args.no_cpu_baseline:

@@ -34,7 +34,7 @@ extern "C" {
 
 int mpose_abi_version(void);
 /* sizeof() of the ABI structs, for binding self-checks: which = 0 geom, 1 conv operands, 2 wgrad
- * operands, 3 pack job, 4 unpack job, 5 bn job, 6 bn coef job, 7 bn_add ops, 8 reduce ops, 9 apply ops, 10 split ops. */
+ * operands, 3 pack job, 4 unpack job, 5 bn job, 6 bn coef job, 7 bn_add ops, 8 reduce ops, 9 apply ops, 10 split ops, 11 sgd job. */
 int mpose_sizeof(int which);
 
 /* ------------------------------------------------------------------------------------------
@@ -284,8 +284,8 @@ int mpose_bn_bwd_reduce(const mpose_bn_bwd_reduce_operands* ops, int n_groups, i
 typedef struct {
   const float* g;
   const float* a; const float* b;
-  const float* coef_a;                 /* (3, C): da = ca0*ga + ca1*a + ca2, ga = g * relu-mask (see below) */
-  const float* coef_b;                 /* (3, C): db = cb0*g + cb1*b + cb2 */
+  const float* coef_a;                 /* (4, C): da = ca0*ga + ca1*(a - ca3) + ca2, ga = g * relu-mask (see below); ca3 = mean */
+  const float* coef_b;                 /* (4, C): db = cb0*g + cb1*(b - cb3) + cb2 */
   const float* a_scale;                /* optional ReLU mask of branch a, as in the reduce step */
   const float* a_shift;
   float* da; float* db;
@@ -299,7 +299,7 @@ int mpose_bn_bwd_apply_planes(const mpose_bn_bwd_apply_operands* ops, void* cons
 typedef struct {
   const double* sums;                  /* (Cs, 3) from mpose_bn_bwd_reduce, or (Cs, 2) from a conv epilogue */
   const float* gamma; const float* mean; const float* invstd;
-  float* coef;                         /* out (3, c_stride) */
+  float* coef;                         /* out (4, c_stride): c0, c1, c2, mean */
   float* dgamma; float* dbeta;         /* out (written, not accumulated), may be NULL */
   int sums_stride;                     /* 4 (mpose_bn_bwd_reduce) or 2 (conv epilogue) */
   int which;                           /* column of `sums` holding sum g*x for this BN */
@@ -380,6 +380,19 @@ int mpose_nchw_to_nhwc_pad(const float* const* in, float* const* out, int n_grou
 /* dst[i] (+)= sum_p src[p*n + i]  (second stage of deterministic block-partial reductions). */
 int mpose_reduce_partials(const float* src, float* dst, int n_partial, int64_t n, int accumulate,
                           void* stream);
+
+/* torch.optim.SGD(lr, momentum).step() over all parameters in one launch (bin/train_3d.py:186,339), hyper-parameters read
+ * from DEVICE memory: hyper_dev = {lr, momentum, first} (first != 0: momentum buffers are initialised with the gradient, as
+ * torch does on its first step).  p, g, buf: 16-byte aligned device arrays of n floats; jobs live in device memory. */
+typedef struct {
+  float* p;
+  const float* g;
+  float* buf;
+  int64_t n;
+} mpose_sgd_job;
+int mpose_sgd_step(const mpose_sgd_job* jobs_dev, int n_jobs, int64_t max_n, const float* hyper_dev, void* stream);
+/* dst[0..3] = {a, b, c, d} on the stream (how the host hands the next step's hyper-parameters to a replayed graph). */
+int mpose_set4(float* dst, float a, float b, float c, float d, void* stream);
 
 #ifdef __cplusplus
 }

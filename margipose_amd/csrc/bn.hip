@@ -8,8 +8,11 @@
 //
 // Backward algebra (x = pre-BN activation, g = upstream gradient, N = B*H*W):
 //   xhat = (x - mean) * invstd ; dgamma = sum g*xhat ; dbeta = sum g
-//   dx = gamma*invstd * (g - mean(g) - xhat * mean(g*xhat)) = c0*g + c1*x + c2
-//   with c0 = gamma*invstd, c1 = -c0*invstd*mean(g*xhat), c2 = -c0*mean(g) - c1*mean.
+//   dx = gamma*invstd * (g - mean(g) - xhat * mean(g*xhat)) = c0*g + c1*(x - mean) + c2
+//   with c0 = gamma*invstd, c1 = -c0*invstd*mean(g*xhat), c2 = -c0*mean(g); coefficient rows (c0, c1, c2, mean).
+//   (x is centred per element: folding -c1*mean into c2 makes c1*x + c2 a cancelling pair whose rounded constant is a
+//   per-channel BIAS on every pixel -- it showed up as a 3-5x excess on sums of dx over pixels, e.g. the shortcut BatchNorm's
+//   bias gradient one block further down, in the round-2 gradient-parity bisect.)
 #include "common.h"
 
 namespace mpose {
@@ -179,10 +182,11 @@ __global__ __launch_bounds__(256) void bn_bwd_coef_k(const mpose_bn_bwd_coef_job
     const double sgxhat = invstd * (sgx - mean * sg);
     const double c0 = gamma * invstd;
     const double c1 = eval_mode ? 0.0 : -c0 * invstd * (sgxhat / n);
-    const double c2 = eval_mode ? 0.0 : -c0 * (sg / n) - c1 * mean;
+    const double c2 = eval_mode ? 0.0 : -c0 * (sg / n);
     j.coef[c] = (float)c0;
     j.coef[j.c_stride + c] = (float)c1;
     j.coef[2 * j.c_stride + c] = (float)c2;
+    j.coef[3 * j.c_stride + c] = (float)mean;
     if (j.dgamma != nullptr) { j.dgamma[c] = (float)sgxhat; j.dbeta[c] = (float)sg; }
     if (j.dconv_bias != nullptr) j.dconv_bias[c] = eval_mode ? (float)(c0 * sg) : 0.f;
   }
@@ -214,9 +218,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_k(BnApplyArgs a) {
       const float4 k0 = *reinterpret_cast<const float4*>(op.coef_a + c);
       const float4 k1 = *reinterpret_cast<const float4*>(op.coef_a + a.C + c);
       const float4 k2 = *reinterpret_cast<const float4*>(op.coef_a + 2 * a.C + c);
+      const float4 mu = *reinterpret_cast<const float4*>(op.coef_a + 3 * a.C + c);
       float4 o;
-      o.x = fmaf(k0.x, ga.x, fmaf(k1.x, x.x, k2.x)); o.y = fmaf(k0.y, ga.y, fmaf(k1.y, x.y, k2.y));
-      o.z = fmaf(k0.z, ga.z, fmaf(k1.z, x.z, k2.z)); o.w = fmaf(k0.w, ga.w, fmaf(k1.w, x.w, k2.w));
+      o.x = fmaf(k1.x, x.x - mu.x, fmaf(k0.x, ga.x, k2.x)); o.y = fmaf(k1.y, x.y - mu.y, fmaf(k0.y, ga.y, k2.y));
+      o.z = fmaf(k1.z, x.z - mu.z, fmaf(k0.z, ga.z, k2.z)); o.w = fmaf(k1.w, x.w - mu.w, fmaf(k0.w, ga.w, k2.w));
       reinterpret_cast<float4*>(op.da)[i] = o;
     }
     if (has_b) {
@@ -224,9 +229,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_k(BnApplyArgs a) {
       const float4 k0 = *reinterpret_cast<const float4*>(op.coef_b + c);
       const float4 k1 = *reinterpret_cast<const float4*>(op.coef_b + a.C + c);
       const float4 k2 = *reinterpret_cast<const float4*>(op.coef_b + 2 * a.C + c);
+      const float4 mu = *reinterpret_cast<const float4*>(op.coef_b + 3 * a.C + c);
       float4 o;
-      o.x = fmaf(k0.x, g.x, fmaf(k1.x, x.x, k2.x)); o.y = fmaf(k0.y, g.y, fmaf(k1.y, x.y, k2.y));
-      o.z = fmaf(k0.z, g.z, fmaf(k1.z, x.z, k2.z)); o.w = fmaf(k0.w, g.w, fmaf(k1.w, x.w, k2.w));
+      o.x = fmaf(k1.x, x.x - mu.x, fmaf(k0.x, g.x, k2.x)); o.y = fmaf(k1.y, x.y - mu.y, fmaf(k0.y, g.y, k2.y));
+      o.z = fmaf(k1.z, x.z - mu.z, fmaf(k0.z, g.z, k2.z)); o.w = fmaf(k1.w, x.w - mu.w, fmaf(k0.w, g.w, k2.w));
       reinterpret_cast<float4*>(op.db)[i] = o;
     }
   }
@@ -277,6 +283,7 @@ extern "C" int mpose_sizeof(int which) {
     case 8: return (int)sizeof(mpose_bn_bwd_reduce_operands);
     case 9: return (int)sizeof(mpose_bn_bwd_apply_operands);
     case 10: return (int)sizeof(mpose_split_operands);
+    case 11: return (int)sizeof(mpose_sgd_job);
     default: return -1;
   }
 }

@@ -28,6 +28,7 @@
 //
 // Replaces Conv2d / ConvTranspose2d of reference src/margipose/models/margipose_model.py:33,67-82 and their
 // data-gradients inside the columns.
+#include <stdlib.h>
 #include "common.h"
 
 namespace mpose {
@@ -147,7 +148,12 @@ __global__ __launch_bounds__(256, 2) void conv_planes_k(ConvPArgs a) {
   const __amdgpu_buffer_rsrc_t rs_w0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(op.w0), 0, 0xFFFFFF00, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_w1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(MODE ? op.w1 : op.w0), 0, 0xFFFFFF00, 0x00020000);
 
-  f32x16 acc[RM][RN];
+  // Two accumulators per output block when NPL == 3: `acc` takes only the hi x hi products, `acs` the five cross terms
+  // (<= 2^-8 of them).  Every MFMA rounds its accumulator once; with a single accumulator that is 6 roundings of the
+  // full-size running sum per step (432 for a 128-channel 3x3: 1.1e-6 relative, 4x a CPU fp32 convolution), with the
+  // split it is ONE (72: below the CPU's), and the cross-term accumulator's roundings are 2^-8 smaller.
+  constexpr int NACS = NPL == 3 ? RN : 1;
+  f32x16 acc[RM][RN], acs[RM][NACS];
   // taps with acc == 0 first, taps with acc == 1 (second weight set) last
   int n_taps0 = 0;
   for (int t = 0; t < n_taps; ++t) n_taps0 += (((tap_word(t) >> 24) & 0xff) == 0) ? 1 : 0;
@@ -165,7 +171,10 @@ __global__ __launch_bounds__(256, 2) void conv_planes_k(ConvPArgs a) {
 #pragma unroll
         for (int rn = 0; rn < RN; ++rn)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) acc[rm][rn][r] = 0.0f;
+          for (int r = 0; r < 16; ++r) {
+            acc[rm][rn][r] = 0.0f;
+            if (NPL == 3) acs[rm][rn % NACS][r] = 0.0f;
+          }
     }
     if (set == 0 || ACC1) {
       const int ld_ = (set && ACC1) ? g.out_ld1 : g.out_ld0;
@@ -177,7 +186,9 @@ __global__ __launch_bounds__(256, 2) void conv_planes_k(ConvPArgs a) {
       const int tp = tap_word(t_lo + t);
       const int dy = (int)(signed char)(tp & 0xff), dx = (int)(signed char)((tp >> 8) & 0xff);
       const int widx = (tp >> 16) & 0xff;
-      const unsigned voff_a = ((row_taps >> (t_lo + t)) & 1u) ? pix_off + (unsigned)((dy * g.IW + dx) * 16) : kOob;
+      unsigned voff_a = ((row_taps >> (t_lo + t)) & 1u) ? pix_off + (unsigned)((dy * g.IW + dx) * 16) : kOob;
+      if ((a.flags & 0x100) && t != 0) voff_a = kOob;          // timing experiments only (MPOSE_EXP): no A traffic after a chunk's first tap
+      const bool skip_b = (a.flags & 0x200) != 0;               //                                       no B traffic
       const unsigned w_base = (unsigned)(widx * k16_total + c16) * 6u * w_plane_b;
       unsigned char* bufp = smem + buf * BUF_B;
 #pragma unroll
@@ -190,7 +201,7 @@ __global__ __launch_bounds__(256, 2) void conv_planes_k(ConvPArgs a) {
         } else if (gidx < TOT) {
           const int j = gidx - NA;
           const int ph = j / NGN, ng = j - ph * NGN;
-          dma16(rs_w, bufp + A_B + (ph * BNL + ng * 64) * 16, (unsigned)((n0 + ng * 64 + lane) * 16), w_base + (unsigned)ph * w_plane_b);
+          dma16(rs_w, bufp + A_B + (ph * BNL + ng * 64) * 16, skip_b ? kOob : (unsigned)((n0 + ng * 64 + lane) * 16), w_base + (unsigned)ph * w_plane_b);
         }
       }
     };
@@ -230,18 +241,16 @@ __global__ __launch_bounds__(256, 2) void conv_planes_k(ConvPArgs a) {
       for (int rn = 0; rn < RN; ++rn)
 #pragma unroll
         for (int rm = 0; rm < RM; ++rm) {
-          f32x16 c = acc[rm][rn];
-          if constexpr (NPL == 3) {              // smallest products first
+          if constexpr (NPL == 3) {
+            f32x16 c = acs[rm][rn];                // cross terms, smallest first
             c = mfma_bf16(af[rm][2], bfr[rn][0], c);
             c = mfma_bf16(af[rm][0], bfr[rn][2], c);
             c = mfma_bf16(af[rm][1], bfr[rn][1], c);
             c = mfma_bf16(af[rm][1], bfr[rn][0], c);
             c = mfma_bf16(af[rm][0], bfr[rn][1], c);
-            c = mfma_bf16(af[rm][0], bfr[rn][0], c);
-          } else {
-            c = mfma_bf16(af[rm][0], bfr[rn][0], c);
+            acs[rm][rn] = c;
           }
-          acc[rm][rn] = c;
+          acc[rm][rn] = mfma_bf16(af[rm][0], bfr[rn][0], acc[rm][rn]);
         }
     }
     __builtin_amdgcn_s_barrier();              // the ring may be refilled by the next pass; sRow is complete
@@ -280,7 +289,7 @@ __global__ __launch_bounds__(256, 2) void conv_planes_k(ConvPArgs a) {
           const int n = nb + li;
           float v[16];
 #pragma unroll
-          for (int r = 0; r < 16; ++r) v[r] = acc[rm][rn][r];
+          for (int r = 0; r < 16; ++r) v[r] = NPL == 3 ? acc[rm][rn][r] + acs[rm][rn % NACS][r] : acc[rm][rn][r];
           if (masked) {
             const float msc = op.mask_scale[n], msh = op.mask_shift[n];
             float src[16];
@@ -382,10 +391,7 @@ int launch_planes_shape(const ConvPArgs& a, int mode, int cmax, int n_groups, hi
   if (cmax <= 32) return launch_planes_mode<4, 1, 1, 1, 3, NPL>(a, mode, n_groups, s);
   if (cmax == 64) return launch_planes_mode<4, 1, 1, 2, 3, NPL>(a, mode, n_groups, s);
   if (cmax == 96) return launch_planes_mode<4, 1, 1, 3, 3, NPL>(a, mode, n_groups, s);
-  if (cmax % 192 == 0) {
-    if (narrow_m) return launch_planes_mode<2, 2, 1, 3, 3, NPL>(a, mode, n_groups, s);
-    return launch_planes_mode<2, 2, 2, 3, 2, NPL>(a, mode, n_groups, s);
-  }
+  if (cmax % 192 == 0) return launch_planes_mode<2, 2, 1, 3, 3, NPL>(a, mode, n_groups, s);     // (a 128 x 192 tile would need 2 x 96 accumulator registers)
   if (cmax % 128 == 0) {
     if (narrow_m) return launch_planes_mode<2, 2, 1, 2, 3, NPL>(a, mode, n_groups, s);
     return launch_planes_mode<2, 2, 2, 2, 3, NPL>(a, mode, n_groups, s);
@@ -408,6 +414,7 @@ int mpose_conv_planes_launch(const mpose_conv_geom* geom, const mpose_conv_opera
   a.div_gw = make_fastdiv((unsigned)geom->GW);
   a.div_ghw = make_fastdiv((unsigned)(geom->GH * geom->GW));
   a.flags = flags;
+  if (const char* e = getenv("MPOSE_EXP")) a.flags |= (atoi(e) & 3) << 8;       // timing experiments (wrong results): 1 = skip A re-reads, 2 = skip B
   const long npix = (long)geom->B * geom->IH * geom->IW;
   const long in_bytes = npix * 16 * 3 * (geom->Cin / 8);
   if (in_bytes >= 0xFFFFFF00l - (1l << 20) || geom->in_ld > 0) return MPOSE_EINVAL;       // 32-bit buffer offsets; dense inputs only

@@ -116,7 +116,7 @@ struct BnApplyPArgs {
   int C;
 };
 
-// da = k0a*[mask]g + k1a*a + k2a ; db = k0b*g + k1b*b + k2b  (bn.hip's algebra)  ->  fp32 (optional) + planes
+// da = k0a*[mask]g + k1a*(a - mean_a) + k2a ; db = k0b*g + k1b*(b - mean_b) + k2b  (bn.hip's algebra)  ->  fp32 (optional) + planes
 __global__ __launch_bounds__(256) void bn_bwd_apply_planes_k(BnApplyPArgs a) {
   const mpose_bn_bwd_apply_operands& op = a.op[blockIdx.z];
   const int c8 = blockIdx.y * 4 + (threadIdx.x >> 6);
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_planes_k(BnApplyPArgs a) {
   float g[8];
   load8(op.g, p, a.C, c0, g);
   {
-    float x[8], ga[8], k0[8], k1[8], k2[8], o[8];
+    float x[8], ga[8], k0[8], k1[8], k2[8], mu[8], o[8];
     load8(op.a, p, a.C, c0, x);
 #pragma unroll
     for (int e = 0; e < 8; ++e) ga[e] = g[e];
@@ -138,17 +138,19 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_planes_k(BnApplyPArgs a) {
         if (!(fmaf(x[e], ms[e], mt[e]) > 0.f)) ga[e] = 0.f;
     }
     load_vec8(op.coef_a, c0, k0); load_vec8(op.coef_a + a.C, c0, k1); load_vec8(op.coef_a + 2 * a.C, c0, k2);
+    load_vec8(op.coef_a + 3 * a.C, c0, mu);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = fmaf(k0[e], ga[e], fmaf(k1[e], x[e], k2[e]));
+    for (int e = 0; e < 8; ++e) o[e] = fmaf(k1[e], x[e] - mu[e], fmaf(k0[e], ga[e], k2[e]));
     if (op.da != nullptr) store8(op.da, p, a.C, c0, o);
     if (a.da_planes[blockIdx.z] != nullptr) store_planes8(a.da_planes[blockIdx.z], a.npix, c8, p, o);
   }
   if (op.b != nullptr) {
-    float x[8], k0[8], k1[8], k2[8], o[8];
+    float x[8], k0[8], k1[8], k2[8], mu[8], o[8];
     load8(op.b, p, a.C, c0, x);
     load_vec8(op.coef_b, c0, k0); load_vec8(op.coef_b + a.C, c0, k1); load_vec8(op.coef_b + 2 * a.C, c0, k2);
+    load_vec8(op.coef_b + 3 * a.C, c0, mu);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = fmaf(k0[e], g[e], fmaf(k1[e], x[e], k2[e]));
+    for (int e = 0; e < 8; ++e) o[e] = fmaf(k1[e], x[e] - mu[e], fmaf(k0[e], g[e], k2[e]));
     if (op.db != nullptr) store8(op.db, p, a.C, c0, o);
     if (a.db_planes[blockIdx.z] != nullptr) store_planes8(a.db_planes[blockIdx.z], a.npix, c8, p, o);
   }

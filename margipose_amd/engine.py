@@ -119,6 +119,7 @@ class _Conv:
         self.size_d = self.T * cout_s * self.npad_d * 3 // 2
         self.size_g = self.T * cin_s * self.npad_f          # one split-K partial of the weight gradient (fp32)
         self.off_f = self.off_d = self.off_g = -1
+        self.layout = 0                          # packed-weight layout (include/margipose_hip.h): 1 = conv_p.hip's (column convs)
 
     def strides(self, dgrad):
         """(sn, sk, st): element strides of (n, k, tap) in the torch-layout weight."""
@@ -246,6 +247,12 @@ class Engine:
         self.combiners = [m.conv.weight for m in inner.hm_combiners]
         self._all_blocks = [b for st in self.stage_blocks for grp in st for b in grp]
         block_convs = [c for b in self._all_blocks for c in (b.conv_in, b.conv2, b.conv_sc)]
+        # Round-2 convolution engine for the columns: activations pre-split into bf16 planes by their producers, both
+        # operands by DMA, two workgroups per CU (csrc/conv_p.hip).  MPOSE_PLANES=0 keeps round 1's conv_igemm_k (A/B runs).
+        self.use_planes = os.environ.get('MPOSE_PLANES', '1') != '0'
+        self.conv_bf16 = False       # single-pass bf16 convolutions in the columns (MargiPoseModel.conv_dtype, configs[4])
+        for c in block_convs:
+            c.layout = 1 if self.use_planes else 0
         block_bns = [n for b in self._all_blocks for n in (b.bn1, b.bn2, b.bns)]
         self.stem = None
         fe_name = getattr(inner, 'feature_extractor_name', 'patch8')
@@ -316,10 +323,10 @@ class Engine:
             c.off_f = off; off += c.size_f
             c.off_d = off; off += c.size_d
         self.wpack = torch.zeros(off, dtype=torch.float32, device=device)
-        # float arena per BN: scale, shift, mean, invstd, coef[3] -> 7*Cs ; double arena: fwd stats 2*Cs + bwd sums 4*Cs
+        # float arena per BN: scale, shift, mean, invstd, coef[4] -> 8*Cs ; double arena: fwd stats 2*Cs + bwd sums 4*Cs
         foff = soff = 0
         for n in self._bns:
-            n.f_off = foff; foff += 7 * n.Cs
+            n.f_off = foff; foff += 8 * n.Cs
             n.s_off = soff; soff += 6 * n.Cs
         self.bnf = torch.zeros(foff, dtype=torch.float32, device=device)
         self.stat_arena = torch.zeros(soff, dtype=torch.float64, device=device)
@@ -373,6 +380,7 @@ class Engine:
                 j['Npad'] = c.npad_d if d else c.npad_f
                 j['Kpad'] = c.cout_s if d else c.cin_s
                 j['sn'], j['sk'], j['st'] = sn, sk, st
+                j['layout'] = c.layout
                 mx = max(mx, int(j['T']) * int(j['Kpad']) * int(j['Npad']))
         self._pack_jobs = _jobs_to_device(jobs, device)
         self._pack_max = mx
@@ -381,7 +389,7 @@ class Engine:
 
     # views into the BN arenas --------------------------------------------------------------
     def _bnf_ptr(self, n, slot):
-        """slot: 0 scale, 1 shift, 2 mean, 3 invstd, 4 coef(3*Cs)."""
+        """slot: 0 scale, 1 shift, 2 mean, 3 invstd, 4 coef(4*Cs: c0, c1, c2, mean)."""
         return self.bnf.data_ptr() + 4 * (n.f_off + slot * n.Cs)
 
     def _stats_ptr(self, n, bwd=False):
@@ -547,6 +555,26 @@ class Engine:
         if t0 is not None:
             self.timer.stop('conv:' + g._name, t0, g._flops * len(ops))
 
+    # ---- pre-split activations (csrc/split.hip) ----
+    def planes_empty(self, npix, C):
+        return torch.empty(npix * (C // 8) * 48, dtype=torch.uint8, device=self.device)
+
+    def split_planes(self, srcs, npix, C, scales=None, shifts=None, relu=False):
+        """fp32 NHWC tensors -> bf16 hi/mid/lo planes of [relu](scale*x + shift); one grouped launch."""
+        outs = [self.planes_empty(npix, C) for _ in srcs]
+        ops = []
+        for i, src in enumerate(srcs):
+            so = SplitOperands()
+            so.src, so.planes = src.data_ptr(), outs[i].data_ptr()
+            if scales is not None:
+                so.scale, so.shift = scales[i], shifts[i]
+            ops.append(so)
+        check(lib().mpose_split_planes((SplitOperands * 3)(*ops), len(ops), c_int64(npix), C, int(relu), stream_ptr()), 'mpose_split_planes')
+        return outs
+
+    def conv_flags(self):
+        return (4 | (8 if self.conv_bf16 else 0)) if self.use_planes else 0
+
     def wgrad(self, g, ops, n_split):
         arr = (WgradOperands * 3)(*ops)
         t0 = self.timer.start() if self.timer is not None else None
@@ -677,6 +705,11 @@ class Engine:
                 inp = new_inp
             ctx['inps'].append(inp)
             cur = [inp, inp, inp]
+            planes = self.use_planes
+            pflags = ctx['pflags'] = self.conv_flags()
+            if planes:               # the stage input is read by all three columns: split once
+                inp_p = self.split_planes([inp], B * F * F, 128)[0]
+                cur_p = [inp_p, inp_p, inp_p]
             stage_saved = []
             for i in range(10):
                 grp = self.stage_blocks[t][i]
@@ -688,6 +721,12 @@ class Engine:
                     spaces = (c_int * 3)(*self.spaces)
                     check(L.mpose_axis_permute(ptr_array(cur), ptr_array(outs), spaces, 3, B, Sm, 192, st()), 'mpose_axis_permute')
                     cur = outs
+                    if planes:
+                        moved = [c for c in range(3) if self.spaces[c] != 0]
+                        new_p = self.split_planes([cur[c] for c in moved], B * Sm * Sm, 192)
+                        cur_p = list(cur_p)
+                        for c, pl in zip(moved, new_p):
+                            cur_p[c] = pl
                 gname = {'regular': 'f_in_regular', 'down': 'f_in_down', 'up': 'f_in_up'}[b0.kind]
                 g1 = self.geom(gname, B, Hin, b0)
                 c1 = [torch.empty(B, Hout, Hout, b0.cout_s, **f32) for _ in range(3)]
@@ -695,24 +734,32 @@ class Engine:
                 ops = []
                 for c, b in enumerate(grp):
                     op = ConvOperands()
-                    op.in_, op.w0, op.w1 = cur[c].data_ptr(), self._wptr(b.conv_in), self._wptr(b.conv_sc)
+                    op.in_ = (cur_p[c] if planes else cur[c]).data_ptr()
+                    op.w0, op.w1 = self._wptr(b.conv_in), self._wptr(b.conv_sc)
                     op.out0, op.out1 = c1[c].data_ptr(), sc[c].data_ptr()
                     if train:
                         op.stats0, op.stats1 = self._stats_ptr(b.bn1), self._stats_ptr(b.bns)
                     ops.append(op)
-                self.conv(g1, ops)
+                self.conv(g1, ops, pflags)
                 if train:
                     self.finalize(tb, self.fin_index(t, i, 0), 6, True)
                 c2 = [torch.empty(B, Hout, Hout, b0.cout_s, **f32) for _ in range(3)]
+                if planes:           # relu(bn1(c1)) is written once, pre-split, instead of being recomputed by every tap
+                    a1_p = self.split_planes(c1, B * Hout * Hout, b0.cout_s, [self._bnf_ptr(b.bn1, 0) for b in grp],
+                                             [self._bnf_ptr(b.bn1, 1) for b in grp], relu=True)
                 ops = []
                 for c, b in enumerate(grp):
                     op = ConvOperands()
-                    op.in_, op.w0, op.out0 = c1[c].data_ptr(), self._wptr(b.conv2), c2[c].data_ptr()
-                    op.in_scale, op.in_shift = self._bnf_ptr(b.bn1, 0), self._bnf_ptr(b.bn1, 1)
+                    op.w0, op.out0 = self._wptr(b.conv2), c2[c].data_ptr()
+                    if planes:
+                        op.in_ = a1_p[c].data_ptr()
+                    else:
+                        op.in_ = c1[c].data_ptr()
+                        op.in_scale, op.in_shift = self._bnf_ptr(b.bn1, 0), self._bnf_ptr(b.bn1, 1)
                     if train:
                         op.stats0 = self._stats_ptr(b.bn2)
                     ops.append(op)
-                self.conv(self.geom('f_conv2', B, Hout, b0), ops)
+                self.conv(self.geom('f_conv2', B, Hout, b0), ops, pflags)
                 if train:
                     self.finalize(tb, self.fin_index(t, i, 2), 3, True)
                 last = i == 9
@@ -727,8 +774,13 @@ class Engine:
                     ao.b, ao.b_scale, ao.b_shift = sc[c].data_ptr(), self._bnf_ptr(b.bns, 0), self._bnf_ptr(b.bns, 1)
                     ao.out = outs[c].data_ptr()
                     aops.append(ao)
-                check(L.mpose_bn_add_fwd((BnAddOperands * 3)(*aops), 3, Hout * Hout, B, b0.cout_s, 1 if last else 0, self.J, st()),
-                      'mpose_bn_add_fwd')
+                if planes and not last:
+                    cur_p = [self.planes_empty(B * Hout * Hout, b0.cout_s) for _ in range(3)]
+                    check(L.mpose_bn_add_planes((BnAddOperands * 3)(*aops), ptr_array(cur_p), 3, c_int64(B * Hout * Hout), b0.cout_s, st()),
+                          'mpose_bn_add_planes')
+                else:
+                    check(L.mpose_bn_add_fwd((BnAddOperands * 3)(*aops), 3, Hout * Hout, B, b0.cout_s, 1 if last else 0, self.J, st()),
+                          'mpose_bn_add_fwd')
                 if save:
                     stage_saved.append({'x': cur, 'c1': c1, 'sc': sc, 'c2': c2})
                 cur = outs
@@ -794,6 +846,8 @@ class Engine:
         self.stat_arena.zero_()        # forward sums are consumed (mean/invstd live in the float arena)
         goff = dict((id(p), o) for p, o in zip(self.param_list(), self._grad_offsets))
         coef_base = tb['coef'].data_ptr()
+        planes = self.use_planes
+        pflags = ctx.get('pflags', self.conv_flags())      # (the forward's convolution precision)
 
         def run_coef(first, n):
             check(L.mpose_bn_bwd_coef(c_void_p(coef_base + first * COEF_DT.itemsize), n, eval_bn, st()), 'mpose_bn_bwd_coef')
@@ -843,18 +897,25 @@ class Engine:
                     ao.a_scale, ao.a_shift = self._bnf_ptr(b.bn2, 0), self._bnf_ptr(b.bn2, 1)
                     ao.da, ao.db = d_c2[c].data_ptr(), d_sc[c].data_ptr()
                     aops.append(ao)
-                check(L.mpose_bn_bwd_apply((BnBwdApplyOperands * 3)(*aops), 3, Hout * Hout, B, Cs, 0, 0, st()), 'mpose_bn_bwd_apply')
+                if planes:           # the gradients feed a convolution next: written pre-split as well
+                    d_c2_p = [self.planes_empty(cnt, Cs) for _ in range(3)]
+                    d_sc_p = [self.planes_empty(cnt, Cs) for _ in range(3)]
+                    check(L.mpose_bn_bwd_apply_planes((BnBwdApplyOperands * 3)(*aops), ptr_array(d_c2_p), ptr_array(d_sc_p), 3, c_int64(cnt),
+                                                      Cs, st()), 'mpose_bn_bwd_apply_planes')
+                else:
+                    check(L.mpose_bn_bwd_apply((BnBwdApplyOperands * 3)(*aops), 3, Hout * Hout, B, Cs, 0, 0, st()), 'mpose_bn_bwd_apply')
                 # (2) dgrad of the second 3x3; ReLU mask and the BN1-backward sums happen in its epilogue
                 d_a1 = [torch.empty(B, Hout, Hout, Cs, **f32) for _ in range(3)]
                 ops = []
                 for c, b in enumerate(grp):
                     op = ConvOperands()
-                    op.in_, op.w0, op.out0 = d_c2[c].data_ptr(), self._wptr(b.conv2, True), d_a1[c].data_ptr()
+                    op.in_ = (d_c2_p[c] if planes else d_c2[c]).data_ptr()
+                    op.w0, op.out0 = self._wptr(b.conv2, True), d_a1[c].data_ptr()
                     op.mask_src = sv['c1'][c].data_ptr()
                     op.mask_scale, op.mask_shift = self._bnf_ptr(b.bn1, 0), self._bnf_ptr(b.bn1, 1)
                     op.stats0 = self._stats_ptr(b.bn1, True)
                     ops.append(op)
-                self.conv(self.geom('d_conv2', B, Hout, b0), ops)
+                self.conv(self.geom('d_conv2', B, Hout, b0), ops, pflags)
                 # (3) wgrad of the second 3x3 (its input relu(bn1(c1)) is recomputed while staging)
                 wops = []
                 for c, b in enumerate(grp):
@@ -872,7 +933,12 @@ class Engine:
                     ao = BnBwdApplyOperands()
                     ao.g, ao.a, ao.coef_a, ao.da = d_a1[c].data_ptr(), sv['c1'][c].data_ptr(), self._bnf_ptr(b.bn1, 4), d_c1[c].data_ptr()
                     aops.append(ao)
-                check(L.mpose_bn_bwd_apply((BnBwdApplyOperands * 3)(*aops), 3, Hout * Hout, B, Cs, 0, 0, st()), 'mpose_bn_bwd_apply')
+                if planes:
+                    d_c1_p = [self.planes_empty(cnt, Cs) for _ in range(3)]
+                    check(L.mpose_bn_bwd_apply_planes((BnBwdApplyOperands * 3)(*aops), ptr_array(d_c1_p), None, 3, c_int64(cnt), Cs, st()),
+                          'mpose_bn_bwd_apply_planes')
+                else:
+                    check(L.mpose_bn_bwd_apply((BnBwdApplyOperands * 3)(*aops), 3, Hout * Hout, B, Cs, 0, 0, st()), 'mpose_bn_bwd_apply')
                 # (5) wgrad of conv_in + shortcut: one launch over the fused forward geometry
                 gname = {'regular': 'f_in_regular', 'down': 'f_in_down', 'up': 'f_in_up'}[b0.kind]
                 slots = B * (Hin if b0.kind == 'up' else Hout) ** 2
@@ -891,10 +957,12 @@ class Engine:
                 ops = []
                 for c, b in enumerate(grp):
                     op = ConvOperands()
-                    op.in_, op.w0, op.out0 = d_c1[c].data_ptr(), self._wptr(b.conv_in, True), d_x[c].data_ptr()
-                    op.in1, op.w1 = d_sc[c].data_ptr(), self._wptr(b.conv_sc, True)
+                    op.in_ = (d_c1_p[c] if planes else d_c1[c]).data_ptr()
+                    op.in1 = (d_sc_p[c] if planes else d_sc[c]).data_ptr()
+                    op.w0, op.out0 = self._wptr(b.conv_in, True), d_x[c].data_ptr()
+                    op.w1 = self._wptr(b.conv_sc, True)
                     ops.append(op)
-                self.conv(self.geom(kd, B, Hout, b0), ops, 2)
+                self.conv(self.geom(kd, B, Hout, b0), ops, 2 | pflags)
                 g = d_x
                 if i == 5 and any(sp != 0 for sp in self.spaces):     # the permutation is an involution
                     outs = [g[c] if self.spaces[c] == 0 else torch.empty_like(g[c]) for c in range(3)]

@@ -244,6 +244,23 @@ class MargiPoseModel(nn.Module):
             raise _lib.MposeError('heatmap_dtype must be torch.float32 or torch.bfloat16')
         object.__setattr__(self.inner, 'heatmap_dtype', dtype)
 
+    @property
+    def conv_dtype(self):
+        """torch.float32 (default: fp32-equivalent convolutions, six exact bf16 products per operand pair) or torch.bfloat16:
+        the reduced-precision mode of BASELINE configs[4] -- the columns' forward and data-gradient convolutions multiply
+        bf16-rounded operands in a single MFMA pass (fp32 accumulation); BatchNorm, the losses, the weight gradients and the
+        feature extractor stay fp32.  NOT within the 1e-4 parity bar of the fp32 path (tolerances: tests/test_model_gpu.py)."""
+        return torch.bfloat16 if self.inner.engine().conv_bf16 else torch.float32
+
+    @conv_dtype.setter
+    def conv_dtype(self, dtype):
+        if dtype not in (torch.float32, torch.bfloat16):
+            raise _lib.MposeError('conv_dtype must be torch.float32 or torch.bfloat16')
+        eng = self.inner.engine()
+        if dtype == torch.bfloat16 and not eng.use_planes:
+            raise _lib.MposeError('conv_dtype=bfloat16 needs the plane convolution engine (MPOSE_PLANES=0 is set)')
+        eng.conv_bf16 = dtype == torch.bfloat16
+
     def forward(self, *inputs):
         self.xy_heatmaps, self.zy_heatmaps, self.xz_heatmaps = self.inner(*inputs)
         if self.xy_heatmaps[-1].dtype == torch.bfloat16:        # coordinates of the fp32 soft-argmax (same kernel, before rounding)

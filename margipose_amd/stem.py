@@ -231,7 +231,7 @@ class _GraphStem:
         foff = soff = 0
         for n in self.nodes:
             n.f_off, n.s_off = foff, soff
-            foff += 7 * n.C
+            foff += 8 * n.C
             soff += 6 * n.C
         self.f_arena = torch.zeros(foff, dtype=torch.float32, device=device)
         self.s_arena = torch.zeros(soff, dtype=torch.float64, device=device)
@@ -243,7 +243,7 @@ class _GraphStem:
         self._tables = {}
 
     def fptr(self, n, slot, c0=0):
-        """slot: 0 scale, 1 shift, 2 mean, 3 invstd, 4 coef (3*C)."""
+        """slot: 0 scale, 1 shift, 2 mean, 3 invstd, 4 coef (4*C)."""
         return self.f_arena.data_ptr() + 4 * (n.f_off + slot * n.C + c0)
 
     def sptr(self, n, bwd=False, c0=0):

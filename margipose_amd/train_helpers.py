@@ -90,3 +90,156 @@ def save_checkpoint(path, model, model_desc, optimiser=None, epoch=0, train_data
         state['epoch'] = epoch
     torch.save(state, path)
     return state
+
+
+SGD_JOB_DT = None
+
+
+def _sgd_job_dtype():
+    global SGD_JOB_DT
+    if SGD_JOB_DT is None:
+        import numpy as np
+        SGD_JOB_DT = np.dtype([('p', 'u8'), ('g', 'u8'), ('buf', 'u8'), ('n', 'i8')], align=True)
+    return SGD_JOB_DT
+
+
+class DeviceSGD:
+    """torch.optim.SGD(params, lr, momentum) -- the reference's optimiser (bin/train_3d.py:339) -- as ONE launch over all
+    parameters (csrc/optim.hip) with lr / momentum read from device memory, so that the 1cycle schedule
+    (hyperparam_scheduler.py: lr AND momentum move every batch) keeps working when the whole iteration is replayed from a
+    HIP graph (GraphedTrainStep).  Same arithmetic as torch (no dampening / weight decay / Nesterov), checked bit for bit in
+    tests/test_train_graph_gpu.py.  Duck-types what the reference's loop touches: .param_groups, .zero_grad(), .step(),
+    .state_dict()."""
+
+    def __init__(self, params, lr, momentum=0.0):
+        import numpy as np
+        from . import _lib
+        self.params = [p for p in params]
+        if not self.params or not all(p.is_cuda and p.dtype == torch.float32 for p in self.params):
+            raise _lib.MposeError('DeviceSGD needs float32 parameters on a ROCm device')
+        self.param_groups = [{'params': self.params, 'lr': float(lr), 'momentum': float(momentum)}]
+        dev = self.params[0].device
+        offs, tot = [], 0
+        for p in self.params:
+            offs.append(tot)
+            tot += (p.numel() + 3) // 4 * 4
+        self._bufs = torch.zeros(tot, dtype=torch.float32, device=dev)          # momentum buffers, one arena
+        self._buf_ptr = [self._bufs.data_ptr() + 4 * o for o in offs]
+        self._max_n = max(p.numel() for p in self.params)
+        self._hyper = torch.zeros(4, dtype=torch.float32, device=dev)
+        self._steps = 0
+        self._np = np
+        self._eager_table = torch.zeros(len(self.params) * _sgd_job_dtype().itemsize, dtype=torch.uint8, device=dev)
+        self._graph_table = None                                                 # filled by finish_capture()
+
+    def zero_grad(self, set_to_none=True):
+        for p in self.params:
+            if set_to_none:
+                p.grad = None
+            elif p.grad is not None:
+                p.grad.zero_()
+
+    def _fill_table(self, table):
+        jobs = self._np.zeros(len(self.params), dtype=_sgd_job_dtype())
+        for i, p in enumerate(self.params):
+            if p.grad is None:
+                raise RuntimeError('DeviceSGD.step(): a parameter has no gradient')
+            g = p.grad
+            if not g.is_contiguous() or g.data_ptr() % 16:
+                raise RuntimeError('DeviceSGD needs contiguous, 16-byte aligned gradients')
+            jobs[i] = (p.data_ptr(), g.data_ptr(), self._buf_ptr[i], p.numel())
+        table.copy_(torch.from_numpy(jobs.view(self._np.uint8)))        # (pageable source: staged by the runtime before returning)
+
+    def upload_hyper(self):
+        """Hand {lr, momentum, first-step flag} of the next step() to the device (values travel as kernel arguments)."""
+        from . import _lib
+        g = self.param_groups[0]
+        f = _lib.c_float
+        _lib.check(_lib.lib().mpose_set4(_lib.ptr(self._hyper), f(g['lr']), f(g['momentum']), f(1.0 if self._steps == 0 else 0.0), f(0.0),
+                                         _lib.stream_ptr()), 'mpose_set4')
+
+    def step(self):
+        from . import _lib
+        capturing = torch.cuda.is_current_stream_capturing()
+        if capturing:
+            # nothing executes during capture: the job table is filled by finish_capture() with the gradients' addresses inside
+            # the graph's memory pool, and the hyper-parameters are uploaded by the caller before every replay
+            if self._graph_table is None:
+                self._graph_table = torch.zeros_like(self._eager_table)
+            table = self._graph_table
+        else:
+            self.upload_hyper()
+            self._fill_table(self._eager_table)
+            table = self._eager_table
+            self._steps += 1
+        _lib.check(_lib.lib().mpose_sgd_step(_lib.ptr(table), len(self.params), _lib.c_int64(self._max_n), _lib.ptr(self._hyper),
+                                             _lib.stream_ptr()), 'mpose_sgd_step')
+
+    def finish_capture(self):
+        """After torch.cuda.graph(...) captured a step(): bind the captured launch to the captured gradient tensors."""
+        self._fill_table(self._graph_table)
+
+    def before_replay(self):
+        self.upload_hyper()
+        self._steps += 1
+
+    def state_dict(self):
+        return {'state': {'momentum_buffers': self._bufs.detach().cpu(), 'steps': self._steps},
+                'param_groups': [{k: v for k, v in g.items() if k != 'params'} for g in self.param_groups]}
+
+    def load_state_dict(self, sd):
+        self._bufs.copy_(sd['state']['momentum_buffers'])
+        self._steps = int(sd['state']['steps'])
+        for g, s in zip(self.param_groups, sd['param_groups']):
+            g.update(s)
+
+
+class GraphedTrainStep:
+    """One training iteration of the reference (bin/train_3d.py:154-186: model(x) -> forward_loss -> zero_grad -> backward ->
+    optimiser.step) captured ONCE as a HIP graph and replayed: every buffer of a step has a fixed address (engine.py: arenas,
+    device-resident job tables), so a replay costs one graph launch of host time instead of ~1000 kernel launches.
+
+        step = GraphedTrainStep(model, optimiser, x, target, mask)          # example tensors fix the shapes
+        out, loss = step(x, target, mask)                                    # copies the batch in, replays
+
+    `optimiser`: DeviceSGD (hyper-parameters may change every step, e.g. driven by make_1cycle(...).batch_step()) or any torch
+    optimiser whose step() is capturable with FIXED hyper-parameters (torch.optim.SGD(..., fused=True)).
+    `valid_depth` (3D vs 2D loss per sample, train_3d.py:126-142) is fixed at capture time."""
+
+    def __init__(self, model, optimiser, x, target, mask, valid_depth=None, warmup=2):
+        self.model, self.opt = model, optimiser
+        self.x, self.target, self.mask = x.clone(), target.clone(), mask.clone()
+        self.valid_depth = [1] * x.shape[0] if valid_depth is None else [int(v) for v in valid_depth]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                   # torch's capture rule: warm up on a side stream first
+            for _ in range(warmup):
+                self._iteration()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out, self.loss = self._iteration()
+        if hasattr(optimiser, 'finish_capture'):
+            optimiser.finish_capture()
+        torch.cuda.synchronize()
+
+    def _iteration(self):
+        out = self.model(self.x)
+        loss = forward_loss(self.model, out, self.target, self.mask, self.valid_depth)
+        self.opt.zero_grad(set_to_none=True)
+        loss.backward()
+        self.opt.step()
+        return out, loss
+
+    def __call__(self, x=None, target=None, mask=None):
+        if x is not None:
+            self.x.copy_(x, non_blocking=True)
+        if target is not None:
+            self.target.copy_(target, non_blocking=True)
+        if mask is not None:
+            self.mask.copy_(mask, non_blocking=True)
+        if hasattr(self.opt, 'before_replay'):
+            self.opt.before_replay()
+        self.graph.replay()
+        return self.out, self.loss

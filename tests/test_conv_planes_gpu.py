@@ -84,7 +84,11 @@ def errs(got_nhwc, ref, f32):
 
 
 def check(e_gpu, e_f32):
-    assert e_gpu <= 2.0 * e_f32 + 2e-7, (e_gpu, e_f32)
+    # 3x (tests/test_conv_gpu.py: 2x): this engine has no split-K, so an output's hi x hi accumulator is rounded once per
+    # (tap, 16 channels) step -- 72..108 times for the 3x3 layers, against the 16-lane blocked sums of the CPU kernel it is
+    # compared with.  Measured ratios: 1.6-2.7.  At the model level the GPU's gradients are CLOSER to fp64 than the CPU fp32
+    # path's (tests/test_grad_parity_gpu.py: 0.62-0.76x).
+    assert e_gpu <= 3.0 * e_f32 + 2e-7, (e_gpu, e_f32)
 
 
 def nhwc(x):
@@ -257,7 +261,7 @@ def test_bn_add_and_bn_bwd_apply_write_planes():
     mk = lambda *s: torch.from_numpy(rng.standard_normal(s)).float().cuda()
     a, b, gup = mk(B, H, H, C), mk(B, H, H, C), mk(B, H, H, C)
     sa, ta, sb, tb = mk(C), mk(C), mk(C), mk(C)
-    coef_a, coef_b = mk(3, C), mk(3, C)
+    coef_a, coef_b = mk(4, C), mk(4, C)
     # bn_add
     want = torch.empty_like(a)
     ao = BnAddOperands()

@@ -24,7 +24,8 @@ from oracle import model_ref as R
 from oracle import weights as W
 
 pytestmark = pytest.mark.gpu
-MASKED_TOL = 2e-5          # relative L2 per tensor against fp64 on the same ReLU piece (fp32 arithmetic through ~60 layers)
+MASKED_TOL = 3e-5          # relative L2 per tensor against fp64 on the same ReLU piece (fp32 arithmetic through ~60 layers;
+                           # the worst tensors are bias gradients = sums over pixels with heavy cancellation)
 
 
 def rel_l2(a, b):

@@ -518,7 +518,7 @@ def test_backward_through_eval_mode_batchnorm(stem):
     assert abs(float(loss.detach()) - l64) <= 1e-4 * abs(l64)
     st = GP.compare('eval_%s' % stem, gpu, r64, r32)
     if stem == 'patch8':
-        assert st['gpu_max'] <= 5e-5 and st['gpu_median'] <= max(1.5 * st['ref32_median'], 2e-6), st
+        assert st['gpu_max'] <= 3e-5 and st['gpu_median'] <= 2.0 * st['ref32_median'], st    # (no batch statistics in eval: the fp32 oracle is at 2.6e-6)
     else:
         assert st['gpu_median'] <= max(1e-4, 1.5 * st['ref32_median']) and st['gpu_p99'] <= max(1e-4, 1.5 * st['ref32_p99']), st
         kb = 'inner.in_cnn.7.bias'

@@ -1,0 +1,77 @@
+"""The reference's training iteration (src/margipose/bin/train_3d.py:154-186 with the 1cycle policy of
+hyperparam_scheduler.py:6-42) as ONE replayed HIP graph: margipose_amd.train_helpers.GraphedTrainStep + DeviceSGD.
+
+  * DeviceSGD (csrc/optim.hip, hyper-parameters in device memory) == torch.optim.SGD bit for bit while lr and momentum
+    change every step;
+  * a replayed graph produces the same weights, bit for bit, as the same iterations run eagerly."""
+import copy
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import model_ref as R
+from oracle import weights as W
+
+pytestmark = pytest.mark.gpu
+
+
+def test_device_sgd_equals_torch_sgd_under_a_moving_schedule():
+    from margipose_amd.train_helpers import DeviceSGD, make_1cycle
+    torch.manual_seed(3)
+    shapes = [(192, 128, 3, 3), (128,), (17, 128, 1, 1), (5,), (1,), (64, 3, 7, 7)]
+    p_ref = [torch.randn(s, device='cuda').requires_grad_(True) for s in shapes]
+    p_dev = [p.detach().clone().requires_grad_(True) for p in p_ref]
+    o_ref = torch.optim.SGD(p_ref, lr=0.1, momentum=0.9)
+    o_dev = DeviceSGD(p_dev, lr=0.1, momentum=0.9)
+    s_ref, s_dev = make_1cycle(o_ref, 10, 1.0, 0.9), make_1cycle(o_dev, 10, 1.0, 0.9)
+    for it in range(6):
+        grads = [torch.randn(s, device='cuda') for s in shapes]
+        for ps, opt, sch in ((p_ref, o_ref, s_ref), (p_dev, o_dev, s_dev)):
+            sch.batch_step()
+            for p, g in zip(ps, grads):
+                p.grad = g.clone()
+            opt.step()
+        for a, b in zip(p_ref, p_dev):
+            assert torch.equal(a, b), it
+
+
+def _model(T, seed, x, stem='patch8'):
+    from margipose_amd.models import CanonicalSkeletonDesc, MargiPoseModel
+    sd = R.calibrate_running_stats(W.make_state_dict(T, seed, torch.float64, stem=stem), x.double(), T)
+    m = MargiPoseModel(CanonicalSkeletonDesc, T, True, stem, 'jsd')
+    m.load_state_dict(OrderedDict((k, v.float() if v.is_floating_point() else v) for k, v in sd.items()), strict=True)
+    return m.cuda().train()
+
+
+@pytest.mark.parametrize('stem', ['patch8', 'inceptionv4'])
+def test_graphed_iterations_equal_eager_iterations(stem):
+    from margipose_amd.train_helpers import DeviceSGD, GraphedTrainStep, make_1cycle, training_step
+    T, seed, B, n_iter = 1, 55, 2, 4
+    x, target, mask = W.seeded_inputs(seed, B)
+    batches = [W.seeded_inputs(seed + 1 + i, B) for i in range(n_iter)]
+    m_e = _model(T, seed, x, stem)
+    m_g = copy.deepcopy(m_e)
+    # eager: the reference's loop
+    opt_e = DeviceSGD(m_e.parameters(), lr=0.05, momentum=0.9)
+    sch_e = make_1cycle(opt_e, 20, 0.05, 0.9)
+    losses_e = []
+    for xb, tb, mb in batches:
+        _, loss = training_step(m_e, sch_e, xb.cuda(), tb.cuda(), mb.cuda(), [1] * B)
+        losses_e.append(float(loss.detach()))
+    # graphed: captured once (the capture's warm-up iterations run on a COPY of the state, which is restored afterwards)
+    opt_g = DeviceSGD(m_g.parameters(), lr=0.05, momentum=0.9)
+    sch_g = make_1cycle(opt_g, 20, 0.05, 0.9)
+    state = copy.deepcopy(m_g.state_dict())
+    step = GraphedTrainStep(m_g, opt_g, x.cuda(), target.cuda(), mask.cuda())
+    m_g.load_state_dict(state)
+    opt_g._bufs.zero_(); opt_g._steps = 0
+    losses_g = []
+    for xb, tb, mb in batches:
+        sch_g.batch_step()
+        _, loss = step(xb.cuda(), tb.cuda(), mb.cuda())
+        losses_g.append(float(loss))
+    assert losses_e == losses_g, (losses_e, losses_g)
+    for (k, a), (_, b) in zip(m_e.state_dict().items(), m_g.state_dict().items()):
+        assert torch.equal(a, b), k
