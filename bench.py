@@ -71,6 +71,7 @@ def parse():
                     help="'inceptionv4' = the reference's default feature extractor; 'resnet*' = its other options; 'patch8' = the light in-repo stem")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
+    ap.add_argument('--no-inference', action='store_true', help='skip the configs[1] inference micro-benchmark (profiling runs)')
     ap.add_argument('--cpu-batch', type=int, default=8)
     ap.add_argument('--no-overlap-wgrad', action='store_true', help='keep the weight-gradient GEMMs on the main stream (the default '
                     'runs them on a side stream, +2.3 %% step rate; the steps whose kernels are bracketed by HIP events for the '
@@ -219,7 +220,14 @@ def main():
     # The iteration is captured once as a HIP graph and replayed (every buffer of a step has a fixed address); eager mode costs
     # ~1000 launches of host time per step.  Under data parallelism the graph would have to contain the RCCL all-reduces: opt-in.
     use_graph = not args.eager and (world == 1 or os.environ.get('MPOSE_DP_GRAPH') == '1')
-    graphed = GraphedTrainStep(model, opt, x, target, mask, warmup=2) if use_graph else None
+    graphed = None
+    if use_graph:
+        try:
+            graphed = GraphedTrainStep(model, opt, x, target, mask, warmup=2)
+        except Exception as e:          # a failed capture must not cost the measurement: fall back to eager launches
+            sys.stderr.write('bench.py: HIP graph capture failed (%s: %s); running eagerly\n' % (type(e).__name__, e))
+            torch.cuda.synchronize()
+            use_graph = False
 
     def step():
         if graphed is not None:
@@ -310,7 +318,7 @@ def main():
         res['tail_config_sizes'] = {
             'configs[2] training, B=%d fp32' % B: dict(tail_microbench(device, B), note='latency-bound: working set in Infinity Cache'),
             'configs[1] inference, B=64 bf16 heatmaps': dict(tail_microbench(device, 64, bf16_out=True), note='latency-bound: working set in Infinity Cache')}
-    if world == 1:
+    if world == 1 and not args.no_inference:
         res['inference'] = inference_microbench(model, device, args.size)
     if world == 1 and not args.no_cpu_baseline:
         res['cpu_baseline'] = cpu_baseline(args.stages, args.size, args.cpu_batch, args.stem)

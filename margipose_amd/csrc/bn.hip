@@ -323,7 +323,7 @@ extern "C" int mpose_bn_bwd_reduce(const mpose_bn_bwd_reduce_operands* ops, int 
   if (a.npix == 0) return 0;
   a.C = C;
   const int rows_per_pass = 256 / (C / 4);
-  int blocks = grid_for(a.npix, rows_per_pass * 16);
+  int blocks = grid_for(a.npix, rows_per_pass * 8);      // (8 pixel rows per thread: 2x the workgroups of round 1 -- the pass is latency-bound)
   if (blocks > 512) blocks = 512;
   a.pix_per_block = (int)((a.npix + blocks - 1) / blocks);
   const int lds = rows_per_pass * C * 4 * 8;

@@ -82,7 +82,7 @@ template <int WM, int WN, int RM, int RN, int NBUF, int MODE, int NPL>
 __global__ __launch_bounds__(256, 2) void conv_planes_k(ConvPArgs a) {
   static_assert(WM * WN == 4, "four waves");
   constexpr bool ACC1 = MODE == 1, SUM2 = MODE == 2;
-  constexpr int NPASS = MODE ? 2 : 1;
+  constexpr int NPASS = ACC1 ? 2 : 1;          // SUM2 runs as ONE pass over all taps (the acc == 1 taps read in1 / w1)
   constexpr int BM = 32 * RM * WM, BN = 32 * RN * WN, BNL = (BN + 63) / 64 * 64;
   constexpr int SGN = BM / 64, NGN = BNL / 64;                 // 64-pixel / 64-column groups = DMA instructions per (plane, half)
   static_assert(SGN == 1 || SGN == 2 || SGN == 4, "slot groups must divide the wave count");
@@ -161,11 +161,9 @@ __global__ __launch_bounds__(256, 2) void conv_planes_k(ConvPArgs a) {
 #pragma unroll 1
   for (int set = 0; set < NPASS; ++set) {
     const int t_lo = set ? n_taps0 : 0;
-    const int nt = set ? n_taps - n_taps0 : (MODE ? n_taps0 : n_taps);
+    const int nt = set ? n_taps - n_taps0 : (ACC1 ? n_taps0 : n_taps);
     const int n_steps = k16_total * nt;
-    const __amdgpu_buffer_rsrc_t rs_w = set ? rs_w1 : rs_w0;
-    const __amdgpu_buffer_rsrc_t rs_in = set ? rs_in1 : rs_in0;
-    if (!SUM2 || set == 0) {
+    {
 #pragma unroll
       for (int rm = 0; rm < RM; ++rm)
 #pragma unroll
@@ -191,17 +189,21 @@ __global__ __launch_bounds__(256, 2) void conv_planes_k(ConvPArgs a) {
       const bool skip_b = (a.flags & 0x200) != 0;               //                                       no B traffic
       const unsigned w_base = (unsigned)(widx * k16_total + c16) * 6u * w_plane_b;
       unsigned char* bufp = smem + buf * BUF_B;
+      const bool second = ACC1 ? set != 0 : (SUM2 && (t_lo + t) >= n_taps0);     // which input / weight set this tap reads
 #pragma unroll
       for (int k = 0; k < (TOT + 3) / 4; ++k) {
         const int gidx = wave + 4 * k;
         if (gidx < NA) {
           const int ph = gidx / SGN;                               // plane * 2 + half
           const unsigned soff = (unsigned)((c16 * 2 + (ph & 1)) * 3 + (ph >> 1)) * a.in_slab;
-          dma16(rs_in, bufp + (ph * BM + sg * 64) * 16, voff_a, soff);
+          if (SUM2 && second) dma16(rs_in1, bufp + (ph * BM + sg * 64) * 16, voff_a, soff);
+          else dma16(rs_in0, bufp + (ph * BM + sg * 64) * 16, voff_a, soff);
         } else if (gidx < TOT) {
           const int j = gidx - NA;
           const int ph = j / NGN, ng = j - ph * NGN;
-          dma16(rs_w, bufp + A_B + (ph * BNL + ng * 64) * 16, skip_b ? kOob : (unsigned)((n0 + ng * 64 + lane) * 16), w_base + (unsigned)ph * w_plane_b);
+          const unsigned voff_b = skip_b ? kOob : (unsigned)((n0 + ng * 64 + lane) * 16);
+          if (second) dma16(rs_w1, bufp + A_B + (ph * BNL + ng * 64) * 16, voff_b, w_base + (unsigned)ph * w_plane_b);
+          else dma16(rs_w0, bufp + A_B + (ph * BNL + ng * 64) * 16, voff_b, w_base + (unsigned)ph * w_plane_b);
         }
       }
     };
@@ -213,49 +215,116 @@ __global__ __launch_bounds__(256, 2) void conv_planes_k(ConvPArgs a) {
       ++issued;
       if (++itp == nt) { itp = 0; ++ic; }
     };
-    for (int p = 0; p < NBUF - 1 && p < n_steps; ++p) issue_next();
-
-#pragma unroll 1
-    for (int s = 0; s < n_steps; ++s) {
-      // step s has landed when at most the DMA of the NBUF-2 later steps is still outstanding
-      if (NBUF > 2 && issued - s - 1 == NBUF - 2) {
+    // Software pipeline with ONE fragment register set ("rolling"): the MFMA blocks of a step run in an order that retires
+    // its fragments one after the other, and each retired fragment's registers are refilled at once with the same fragment
+    // of step s+1 -- whose MFMAs therefore never wait for LDS, at no register cost (a second fragment set would not fit
+    // beside the two accumulator sets of the 64 x 64 wave tile).  The ring slot of step s is free once all its fragments
+    // sit in registers, which is where the step's one barrier goes: after the first group of blocks.
+    //     RM == 2:  blocks (0,*) | sync | A(rm0) <- s+1 | (1,0) B(0) <- s+1 | (1,1) B(1) <- s+1 ... | A(rm1) <- s+1
+    //     RM == 1:  block  (0,0) | sync | B(0), A' <- s+1 | (0,1) B(1) <- s+1 | ...  | A = A'   (A is used by every block: second set)
+    //     sync = wait until step s+1 has landed (mine) ; lgkmcnt(0) ; s_barrier (everyone's) ; issue the DMA of step s+NBUF
+    auto wait_steps_outstanding = [&](int k) {         // at most k steps' worth of this wave's DMA still in flight
+      if (NBUF > 2 && k == NBUF - 2) {
         if (wave < L_REM) wait_vmcnt<(NBUF - 2) * (L_LO + 1)>(); else wait_vmcnt<(NBUF - 2) * L_LO>();
+      } else if (NBUF > 2 && k == NBUF - 1) {
+        if (wave < L_REM) wait_vmcnt<(NBUF - 1) * (L_LO + 1)>(); else wait_vmcnt<(NBUF - 1) * L_LO>();
       } else {
         wait_vmcnt<0>();
       }
-      __builtin_amdgcn_s_barrier();            // everyone's share of step s is in LDS; everyone is done with step s-1's buffer
-      if (issued < n_steps) issue_next();      // ... which the DMA of step s + NBUF - 1 may now overwrite
-      const int buf = s % NBUF;
-      const unsigned char* pa = smem + buf * BUF_B + (lh * BM + wm * 32 * RM + li) * 16;
-      const unsigned char* pb = smem + buf * BUF_B + A_B + (lh * BNL + wn * 32 * RN + li) * 16;
-      bf16x8 af[RM][NPL], bfr[RN][NPL];
+    };
+    bf16x8 af[RM][NPL], bfr[RN][NPL], afn[NPL];
+    auto read_a = [&](int step, int rm, bf16x8 (&dst)[NPL]) {
+      const unsigned char* pa = smem + (step % NBUF) * BUF_B + (lh * BM + wm * 32 * RM + rm * 32 + li) * 16;
 #pragma unroll
-      for (int rm = 0; rm < RM; ++rm)
+      for (int pl = 0; pl < NPL; ++pl) dst[pl] = *reinterpret_cast<const bf16x8*>(pa + pl * 2 * BM * 16);
+    };
+    auto read_b = [&](int step, int rn, bf16x8 (&dst)[NPL]) {
+      const unsigned char* pb = smem + (step % NBUF) * BUF_B + A_B + (lh * BNL + wn * 32 * RN + rn * 32 + li) * 16;
 #pragma unroll
-        for (int pl = 0; pl < NPL; ++pl) af[rm][pl] = *reinterpret_cast<const bf16x8*>(pa + (pl * 2 * BM + rm * 32) * 16);
+      for (int pl = 0; pl < NPL; ++pl) dst[pl] = *reinterpret_cast<const bf16x8*>(pb + pl * 2 * BNL * 16);
+    };
+    auto block = [&](int rm, int rn) {
+      if constexpr (NPL == 3) {
+        f32x16 c = acs[rm][rn];                  // cross terms, smallest first
+        c = mfma_bf16(af[rm][2], bfr[rn][0], c);
+        c = mfma_bf16(af[rm][0], bfr[rn][2], c);
+        c = mfma_bf16(af[rm][1], bfr[rn][1], c);
+        c = mfma_bf16(af[rm][1], bfr[rn][0], c);
+        c = mfma_bf16(af[rm][0], bfr[rn][1], c);
+        acs[rm][rn] = c;
+      }
+      acc[rm][rn] = mfma_bf16(af[rm][0], bfr[rn][0], acc[rm][rn]);
+    };
+    auto sync = [&](int s_, bool more) {
+      if (more) wait_steps_outstanding(issued - s_ - 2);
+      __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0) -- the builtin, so that hipcc's own wait-count bookkeeping sees it
+      __builtin_amdgcn_s_barrier();
+      if (issued < n_steps) issue_next();
+    };
+    for (int p = 0; p < NBUF && p < n_steps; ++p) issue_next();
+    if (n_steps > 0) {
+      wait_steps_outstanding(issued - 1);
+      __builtin_amdgcn_s_barrier();
 #pragma unroll
-      for (int rn = 0; rn < RN; ++rn)
+      for (int rm = 0; rm < RM; ++rm) read_a(0, rm, af[rm]);
 #pragma unroll
-        for (int pl = 0; pl < NPL; ++pl) bfr[rn][pl] = *reinterpret_cast<const bf16x8*>(pb + (pl * 2 * BNL + rn * 32) * 16);
+      for (int rn = 0; rn < RN; ++rn) read_b(0, rn, bfr[rn]);
+    }
+    // (the loop is rotated -- sync(s), second group of step s, first group of step s+1 -- so that every prefetched fragment is
+    //  consumed inside the iteration that fetched it and hipcc can place exact lgkmcnt counts instead of a drain at the top)
+    auto group0 = [&]() {
+      if constexpr (RM == 2) {
 #pragma unroll
-      for (int rn = 0; rn < RN; ++rn)
+        for (int rn = 0; rn < RN; ++rn) block(0, rn);
+      } else if constexpr (RN > 1) {
+        block(0, 0);
+      }
+    };
+    if (n_steps > 0) group0();
+#pragma unroll 1
+    for (int s = 0; s < n_steps; ++s) {
+      const bool more = s + 1 < n_steps;
+      sync(s, more);
+      // (the prefetches are unconditional -- after the last step they read a stale slot and the values are dropped -- so that
+      //  the iteration is one basic block and hipcc counts the LDS reads exactly)
+      // (sched_barrier: hipcc's list scheduler would otherwise hoist every MFMA whose operands are ready above the LDS reads
+      //  and sink the reads to the end of the step, which re-exposes exactly the latency this order is meant to hide)
+      if constexpr (RM == 2) {
+        read_a(s + 1, 0, af[0]);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int rm = 0; rm < RM; ++rm) {
-          if constexpr (NPL == 3) {
-            f32x16 c = acs[rm][rn];                // cross terms, smallest first
-            c = mfma_bf16(af[rm][2], bfr[rn][0], c);
-            c = mfma_bf16(af[rm][0], bfr[rn][2], c);
-            c = mfma_bf16(af[rm][1], bfr[rn][1], c);
-            c = mfma_bf16(af[rm][1], bfr[rn][0], c);
-            c = mfma_bf16(af[rm][0], bfr[rn][1], c);
-            acs[rm][rn] = c;
-          }
-          acc[rm][rn] = mfma_bf16(af[rm][0], bfr[rn][0], acc[rm][rn]);
+        for (int rn = 0; rn < RN; ++rn) {
+          block(1, rn);
+          __builtin_amdgcn_sched_barrier(0);
+          read_b(s + 1, rn, bfr[rn]);
+          if (rn == RN - 1) read_a(s + 1, 1, af[1]);
+          __builtin_amdgcn_sched_barrier(0);
         }
+      } else if constexpr (RN == 1) {      // a single block per step: both fragments double-buffered
+        bf16x8 bfn[NPL];
+        read_b(s + 1, 0, bfn);
+        read_a(s + 1, 0, afn);
+        __builtin_amdgcn_sched_barrier(0);
+        block(0, 0);
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) { af[0][pl] = afn[pl]; bfr[0][pl] = bfn[pl]; }
+      } else {
+        read_b(s + 1, 0, bfr[0]);
+        read_a(s + 1, 0, afn);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int rn = 1; rn < RN; ++rn) {
+          block(0, rn);
+          __builtin_amdgcn_sched_barrier(0);
+          read_b(s + 1, rn, bfr[rn]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) af[0][pl] = afn[pl];
+      }
+      if (more) group0();
     }
     __builtin_amdgcn_s_barrier();              // the ring may be refilled by the next pass; sRow is complete
-
-    if (SUM2 && set == 0) continue;            // the second input accumulates on top; one epilogue after it
 
     // ---- epilogue (branch-free: rows beyond M carry an offset the buffer unit rejects) ----
     const int oset = SUM2 ? 0 : set;

@@ -4,7 +4,8 @@
 // :339; the 1cycle policy of hyperparam_scheduler.py:6-42 changes lr AND momentum every batch).  Reading lr / momentum from
 // device memory is what lets the whole iteration (forward, loss, backward, update) be replayed as one HIP graph while the
 // schedule keeps moving: the host only refreshes three floats per step.  Arithmetic identical to torch (no dampening, no
-// weight decay, no Nesterov):   buf = g (first step) | momentum*buf + g ;   p -= lr * buf.
+// weight decay, no Nesterov):   buf = g (first step) | fma(momentum, buf, g) ;   p = fma(-lr, buf, p)  -- one rounding each,
+// where torch's unfused path rounds the product first: the two agree to an ulp per step, not bit for bit.
 #include "common.h"
 
 namespace mpose {
@@ -23,19 +24,19 @@ __global__ __launch_bounds__(256) void sgd_step_k(const mpose_sgd_job* __restric
     float4 b = g;
     if (!first) {
       const float4 o = b4[i];
-      b.x = mom * o.x + g.x; b.y = mom * o.y + g.y; b.z = mom * o.z + g.z; b.w = mom * o.w + g.w;
+      b.x = fmaf(mom, o.x, g.x); b.y = fmaf(mom, o.y, g.y); b.z = fmaf(mom, o.z, g.z); b.w = fmaf(mom, o.w, g.w);
     }
     b4[i] = b;
     float4 p = p4[i];
-    p.x -= lr * b.x; p.y -= lr * b.y; p.z -= lr * b.z; p.w -= lr * b.w;
+    p.x = fmaf(-lr, b.x, p.x); p.y = fmaf(-lr, b.y, p.y); p.z = fmaf(-lr, b.z, p.z); p.w = fmaf(-lr, b.w, p.w);
     p4[i] = p;
   }
   if (blockIdx.x == 0) {
     for (long i = (n4 << 2) + threadIdx.x; i < j.n; i += 256) {
       const float g = j.g[i];
-      const float b = first ? g : mom * j.buf[i] + g;
+      const float b = first ? g : fmaf(mom, j.buf[i], g);
       j.buf[i] = b;
-      j.p[i] -= lr * b;
+      j.p[i] = fmaf(-lr, b, j.p[i]);
     }
   }
 }

@@ -107,8 +107,8 @@ class DeviceSGD:
     """torch.optim.SGD(params, lr, momentum) -- the reference's optimiser (bin/train_3d.py:339) -- as ONE launch over all
     parameters (csrc/optim.hip) with lr / momentum read from device memory, so that the 1cycle schedule
     (hyperparam_scheduler.py: lr AND momentum move every batch) keeps working when the whole iteration is replayed from a
-    HIP graph (GraphedTrainStep).  Same arithmetic as torch (no dampening / weight decay / Nesterov), checked bit for bit in
-    tests/test_train_graph_gpu.py.  Duck-types what the reference's loop touches: .param_groups, .zero_grad(), .step(),
+    HIP graph (GraphedTrainStep).  Same arithmetic as torch (no dampening / weight decay / Nesterov) up to fused-multiply-add
+    rounding, checked in tests/test_train_graph_gpu.py.  Duck-types what the reference's loop touches: .param_groups, .zero_grad(), .step(),
     .state_dict()."""
 
     def __init__(self, params, lr, momentum=0.0):
@@ -130,7 +130,8 @@ class DeviceSGD:
         self._steps = 0
         self._np = np
         self._eager_table = torch.zeros(len(self.params) * _sgd_job_dtype().itemsize, dtype=torch.uint8, device=dev)
-        self._graph_table = None                                                 # filled by finish_capture()
+        self._graph_table = torch.zeros_like(self._eager_table)                  # filled by finish_capture() (allocated HERE: an
+        #   allocation inside the capture would come from the graph's pool and its zero-fill would be replayed before every step)
 
     def zero_grad(self, set_to_none=True):
         for p in self.params:
@@ -164,8 +165,6 @@ class DeviceSGD:
         if capturing:
             # nothing executes during capture: the job table is filled by finish_capture() with the gradients' addresses inside
             # the graph's memory pool, and the hyper-parameters are uploaded by the caller before every replay
-            if self._graph_table is None:
-                self._graph_table = torch.zeros_like(self._eager_table)
             table = self._graph_table
         else:
             self.upload_hyper()
