@@ -261,6 +261,27 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
 
+    # Data parallel: the collective on its own -- each gradient bucket's all-reduce (the slices Engine._finish_bucket sends while
+    # the backward pass runs), timed back to back after the step loop: ms and bus bandwidth 2(N-1)/N * bytes / time, to be read
+    # against the 7 x ~153 GB/s of xGMI links per GPU.  Never measured before the driver's first multi-GPU run.
+    allreduce = None
+    if world > 1:
+        eng = model.inner.engine()
+        allreduce = []
+        for bi, (lo, hi) in enumerate(eng._buckets):
+            sl = eng.gflat[lo:hi]
+            for _ in range(2):
+                torch.distributed.all_reduce(sl)
+            barrier()
+            t1 = time.perf_counter()
+            n_rep = 5
+            for _ in range(n_rep):
+                torch.distributed.all_reduce(sl)
+            torch.cuda.synchronize()
+            sec = (time.perf_counter() - t1) / n_rep
+            nbytes = (hi - lo) * 4
+            allreduce.append({'bucket': bi, 'what': 'stem' if bi == len(eng._buckets) - 1 else 'stage %d' % (args.stages - 1 - bi),
+                              'bytes': nbytes, 'ms': 1e3 * sec, 'bus_GBps': 2.0 * (world - 1) / world * nbytes / sec / 1e9})
     if rank != 0:
         if world > 1:
             torch.distributed.barrier()
@@ -318,6 +339,9 @@ def main():
         res['tail_config_sizes'] = {
             'configs[2] training, B=%d fp32' % B: dict(tail_microbench(device, B), note='latency-bound: working set in Infinity Cache'),
             'configs[1] inference, B=64 bf16 heatmaps': dict(tail_microbench(device, 64, bf16_out=True), note='latency-bound: working set in Infinity Cache')}
+    if allreduce is not None:
+        res['allreduce_buckets'] = {'buckets': allreduce, 'xgmi_peak_GBps_per_gpu': 7 * 153.0, 'total_bytes': sum(b['bytes'] for b in allreduce),
+                                    'total_ms_if_serial': sum(b['ms'] for b in allreduce)}
     if world == 1 and not args.no_inference:
         res['inference'] = inference_microbench(model, device, args.size)
     if world == 1 and not args.no_cpu_baseline:

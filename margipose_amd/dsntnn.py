@@ -148,21 +148,37 @@ def euclidean_losses(actual, target):
 
 
 def make_gauss(means, size, sigma, normalize=True):
-    """Draw Gaussians (reference dsntnn.py:154-195); API-surface helper (2D), the loss kernels
-    regenerate their targets in registers and never call this."""
-    if len(size) != 2:
-        raise _lib.MposeError('make_gauss supports 2D heatmaps only')
-    h, w = size
-    xs = _normalized_linspace(w, dtype=means.dtype, device=means.device)
-    ys = _normalized_linspace(h, dtype=means.dtype, device=means.device)
-    kx = -0.5 * (1.0 / (2.0 * sigma / w)) ** 2
-    ky = -0.5 * (1.0 / (2.0 * sigma / h)) ** 2
-    ex = ((xs - means[..., 0:1]) ** 2 * kx).exp()
-    ey = ((ys - means[..., 1:2]) ** 2 * ky).exp()
-    gauss = ey.unsqueeze(-1) * ex.unsqueeze(-2)
+    """Separable Gaussians of standard deviation `sigma` PIXELS centred at `means` (normalised coordinates, ordered x, y, z, ...
+    while `size` is ordered [..., depth, height, width]) on a grid of `size` cells -- reference dsntnn.py:154-195, any number of
+    dimensions, differentiable w.r.t. `means`.  API-surface helper built from device tensor ops: the loss kernels regenerate
+    their targets in registers (csrc/tail.hip) and never call this."""
+    n = len(size)
+    if means.size(-1) != n:
+        raise _lib.MposeError('make_gauss: %d-dimensional means for a %d-dimensional grid' % (means.size(-1), n))
+    out = None
+    for axis in range(n):                       # axis 0 = x = the LAST grid dimension
+        length = size[n - 1 - axis]
+        grid = _normalized_linspace(length, dtype=means.dtype, device=means.device)
+        inv_std = length / (2.0 * sigma)         # 1 / (sigma pixels in normalised units)
+        factor = torch.exp(-0.5 * ((grid - means[..., axis:axis + 1]) * inv_std) ** 2)      # (..., length)
+        shape = list(factor.shape[:-1]) + [1] * n
+        shape[len(shape) - 1 - axis] = length
+        factor = factor.reshape(shape)
+        out = factor if out is None else out * factor
     if not normalize:
-        return gauss
-    return gauss / (gauss.sum((-1, -2), keepdim=True) + 1e-24)
+        return out
+    total = out.sum(dim=tuple(range(-n, 0)), keepdim=True)
+    return out / (total + 1e-24)
+
+
+def _js_from_tensors(p, q, ndims):
+    """reference dsntnn.py:198-207 with device tensor ops (differentiable in both arguments)."""
+    eps = 1e-24
+    m = 0.5 * (p + q)
+    dims = tuple(range(-ndims, 0))
+    kl_pm = (p * ((p + eps).log() - (m + eps).log())).sum(dims)
+    kl_qm = (q * ((q + eps).log() - (m + eps).log())).sum(dims)
+    return 0.5 * kl_pm + 0.5 * kl_qm
 
 
 class _JsRegLosses(torch.autograd.Function):
@@ -190,12 +206,16 @@ class _JsRegLosses(torch.autograd.Function):
 
 def js_reg_losses(heatmaps, mu_t, sigma_t):
     """Jensen-Shannon divergence between heatmaps and target Gaussians (reference dsntnn.py:220-232).
-    Targets are constants here (as in every reference call site): no gradient flows to `mu_t`."""
+    2D heatmaps with constant targets -- every reference call site -- run the fused kernel (Gaussians regenerated in registers).
+    The rest of the reference's API (a gradient w.r.t. `mu_t`, 1D / 3D heatmaps) is off the hot path and is composed from
+    make_gauss + device tensor ops, so autograd reaches the means as it does in the reference."""
     ndims = mu_t.size(-1)
     assert heatmaps.dim() == ndims + 2, 'expected heatmaps to be a {}D tensor'.format(ndims + 2)
     assert heatmaps.size()[:-ndims] == mu_t.size()[:-1]
-    if mu_t.requires_grad:
-        raise _lib.MposeError('js_reg_losses: gradients w.r.t. the target means are not implemented')
+    if ndims != 2 or (mu_t.requires_grad and torch.is_grad_enabled()):
+        if not heatmaps.is_cuda:
+            raise _lib.MposeError('heatmaps must live on a ROCm device: margipose_amd has no CPU path')
+        return _js_from_tensors(heatmaps, make_gauss(mu_t, heatmaps.size()[2:], sigma_t), ndims)
     return _JsRegLosses.apply(heatmaps, mu_t, sigma_t)
 
 

@@ -627,17 +627,28 @@ class Engine:
               'mpose_pack_weights')
 
     # ------------------------------------------------------------------ forward
-    def forward(self, x, train, save, hm_bf16=False):
+    def forward(self, x, train, save, hm_bf16=False, features=None):
         """x: (B, 3, S, S) NCHW device tensor.  Returns (heatmap lists [3][T], xyz of last stage, ctx).
-        hm_bf16 (inference only): heatmaps are stored as bf16; the soft-argmax coordinates stay fp32."""
+        hm_bf16 (inference only): heatmaps are stored as bf16; the soft-argmax coordinates stay fp32.
+        features (forward only): a (B, 128, F, F) NCHW feature tensor fed to the stages in place of the feature extractor's
+        output (`x` is ignored) -- how the reference's per-column fixtures drive a HeatmapColumn on its own."""
         if hm_bf16 and (train or save):
             raise _lib.MposeError('bf16 heatmaps are an inference storage mode (eval, no autograd)')
         L = lib()
-        if isinstance(x, torch.Tensor) and x.dtype == torch.uint8 and x.is_cuda:
+        if features is not None:
+            if save:
+                raise _lib.MposeError('features= is a forward-only entry')
+            features = _lib.dev_f32(features.contiguous(), 'features')
+            B, C3, S, S2 = features.shape[0], 3, 8 * features.shape[2], 8 * features.shape[3]
+            if features.shape[1] != 128:
+                raise _lib.MposeError('features must have 128 channels')
+            x = features
+        elif isinstance(x, torch.Tensor) and x.dtype == torch.uint8 and x.is_cuda:
             x = x.contiguous()         # raw RGB frames: normalised on the fly by the stem's first load (mpose_frames_u8)
+            B, C3, S, S2 = x.shape
         else:
             x = _lib.dev_f32(x.contiguous(), 'input')
-        B, C3, S, S2 = x.shape
+            B, C3, S, S2 = x.shape
         if C3 != 3 or S != S2 or S % 16 != 0:
             raise _lib.MposeError('expected a (B, 3, S, S) input with S %% 16 == 0, got %s' % (tuple(x.shape),))
         F = S // 8
@@ -668,7 +679,9 @@ class Engine:
         else:
             self.finalize(tb, 1, self.T * 90, False)
 
-        if self.stem is not None:
+        if features is not None:
+            inp = features.permute(0, 2, 3, 1).contiguous()
+        elif self.stem is not None:
             # ---- InceptionV4 feature extractor (stem.py) ----
             inp, ctx['stem_ctx'] = self.stem.forward(x, train, save)
         else:

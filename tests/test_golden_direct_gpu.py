@@ -1,0 +1,91 @@
+"""Reference-generated fixtures consumed DIRECTLY by the HIP path (tools/make_golden.py ran the imported reference):
+
+  * tests/golden/column_{xy,zy,xz}.npz -- one HeatmapColumn (reference models/margipose_model.py:43-100) on a given feature
+    tensor, eval and train mode: the engine is fed the fixture's features (Engine.forward(features=...)) and its heatmaps are
+    compared with flat_softmax of the reference's logits;
+  * tests/golden/axis_permutation.npz -- the column's axis permutation (:91-99) through mpose_axis_permute;
+  * tests/golden/frames_u8.npz -- `ImageSpecs.convert` normalisation (data_specs.py:6-13,38-39) of uint8 frames through
+    mpose_frames_u8 and through the InceptionV4 stem's fused first-layer gather (mpose_im2col_k3s2)."""
+import ctypes
+import os
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import weights as W
+
+pytestmark = pytest.mark.gpu
+PLANES = ('xy', 'zy', 'xz')
+
+
+def rel(a, b):
+    a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+@pytest.mark.parametrize('space', PLANES)
+def test_column_fixture_through_the_engine(golden_dir, space):
+    from margipose_amd.models import CanonicalSkeletonDesc, MargiPoseModel
+    g = np.load(os.path.join(golden_dir, 'column_%s.npz' % space), allow_pickle=True)
+    seed = int(g['seed'])
+    c = PLANES.index(space)
+    x = torch.from_numpy(np.random.default_rng(seed + 1000).standard_normal((2, 128, 32, 32))).float().cuda()
+    m = MargiPoseModel(CanonicalSkeletonDesc, 1, True, 'patch8', 'jsd')
+    col_sd = W.column_state_dict('c', seed, torch.float32)
+    sd = m.state_dict()
+    for k, v in col_sd.items():                      # the fixture's weights go into the column of its own space
+        sd['inner.%s_hm_cnns.0.%s' % (space, k[2:])] = v
+    m.load_state_dict(sd)
+    m = m.cuda()
+    eng = m.inner.engine()
+    for train, key, tol in ((False, 'logits_eval_f64', 1e-4), (True, 'logits_train_f64', 1e-4)):
+        with torch.no_grad():
+            hms, _, _ = eng.forward(None, train, False, features=x)
+        want = torch.softmax(torch.from_numpy(g[key]).flatten(2), -1).view(2, 17, 32, 32)
+        got = hms[c][0].cpu().double()
+        assert rel(got, want) < tol, (space, train, rel(got, want))
+    # train mode updated the running statistics exactly once, with the reference's values
+    running = np.concatenate([b.detach().cpu().numpy().flatten() for k, b in getattr(m.inner, space + '_hm_cnns')[0].named_buffers()
+                              if 'running' in k])
+    assert rel(running, g['running']) < 1e-5
+
+
+def test_axis_permutation_fixture(golden_dir):
+    from margipose_amd import _lib
+    g = np.load(os.path.join(golden_dir, 'axis_permutation.npz'))
+    L = _lib.lib()
+    for S in (16, 24):
+        x = torch.arange(192 * S * S, dtype=torch.float32).view(1, 192, S, S).permute(0, 2, 3, 1).contiguous().cuda()     # NHWC
+        ins = [x, x.clone(), x.clone()]
+        outs = [torch.empty_like(x) for _ in range(3)]
+        spaces = (ctypes.c_int * 3)(0, 1, 2)
+        _lib.check(L.mpose_axis_permute(_lib.ptr_array(ins), _lib.ptr_array(outs), spaces, 3, 1, S, 192, _lib.stream_ptr()), 'permute')
+        torch.cuda.synchronize()
+        for c, space in enumerate(PLANES):
+            got = (x if space == 'xy' else outs[c]).permute(0, 3, 1, 2).cpu().numpy().astype(np.int64)
+            assert np.array_equal(got, g['%s_%d' % (space, S)].astype(np.int64)), (space, S)
+
+
+def test_uint8_frames_against_the_reference_normalisation(golden_dir):
+    from margipose_amd import _lib
+    g = np.load(os.path.join(golden_dir, 'frames_u8.npz'))
+    L = _lib.lib()
+    frames = torch.from_numpy(g['frames']).cuda()
+    B, _, H, Wd = frames.shape
+    mean3 = (ctypes.c_float * 3)(*[float(v) for v in g['mean']])
+    std3 = (ctypes.c_float * 3)(*[float(v) for v in g['stddev']])
+    out = torch.empty(B, 3, H, Wd, device='cuda')
+    _lib.check(L.mpose_frames_u8(ctypes.c_void_p(frames.data_ptr()), mean3, std3, _lib.ptr(out), B, H, Wd, 0, _lib.stream_ptr()), 'frames_u8')
+    torch.cuda.synchronize()
+    assert float((out.cpu().double() - torch.from_numpy(g['expected_f64'])).abs().max()) < 5e-7        # fp32 rounding of O(1) values
+    assert float((out.cpu() - torch.from_numpy(g['expected_f32'])).abs().max()) < 5e-7
+    # the InceptionV4 stem's first-layer gather: patches of the uint8 frames == patches of the reference-normalised floats
+    ref = torch.from_numpy(g['expected_f32']).cuda()
+    pu = torch.empty(B, H // 2, Wd // 2, 32, device='cuda')
+    pf = torch.empty_like(pu)
+    _lib.check(L.mpose_im2col_k3s2(ctypes.c_void_p(frames.data_ptr()), 1, mean3, std3, _lib.ptr(pu), B, H, Wd, _lib.stream_ptr()), 'im2col u8')
+    _lib.check(L.mpose_im2col_k3s2(ctypes.c_void_p(ref.data_ptr()), 0, None, None, _lib.ptr(pf), B, H, Wd, _lib.stream_ptr()), 'im2col f32')
+    torch.cuda.synchronize()
+    assert float((pu - pf).abs().max()) < 5e-7

@@ -80,3 +80,26 @@ def test_geometry_tables():
     assert sum(len([x for x in t if x[3] == 0]) for _, _, t in cls) == 9
     # each kernel tap appears exactly once across the parity classes
     assert sorted(x[2] for _, _, t in cls for x in t if x[3] == 0) == list(range(9))
+
+
+def test_make_gauss_any_dimension_and_js_gradient_to_the_means(golden_dir):
+    """margipose_amd.dsntnn.make_gauss (reference dsntnn.py:154-195: 1D / 2D / 3D grids, normalised or not) and the general
+    js_reg_losses path with a gradient w.r.t. the target means, against reference-generated values (tests/golden/gauss_nd.npz).
+    Host tensors: this corner of the API is composed from tensor ops (the hot path's fused kernels are covered on the GPU)."""
+    import numpy as np
+    import torch
+    from margipose_amd import dsntnn
+    g = np.load(os.path.join(golden_dir, 'gauss_nd.npz'))
+    for tag in ('1d', '2d', '3d'):
+        mu = torch.tensor(g['mu_' + tag])
+        size = tuple(int(v) for v in g['size_' + tag])
+        for norm in (1, 0):
+            got = dsntnn.make_gauss(mu, size, 1.3, normalize=bool(norm))
+            assert tuple(got.shape) == tuple(g['gauss_%s_%d' % (tag, norm)].shape)
+            assert float((got - torch.tensor(g['gauss_%s_%d' % (tag, norm)])).abs().max()) < 1e-14
+    mu = torch.tensor(g['js_mu'], requires_grad=True)
+    hm = torch.tensor(g['js_hm'])
+    js = dsntnn._js_from_tensors(hm, dsntnn.make_gauss(mu, (8, 8), 1.0), 2)
+    d, = torch.autograd.grad(js.sum(), mu)
+    assert float((js.detach() - torch.tensor(g['js_val'])).abs().max()) < 1e-14
+    assert float((d - torch.tensor(g['js_dmu'])).abs().max()) < 1e-13

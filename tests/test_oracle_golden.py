@@ -159,3 +159,13 @@ def test_model_T2_vs_reference(golden_dir):
     np.testing.assert_allclose(heads, g['ghead_mixed_f64'], rtol=1e-6, atol=1e-12)
     running = np.concatenate([v.numpy().flatten() for k, v in sd.items() if 'running' in k])
     np.testing.assert_allclose(running, g['running_after'], rtol=1e-10)
+
+
+def test_frames_normalisation_fixture(golden_dir):
+    """tests/golden/frames_u8.npz (reference data_specs.normalize_pixels on to_tensor'd uint8 frames) == (x/255 - mean)/std,
+    the formula margipose_amd's uint8 entry implements on the device (mpose_frames_u8, mpose_im2col_k3s2)."""
+    g = _load(golden_dir, 'frames_u8.npz')
+    x = g['frames'].astype(np.float64) / 255.0
+    want = (x - g['mean'].reshape(1, 3, 1, 1)) / g['stddev'].reshape(1, 3, 1, 1)
+    assert np.abs(want - g['expected_f64']).max() < 1e-12
+    assert np.abs(want - g['expected_f32']).max() < 5e-7

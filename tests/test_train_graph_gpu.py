@@ -76,3 +76,25 @@ def test_graphed_iterations_equal_eager_iterations(stem):
     assert losses_e == losses_g, (losses_e, losses_g)
     for (k, a), (_, b) in zip(m_e.state_dict().items(), m_g.state_dict().items()):
         assert torch.equal(a, b), k
+
+
+def test_batch_stager_pinned_double_buffer():
+    """train_helpers.BatchStager (reference bin/train_3d.py:158-161 done with pinned double buffers on a copy stream): values
+    arrive intact for float and uint8 frames, slots rotate, and the consumer needs no host synchronisation."""
+    from margipose_amd.train_helpers import BatchStager
+    st = BatchStager('cuda:0')
+    rng = np.random.default_rng(5)
+    seen = []
+    for it in range(5):
+        u8 = it % 2 == 1
+        inp = torch.from_numpy(rng.integers(0, 256, (4, 3, 32, 32), dtype=np.uint8)) if u8 else torch.from_numpy(rng.standard_normal((4, 3, 32, 32)))
+        batch = {'input': inp, 'target': torch.from_numpy(rng.uniform(-1, 1, (4, 17, 4))), 'joint_mask': torch.ones(4, 17, dtype=torch.float64),
+                 'valid_depth': [1, 1, 0, 1]}
+        dev = st.stage(batch)
+        assert dev['valid_depth'] == [1, 1, 0, 1]
+        assert dev['input'].is_cuda and dev['input'].dtype == (torch.uint8 if u8 else torch.float32)
+        assert dev['target'].dtype == torch.float32 and dev['joint_mask'].dtype == torch.float32
+        seen.append((dev['input'].float().sum() + dev['target'].sum(), float(inp.double().sum() + batch['target'].sum())))
+    torch.cuda.synchronize()
+    for got, want in seen:
+        assert abs(float(got) - want) <= 1e-3 * max(1.0, abs(want))

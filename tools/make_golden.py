@@ -275,8 +275,40 @@ def gen_train_curve():
     npz('train_curve.npz', seed=seed, **res)
 
 
+# ------------------------------------------------------------------ input normalisation (data_specs.py)
+def gen_frames():
+    """`ImageSpecs.convert` = normalize_pixels(to_tensor(img), mean, std) (data_specs.py:6-13,38-39).  torchvision is absent
+    from this image, so `to_tensor` (published behaviour for uint8 HWC images: CHW float32, divided by 255) is applied here and
+    the REFERENCE's own normalize_pixels + the ImageSpecs constants it is called with (margipose_model.py:207) do the rest."""
+    from margipose import data_specs as ds
+    rng = np.random.default_rng(901)
+    frames = rng.integers(0, 256, (2, 3, 16, 16), dtype=np.uint8)
+    specs = ds.ImageSpecs(256, mean=ds.ImageSpecs.IMAGENET_MEAN, stddev=ds.ImageSpecs.IMAGENET_STDDEV)
+    out32 = np.stack([t2n(ds.normalize_pixels(torch.from_numpy(f).float().div(255), specs.mean, specs.stddev)) for f in frames])
+    out64 = np.stack([t2n(ds.normalize_pixels(torch.from_numpy(f).double().div(255), specs.mean, specs.stddev)) for f in frames])
+    npz('frames_u8.npz', frames=frames, mean=np.array(specs.mean), stddev=np.array(specs.stddev), expected_f32=out32, expected_f64=out64)
+
+
+# ------------------------------------------------------------------ make_gauss in 1, 2, 3 dimensions + d js / d mu
+def gen_gauss_nd():
+    rng = np.random.default_rng(911)
+    res = {}
+    for tag, size in (('1d', (5,)), ('2d', (6, 10)), ('3d', (4, 6, 8))):
+        mu = rng.uniform(-1, 1, (2, 3, len(size)))
+        res['mu_' + tag] = mu
+        res['size_' + tag] = np.array(size)
+        for norm in (True, False):
+            res['gauss_%s_%d' % (tag, int(norm))] = t2n(dsntnn.make_gauss(torch.tensor(mu), size, 1.3, normalize=norm))
+    mu = torch.tensor(rng.uniform(-1, 1, (2, 3, 2)), requires_grad=True)
+    hm = torch.softmax(torch.tensor(rng.standard_normal((2, 3, 64))), -1).view(2, 3, 8, 8)
+    js = dsntnn.js_reg_losses(hm, mu, 1.0)
+    g, = torch.autograd.grad(js.sum(), mu)
+    res.update(js_mu=t2n(mu), js_hm=t2n(hm), js_val=t2n(js), js_dmu=t2n(g))
+    npz('gauss_nd.npz', **res)
+
+
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ['keys', 'tail', 'perm', 'column', 'model', 'curve']
+    which = sys.argv[1:] or ['keys', 'tail', 'perm', 'column', 'model', 'curve', 'frames', 'gauss']
     for w in which:
-        {'keys': gen_keys, 'tail': gen_tail, 'perm': gen_perm, 'column': gen_column, 'model': gen_model, 'curve': gen_train_curve}[w]()
+        {'keys': gen_keys, 'tail': gen_tail, 'perm': gen_perm, 'column': gen_column, 'model': gen_model, 'curve': gen_train_curve, 'frames': gen_frames, 'gauss': gen_gauss_nd}[w]()

@@ -15,7 +15,7 @@ def short(name):
 
 
 def main(out):
-    for f in glob.glob(os.path.join(out, 'trace', '**', '*kernel_stats.csv'), recursive=True):
+    for f in glob.glob(os.path.join(out, 'trace', '**', '*kernel_stats.csv'), recursive=True) + glob.glob(os.path.join(out, 'tail', '**', '*kernel_stats.csv'), recursive=True):
         print('== kernel stats (%s)' % os.path.relpath(f, out))
         rows = list(csv.DictReader(open(f)))
         tot = sum(float(r['TotalDurationNs']) for r in rows)
