@@ -76,9 +76,10 @@ def parse():
     ap.add_argument('--no-overlap-wgrad', action='store_true', help='keep the weight-gradient GEMMs on the main stream (the default '
                     'runs them on a side stream, +2.3 %% step rate; the steps whose kernels are bracketed by HIP events for the '
                     'roofline block always run serially, so per-kernel durations are clean)')
-    ap.add_argument('--eager', action='store_true', help='enqueue every step from Python (about 1000 launches) instead of replaying '
-                    'the captured HIP graph of the iteration (train_helpers.GraphedTrainStep); multi-GPU runs are eager unless '
-                    'MPOSE_DP_GRAPH=1')
+    ap.add_argument('--graph', action='store_true', help='replay the captured HIP graph of the iteration (train_helpers.GraphedTrainStep) instead '
+                    'of enqueueing ~1000 launches per step from Python.  Bit-identical results; the step is GPU-bound, and a replay '
+                    'measured ~1 %% SLOWER than eager launches (37.2 vs 36.8 ms, one box), so the benchmark default is eager')
+    ap.add_argument('--eager', action='store_true', help='(default) kept for scripts')
     ap.add_argument('--conv-dtype', default='f32', choices=['f32', 'bf16'], help="'bf16' = BASELINE configs[4]'s reduced-precision "
                     'convolutions (model.conv_dtype = torch.bfloat16): a DIFFERENT workload, reported with dtype bf16, never the headline')
     return ap.parse_args()
@@ -219,7 +220,7 @@ def main():
 
     # The iteration is captured once as a HIP graph and replayed (every buffer of a step has a fixed address); eager mode costs
     # ~1000 launches of host time per step.  Under data parallelism the graph would have to contain the RCCL all-reduces: opt-in.
-    use_graph = not args.eager and (world == 1 or os.environ.get('MPOSE_DP_GRAPH') == '1')
+    use_graph = args.graph and not args.eager and (world == 1 or os.environ.get('MPOSE_DP_GRAPH') == '1')
     graphed = None
     if use_graph:
         try:

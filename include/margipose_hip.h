@@ -142,6 +142,17 @@ typedef struct {
   const float* mask_scale;
   const float* mask_shift;
   const float* in1;                    /* MPOSE_CONV_SUM_INPUTS: input of the taps with acc == 1 (same shape as `in`) */
+  /* Fused output stage of the plane engine (MPOSE_CONV_PLANES_IN only; inference: BatchNorm with running statistics is a
+   * per-channel affine map, so a ResidualBlock needs no elementwise pass at all):
+   *     y0 = [relu](epi_scale0 * conv0 + epi_shift0) [+ add_scale * add_src + add_shift]      (MPOSE_CONV_EPI_RELU0)
+   * y0 is written as fp32 NHWC to out0 (may then be NULL) and/or as pre-split planes P8[Cout0/8][3][B*OH*OW][8] to
+   * out0_planes -- what the next convolution reads.  Not combined with stats / mask_src / MPOSE_CONV_ACCUMULATE. */
+  const float* epi_scale0;
+  const float* epi_shift0;
+  const float* add_src;                /* fp32 NHWC, same shape as out0 (the shortcut branch), or NULL */
+  const float* add_scale;
+  const float* add_shift;
+  void* out0_planes;
 } mpose_conv_operands;
 
 #define MPOSE_CONV_ACCUMULATE 1   /* out0 += result */
@@ -150,6 +161,7 @@ typedef struct {
                                    * BatchNorm kernels write it), `w0` / `w1` are packed with layout 1; in_scale must be NULL
                                    * (the producer already applied BatchNorm + ReLU) and in_ld 0.  Runs conv_p.hip's engine:
                                    * both operands reach LDS by DMA, two workgroups per CU. */
+#define MPOSE_CONV_EPI_RELU0 16    /* with the fused output stage of mpose_conv_operands: ReLU after epi_scale0 / epi_shift0 */
 #define MPOSE_CONV_BF16 8         /* with MPOSE_CONV_PLANES_IN: multiply the hi planes only (bf16 x bf16 -> fp32, one MFMA per
                                    * fragment pair): the reduced-precision mode of BASELINE configs[4], NOT fp32-equivalent */
 #define MPOSE_CONV_SUM_INPUTS 2   /* taps with acc == 1 read `in1` through `w1` and add into out0 (one pass, one
@@ -280,6 +292,11 @@ typedef struct {
 
 int mpose_bn_bwd_reduce(const mpose_bn_bwd_reduce_operands* ops, int n_groups, int pixels_per_image,
                         int B, int C, int layout, int c_keep, void* stream);
+/* The same sums WRITTEN (not accumulated) through per-workgroup partial sums in a caller-provided workspace (no atomics,
+ * deterministic order): what the engine uses. */
+int64_t mpose_bn_bwd_reduce_ws_bytes(int n_groups, int pixels_per_image, int B, int C);
+int mpose_bn_bwd_reduce_ws(const mpose_bn_bwd_reduce_operands* ops, int n_groups, int pixels_per_image, int B, int C,
+                           void* workspace, int64_t workspace_bytes, void* stream);
 
 typedef struct {
   const float* g;

@@ -17,7 +17,7 @@ c_int = ctypes.c_int
 c_float = ctypes.c_float
 c_int64 = ctypes.c_int64
 
-ABI_VERSION = 6          # must equal mpose_abi_version() of the library (csrc/tail.hip)
+ABI_VERSION = 8          # must equal mpose_abi_version() of the library (csrc/tail.hip)
 MAX_GROUP = 3
 MAX_TAPS = 12
 MAX_CLASSES = 4
@@ -40,6 +40,7 @@ def lib():
             raise MposeError('libmargipose_hip.so ABI version mismatch')
         _LIB.mpose_planes_bytes.restype = c_int64
         _LIB.mpose_planes_bytes.argtypes = [c_int64, c_int]
+        _LIB.mpose_bn_bwd_reduce_ws_bytes.restype = c_int64
     return _LIB
 
 
@@ -98,7 +99,9 @@ class ConvOperands(ctypes.Structure):
     _fields_ = [('in_', c_void_p), ('in_scale', c_void_p), ('in_shift', c_void_p),
                 ('w0', c_void_p), ('w1', c_void_p), ('out0', c_void_p), ('out1', c_void_p),
                 ('stats0', c_void_p), ('stats1', c_void_p),
-                ('mask_src', c_void_p), ('mask_scale', c_void_p), ('mask_shift', c_void_p), ('in1', c_void_p)]
+                ('mask_src', c_void_p), ('mask_scale', c_void_p), ('mask_shift', c_void_p), ('in1', c_void_p),
+                ('epi_scale0', c_void_p), ('epi_shift0', c_void_p), ('add_src', c_void_p), ('add_scale', c_void_p),
+                ('add_shift', c_void_p), ('out0_planes', c_void_p)]
 
 
 class WgradOperands(ctypes.Structure):

@@ -98,6 +98,7 @@ struct BnReduceArgs {
   mpose_bn_bwd_reduce_operands op[MPOSE_MAX_GROUP];
   long npix;
   int C, pix_per_block;
+  double* partials;       // when non-NULL: [group][block][C][4] per-workgroup sums (no atomics; bn_bwd_reduce_finish_k adds them up)
 };
 
 __global__ __launch_bounds__(256) void bn_bwd_reduce_k(BnReduceArgs a) {
@@ -164,10 +165,30 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_k(BnReduceArgs a) {
       const double* d = sred + ((long)r * a.C + c) * 4;
       s0 += d[0]; s1 += d[1]; s2 += d[2]; s3 += d[3];
     }
-    atomicAdd(op.sums + (size_t)c * 4, s0);
-    atomicAdd(op.sums + (size_t)c * 4 + 1, s1);
-    if (has_b) { atomicAdd(op.sums + (size_t)c * 4 + 2, s2); atomicAdd(op.sums + (size_t)c * 4 + 3, s3); }
+    if (a.partials != nullptr) {
+      double* d = a.partials + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * a.C + c) * 4;
+      d[0] = s0; d[1] = s1; d[2] = s2; d[3] = s3;
+    } else {
+      atomicAdd(op.sums + (size_t)c * 4, s0);
+      atomicAdd(op.sums + (size_t)c * 4 + 1, s1);
+      if (has_b) { atomicAdd(op.sums + (size_t)c * 4 + 2, s2); atomicAdd(op.sums + (size_t)c * 4 + 3, s3); }
+    }
   }
+}
+
+// sums[c][k] = sum over the launch's workgroups of their partial sums, in workgroup order (deterministic; the fp64 atomics of
+// the one-kernel form were what bounded it: 768 workgroups x 512 atomics on 512 addresses, and twice the workgroups ran SLOWER)
+__global__ __launch_bounds__(256) void bn_bwd_reduce_finish_k(BnReduceArgs a, int n_blocks) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= a.C * 4) return;
+  const double* p = a.partials + (size_t)blockIdx.y * n_blocks * a.C * 4 + e;
+  double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+  int b = 0;
+  for (; b + 4 <= n_blocks; b += 4) {
+    t0 += p[(size_t)b * a.C * 4]; t1 += p[(size_t)(b + 1) * a.C * 4]; t2 += p[(size_t)(b + 2) * a.C * 4]; t3 += p[(size_t)(b + 3) * a.C * 4];
+  }
+  for (; b < n_blocks; ++b) t0 += p[(size_t)b * a.C * 4];
+  a.op[blockIdx.y].sums[e] = (t0 + t1) + (t2 + t3);
 }
 
 // eval_mode: the forward normalised with the RUNNING statistics (constants), so dx = gamma*invstd*g (c1 = c2 = 0);
@@ -323,11 +344,42 @@ extern "C" int mpose_bn_bwd_reduce(const mpose_bn_bwd_reduce_operands* ops, int 
   if (a.npix == 0) return 0;
   a.C = C;
   const int rows_per_pass = 256 / (C / 4);
-  int blocks = grid_for(a.npix, rows_per_pass * 8);      // (8 pixel rows per thread: 2x the workgroups of round 1 -- the pass is latency-bound)
+  int blocks = grid_for(a.npix, rows_per_pass * 16);     // (halving this to 8 pixel rows per thread was measured SLOWER: 61 vs 45 us, the fp64 atomics of 2x the workgroups)
   if (blocks > 512) blocks = 512;
   a.pix_per_block = (int)((a.npix + blocks - 1) / blocks);
   const int lds = rows_per_pass * C * 4 * 8;
   bn_bwd_reduce_k<<<dim3(blocks, n_groups), 256, lds, (hipStream_t)stream>>>(a);
+  return launch_status();
+}
+
+extern "C" int64_t mpose_bn_bwd_reduce_ws_bytes(int n_groups, int pixels_per_image, int B, int C) {
+  const long npix = (long)B * pixels_per_image;
+  long blocks = (npix + 63) / 64;
+  if (blocks > 1024) blocks = 1024;
+  if (blocks < 1) blocks = 1;
+  return (int64_t)n_groups * blocks * C * 4 * 8;
+}
+
+// Same sums as mpose_bn_bwd_reduce, WRITTEN (not accumulated), through per-workgroup partial sums in a caller-provided workspace
+// of at least mpose_bn_bwd_reduce_ws_bytes(): no atomics, more and smaller workgroups, deterministic order.
+extern "C" int mpose_bn_bwd_reduce_ws(const mpose_bn_bwd_reduce_operands* ops, int n_groups, int pixels_per_image, int B, int C,
+                                      void* workspace, int64_t workspace_bytes, void* stream) {
+  if (n_groups < 1 || n_groups > MPOSE_MAX_GROUP || (C & 3) || C > 1024 || !workspace) return MPOSE_EINVAL;
+  if (workspace_bytes < mpose_bn_bwd_reduce_ws_bytes(n_groups, pixels_per_image, B, C)) return MPOSE_EINVAL;
+  BnReduceArgs a{};
+  for (int i = 0; i < n_groups; ++i) a.op[i] = ops[i];
+  a.npix = (long)B * pixels_per_image;
+  if (a.npix == 0) return 0;
+  a.C = C;
+  long blocks = (a.npix + 63) / 64;
+  if (blocks > 1024) blocks = 1024;
+  a.pix_per_block = (int)((a.npix + blocks - 1) / blocks);
+  a.partials = reinterpret_cast<double*>(workspace);
+  const int rows_per_pass = 256 / (C / 4);
+  const int lds = rows_per_pass * C * 4 * 8;
+  hipStream_t s = (hipStream_t)stream;
+  bn_bwd_reduce_k<<<dim3((unsigned)blocks, n_groups), 256, lds, s>>>(a);
+  bn_bwd_reduce_finish_k<<<dim3((C * 4 + 255) / 256, n_groups), 256, 0, s>>>(a, (int)blocks);
   return launch_status();
 }
 

@@ -1035,7 +1035,9 @@ extern "C" int mpose_conv_fwd(const mpose_conv_geom* geom, const mpose_conv_oper
   }
   for (int i = 0; i < n_groups; ++i) {
     a.op[i] = ops[i];
-    if (!ops[i].in || !ops[i].w0 || !ops[i].out0) return MPOSE_EINVAL;
+    if (!ops[i].in || !ops[i].w0) return MPOSE_EINVAL;
+    if (!ops[i].out0 && !((flags & MPOSE_CONV_PLANES_IN) && ops[i].out0_planes)) return MPOSE_EINVAL;
+    if (!(flags & MPOSE_CONV_PLANES_IN) && (ops[i].epi_scale0 || ops[i].add_src || ops[i].out0_planes)) return MPOSE_EINVAL;
     if (acc1 && (!ops[i].w1 || !ops[i].out1)) return MPOSE_EINVAL;
     if ((ops[i].in_scale != nullptr) != (ops[0].in_scale != nullptr)) return MPOSE_EINVAL;
     if (ops[i].in_scale && (acc1 || !ops[i].in_shift)) return MPOSE_EINVAL;

@@ -37,6 +37,8 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) void* lds_void_p;
 
 struct FastDiv {
@@ -91,14 +93,22 @@ __global__ __launch_bounds__(256, 2) void conv_planes_k(ConvPArgs a) {
   constexpr int L_LO = TOT / 4, L_REM = TOT % 4;               // per wave: L_LO (+1 for waves < L_REM)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned* sRow = reinterpret_cast<unsigned*>(smem + NBUF * BUF_B);                 // [BM] output row byte offsets
-  float* sRed = reinterpret_cast<float*>(smem + NBUF * BUF_B + BM * 4);              // [2 sets][4 waves][32*RN][2]
+  unsigned* sPix = reinterpret_cast<unsigned*>(smem + NBUF * BUF_B + BM * 4);        // [BM] output pixel index (fused plane output)
+  float* sRed = reinterpret_cast<float*>(smem + NBUF * BUF_B + 2 * BM * 4);          // [2 sets][4 waves][32*RN][2]
+  constexpr int TILE_PITCH = 32 * RN + 4;                                            // floats per row of a wave's staged output tile
+  constexpr bool TILE_FITS = 4 * 32 * RM * TILE_PITCH * 4 <= NBUF * BUF_B;            // the fused plane output stages the tile in the (free) ring
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lh = lane >> 5;
   const int wm = wave % WM, wn = wave / WM;
   const mpose_conv_geom& g = a.g;
-  const int cls = blockIdx.x / a.n_mtiles;
-  const int m0 = (blockIdx.x - cls * a.n_mtiles) * BM;
+  // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed placement, speed only), each XCD has its own L2; giving an
+  // XCD a CONTIGUOUS run of pixel tiles lets neighbouring tiles share their halo rows (and a class's tiles their weights)
+  // in one L2 instead of fetching them once per XCD (HBM-side reads were 1.9x the algorithmic bytes with the plain order).
+  unsigned bid = blockIdx.x;
+  if ((gridDim.x & 7u) == 0 && !(a.flags & 0x400)) bid = (bid & 7u) * (gridDim.x >> 3) + (bid >> 3);
+  const int cls = bid / a.n_mtiles;
+  const int m0 = (bid - cls * a.n_mtiles) * BM;
   const int n0 = blockIdx.y * BN;
   const mpose_conv_operands& op = a.op[blockIdx.z];
   const int n_taps = g.cls[cls].n_taps;
@@ -137,6 +147,7 @@ __global__ __launch_bounds__(256, 2) void conv_planes_k(ConvPArgs a) {
       const unsigned gx = rem - gy * (unsigned)g.GW;
       const unsigned pix = (b * (unsigned)g.OH + (gy * g.out_mul + oyc)) * (unsigned)g.OW + (gx * g.out_mul + oxc);
       sRow[tid] = (int)m < a.M ? pix * (unsigned)out_ld * 4u : 0xFFFFF000u;
+      sPix[tid] = (int)m < a.M ? pix : 0xFFFFFFFFu;
     }
   };
 
@@ -333,10 +344,18 @@ __global__ __launch_bounds__(256, 2) void conv_planes_k(ConvPArgs a) {
     double* stats = oset ? op.stats1 : op.stats0;
     const bool masked = (oset == 0) && op.mask_src != nullptr;
     const bool accumulate = (oset == 0) && (a.flags & 1);
+    // fused output stage (inference): y = [relu](scale*conv + shift) [+ add_scale*add_src + add_shift] -> fp32 and/or planes
+    const bool epi = (oset == 0) && op.epi_scale0 != nullptr;
+    const bool epi_relu = (a.flags & 16) != 0;
+    const bool epi_add = epi && op.add_src != nullptr;
+    void* out_planes = (TILE_FITS && oset == 0) ? op.out0_planes : nullptr;
+    const bool store_f32 = outp != nullptr;
+    float* tile = reinterpret_cast<float*>(smem) + wave * (32 * RM * TILE_PITCH);     // (the ring is free: every wave passed the barrier above)
     const int old_ = oset ? g.out_ld1 : g.out_ld0;
     const int out_ld = old_ > 0 ? old_ : cout;
     const unsigned out_bytes = (unsigned)((((long)g.B * g.OH * g.OW - 1) * out_ld + cout) * 4);
-    const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(outp, 0, out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(outp, 0, store_f32 ? out_bytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(epi_add ? op.add_src : op.w0), 0, epi_add ? out_bytes : 0u, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_m = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(masked ? op.mask_src : outp), 0, out_bytes, 0x00020000);
     float csum[RN], csq[RN];
 #pragma unroll
@@ -379,6 +398,27 @@ __global__ __launch_bounds__(256, 2) void conv_planes_k(ConvPArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) v[r] += old[r];
           }
+          if (epi) {
+            const float esc = op.epi_scale0[n], esh = op.epi_shift0[n];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              v[r] = fmaf(v[r], esc, esh);
+              if (epi_relu) v[r] = fmaxf(v[r], 0.f);
+            }
+            if (epi_add) {
+              const float asc = op.add_scale[n], ash = op.add_shift[n];
+              float src[16];
+#pragma unroll
+              for (int r = 0; r < 16; ++r)
+                src[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_a, (int)(voff[r] + (unsigned)(rn * 128)), 0, 0));
+#pragma unroll
+              for (int r = 0; r < 16; ++r) v[r] += fmaf(src[r], asc, ash);
+            }
+          }
+          if (out_planes != nullptr) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tile[(rm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * TILE_PITCH + rn * 32 + li] = v[r];
+          }
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[r]), rs_o, (int)(voff[r] + (unsigned)(rn * 128)), 0, 0);
@@ -387,6 +427,38 @@ __global__ __launch_bounds__(256, 2) void conv_planes_k(ConvPArgs a) {
           }
         }
       }
+    }
+    if (out_planes != nullptr) {
+      // The wave's fp32 tile sits in LDS [row][column] (pitch 32*RN + 4 floats: a 16-lane group reading 8 consecutive channels of
+      // 16 consecutive rows touches every bank once).  Lane = row: 64 consecutive pixels x 16 B per (octet, plane) -> 1 KiB stores.
+      __builtin_amdgcn_wave_barrier();
+      const long npix_out = (long)g.B * g.OH * g.OW;
+      constexpr int ROWS = 32 * RM, OCTS = 4 * RN;
+#pragma unroll 1
+      for (int p = lane; p < ROWS * OCTS; p += 64) {
+        const int row = p % ROWS, oc = p / ROWS;
+        const int nb = ncol0 + oc * 8;
+        const unsigned pix = sPix[wm * ROWS + row];
+        const float4 lo4 = *reinterpret_cast<const float4*>(tile + row * TILE_PITCH + oc * 8);
+        const float4 hi4 = *reinterpret_cast<const float4*>(tile + row * TILE_PITCH + oc * 8 + 4);
+        if (nb < cout && pix != 0xFFFFFFFFu) {
+          const float v8[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+          u32x4 ph, pm, pl;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float x0 = v8[2 * e], x1 = v8[2 * e + 1];
+            const unsigned h = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{x0, x1}, bf16x2));
+            const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xFFFF0000u);
+            const unsigned m = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{r0, r1}, bf16x2));
+            const float q0 = r0 - __uint_as_float(m << 16), q1 = r1 - __uint_as_float(m & 0xFFFF0000u);
+            const unsigned l = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{q0, q1}, bf16x2));
+            ph[e] = h; pm[e] = m; pl[e] = l;
+          }
+          u32x4* d = reinterpret_cast<u32x4*>(out_planes) + (long)(nb >> 3) * 3 * npix_out + pix;
+          d[0] = ph; d[npix_out] = pm; d[2 * npix_out] = pl;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
     }
     if (stats != nullptr) {
 #pragma unroll
@@ -426,7 +498,7 @@ __global__ __launch_bounds__(256, 2) void conv_planes_k(ConvPArgs a) {
 template <int WM, int WN, int RM, int RN, int NBUF, int MODE, int NPL>
 int launch_planes(const ConvPArgs& a0, int n_groups, hipStream_t s) {
   constexpr int BM = 32 * RM * WM, BN = 32 * RN * WN, BNL = (BN + 63) / 64 * 64;
-  constexpr int lds = NBUF * (NPL * 2 * BM * 16 + NPL * 2 * BNL * 16) + BM * 4 + 2 * 4 * 32 * RN * 2 * 4;
+  constexpr int lds = NBUF * (NPL * 2 * BM * 16 + NPL * 2 * BNL * 16) + 2 * BM * 4 + 2 * 4 * 32 * RN * 2 * 4;
   static_assert(2 * lds <= 160 * 1024, "two workgroups per CU");
   static bool attr_set = false;
   if (!attr_set) {
@@ -483,12 +555,21 @@ int mpose_conv_planes_launch(const mpose_conv_geom* geom, const mpose_conv_opera
   a.div_gw = make_fastdiv((unsigned)geom->GW);
   a.div_ghw = make_fastdiv((unsigned)(geom->GH * geom->GW));
   a.flags = flags;
-  if (const char* e = getenv("MPOSE_EXP")) a.flags |= (atoi(e) & 3) << 8;       // timing experiments (wrong results): 1 = skip A re-reads, 2 = skip B
+  if (const char* e = getenv("MPOSE_EXP")) a.flags |= (atoi(e) & 7) << 8;       // timing experiments: 1 = skip A re-reads, 2 = skip B (wrong results); 4 = plain tile order
   const long npix = (long)geom->B * geom->IH * geom->IW;
   const long in_bytes = npix * 16 * 3 * (geom->Cin / 8);
   if (in_bytes >= 0xFFFFFF00l - (1l << 20) || geom->in_ld > 0) return MPOSE_EINVAL;       // 32-bit buffer offsets; dense inputs only
   if ((long)geom->Npad0 * 16 * 6 * (geom->Cin / 16) * MPOSE_MAX_TAPS >= 0xFFFFFF00l) return MPOSE_EINVAL;
   a.in_slab = (unsigned)(npix * 16);
+  for (int i = 0; i < n_groups; ++i) {
+    const mpose_conv_operands& o = ops[i];
+    const bool epi = o.epi_scale0 != nullptr || o.out0_planes != nullptr || o.add_src != nullptr;
+    if (!epi) continue;
+    if ((flags & (MPOSE_CONV_BF16 | MPOSE_CONV_ACCUMULATE)) || o.stats0 || o.mask_src) return MPOSE_EINVAL;    // inference-only stage
+    if ((o.epi_scale0 != nullptr) != (o.epi_shift0 != nullptr)) return MPOSE_EINVAL;
+    if (o.add_src && (!o.epi_scale0 || !o.add_scale || !o.add_shift)) return MPOSE_EINVAL;
+    if (geom->out_ld0 > 0 && geom->out_ld0 != geom->Cout0) return MPOSE_EINVAL;
+  }
   hipStream_t s = (hipStream_t)stream;
   if (flags & MPOSE_CONV_BF16) return launch_planes_shape<1>(a, mode, cmax, n_groups, s);
   return launch_planes_shape<3>(a, mode, cmax, n_groups, s);

@@ -572,6 +572,17 @@ class Engine:
         check(lib().mpose_split_planes((SplitOperands * 3)(*ops), len(ops), c_int64(npix), C, int(relu), stream_ptr()), 'mpose_split_planes')
         return outs
 
+    def bn_bwd_reduce(self, rops, pixels_per_image, B, C):
+        """BatchNorm-backward sums of one grouped launch (mpose_bn_bwd_reduce_ws: per-workgroup partials, no atomics)."""
+        L = lib()
+        n = len(rops)
+        need = int(L.mpose_bn_bwd_reduce_ws_bytes(n, pixels_per_image, B, C))
+        ws = getattr(self, '_reduce_ws', None)
+        if ws is None or ws.numel() < need or ws.device != self.device:
+            self._reduce_ws = ws = torch.empty(max(need, 8 << 20), dtype=torch.uint8, device=self.device)
+        check(L.mpose_bn_bwd_reduce_ws((BnBwdReduceOperands * 3)(*rops), n, pixels_per_image, B, C, ptr(ws), c_int64(ws.numel()), stream_ptr()),
+              'mpose_bn_bwd_reduce_ws')
+
     def conv_flags(self):
         return (4 | (8 if self.conv_bf16 else 0)) if self.use_planes else 0
 
@@ -742,58 +753,87 @@ class Engine:
                             cur_p[c] = pl
                 gname = {'regular': 'f_in_regular', 'down': 'f_in_down', 'up': 'f_in_up'}[b0.kind]
                 g1 = self.geom(gname, B, Hin, b0)
-                c1 = [torch.empty(B, Hout, Hout, b0.cout_s, **f32) for _ in range(3)]
+                last = i == 9
+                npix_o = B * Hout * Hout
+                # Inference on the plane engine: BatchNorm with running statistics is a per-channel affine map, so it (and the
+                # ReLU, and the block's residual sum) run in the convolutions' epilogues, which write the next convolution's
+                # pre-split planes directly -- a ResidualBlock is two launches and no elementwise pass (reference :31-40).
+                fused = planes and not train and not save and not self.conv_bf16
+                c1 = None if fused else [torch.empty(B, Hout, Hout, b0.cout_s, **f32) for _ in range(3)]
                 sc = [torch.empty(B, Hout, Hout, b0.cout_s, **f32) for _ in range(3)]
+                if fused:
+                    a1_p = [self.planes_empty(npix_o, b0.cout_s) for _ in range(3)]
                 ops = []
                 for c, b in enumerate(grp):
                     op = ConvOperands()
                     op.in_ = (cur_p[c] if planes else cur[c]).data_ptr()
                     op.w0, op.w1 = self._wptr(b.conv_in), self._wptr(b.conv_sc)
-                    op.out0, op.out1 = c1[c].data_ptr(), sc[c].data_ptr()
+                    op.out1 = sc[c].data_ptr()
+                    if fused:
+                        op.out0_planes = a1_p[c].data_ptr()
+                        op.epi_scale0, op.epi_shift0 = self._bnf_ptr(b.bn1, 0), self._bnf_ptr(b.bn1, 1)
+                    else:
+                        op.out0 = c1[c].data_ptr()
                     if train:
                         op.stats0, op.stats1 = self._stats_ptr(b.bn1), self._stats_ptr(b.bns)
                     ops.append(op)
-                self.conv(g1, ops, pflags)
+                self.conv(g1, ops, pflags | (16 if fused else 0))
                 if train:
                     self.finalize(tb, self.fin_index(t, i, 0), 6, True)
-                c2 = [torch.empty(B, Hout, Hout, b0.cout_s, **f32) for _ in range(3)]
-                if planes:           # relu(bn1(c1)) is written once, pre-split, instead of being recomputed by every tap
-                    a1_p = self.split_planes(c1, B * Hout * Hout, b0.cout_s, [self._bnf_ptr(b.bn1, 0) for b in grp],
+                if planes and not fused:     # relu(bn1(c1)) is written once, pre-split, instead of being recomputed by every tap
+                    a1_p = self.split_planes(c1, npix_o, b0.cout_s, [self._bnf_ptr(b.bn1, 0) for b in grp],
                                              [self._bnf_ptr(b.bn1, 1) for b in grp], relu=True)
+                fuse2 = fused and not last
+                need_f32 = (not fuse2) or (i == 4 and any(sp != 0 for sp in self.spaces))     # the axis permutation reads fp32
+                c2 = None if fuse2 else [torch.empty(B, Hout, Hout, b0.cout_s, **f32) for _ in range(3)]
+                if last:
+                    outs = [torch.empty(B, self.J, F, F, **f32) for _ in range(3)]
+                elif need_f32:
+                    outs = [torch.empty(B, Hout, Hout, b0.cout_s, **f32) for _ in range(3)]
+                else:
+                    outs = [None, None, None]
+                if fuse2:
+                    nxt_p = [self.planes_empty(npix_o, b0.cout_s) for _ in range(3)]
                 ops = []
                 for c, b in enumerate(grp):
                     op = ConvOperands()
-                    op.w0, op.out0 = self._wptr(b.conv2), c2[c].data_ptr()
+                    op.w0 = self._wptr(b.conv2)
                     if planes:
                         op.in_ = a1_p[c].data_ptr()
                     else:
                         op.in_ = c1[c].data_ptr()
                         op.in_scale, op.in_shift = self._bnf_ptr(b.bn1, 0), self._bnf_ptr(b.bn1, 1)
+                    if fuse2:
+                        op.out0_planes = nxt_p[c].data_ptr()
+                        if outs[c] is not None:
+                            op.out0 = outs[c].data_ptr()
+                        op.epi_scale0, op.epi_shift0 = self._bnf_ptr(b.bn2, 0), self._bnf_ptr(b.bn2, 1)
+                        op.add_src, op.add_scale, op.add_shift = sc[c].data_ptr(), self._bnf_ptr(b.bns, 0), self._bnf_ptr(b.bns, 1)
+                    else:
+                        op.out0 = c2[c].data_ptr()
                     if train:
                         op.stats0 = self._stats_ptr(b.bn2)
                     ops.append(op)
-                self.conv(self.geom('f_conv2', B, Hout, b0), ops, pflags)
+                self.conv(self.geom('f_conv2', B, Hout, b0), ops, pflags | (16 if fuse2 else 0))
                 if train:
                     self.finalize(tb, self.fin_index(t, i, 2), 3, True)
-                last = i == 9
-                if last:
-                    outs = [torch.empty(B, self.J, F, F, **f32) for _ in range(3)]
+                if fuse2:
+                    cur_p = nxt_p
                 else:
-                    outs = [torch.empty(B, Hout, Hout, b0.cout_s, **f32) for _ in range(3)]
-                aops = []
-                for c, b in enumerate(grp):
-                    ao = BnAddOperands()
-                    ao.a, ao.a_scale, ao.a_shift = c2[c].data_ptr(), self._bnf_ptr(b.bn2, 0), self._bnf_ptr(b.bn2, 1)
-                    ao.b, ao.b_scale, ao.b_shift = sc[c].data_ptr(), self._bnf_ptr(b.bns, 0), self._bnf_ptr(b.bns, 1)
-                    ao.out = outs[c].data_ptr()
-                    aops.append(ao)
-                if planes and not last:
-                    cur_p = [self.planes_empty(B * Hout * Hout, b0.cout_s) for _ in range(3)]
-                    check(L.mpose_bn_add_planes((BnAddOperands * 3)(*aops), ptr_array(cur_p), 3, c_int64(B * Hout * Hout), b0.cout_s, st()),
-                          'mpose_bn_add_planes')
-                else:
-                    check(L.mpose_bn_add_fwd((BnAddOperands * 3)(*aops), 3, Hout * Hout, B, b0.cout_s, 1 if last else 0, self.J, st()),
-                          'mpose_bn_add_fwd')
+                    aops = []
+                    for c, b in enumerate(grp):
+                        ao = BnAddOperands()
+                        ao.a, ao.a_scale, ao.a_shift = c2[c].data_ptr(), self._bnf_ptr(b.bn2, 0), self._bnf_ptr(b.bn2, 1)
+                        ao.b, ao.b_scale, ao.b_shift = sc[c].data_ptr(), self._bnf_ptr(b.bns, 0), self._bnf_ptr(b.bns, 1)
+                        ao.out = outs[c].data_ptr()
+                        aops.append(ao)
+                    if planes and not last:
+                        cur_p = [self.planes_empty(npix_o, b0.cout_s) for _ in range(3)]
+                        check(L.mpose_bn_add_planes((BnAddOperands * 3)(*aops), ptr_array(cur_p), 3, c_int64(npix_o), b0.cout_s, st()),
+                              'mpose_bn_add_planes')
+                    else:
+                        check(L.mpose_bn_add_fwd((BnAddOperands * 3)(*aops), 3, Hout * Hout, B, b0.cout_s, 1 if last else 0, self.J, st()),
+                              'mpose_bn_add_fwd')
                 if save:
                     stage_saved.append({'x': cur, 'c1': c1, 'sc': sc, 'c2': c2})
                 cur = outs
@@ -898,7 +938,7 @@ class Engine:
                     ro.a_scale, ro.a_shift = self._bnf_ptr(b.bn2, 0), self._bnf_ptr(b.bn2, 1)     # ReLU after the second BN
                     ro.sums = self._stats_ptr(b.bn2, True)
                     rops.append(ro)
-                check(L.mpose_bn_bwd_reduce((BnBwdReduceOperands * 3)(*rops), 3, Hout * Hout, B, Cs, 0, 0, st()), 'mpose_bn_bwd_reduce')
+                self.bn_bwd_reduce(rops, Hout * Hout, B, Cs)
                 run_coef(jb, 6)
                 d_c2 = [torch.empty(B, Hout, Hout, Cs, **f32) for _ in range(3)]
                 d_sc = [torch.empty(B, Hout, Hout, Cs, **f32) for _ in range(3)]
@@ -1014,7 +1054,7 @@ class Engine:
                 check(L.mpose_relu_bwd(ptr(D), ptr(ctx['stem_out']), ptr(gm), c_int64(gm.numel()), st()), 'mpose_relu_bwd')
                 ro = BnBwdReduceOperands()
                 ro.g, ro.a, ro.sums = gm.data_ptr(), ctx['stem_raw'].data_ptr(), self._stats_ptr(n, True)
-                check(L.mpose_bn_bwd_reduce((BnBwdReduceOperands * 3)(ro), 1, F * F, B, 128, 0, 0, st()), 'mpose_bn_bwd_reduce')
+                self.bn_bwd_reduce([ro], F * F, B, 128)
                 run_coef(self.T * 90, 1)
                 d_raw = torch.empty_like(D)
                 ao = BnBwdApplyOperands()

@@ -405,7 +405,7 @@ class _GraphStem:
             ro.g, ro.a, ro.sums = g.data_ptr(), raw[n.name].data_ptr(), self.sptr(n, True)
             if n.relu:
                 ro.a_scale, ro.a_shift = self.fptr(n, 0), self.fptr(n, 1)
-            check(L.mpose_bn_bwd_reduce((BnBwdReduceOperands * 3)(ro), 1, H * H, B, n.C, 0, 0, st()), 'mpose_bn_bwd_reduce')
+            eng.bn_bwd_reduce([ro], H * H, B, n.C)
             c0_, nc = tb['coef_range'][n.name]
             if nc:
                 check(L.mpose_bn_bwd_coef(c_void_p(tb['coef'].data_ptr() + c0_ * eng.COEF_ITEMSIZE), nc, 0 if ctx.get('train', True) else 1, st()), 'mpose_bn_bwd_coef')

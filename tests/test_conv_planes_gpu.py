@@ -292,3 +292,46 @@ def test_bn_add_and_bn_bwd_apply_write_planes():
     for p, t in ((pa, da_w), (pb, db_w)):
         back = planes_to_f64(p, npix, C).view(B, H, H, C)
         assert float(((back - t.double()).abs() / t.double().abs().clamp_min(1e-30)).max()) <= 2.0 ** -24
+
+
+@pytest.mark.parametrize('B,H,cin,cout,with_f32', [(2, 32, 128, 128, True), (4, 16, 192, 192, False), (3, 8, 32, 32, True), (1, 12, 64, 96, False)])
+def test_planes_fused_output_stage(B, H, cin, cout, with_f32):
+    """Inference epilogue: y = relu(scale*conv + shift) + (add_scale*add_src + add_shift) written as pre-split planes (what the
+    next convolution reads) and optionally as fp32 -- a ResidualBlock's second half (reference models/margipose_model.py:34-40
+    with BatchNorm in eval mode) in ONE launch."""
+    L, _lib, eng = _env()
+    from margipose_amd._lib import ConvOperands
+    rng = np.random.default_rng(B * 31 + H)
+    x = torch.from_numpy(rng.standard_normal((B, cin, H, H))).float()
+    w = torch.from_numpy(rng.standard_normal((cout, cin, 3, 3)) * (2.0 / (9 * cin)) ** 0.5).float()
+    mk = lambda *s: torch.from_numpy(rng.standard_normal(s)).float()
+    sc, sh, asc, ash = mk(cout).abs() + 0.5, mk(cout) * 0.3, mk(cout), mk(cout) * 0.3
+    add = mk(B, cout, H, H)
+    packed, npad = pack(w.cuda(), cout, cin, 9)
+    t9 = [(ky - 1, kx - 1, ky * 3 + kx, 0) for ky, kx in eng.TAPS3]
+    g = eng._geom(B, H, cin, H, cout, 0, H, 1, 1, [(0, 0, t9)], npad)
+    npix = B * H * H
+    out = torch.full((B, H, H, cout), float('nan'), device='cuda')
+    planes = torch.full((int(L.mpose_planes_bytes(npix, cout)),), 0x7f, dtype=torch.uint8, device='cuda')
+    xin = to_planes(nhwc(x))
+    dev = [t.cuda() for t in (sc, sh, asc, ash)]
+    addg = nhwc(add)
+    op = ConvOperands()
+    op.in_, op.w0 = xin.data_ptr(), packed.data_ptr()
+    if with_f32:
+        op.out0 = out.data_ptr()
+    op.out0_planes = planes.data_ptr()
+    op.epi_scale0, op.epi_shift0 = dev[0].data_ptr(), dev[1].data_ptr()
+    op.add_src, op.add_scale, op.add_shift = addg.data_ptr(), dev[2].data_ptr(), dev[3].data_ptr()
+    _lib.check(L.mpose_conv_fwd(ctypes.byref(g), (ConvOperands * 1)(op), 1, PLANES_IN | 16, _lib.stream_ptr()), 'conv fused')
+    torch.cuda.synchronize()
+    v = lambda t: t.double().view(1, cout, 1, 1)
+    ref = torch.relu(F.conv2d(x.double(), w.double(), padding=1) * v(sc) + v(sh)) + (add.double() * v(asc) + v(ash))
+    f32 = torch.relu(F.conv2d(x, w, padding=1) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)) + (add * asc.view(1, -1, 1, 1) + ash.view(1, -1, 1, 1))
+    got_p = planes_to_f64(planes, npix, cout).view(B, H, H, cout).permute(0, 3, 1, 2)
+    scale = ref.abs().max()
+    e_p, e_f32 = float((got_p - ref).abs().max() / scale), float((f32.double() - ref).abs().max() / scale)
+    check(e_p, e_f32)
+    if with_f32:
+        got = out.cpu().double().permute(0, 3, 1, 2)
+        assert float((got - got_p).abs().max() / scale) <= 2.0 ** -24      # the planes ARE the fp32 result, split

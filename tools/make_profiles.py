@@ -1,0 +1,79 @@
+#!/usr/bin/env python
+"""Assemble the committed profiles/ files of a round from a tools/profile.sh output directory (gpurun_out/prof_<tag>/).
+   python tools/make_profiles.py r2"""
+import collections, csv, glob, json, os, re, shutil, statistics, sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r2'
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(ROOT, 'gpurun_out', 'prof_' + tag)
+dst = os.path.join(ROOT, 'profiles')
+
+
+def short(n):
+    return re.sub(r'\(anonymous namespace\)::|mpose::|void ', '', n)
+
+
+shutil.copy(os.path.join(src, 'summary.txt'), os.path.join(dst, tag + '_rocprofv3_summary.txt'))
+for sub, name in (('trace', 'kernel_stats'), ('tail', 'tail_kernel_stats')):
+    for f in glob.glob(os.path.join(src, sub, '**', '*kernel_stats.csv'), recursive=True):
+        shutil.copy(f, os.path.join(dst, '%s_%s.csv' % (tag, name)))
+
+# ---- soft-argmax kernel by problem size (the stats file mixes the three sizes of tools/prof_tail.py) ----
+rows = [r for f in glob.glob(os.path.join(src, 'tail', '**', '*kernel_trace.csv'), recursive=True) for r in csv.DictReader(open(f))]
+by = collections.defaultdict(list)
+for r in rows:
+    if 'softmax_dsnt' in r['Kernel_Name']:
+        by[(short(r['Kernel_Name']).split('(')[0], int(r['Grid_Size_X']) // 192 // 17)].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
+tail = {}
+for (k, B), v in sorted(by.items(), key=lambda kv: -kv[0][1]):
+    bf16 = 'false, true, true' in k
+    nbytes = 3 * B * 17 * 1024 * (6 if bf16 else 8) + B * 17 * 12
+    med = statistics.median(v)
+    tail['B=%d %s heatmaps' % (B, 'bf16' if bf16 else 'fp32')] = {
+        'kernel': k, 'launches': len(v), 'median_us': med, 'mean_us': sum(v) / len(v), 'algorithmic_bytes': nbytes,
+        'GBps': nbytes / med / 1e3, 'frac_of_8TBps': nbytes / med / 1e3 / 8000.0}
+json.dump({'_source': 'rocprofv3 --kernel-trace --stats -- python tools/prof_tail.py (the loops of bench.py::tail_microbench); kernel durations by '
+                      'problem size from the trace csv', **tail}, open(os.path.join(dst, tag + '_tail_by_size.json'), 'w'), indent=1)
+
+# ---- per-template PMC averages -> traffic / MFMA-busy json that bench.py reads ----
+ctr = collections.defaultdict(lambda: collections.defaultdict(list))
+for sub in ('pmc_sq', 'pmc_lds', 'pmc_fetch', 'pmc_write'):
+    for f in glob.glob(os.path.join(src, sub, '**', '*counter_collection.csv'), recursive=True):
+        for r in csv.DictReader(open(f)):
+            ctr[(short(r['Kernel_Name']).split('(')[0], int(r['Grid_Size']))][r['Counter_Name']].append(float(r['Counter_Value']))
+labels = {   # bench.py kernel tag -> (template, threads in the grid) at B = 32, three column groups
+    'conv:f_conv2/32x32/128->128': ('conv_planes_k<2, 2, 2, 2, 3, 0, 3>', 256 * 3 * 256, 3 * 32768 * (128 * 6 + 128 * 4) + 3 * 9 * 128 * 128 * 6),
+    'conv:d_conv2/32x32/128->128': ('conv_planes_k<2, 2, 2, 2, 3, 0, 3>', 256 * 3 * 256, 3 * 32768 * (128 * 6 + 128 * 4 + 128 * 4) + 3 * 9 * 128 * 128 * 6),
+    'conv:f_in_regular/32x32/128->128': ('conv_planes_k<2, 2, 2, 2, 3, 1, 3>', 256 * 3 * 256, 3 * 32768 * (128 * 6 + 2 * 128 * 4) + 3 * 10 * 128 * 128 * 6),
+    'conv:d_in_regular/32x32/128->128': ('conv_planes_k<2, 2, 2, 2, 3, 2, 3>', 256 * 3 * 256, 3 * 32768 * (2 * 128 * 6 + 128 * 4) + 3 * 10 * 128 * 128 * 6),
+    'conv:f_conv2/16x16/192->192': ('conv_planes_k<2, 2, 1, 3, 3, 0, 3>', 128 * 3 * 256, 3 * 8192 * (192 * 6 + 192 * 4) + 3 * 9 * 192 * 192 * 6),
+    'conv:d_conv2/16x16/192->192': ('conv_planes_k<2, 2, 1, 3, 3, 0, 3>', 128 * 3 * 256, 3 * 8192 * (192 * 6 + 192 * 8) + 3 * 9 * 192 * 192 * 6),
+    'wgrad:f_conv2/32x32/128->128': ('conv_wgrad_k<4, 4>', None, 3 * 32768 * 128 * 8),
+    'wgrad:f_conv2/16x16/192->192': ('conv_wgrad_k<3, 3>', None, 3 * 8192 * 192 * 8),
+}
+out = {'_source': 'rocprofv3 --kernel-trace --pmc <one counter group per run> of `python bench.py --steps 1 --warmup 1 --no-cpu-baseline '
+                  '--no-kernel-timing --no-overlap-wgrad --eager --no-inference` (tools/profile.sh %s): per-dispatch averages of the kernel '
+                  'template (and grid) the label launches; hbm_bytes = 2 x FETCH_SIZE (16-byte/lane streams are tallied at half their bytes on '
+                  'gfx950, MI355X_MICROARCH.md) + WRITE_SIZE; mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs)' % tag}
+for label, (templ, grid, alg) in labels.items():
+    keys = [k for k in ctr if k[0] == templ and (grid is None or k[1] == grid)]
+    if not keys:
+        continue
+    def avg(c):
+        vals = [v for k in keys for v in ctr[k].get(c, [])]
+        return sum(vals) / len(vals) if vals else None
+    fe, wr, busy, gui = avg('FETCH_SIZE'), avg('WRITE_SIZE'), avg('SQ_VALU_MFMA_BUSY_CYCLES'), avg('GRBM_GUI_ACTIVE')
+    conf, idx = avg('SQ_LDS_BANK_CONFLICT'), avg('SQ_LDS_IDX_ACTIVE')
+    e = {'kernel': templ + (' grid %d' % grid if grid else ''), 'algorithmic_bytes': alg}
+    if fe is not None and wr is not None:
+        e.update(fetch_size_kb_reported=fe, write_size_kb_reported=wr, hbm_bytes_per_launch=int(2 * fe * 1024 + wr * 1024))
+    if busy is not None and gui:
+        e['mfma_busy_frac'] = busy / (gui / 8 * 1024)
+        e['shader_clock_GHz_note'] = 'GRBM_GUI_ACTIVE / 8 = %.0f cycles per launch' % (gui / 8)
+    if conf is not None and idx:
+        e['lds_bank_conflict_frac'] = conf / idx
+    out[label] = e
+json.dump(out, open(os.path.join(dst, tag + '_pmc_traffic.json'), 'w'), indent=1)
+print(json.dumps({k: {kk: vv for kk, vv in v.items() if kk in ('mfma_busy_frac', 'hbm_bytes_per_launch', 'algorithmic_bytes', 'lds_bank_conflict_frac')}
+                  for k, v in out.items() if isinstance(v, dict)}, indent=1))
+print(json.dumps(tail, indent=1))
