@@ -682,6 +682,8 @@ class Engine:
             self._pending = weakref.ref(ctx)
             ctx['param_versions'] = [p._version for p in self.param_list()]
 
+        # (repacked on every forward, 0.33 ms: a cache keyed on the parameters' version counters would miss `p.data` updates and
+        #  anything a replayed graph or a raw kernel such as DeviceSGD writes)
         self.pack_weights()
         if train:
             self.stat_arena.zero_()

@@ -171,6 +171,7 @@ class DeviceSGD:
             self._fill_table(self._eager_table)
             table = self._eager_table
             self._steps += 1
+            torch.autograd.graph.increment_version(self.params)       # the kernel writes the parameters behind autograd's back
         _lib.check(_lib.lib().mpose_sgd_step(_lib.ptr(table), len(self.params), _lib.c_int64(self._max_n), _lib.ptr(self._hyper),
                                              _lib.stream_ptr()), 'mpose_sgd_step')
 
@@ -181,6 +182,7 @@ class DeviceSGD:
     def before_replay(self):
         self.upload_hyper()
         self._steps += 1
+        torch.autograd.graph.increment_version(self.params)
 
     def state_dict(self):
         return {'state': {'momentum_buffers': self._bufs.detach().cpu(), 'steps': self._steps},

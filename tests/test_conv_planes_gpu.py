@@ -328,7 +328,7 @@ def test_planes_fused_output_stage(B, H, cin, cout, with_f32):
     v = lambda t: t.double().view(1, cout, 1, 1)
     ref = torch.relu(F.conv2d(x.double(), w.double(), padding=1) * v(sc) + v(sh)) + (add.double() * v(asc) + v(ash))
     f32 = torch.relu(F.conv2d(x, w, padding=1) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)) + (add * asc.view(1, -1, 1, 1) + ash.view(1, -1, 1, 1))
-    got_p = planes_to_f64(planes, npix, cout).view(B, H, H, cout).permute(0, 3, 1, 2)
+    got_p = planes_to_f64(planes, npix, cout).cpu().view(B, H, H, cout).permute(0, 3, 1, 2)
     scale = ref.abs().max()
     e_p, e_f32 = float((got_p - ref).abs().max() / scale), float((f32.double() - ref).abs().max() / scale)
     check(e_p, e_f32)
