@@ -302,7 +302,7 @@ def main():
                             'random init)' % args.stem if args.stem.startswith('resnet') else
                             'patch8 (in-repo deterministic stem; the InceptionV4 stem is available with --stem inceptionv4)'), 'parallelism': 'dp%d' % world, 'overlap_wgrad': (not args.no_overlap_wgrad) and world == 1,
                    'step_dispatch': 'hip graph replay (train_helpers.GraphedTrainStep)' if use_graph else 'eager launches',
-                   'conv_engine': 'planes (conv_p.hip)' if model.inner.engine().use_planes else 'round-1 igemm (conv.hip)',
+                   'conv_engine': 'planes (conv_p.hip)' if model.inner.engine().planes_for(True, True) else 'igemm (conv.hip)',
                    'final_loss': loss_value},
     }
     if timer is not None:

@@ -247,12 +247,17 @@ class Engine:
         self.combiners = [m.conv.weight for m in inner.hm_combiners]
         self._all_blocks = [b for st in self.stage_blocks for grp in st for b in grp]
         block_convs = [c for b in self._all_blocks for c in (b.conv_in, b.conv2, b.conv_sc)]
-        # Round-2 convolution engine for the columns: activations pre-split into bf16 planes by their producers, both
-        # operands by DMA, two workgroups per CU (csrc/conv_p.hip).  MPOSE_PLANES=0 keeps round 1's conv_igemm_k (A/B runs).
-        self.use_planes = os.environ.get('MPOSE_PLANES', '1') != '0'
+        # Two convolution engines serve the columns.  conv_igemm_k (csrc/conv.hip) reads fp32 activations and splits them in its
+        # K loop; conv_planes_k (csrc/conv_p.hip) reads activations PRE-split into bf16 planes by their producers, both operands
+        # by DMA, two workgroups per CU.  On one box the convolutions themselves take the same time (19.1 vs 19.0 ms per training
+        # step), but in training the weight-gradient kernel still wants fp32 operands, so every producer writes 18 instead of
+        # 12 bytes per element (+2.2 ms per step): fp32 TRAINING stays on conv_igemm_k.  Inference (BatchNorm + ReLU + residual
+        # fused into the plane engine's epilogue, no fp32 round trip) and the single-pass bf16 mode run on the plane engine.
+        # MPOSE_PLANES=1 / 0 forces one engine everywhere (A/B runs).
+        self.planes_mode = os.environ.get('MPOSE_PLANES', 'auto')
         self.conv_bf16 = False       # single-pass bf16 convolutions in the columns (MargiPoseModel.conv_dtype, configs[4])
         for c in block_convs:
-            c.layout = 1 if self.use_planes else 0
+            c.layout = 1             # packed-weight layout when the plane engine runs (layout 0 otherwise; see pack_weights)
         block_bns = [n for b in self._all_blocks for n in (b.bn1, b.bn2, b.bns)]
         self.stem = None
         fe_name = getattr(inner, 'feature_extractor_name', 'patch8')
@@ -380,9 +385,13 @@ class Engine:
                 j['Npad'] = c.npad_d if d else c.npad_f
                 j['Kpad'] = c.cout_s if d else c.cin_s
                 j['sn'], j['sk'], j['st'] = sn, sk, st
-                j['layout'] = c.layout
+                j['layout'] = 0
                 mx = max(mx, int(j['T']) * int(j['Kpad']) * int(j['Npad']))
-        self._pack_jobs = _jobs_to_device(jobs, device)
+        jobs_p = jobs.copy()
+        for i, c in enumerate(self._convs):
+            jobs_p[2 * i]['layout'] = jobs_p[2 * i + 1]['layout'] = c.layout
+        self._pack_jobs = (_jobs_to_device(jobs, device), _jobs_to_device(jobs_p, device))     # [0] igemm engine, [1] plane engine
+        self._packed_for = None      # which of the two the packed arena currently holds
         self._pack_max = mx
         self._tables = {}
         self._arena_key = key
@@ -583,8 +592,14 @@ class Engine:
         check(L.mpose_bn_bwd_reduce_ws((BnBwdReduceOperands * 3)(*rops), n, pixels_per_image, B, C, ptr(ws), c_int64(ws.numel()), stream_ptr()),
               'mpose_bn_bwd_reduce_ws')
 
-    def conv_flags(self):
-        return (4 | (8 if self.conv_bf16 else 0)) if self.use_planes else 0
+    def planes_for(self, train, save):
+        """Which engine a forward (and its backward) runs the columns on: see __init__."""
+        if self.planes_mode in ('0', '1'):
+            return self.planes_mode == '1'
+        return self.conv_bf16 or not (train or save)
+
+    def conv_flags(self, planes):
+        return (4 | (8 if self.conv_bf16 else 0)) if planes else 0
 
     def wgrad(self, g, ops, n_split):
         arr = (WgradOperands * 3)(*ops)
@@ -633,9 +648,10 @@ class Engine:
         check(lib().mpose_bn_finalize(c_void_p(base), n, int(train), ctypes.c_float(BN_EPS), ctypes.c_float(BN_MOMENTUM),
                                       stream_ptr()), 'mpose_bn_finalize')
 
-    def pack_weights(self):
-        check(lib().mpose_pack_weights(ptr(self._pack_jobs), 2 * len(self._convs), self._pack_max, stream_ptr()),
+    def pack_weights(self, planes):
+        check(lib().mpose_pack_weights(ptr(self._pack_jobs[1 if planes else 0]), 2 * len(self._convs), self._pack_max, stream_ptr()),
               'mpose_pack_weights')
+        self._packed_for = bool(planes)
 
     # ------------------------------------------------------------------ forward
     def forward(self, x, train, save, hm_bf16=False, features=None):
@@ -684,7 +700,8 @@ class Engine:
 
         # (repacked on every forward, 0.33 ms: a cache keyed on the parameters' version counters would miss `p.data` updates and
         #  anything a replayed graph or a raw kernel such as DeviceSGD writes)
-        self.pack_weights()
+        planes = ctx['planes'] = self.planes_for(train, save)
+        self.pack_weights(planes)
         if train:
             self.stat_arena.zero_()
         elif self.stem is None:
@@ -731,8 +748,7 @@ class Engine:
                 inp = new_inp
             ctx['inps'].append(inp)
             cur = [inp, inp, inp]
-            planes = self.use_planes
-            pflags = ctx['pflags'] = self.conv_flags()
+            pflags = ctx['pflags'] = self.conv_flags(planes)
             if planes:               # the stage input is read by all three columns: split once
                 inp_p = self.split_planes([inp], B * F * F, 128)[0]
                 cur_p = [inp_p, inp_p, inp_p]
@@ -901,8 +917,10 @@ class Engine:
         self.stat_arena.zero_()        # forward sums are consumed (mean/invstd live in the float arena)
         goff = dict((id(p), o) for p, o in zip(self.param_list(), self._grad_offsets))
         coef_base = tb['coef'].data_ptr()
-        planes = self.use_planes
-        pflags = ctx.get('pflags', self.conv_flags())      # (the forward's convolution precision)
+        planes = ctx['planes']
+        pflags = ctx['pflags']         # (the forward's convolution engine and precision)
+        if self._packed_for != planes:     # a forward on the other engine ran in between: the parameters are unchanged (checked
+            self.pack_weights(planes)      # above), so this restores exactly the packing of this context's forward
 
         def run_coef(first, n):
             check(L.mpose_bn_bwd_coef(c_void_p(coef_base + first * COEF_DT.itemsize), n, eval_bn, st()), 'mpose_bn_bwd_coef')

@@ -257,7 +257,7 @@ class MargiPoseModel(nn.Module):
         if dtype not in (torch.float32, torch.bfloat16):
             raise _lib.MposeError('conv_dtype must be torch.float32 or torch.bfloat16')
         eng = self.inner.engine()
-        if dtype == torch.bfloat16 and not eng.use_planes:
+        if dtype == torch.bfloat16 and eng.planes_mode == '0':
             raise _lib.MposeError('conv_dtype=bfloat16 needs the plane convolution engine (MPOSE_PLANES=0 is set)')
         eng.conv_bf16 = dtype == torch.bfloat16
 

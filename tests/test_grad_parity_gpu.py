@@ -121,21 +121,27 @@ def mask_flips(a, b):
     return sum(int((a[k] != b[k]).sum()) for k in a), n
 
 
-@pytest.mark.parametrize('T,B', [(1, 2), (2, 2), (1, 8), (3, 4)])
-def test_grads_on_the_same_relu_piece(T, B):
+@pytest.mark.parametrize('T,B,engine', [(1, 2, 'auto'), (2, 2, 'auto'), (1, 8, 'auto'), (3, 4, 'auto'), (2, 2, 'planes'), (1, 8, 'planes')])
+def test_grads_on_the_same_relu_piece(T, B, engine):
+    """engine 'auto' = what training runs by default (conv_igemm_k for the columns); 'planes' forces the plane engine
+    (conv_planes_k: pre-split operands, two accumulators) through the same step."""
     seed = 700 + 10 * T + B
     x, target, mask = W.seeded_inputs(seed + 1000, B)
     rng = np.random.default_rng(seed)
     mask = torch.tensor((rng.uniform(0, 1, (B, 17)) > 0.2).astype(np.float32))
     m, sd = build(T, seed, x)
+    tag = 'T%d_B%d' % (T, B)
+    if engine == 'planes':
+        m.inner.engine().planes_mode = '1'
+        tag += '_planes'
     gpu, masks, loss_gpu = gpu_step(m, x, target, mask)
     own = {}
     free64, _ = oracle_grads(sd, T, x, target, mask, torch.float64, record=own)      # the oracle on ITS piece (for the record)
     ref64, loss64 = oracle_grads(sd, T, x, target, mask, torch.float64, masks=masks)
     ref32, _ = oracle_grads(sd, T, x, target, mask, torch.float32, masks=masks)
     flips, total = mask_flips(masks, own)
-    free = compare('free_T%d_B%d' % (T, B), gpu, free64, ref32)
-    st = compare('masked_T%d_B%d' % (T, B), gpu, ref64, ref32,
+    free = compare('free_' + tag, gpu, free64, ref32)
+    st = compare('masked_' + tag, gpu, ref64, ref32,
                  {'relu_sites_flipped_vs_fp64': flips, 'relu_sites': total, 'free_running_gpu_median': free['gpu_median'],
                   'free_running_gpu_max': free['gpu_max']})
     assert abs(loss_gpu - loss64) <= 1e-5 * abs(loss64)

@@ -135,14 +135,17 @@ def grad_noise_gate(name, gpu, ref64, ref32):
     assert stats['zero_grad_abs_max'] < 1e-4, stats
 
 
-@pytest.mark.parametrize('T,B', [(1, 2), (2, 2), (1, 8), (1, 3)])
-def test_train_step_vs_oracle(T, B):
+@pytest.mark.parametrize('T,B,planes', [(1, 2, False), (2, 2, False), (1, 8, False), (1, 3, False), (1, 2, True)])
+def test_train_step_vs_oracle(T, B, planes):
+    """planes=True forces the plane convolution engine (inference's and the bf16 mode's) through an fp32 training step."""
     seed = 500 + T
     x, target, mask = W.seeded_inputs(seed + 1000, B)
     rng = np.random.default_rng(seed)
     mask = torch.tensor((rng.uniform(0, 1, (B, 17)) > 0.2).astype(np.float32))
     from margipose_amd import dsntnn
     m = build(T, seed, x).train()
+    if planes:
+        m.inner.engine().planes_mode = '1'
     xg = x.cuda().requires_grad_(True)
     out = m(xg)
     l3 = m.forward_3d_losses(out, target.cuda())
@@ -162,13 +165,14 @@ def test_train_step_vs_oracle(T, B):
             errs['buf:' + k] = rel(sd[k].cpu(), v)
         if k.endswith('num_batches_tracked'):
             assert int(sd[k]) == 1
-    report('train_T%d_B%d' % (T, B), errs)
+    name = 'train_T%d_B%d%s' % (T, B, '_planes' if planes else '')
+    report(name, errs)
     # gradients: gated on the reference's own fp32 noise floor
     gpu = OrderedDict((k, p.grad.cpu()) for k, p in m.named_parameters())
     gpu['__dx__'] = xg.grad.cpu()
     r64 = OrderedDict(ref['grads']); r64['__dx__'] = ref['dx']
     r32 = OrderedDict(ref32['grads']); r32['__dx__'] = ref32['dx']
-    grad_noise_gate('train_T%d_B%d' % (T, B), gpu, r64, r32)
+    grad_noise_gate(name, gpu, r64, r32)
 
 
 def test_model_T2_vs_reference_golden(golden_dir):
