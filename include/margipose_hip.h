@@ -153,6 +153,13 @@ typedef struct {
   const float* add_scale;
   const float* add_shift;
   void* out0_planes;
+  /* MPOSE_CONV_F16X3: largest magnitudes (one float each, device memory) of the tensors as the K loop sees them --
+   * `in` AFTER the in_scale / in_shift / ReLU prologue, `in1`, and the torch-layout weights behind w0 / w1 -- written by
+   * mpose_absmax / mpose_weights_absmax.  A value below the true maximum overflows fp16 (inf / NaN results). */
+  const float* in_amax;
+  const float* in1_amax;
+  const float* w0_amax;
+  const float* w1_amax;
 } mpose_conv_operands;
 
 #define MPOSE_CONV_ACCUMULATE 1   /* out0 += result */
@@ -164,6 +171,16 @@ typedef struct {
 #define MPOSE_CONV_EPI_RELU0 16    /* with the fused output stage of mpose_conv_operands: ReLU after epi_scale0 / epi_shift0 */
 #define MPOSE_CONV_BF16 8         /* with MPOSE_CONV_PLANES_IN: multiply the hi planes only (bf16 x bf16 -> fp32, one MFMA per
                                    * fragment pair): the reduced-precision mode of BASELINE configs[4], NOT fp32-equivalent */
+#define MPOSE_CONV_F16X3 32       /* fp32 convolution as THREE fp16 MFMA products instead of six bf16 ones (conv.hip engine only).
+                                   * x * 2^k = h + l with two fp16 values (11 significant bits each, |x - (h+l) 2^-k| <= 2^-22 |x|),
+                                   * k = 141 - biased_exponent(amax) (clamped to [-113, 114]) so that the tensor's largest
+                                   * magnitude lands in [2^14, 2^15); a*b ~= ah*bh + ah*bl + al*bh (products exact in the fp32
+                                   * accumulator, the dropped al*bl <= 2^-22 |ab|); the accumulator is scaled back by
+                                   * 2^-(ka+kb) (exact).  gfx950's fp16 MFMA honours subnormals (tools/probe/f16_probe), so elements
+                                   * far below amax degrade gradually (absolute error 2^-25 * 2^-k).  Measured against fp64 the
+                                   * result is as close as the six-product bf16 form (tests/test_conv_gpu.py) at half the matrix
+                                   * work.  Needs ops[i].in_amax / w0_amax (+ in1_amax / w1_amax with a second input / weight set)
+                                   * and weights packed with layout 2. */
 #define MPOSE_CONV_SUM_INPUTS 2   /* taps with acc == 1 read `in1` through `w1` and add into out0 (one pass, one
                                    * output): the data-gradient of a ResidualBlock's input, dX = conv_in^T(dC1) +
                                    * shortcut^T(dSC), models/margipose_model.py:39 */
@@ -185,6 +202,11 @@ typedef struct {
   const float* gout1;
   float* dw0;                          /* (n_split, n_widx0, Cin/4, Npad0, 4) partial sums */
   float* dw1;
+  /* When in_amax != NULL (all groups alike) the launch runs the three-product fp16 form (see MPOSE_CONV_F16X3): largest
+   * magnitudes of `in` (after the prologue), gout0 and gout1 as written by mpose_absmax. */
+  const float* in_amax;
+  const float* gout0_amax;
+  const float* gout1_amax;
 } mpose_wgrad_operands;
 
 /* Number of (tap, input-channel tile, output-channel tile) work units of one group's weight-gradient launch;
@@ -198,13 +220,30 @@ int mpose_conv_wgrad(const mpose_conv_geom* geom, const mpose_wgrad_operands* op
 /* Batched weight (re)packing and gradient un-packing; jobs live in device memory. */
 typedef struct {
   const float* src;                    /* torch-layout weight */
-  float* dst;                          /* packed bf16 planes, 1.5 floats per element:
-                                        *   layout 0: [T][Kpad/16][3 (hi,mid,lo)][Npad][2][8]   (conv.hip: fragments from L2)
-                                        *   layout 1: [T][Kpad/16][3][2 (k half)][Npad][8]      (conv_p.hip: B tiles by DMA) */
+  float* dst;                          /* packed 16-bit planes, at most 1.5 floats per element:
+                                        *   layout 0: [T][Kpad/16][3 (hi,mid,lo)][Npad][2][8] bf16  (conv.hip: fragments from L2)
+                                        *   layout 1: [T][Kpad/16][3][2 (k half)][Npad][8] bf16     (conv_p.hip: B tiles by DMA)
+                                        *   layout 2: [T][Kpad/16][2 (h,l)][Npad][2][8] fp16 of w * 2^k(*amax)   (MPOSE_CONV_F16X3) */
   int N, K, T, Npad, Kpad;
   int64_t sn, sk, st;                  /* element strides of n, k, tap in src */
   int layout;
+  float* amax;                         /* layout 2: max |src| (N*K*T contiguous floats), written by mpose_weights_absmax */
 } mpose_pack_job;
+
+/* *jobs[i].amax = max |jobs[i].src[0 .. N*K*T)| for every job with amax != NULL (one workgroup per job; before mpose_pack_weights). */
+int mpose_weights_absmax(const mpose_pack_job* jobs_dev, int n_jobs, void* stream);
+
+/* Largest magnitude of up to MPOSE_ABSMAX_MAX activation tensors (npix x C fp32, NHWC dense) as a convolution's K loop will
+ * see them: *dst = max(*dst, max |[relu](scale[c] * src + shift[c])|), scale NULL = identity.  dst is accumulated with an
+ * atomic max on the float's bit pattern: zero it before the first launch that targets it. */
+#define MPOSE_ABSMAX_MAX 6
+typedef struct {
+  const float* src;
+  const float* scale;
+  const float* shift;
+  float* dst;
+} mpose_absmax_operands;
+int mpose_absmax(const mpose_absmax_operands* ops, int n_tensors, int64_t npix, int C, int relu, void* stream);
 
 int mpose_pack_weights(const mpose_pack_job* jobs_dev, int n_jobs, int max_elems_per_job,
                        void* stream);

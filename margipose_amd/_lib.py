@@ -17,7 +17,7 @@ c_int = ctypes.c_int
 c_float = ctypes.c_float
 c_int64 = ctypes.c_int64
 
-ABI_VERSION = 8          # must equal mpose_abi_version() of the library (csrc/tail.hip)
+ABI_VERSION = 9          # must equal mpose_abi_version() of the library (csrc/tail.hip)
 MAX_GROUP = 3
 MAX_TAPS = 12
 MAX_CLASSES = 4
@@ -101,12 +101,18 @@ class ConvOperands(ctypes.Structure):
                 ('stats0', c_void_p), ('stats1', c_void_p),
                 ('mask_src', c_void_p), ('mask_scale', c_void_p), ('mask_shift', c_void_p), ('in1', c_void_p),
                 ('epi_scale0', c_void_p), ('epi_shift0', c_void_p), ('add_src', c_void_p), ('add_scale', c_void_p),
-                ('add_shift', c_void_p), ('out0_planes', c_void_p)]
+                ('add_shift', c_void_p), ('out0_planes', c_void_p),
+                ('in_amax', c_void_p), ('in1_amax', c_void_p), ('w0_amax', c_void_p), ('w1_amax', c_void_p)]
 
 
 class WgradOperands(ctypes.Structure):
     _fields_ = [('in_', c_void_p), ('in_scale', c_void_p), ('in_shift', c_void_p),
-                ('gout0', c_void_p), ('gout1', c_void_p), ('dw0', c_void_p), ('dw1', c_void_p)]
+                ('gout0', c_void_p), ('gout1', c_void_p), ('dw0', c_void_p), ('dw1', c_void_p),
+                ('in_amax', c_void_p), ('gout0_amax', c_void_p), ('gout1_amax', c_void_p)]
+
+
+class AbsmaxOperands(ctypes.Structure):
+    _fields_ = [('src', c_void_p), ('scale', c_void_p), ('shift', c_void_p), ('dst', c_void_p)]
 
 
 class BnAddOperands(ctypes.Structure):

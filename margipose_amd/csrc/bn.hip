@@ -314,6 +314,7 @@ extern "C" int mpose_sizeof(int which) {
     case 9: return (int)sizeof(mpose_bn_bwd_apply_operands);
     case 10: return (int)sizeof(mpose_split_operands);
     case 11: return (int)sizeof(mpose_sgd_job);
+    case 12: return (int)sizeof(mpose_absmax_operands);
     default: return -1;
   }
 }

@@ -29,6 +29,23 @@ __device__ __forceinline__ float cell_coord(int i, float two_over_l, float first
   return fmaf((float)i, two_over_l, first);
 }
 
+// MPOSE_CONV_F16X3 (include/margipose_hip.h): exponent k of the power-of-two scale that puts a tensor whose largest magnitude is
+// `amax` into fp16's upper range, amax * 2^k in [2^14, 2^15).  The packer, both convolution kernels and the weight-gradient
+// kernel all derive k from the same float with this function.
+__host__ __device__ __forceinline__ int f16_scale_exp(float amax) {
+  unsigned bits;
+  __builtin_memcpy(&bits, &amax, 4);
+  int e = (int)((bits >> 23) & 0xffu);
+  e = e < 27 ? 27 : (e > 254 ? 254 : e);        // amax < 2^-100 (all-zero tensors): 2^114; inf / NaN: 2^-113
+  return 141 - e;
+}
+__host__ __device__ __forceinline__ float pow2f(int k) {       // 2^k, -126 <= k <= 127
+  const unsigned bits = (unsigned)(127 + k) << 23;
+  float f;
+  __builtin_memcpy(&f, &bits, 4);
+  return f;
+}
+
 struct Ptr3 {
   const float* p[MPOSE_MAX_GROUP];
 };

@@ -103,6 +103,20 @@ __device__ __forceinline__ f32x16 mfma_bf16(const bf16x8 a, const bf16x8 b, cons
 }
 __device__ __forceinline__ bf16x8 as_bf16x8(const u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
 
+// MPOSE_CONV_F16X3: x (already multiplied by the tensor's power-of-two scale, |x| < 2^15) -> two fp16 values with
+// x == h + l up to 2^-22 |x| (round to nearest twice; the subtraction is exact).  v_cvt_pk_f16_f32 rounds a pair.
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void split2h(const float x0, const float x1, unsigned& h, unsigned& l) {
+  const f16x2 hh = __builtin_convertvector(f32x2{x0, x1}, f16x2);
+  h = __builtin_bit_cast(unsigned, hh);
+  const float r0 = x0 - (float)hh[0], r1 = x1 - (float)hh[1];
+  l = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{r0, r1}, f16x2));
+}
+__device__ __forceinline__ f32x16 mfma_f16(const u32x4 a, const u32x4 b, const f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
 // Forward / data-gradient kernel: fp32 convolution on the bf16 matrix cores ("bf16x6").
 //
 // Why: gfx950's fp32 MFMA (v_mfma_f32_32x32x2_f32) runs on the SIMD's 32 fp32 FMA lanes -- measured 147 TFLOP/s
@@ -130,9 +144,13 @@ __device__ __forceinline__ bf16x8 as_bf16x8(const u32x4 v) { return __builtin_bi
 // MODE 0: one pass.  MODE 1: taps with acc == 1 are a second pass into a second output (fused shortcut, forward).
 // MODE 2 (MPOSE_CONV_SUM_INPUTS): they are a second pass over a second INPUT that keeps accumulating into the same
 // tile -- dX = conv_in^T(dC1) + shortcut^T(dSC) -- with one epilogue.
-template <int RN, int MODE, int KS, bool PRO>
+// NPL = 3: the six-product bf16 form above.  NPL = 2 (MPOSE_CONV_F16X3): operands split into TWO fp16 planes after a
+// per-tensor power-of-two scale, three products per k-group (al*bh, ah*bl, ah*bh), accumulators scaled back (exactly) after
+// the K loop -- half the matrix work, two thirds of the LDS and L2 fragment traffic, 4 instead of 5.5 VALU per element.
+template <int RN, int MODE, int KS, bool PRO, int NPL>
 __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
   constexpr bool ACC1 = MODE == 1, SUM2 = MODE == 2;
+  constexpr bool F16 = NPL == 2;
   constexpr int NPASS = MODE ? 2 : 1;
   constexpr int BM = 256 / KS;
   constexpr int BN = 32 * RN;
@@ -207,8 +225,16 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
   float4 ra[8];                          // A rows in flight: global -> registers -> (BN+ReLU, split) -> LDS
   float4 rsc_c = make_float4(1.f, 1.f, 1.f, 1.f), rsh_c = make_float4(0.f, 0.f, 0.f, 0.f), rsc_n = rsc_c, rsh_n = rsh_c;
   unsigned pad_c = 0, pad_n = 0;         // bit j: row j of the tile being staged / being loaded is padding (PRO only)
-  u32x4 fb[2][RN][3];                    // B-fragment ring: [k-group][column block][plane] of the NEXT use
-  bf16x8 afA[2][3], afB[2][3];           // A fragments [row block][plane] of k-group 0 / 1
+  u32x4 fb[2][RN][NPL];                  // B-fragment ring: [k-group][column block][plane] of the NEXT use
+  u32x4 afA[2][NPL], afB[2][NPL];        // A fragments [row block][plane] of k-group 0 / 1
+  // F16: scale exponents of this launch's tensors (SGPRs).  Pass `set` multiplies input ka[set] with weights kw[set].
+  int ka0 = 0, ka1 = 0, kw0 = 0, kw1 = 0;
+  if (F16) {
+    ka0 = f16_scale_exp(*op.in_amax);
+    ka1 = SUM2 ? f16_scale_exp(*op.in1_amax) : ka0;
+    kw0 = f16_scale_exp(*op.w0_amax);
+    kw1 = MODE ? f16_scale_exp(*op.w1_amax) : kw0;
+  }
   const int oyc = g.cls[cls].oy, oxc = g.cls[cls].ox;
 
   // Taps with acc == 0 (the convolution proper) come first in a class's tap list, taps with acc == 1 (the fused
@@ -225,6 +251,7 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
     const int n_iter = n_chunks * nt;
     const __amdgpu_buffer_rsrc_t rs_w = set ? rs_w1 : rs_w0;
     const __amdgpu_buffer_rsrc_t rs_in = set ? rs_in1 : rs_in0;
+    const float a_mul = F16 ? pow2f(set ? ka1 : ka0) : 1.f;
     if (!SUM2 || set == 0) {
 #pragma unroll
       for (int rm = 0; rm < 2; ++rm)
@@ -244,14 +271,14 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
       const int dy = (int)(signed char)(tp & 0xff), dx = (int)(signed char)((tp >> 8) & 0xff);
       const int widx = (tp >> 16) & 0xff;
       ti.a_soff = (unsigned)(((dy * g.IW + dx) * in_ld + ti.c * KC) * 4 + a.in_bias);
-      ti.w_soff = (unsigned)(widx * k16_total + ti.c * (KC / 16)) * 3u * plane_b;
+      ti.w_soff = (unsigned)(widx * k16_total + ti.c * (KC / 16)) * (unsigned)NPL * plane_b;
       return ti;
     };
     auto tile_info = [&](int it) { const int c = it / nt; return tile_ct(c, it - c * nt); };
     auto load_b = [&](const TileInfo& ti, int s_, int rn) {
-      const unsigned so = ti.w_soff + (unsigned)s_ * 3u * plane_b;
+      const unsigned so = ti.w_soff + (unsigned)s_ * (unsigned)NPL * plane_b;
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl)
+      for (int pl = 0; pl < NPL; ++pl)
         fb[s_][rn][pl] = buf_load4u(rs_w, w_voff + (unsigned)(rn * 1024), so + (unsigned)pl * plane_b);
     };
     // one row (16 bytes per lane) of the A tile described by `ti`
@@ -264,6 +291,10 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
       if (pro) {
         sc = *reinterpret_cast<const float4*>(op.in_scale + ti.c * KC + a_col4 * 4);
         sh = *reinterpret_cast<const float4*>(op.in_shift + ti.c * KC + a_col4 * 4);
+        if (F16) {     // relu(s*x + t) * 2^k == relu((s 2^k) x + t 2^k): the tensor scale rides on the prologue (exact)
+          sc.x *= a_mul; sc.y *= a_mul; sc.z *= a_mul; sc.w *= a_mul;
+          sh.x *= a_mul; sh.y *= a_mul; sh.z *= a_mul; sh.w *= a_mul;
+        }
       }
     };
     // BN + ReLU of the producing layer (PRO) and the bf16 split happen at LDS-store time; padding rows are already
@@ -274,41 +305,62 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
         v.x = pad ? 0.f : fmaxf(fmaf(v.x, sc.x, sh.x), 0.f); v.y = pad ? 0.f : fmaxf(fmaf(v.y, sc.y, sh.y), 0.f);
         v.z = pad ? 0.f : fmaxf(fmaf(v.z, sc.z, sh.z), 0.f); v.w = pad ? 0.f : fmaxf(fmaf(v.w, sc.w, sh.w), 0.f);
       }
-      uint2 h, m, l;
-      split4(v, h, m, l);
       unsigned char* dA = sA + buf * A_TILE_B + ((lane >> 3) + 8 * j) * A_ROW_B + a_col4 * 8;
-      *reinterpret_cast<uint2*>(dA) = h;
-      *reinterpret_cast<uint2*>(dA + A_PLANE_B) = m;
-      *reinterpret_cast<uint2*>(dA + 2 * A_PLANE_B) = l;
+      if constexpr (F16) {
+        if (!pro) { v.x *= a_mul; v.y *= a_mul; v.z *= a_mul; v.w *= a_mul; }
+        uint2 h, l;
+        split2h(v.x, v.y, h.x, l.x);
+        split2h(v.z, v.w, h.y, l.y);
+        *reinterpret_cast<uint2*>(dA) = h;
+        *reinterpret_cast<uint2*>(dA + A_PLANE_B) = l;
+      } else {
+        uint2 h, m, l;
+        split4(v, h, m, l);
+        *reinterpret_cast<uint2*>(dA) = h;
+        *reinterpret_cast<uint2*>(dA + A_PLANE_B) = m;
+        *reinterpret_cast<uint2*>(dA + 2 * A_PLANE_B) = l;
+      }
     };
     auto load_a_row = [&](const TileInfo& ti, int j) { load_row(ti, j, ra[j], pad_n); };
     auto stage_row = [&](int buf, int j) { stage(buf, j, ra[j], pad_c, rsc_c, rsh_c); };
     auto rotate_stage_state = [&]() { pad_c = pad_n; rsc_c = rsc_n; rsh_c = rsh_n; };
-    auto read_frags = [&](int buf, int s_, bf16x8 (&af)[2][3]) {
+    auto read_frags = [&](int buf, int s_, u32x4 (&af)[2][NPL]) {
       const unsigned char* cA = sA + buf * A_TILE_B + li * A_ROW_B + s_ * 32 + lh * 16;
 #pragma unroll
       for (int rm = 0; rm < 2; ++rm)
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
-          af[rm][pl] = *reinterpret_cast<const bf16x8*>(cA + rm * 32 * A_ROW_B + pl * A_PLANE_B);
+        for (int pl = 0; pl < NPL; ++pl)
+          af[rm][pl] = *reinterpret_cast<const u32x4*>(cA + rm * 32 * A_ROW_B + pl * A_PLANE_B);
     };
     // The six bf16 products of one 16-channel k-group (smallest terms first) for all 2 x RN accumulator blocks,
     // each column block followed by the refill of its B fragments with the same k-group of tile `nb`.  `side(rn)`
     // is the staging work the caller wants issued between the MFMAs of column block rn.
-    auto mfma_group = [&](int s_, const bf16x8 (&af)[2][3], const TileInfo& nb, auto&& side) {
+    auto mfma_group = [&](int s_, const u32x4 (&af)[2][NPL], const TileInfo& nb, auto&& side) {
 #pragma unroll
       for (int rn = 0; rn < RN; ++rn) {
-        const bf16x8 bh = as_bf16x8(fb[s_][rn][0]), bm = as_bf16x8(fb[s_][rn][1]), bl = as_bf16x8(fb[s_][rn][2]);
+        if constexpr (F16) {
+          const u32x4 bh = fb[s_][rn][0], bl = fb[s_][rn][1];
 #pragma unroll
-        for (int rm = 0; rm < 2; ++rm) {
-          f32x16 c = acc0[rm][rn];
-          c = mfma_bf16(af[rm][2], bh, c);
-          c = mfma_bf16(af[rm][0], bl, c);
-          c = mfma_bf16(af[rm][1], bm, c);
-          c = mfma_bf16(af[rm][1], bh, c);
-          c = mfma_bf16(af[rm][0], bm, c);
-          c = mfma_bf16(af[rm][0], bh, c);
-          acc0[rm][rn] = c;
+          for (int rm = 0; rm < 2; ++rm) {
+            f32x16 c = acc0[rm][rn];
+            c = mfma_f16(af[rm][1], bh, c);
+            c = mfma_f16(af[rm][0], bl, c);
+            c = mfma_f16(af[rm][0], bh, c);
+            acc0[rm][rn] = c;
+          }
+        } else {
+          const bf16x8 bh = as_bf16x8(fb[s_][rn][0]), bm = as_bf16x8(fb[s_][rn][1]), bl = as_bf16x8(fb[s_][rn][NPL - 1]);
+#pragma unroll
+          for (int rm = 0; rm < 2; ++rm) {
+            f32x16 c = acc0[rm][rn];
+            c = mfma_bf16(as_bf16x8(af[rm][NPL - 1]), bh, c);
+            c = mfma_bf16(as_bf16x8(af[rm][0]), bl, c);
+            c = mfma_bf16(as_bf16x8(af[rm][1]), bm, c);
+            c = mfma_bf16(as_bf16x8(af[rm][1]), bh, c);
+            c = mfma_bf16(as_bf16x8(af[rm][0]), bm, c);
+            c = mfma_bf16(as_bf16x8(af[rm][0]), bh, c);
+            acc0[rm][rn] = c;
+          }
         }
         load_b(nb, s_, rn);
         side(rn);
@@ -386,6 +438,18 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
       mfma_group(1, afB, t1, [&](int) {});          // last tile, k-group 1
     }
 
+    if constexpr (F16) {
+      // back to the tensors' own units (v_ldexp_f32: exact).  Under SUM2 the first pass is re-expressed in the second pass's
+      // units instead, so that both inputs accumulate into one tile.
+      const int k_this = (set ? ka1 : ka0) + (set ? kw1 : kw0);
+      const int shift = (SUM2 && set == 0) ? (ka1 + kw1) - k_this : -k_this;
+#pragma unroll
+      for (int rm = 0; rm < 2; ++rm)
+#pragma unroll
+        for (int rn = 0; rn < RN; ++rn)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc0[rm][rn][r] = __builtin_ldexpf(acc0[rm][rn][r], shift);
+    }
     if (SUM2 && set == 0) continue;          // the second input accumulates on top; one exchange + epilogue after it
     // ---- split-K exchange.  The KS waves of a group hold partial sums of the same 64 x 32*RN tile.  Each of them OWNS
     //      a share of its 2*RN accumulator blocks (KS = 2: the row block rm == kh; KS = 4: row block kh & 1, column
@@ -571,13 +635,13 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
   }
 }
 
-template <int RN, int MODE, int KS, bool PRO>
+template <int RN, int MODE, int KS, bool PRO, int NPL>
 int launch_conv(const ConvArgs& a0, int n_groups, hipStream_t s) {
   constexpr int BN = 32 * RN;
   constexpr int lds = 4 * 2 * A_TILE_B + 2 * 4 * BN * 2 * 4 + 4 * 64 * 4;
   static bool attr_set = false;          // > 64 KiB of dynamic LDS has to be requested once per kernel
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_k<RN, MODE, KS, PRO>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_k<RN, MODE, KS, PRO, NPL>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
       return MPOSE_EINVAL;
     attr_set = true;
   }
@@ -585,7 +649,7 @@ int launch_conv(const ConvArgs& a0, int n_groups, hipStream_t s) {
   a.n_mtiles = (a.M + 256 / KS - 1) / (256 / KS);
   const int cmax = a.g.Cout1 > a.g.Cout0 ? a.g.Cout1 : a.g.Cout0;
   dim3 grid(a.n_mtiles * a.g.n_classes, (cmax + BN - 1) / BN, n_groups);
-  conv_igemm_k<RN, MODE, KS, PRO><<<grid, 256, lds, s>>>(a);
+  conv_igemm_k<RN, MODE, KS, PRO, NPL><<<grid, 256, lds, s>>>(a);
   return launch_status();
 }
 
@@ -597,7 +661,7 @@ int launch_conv(const ConvArgs& a0, int n_groups, hipStream_t s) {
 // predicted, 98/108/103 measured (same order).  The choice is made for a NOMINAL batch of 32 images, not the actual
 // one: the summation order of a sample then does not depend on how many other samples share its launch, so a
 // data-parallel shard reproduces the full batch's per-sample results bit for bit.
-template <int RN>
+template <int RN, int NPL>
 inline int pick_ks(const ConvArgs& a, int cmax, int n_groups) {
   const int n_iter = (a.g.Cin / KC) * a.g.cls[0].n_taps;
   const long m_nominal = 32l * a.g.GH * a.g.GW;
@@ -608,27 +672,33 @@ inline int pick_ks(const ConvArgs& a, int cmax, int n_groups) {
     const long wgs = ((m_nominal + 256 / ks - 1) / (256 / ks)) * a.g.n_classes * ((cmax + 32 * RN - 1) / (32 * RN)) * n_groups;
     const long rounds = (wgs + 255) / 256;
     const double exchange = ks == 1 ? 0.0 : (ks == 2 ? 1.5 : 2.5);
-    const double cost = (double)rounds * (9.5 + exchange + (double)((n_iter + ks - 1) / ks) * (0.65 + 0.49 * RN));
+    const double per_iter = NPL == 2 ? 0.55 + 0.27 * RN : 0.65 + 0.49 * RN;      // (three instead of six products per k-group)
+    const double cost = (double)rounds * (9.5 + exchange + (double)((n_iter + ks - 1) / ks) * per_iter);
     if (ks == 1 || cost < 0.97 * best_cost) { best = ks; best_cost = cost; }     // ties go to the smaller split
   }
   return best;
 }
 
-template <int RN, int MODE, bool PRO>
+template <int RN, int MODE, bool PRO, int NPL>
 int launch_conv_kp(const ConvArgs& a, int cmax, int n_groups, hipStream_t s) {
-  const int ks = pick_ks<RN>(a, cmax, n_groups);
+  const int ks = pick_ks<RN, NPL>(a, cmax, n_groups);
   if constexpr (RN > 1) {                  // (32-wide tiles never profit from a 4-way split)
-    if (ks == 4) return launch_conv<RN, MODE, 4, PRO>(a, n_groups, s);
+    if (ks == 4) return launch_conv<RN, MODE, 4, PRO, NPL>(a, n_groups, s);
   }
-  if (ks >= 2) return launch_conv<RN, MODE, 2, PRO>(a, n_groups, s);
-  return launch_conv<RN, MODE, 1, PRO>(a, n_groups, s);
+  if (ks >= 2) return launch_conv<RN, MODE, 2, PRO, NPL>(a, n_groups, s);
+  return launch_conv<RN, MODE, 1, PRO, NPL>(a, n_groups, s);
+}
+template <int RN, int NPL>
+int launch_conv_ks_p(const ConvArgs& a, int mode, int cmax, int n_groups, hipStream_t s) {
+  if (mode == 1) return launch_conv_kp<RN, 1, false, NPL>(a, cmax, n_groups, s);
+  if (mode == 2) return launch_conv_kp<RN, 2, false, NPL>(a, cmax, n_groups, s);
+  if (a.op[0].in_scale != nullptr) return launch_conv_kp<RN, 0, true, NPL>(a, cmax, n_groups, s);
+  return launch_conv_kp<RN, 0, false, NPL>(a, cmax, n_groups, s);
 }
 template <int RN>
 int launch_conv_ks(const ConvArgs& a, int mode, int cmax, int n_groups, hipStream_t s) {
-  if (mode == 1) return launch_conv_kp<RN, 1, false>(a, cmax, n_groups, s);
-  if (mode == 2) return launch_conv_kp<RN, 2, false>(a, cmax, n_groups, s);
-  if (a.op[0].in_scale != nullptr) return launch_conv_kp<RN, 0, true>(a, cmax, n_groups, s);
-  return launch_conv_kp<RN, 0, false>(a, cmax, n_groups, s);
+  if (a.flags & MPOSE_CONV_F16X3) return launch_conv_ks_p<RN, 2>(a, mode, cmax, n_groups, s);
+  return launch_conv_ks_p<RN, 3>(a, mode, cmax, n_groups, s);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -664,7 +734,9 @@ struct WgradArgs {
   int n_ytiles, n_groups, chunk, total;
 };
 
-template <int KB, int NB>   // wave tile: 32*KB input channels x 32*NB output channels
+// F16 (operands carry in_amax / gout*_amax): both operands are scaled by their tensor's power of two and split into TWO fp16
+// values, three products per block (MPOSE_CONV_F16X3 in the header), accumulators scaled back before the cross-wave sum.
+template <int KB, int NB, bool F16>   // wave tile: 32*KB input channels x 32*NB output channels
 __global__ __launch_bounds__(256, 1) void conv_wgrad_k(WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];     // cross-wave reduction scratch
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -716,11 +788,15 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_k(WgradArgs a) {
   const int x_pix = g.in_mul * in_ld * 4, g_pix = g.out_mul * g_ld * 4;        // byte stride between consecutive slots
   const int x_lane = (k0 + li) * 4, g_lane = (n0 + li) * 4;
   const bool pro = op.in_scale != nullptr;
+  const int kx = F16 ? f16_scale_exp(*op.in_amax) : 0;
+  const int kg = F16 ? f16_scale_exp(*(second ? op.gout1_amax : op.gout0_amax)) : 0;
+  const float x_mul = pow2f(kx), g_mul = pow2f(kg);
   float psc[KB], psh[KB];
 #pragma unroll
   for (int kb = 0; kb < KB; ++kb) {
     psc[kb] = pro ? op.in_scale[k0 + kb * 32 + li] : 1.f;
     psh[kb] = pro ? op.in_shift[k0 + kb * 32 + li] : 0.f;
+    if (F16 && pro) { psc[kb] *= x_mul; psh[kb] *= x_mul; }      // relu(s x + t) 2^k == relu((s 2^k) x + t 2^k)
   }
 
   // ---- scalar cursor over (slot row, octet); only rows whose tap-shifted input row is in bounds ----
@@ -794,12 +870,16 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_k(WgradArgs a) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) rgv[nb][j] = buf_load1(rs_g, (unsigned)ln.gv + (unsigned)(nb * 128), (unsigned)(j * g_pix));
   };
-  struct Frag { u32x4 h, m, l; };
-  auto split8 = [&](const float (&v)[8], Frag& f) {
+  struct Frag { u32x4 h, m, l; };          // (F16: h and l only)
+  auto split8 = [&](const float (&v)[8], Frag& f, const float mul) {
     unsigned hh[4], mm[4], ll[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) split2(v[2 * q], v[2 * q + 1], hh[q], mm[q], ll[q]);
-    f.h = u32x4{hh[0], hh[1], hh[2], hh[3]}; f.m = u32x4{mm[0], mm[1], mm[2], mm[3]}; f.l = u32x4{ll[0], ll[1], ll[2], ll[3]};
+    for (int q = 0; q < 4; ++q) {
+      if constexpr (F16) split2h(v[2 * q] * mul, v[2 * q + 1] * mul, hh[q], ll[q]);
+      else split2(v[2 * q], v[2 * q + 1], hh[q], mm[q], ll[q]);
+    }
+    f.h = u32x4{hh[0], hh[1], hh[2], hh[3]}; f.l = u32x4{ll[0], ll[1], ll[2], ll[3]};
+    if constexpr (!F16) f.m = u32x4{mm[0], mm[1], mm[2], mm[3]};
   };
   auto split_x = [&](int kb, unsigned mask, Frag& f) {       // BN+ReLU prologue, column mask, split
     float xv[8];
@@ -809,7 +889,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_k(WgradArgs a) {
       if (pro) v = fmaxf(fmaf(v, psc[kb], psh[kb]), 0.f);
       xv[j] = ((mask >> j) & 1u) ? v : 0.f;
     }
-    split8(xv, f);
+    split8(xv, f, (F16 && !pro) ? x_mul : 1.f);
   };
 
   // B fragments of the next group wait in a wave-private LDS area (48 registers less than a second register set)
@@ -825,7 +905,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_k(WgradArgs a) {
     ln1 = next_lane();                            // group 1
     mask_q1 = ln1.mask;
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) { split8(rgv[nb], bc[nb]); load_g(ln1, nb); }
+    for (int nb = 0; nb < NB; ++nb) { split8(rgv[nb], bc[nb], g_mul); load_g(ln1, nb); }
     split_x(0, mask_q, aF[0]);
     load_x(ln1, 0);
 
@@ -839,9 +919,10 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_k(WgradArgs a) {
 #pragma unroll
         for (int nb = kb * NB / KB; nb < (kb + 1) * NB / KB; ++nb) {
           Frag t;
-          split8(rgv[nb], t);
+          split8(rgv[nb], t, g_mul);
           load_g(ln2, nb);
-          sB[(nb * 3 + 0) * 64] = t.h; sB[(nb * 3 + 1) * 64] = t.m; sB[(nb * 3 + 2) * 64] = t.l;
+          sB[(nb * 3 + 0) * 64] = t.h; sB[(nb * 3 + 2) * 64] = t.l;
+          if constexpr (!F16) sB[(nb * 3 + 1) * 64] = t.m;
         }
         if (kb + 1 < KB) { split_x(kb + 1, mask_q, an); load_x(ln1, kb + 1); }
         else { split_x(0, mask_q1, an); load_x(ln2, 0); }
@@ -849,29 +930,44 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_k(WgradArgs a) {
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
           f32x16 c = acc[kb][nb];
-          c = mfma_bf16(as_bf16x8(ac.l), as_bf16x8(bc[nb].h), c);
-          c = mfma_bf16(as_bf16x8(ac.h), as_bf16x8(bc[nb].l), c);
-          c = mfma_bf16(as_bf16x8(ac.m), as_bf16x8(bc[nb].m), c);
-          c = mfma_bf16(as_bf16x8(ac.m), as_bf16x8(bc[nb].h), c);
-          c = mfma_bf16(as_bf16x8(ac.h), as_bf16x8(bc[nb].m), c);
-          c = mfma_bf16(as_bf16x8(ac.h), as_bf16x8(bc[nb].h), c);
+          if constexpr (F16) {
+            c = mfma_f16(ac.l, bc[nb].h, c);
+            c = mfma_f16(ac.h, bc[nb].l, c);
+            c = mfma_f16(ac.h, bc[nb].h, c);
+          } else {
+            c = mfma_bf16(as_bf16x8(ac.l), as_bf16x8(bc[nb].h), c);
+            c = mfma_bf16(as_bf16x8(ac.h), as_bf16x8(bc[nb].l), c);
+            c = mfma_bf16(as_bf16x8(ac.m), as_bf16x8(bc[nb].m), c);
+            c = mfma_bf16(as_bf16x8(ac.m), as_bf16x8(bc[nb].h), c);
+            c = mfma_bf16(as_bf16x8(ac.h), as_bf16x8(bc[nb].m), c);
+            c = mfma_bf16(as_bf16x8(ac.h), as_bf16x8(bc[nb].h), c);
+          }
           acc[kb][nb] = c;
           if (kb == KB - 1) {                     // last use in this group: fetch the next group's fragments
-            bc[nb].h = sB[(nb * 3 + 0) * 64]; bc[nb].m = sB[(nb * 3 + 1) * 64]; bc[nb].l = sB[(nb * 3 + 2) * 64];
+            bc[nb].h = sB[(nb * 3 + 0) * 64]; bc[nb].l = sB[(nb * 3 + 2) * 64];
+            if constexpr (!F16) bc[nb].m = sB[(nb * 3 + 1) * 64];
           }
         }
-        // interleave: the region's ~6 VALU instructions per MFMA go into the MFMAs' shadows
+        // interleave: the region's VALU instructions (~6 per MFMA with six products, ~9 with three) go into the MFMAs' shadows
 #pragma unroll
-        for (int i = 0; i < 6 * NB; ++i) {
+        for (int i = 0; i < (F16 ? 3 : 6) * NB; ++i) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
-          if (i % 2 == 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, F16 ? 9 : 6, 0);
+          if (F16 || i % 2 == 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
         }
         __builtin_amdgcn_sched_barrier(0);        // keep each region's loads and splits inside the region
       }
       if (KB & 1) aF[0] = aF[1];
       mask_q = mask_q1; mask_q1 = ln2.mask; ln1 = ln2;
     }
+  }
+  if constexpr (F16) {                            // back to the tensors' own units (exact)
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[kb][nb][r] = __builtin_ldexpf(acc[kb][nb][r], -(kx + kg));
   }
   __syncthreads();                                // the reduction below reuses the LDS of slower waves' B areas
 
@@ -913,19 +1009,23 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_k(WgradArgs a) {
   }
 }
 
-template <int KB, int NB>
-int launch_wgrad(const WgradArgs& a, hipStream_t s) {
+template <int KB, int NB, bool F16>
+int launch_wgrad_p(const WgradArgs& a, hipStream_t s) {
   constexpr int items = KB * NB * 4;
   constexpr int lds_red = 4 * (items > 32 ? items / 2 : items) * 64 * 16, lds_b = 4 * NB * 3 * 64 * 16;
   constexpr int lds = lds_red > lds_b ? lds_red : lds_b;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_k<KB, NB>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_k<KB, NB, F16>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
       return MPOSE_EINVAL;
     attr_set = true;
   }
-  conv_wgrad_k<KB, NB><<<dim3(8 * a.chunk), 256, lds, s>>>(a);
+  conv_wgrad_k<KB, NB, F16><<<dim3(8 * a.chunk), 256, lds, s>>>(a);
   return launch_status();
+}
+template <int KB, int NB>
+int launch_wgrad(const WgradArgs& a, hipStream_t s) {
+  return a.op[0].in_amax != nullptr ? launch_wgrad_p<KB, NB, true>(a, s) : launch_wgrad_p<KB, NB, false>(a, s);
 }
 template <int KB>
 int launch_wgrad_n(const WgradArgs& a, int nb, hipStream_t s) {
@@ -948,6 +1048,7 @@ __global__ __launch_bounds__(256) void pack_weights_k(const mpose_pack_job* __re
   const long total = (long)j.T * j.Kpad * j.Npad;
   __bf16* dst = reinterpret_cast<__bf16*>(j.dst);
   const long plane = (long)j.Npad * 16;
+  const float w_mul = (j.layout == 2 && j.amax != nullptr) ? pow2f(f16_scale_exp(*j.amax)) : 1.f;
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
     const int k_lo = (int)(e & 15);              // half * 8 + j
     long r = e >> 4;
@@ -957,6 +1058,14 @@ __global__ __launch_bounds__(256) void pack_weights_k(const mpose_pack_job* __re
     const int k = k16 * 16 + k_lo;
     float v = 0.f;
     if (n < j.N && k < j.K) v = j.src[n * j.sn + k * j.sk + t * j.st];
+    if (j.layout == 2) {           // two fp16 planes of w * 2^k (MPOSE_CONV_F16X3)
+      const float vs = v * w_mul;
+      const _Float16 h = (_Float16)vs;
+      const _Float16 l = (_Float16)(vs - (float)h);
+      _Float16* d = reinterpret_cast<_Float16*>(j.dst) + ((long)(t * (j.Kpad / 16) + k16) * 2) * plane + (long)n * 16 + k_lo;
+      d[0] = h; d[plane] = l;
+      continue;
+    }
     const __bf16 h = (__bf16)v;
     const float r1 = v - (float)h;
     const __bf16 m = (__bf16)r1;
@@ -1047,6 +1156,7 @@ extern "C" int mpose_conv_fwd(const mpose_conv_geom* geom, const mpose_conv_oper
   if (a.M == 0) return 0;
   if (flags & MPOSE_CONV_PLANES_IN) {      // pre-split activations: conv_p.hip
     if (ops[0].in_scale || (geom->Cout0 % 32) || (acc1 && (geom->Cout1 % 32)) || (geom->Npad0 % 64)) return MPOSE_EINVAL;
+    if (flags & MPOSE_CONV_F16X3) return MPOSE_EINVAL;
     const int cm = (acc1 && geom->Cout1 > geom->Cout0) ? geom->Cout1 : geom->Cout0;
     if (cm > geom->Npad0) return MPOSE_EINVAL;
     const int ldm = geom->out_ld0 > geom->out_ld1 ? geom->out_ld0 : geom->out_ld1;
@@ -1054,6 +1164,13 @@ extern "C" int mpose_conv_fwd(const mpose_conv_geom* geom, const mpose_conv_oper
     return mpose_conv_planes_launch(geom, ops, n_groups, flags, sum_inputs ? 2 : (acc1 ? 1 : 0), cm, stream);
   }
   if (flags & MPOSE_CONV_BF16) return MPOSE_EINVAL;
+  if (flags & MPOSE_CONV_F16X3) {
+    for (int i = 0; i < n_groups; ++i) {
+      if (!ops[i].in_amax || !ops[i].w0_amax) return MPOSE_EINVAL;
+      if (sum_inputs && (!ops[i].in1_amax || !ops[i].w1_amax)) return MPOSE_EINVAL;
+      if (acc1 && !ops[i].w1_amax) return MPOSE_EINVAL;
+    }
+  }
   a.div_gw = make_fastdiv((unsigned)geom->GW);
   a.div_ghw = make_fastdiv((unsigned)(geom->GH * geom->GW));
   a.flags = flags;
@@ -1121,6 +1238,8 @@ extern "C" int mpose_conv_wgrad(const mpose_conv_geom* geom, const mpose_wgrad_o
     if (!ops[i].in || !ops[i].gout0 || !ops[i].dw0) return MPOSE_EINVAL;
     if (acc1 && (!ops[i].gout1 || !ops[i].dw1)) return MPOSE_EINVAL;
     if (ops[i].in_scale && !ops[i].in_shift) return MPOSE_EINVAL;
+    if ((ops[i].in_amax != nullptr) != (ops[0].in_amax != nullptr)) return MPOSE_EINVAL;
+    if (ops[i].in_amax && (!ops[i].gout0_amax || (acc1 && !ops[i].gout1_amax))) return MPOSE_EINVAL;
   }
   const int n_rows = geom->B * geom->GH;
   if (n_rows == 0 || a.n_entries == 0) return 0;

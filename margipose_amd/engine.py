@@ -24,7 +24,7 @@ import torch
 import torch.distributed
 
 from . import _lib
-from ._lib import (BnAddOperands, BnBwdApplyOperands, BnBwdReduceOperands, ConvGeom, ConvOperands, SplitOperands, WgradOperands, c_int,
+from ._lib import (BnAddOperands, BnBwdApplyOperands, BnBwdReduceOperands, AbsmaxOperands, ConvGeom, ConvOperands, SplitOperands, WgradOperands, c_int,
                    c_int64, c_void_p, check, lib, ptr, ptr_array, stream_ptr)
 
 BN_EPS = 1e-5
@@ -38,7 +38,7 @@ def _rup(a, b):
 
 # numpy mirrors of the device-resident job structs (checked against mpose_sizeof at start-up)
 PACK_DT = np.dtype([('src', 'u8'), ('dst', 'u8'), ('N', 'i4'), ('K', 'i4'), ('T', 'i4'), ('Npad', 'i4'), ('Kpad', 'i4'),
-                    ('sn', 'i8'), ('sk', 'i8'), ('st', 'i8'), ('layout', 'i4')], align=True)
+                    ('sn', 'i8'), ('sk', 'i8'), ('st', 'i8'), ('layout', 'i4'), ('amax', 'u8')], align=True)
 UNPACK_DT = np.dtype([('src', 'u8'), ('dst', 'u8'), ('N', 'i4'), ('K', 'i4'), ('T', 'i4'), ('Npad', 'i4'), ('Kpad', 'i4'),
                       ('n_split', 'i4'), ('sn', 'i8'), ('sk', 'i8'), ('st', 'i8'), ('accumulate', 'i4')], align=True)
 BN_DT = np.dtype([('stats', 'u8'), ('gamma', 'u8'), ('beta', 'u8'), ('running_mean', 'u8'), ('running_var', 'u8'),
@@ -59,7 +59,7 @@ def _check_struct_sizes():
     expect = {0: ctypes.sizeof(ConvGeom), 1: ctypes.sizeof(ConvOperands), 2: ctypes.sizeof(WgradOperands),
               3: PACK_DT.itemsize, 4: UNPACK_DT.itemsize, 5: BN_DT.itemsize, 6: COEF_DT.itemsize,
               7: ctypes.sizeof(BnAddOperands), 8: ctypes.sizeof(BnBwdReduceOperands), 9: ctypes.sizeof(BnBwdApplyOperands),
-              10: ctypes.sizeof(SplitOperands)}
+              10: ctypes.sizeof(SplitOperands), 12: ctypes.sizeof(AbsmaxOperands)}
     for which, size in expect.items():
         got = L.mpose_sizeof(which)
         if got != size:
