@@ -302,9 +302,15 @@ def main():
                             'random init)' % args.stem if args.stem.startswith('resnet') else
                             'patch8 (in-repo deterministic stem; the InceptionV4 stem is available with --stem inceptionv4)'), 'parallelism': 'dp%d' % world, 'overlap_wgrad': (not args.no_overlap_wgrad) and world == 1,
                    'step_dispatch': 'hip graph replay (train_helpers.GraphedTrainStep)' if use_graph else 'eager launches',
-                   'conv_engine': 'planes (conv_p.hip)' if model.inner.engine().planes_for(True, True) else 'igemm (conv.hip)',
+                   'conv_engine': {0: 'conv_igemm_k / conv_wgrad_k (conv.hip), six bf16 products per fp32 multiply-add',
+                                   1: 'plane engine (conv_p.hip)',
+                                   2: 'conv_igemm_k / conv_wgrad_k (conv.hip), three fp16 products per fp32 multiply-add of per-tensor-scaled, '
+                                      'two-way split operands (MPOSE_CONV_F16X3: fp32-equivalent, tests/test_conv_f16x3_gpu.py)'}[
+                                       model.inner.engine().conv_mode_for(True, True)],
                    'final_loss': loss_value},
     }
+    products = 3.0 if model.inner.engine().conv_mode_for(True, True) == 2 else 6.0
+    peak_equiv = PEAK_BF16_MFMA_TFLOPS / products
     if timer is not None:
         summ = timer.summary()
         convs = {k: v for k, v in summ.items() if k.startswith('conv:') or k.startswith('wgrad:')}
@@ -315,18 +321,21 @@ def main():
             all_flops = sum(v['work'] for v in convs.values())
             all_ms = sum(v['total_ms'] for v in convs.values())
             tr_bytes, tr_detail = traffic_fields(top[0])
-            res['roofline'] = {'bound': 'mfma', 'achieved': tf, 'peak': PEAK_BF16X6_TFLOPS, 'unit': 'TFLOP/s',
-                               'frac': tf / PEAK_BF16X6_TFLOPS, 'traffic': tr_bytes, 'traffic_detail': tr_detail, 'kernel': top[0],
+            res['roofline'] = {'bound': 'mfma', 'achieved': tf, 'peak': peak_equiv, 'unit': 'TFLOP/s',
+                               'frac': tf / peak_equiv, 'traffic': tr_bytes, 'traffic_detail': tr_detail, 'kernel': top[0],
                                'mfma_busy_frac_pmc': (tr_detail or {}).get('mfma_busy_frac'),
                                'avg_launch_us': top[1]['avg_us'], 'launches': top[1]['n'],
                                'event_bracket_overhead_us_subtracted': 1e3 * timer.bracket_ms,
                                'flops_per_launch': top[1]['work_per_launch'],
-                               'note': 'achieved = algorithmic fp32 FLOPs / launch duration; the kernel executes 6 bf16 MFMA FLOPs '
-                                       'per algorithmic FLOP (3-way split operands), so peak = dense bf16 MFMA peak 2500 / 6; '
-                                       'the plain fp32 MFMA peak is %.1f' % PEAK_FP32_MFMA_TFLOPS,
-                               'bf16_mfma_tflops_executed': 6.0 * tf,
+                               'note': 'achieved = algorithmic fp32 FLOPs / launch duration; the kernel executes %d 16-bit MFMA FLOPs '
+                                       'per algorithmic FLOP (split operands), so peak = dense 16-bit MFMA peak 2500 / %d (fp16 and bf16 '
+                                       'MFMA run at the same rate: tools/probe/f16_probe); the plain fp32 MFMA peak is %.1f'
+                                       % (products, products, PEAK_FP32_MFMA_TFLOPS),
+                               'mfma_tflops_executed': products * tf,
                                'all_conv_kernels_tflops': all_flops / (all_ms * 1e-3) / 1e12,
-                               'all_conv_kernels_frac': all_flops / (all_ms * 1e-3) / 1e12 / PEAK_BF16X6_TFLOPS,
+                               'all_conv_kernels_frac_note': 'column convolutions over their own peak; the feature extractor still runs '
+                                                             'the six-product form and is priced as if it did not (understates)',
+                               'all_conv_kernels_frac': all_flops / (all_ms * 1e-3) / 1e12 / peak_equiv,
                                'conv_share_of_step_gpu_time': (all_ms / max(1, timed_steps)) / (1e3 * dt / args.steps),
                                'kernel_timed_steps': timed_steps}
         res['kernel_time_breakdown_ms_per_step'] = {k: round(v['total_ms'] / max(1, timed_steps), 3) for k, v in

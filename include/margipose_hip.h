@@ -153,9 +153,9 @@ typedef struct {
   const float* add_scale;
   const float* add_shift;
   void* out0_planes;
-  /* MPOSE_CONV_F16X3: largest magnitudes (one float each, device memory) of the tensors as the K loop sees them --
-   * `in` AFTER the in_scale / in_shift / ReLU prologue, `in1`, and the torch-layout weights behind w0 / w1 -- written by
-   * mpose_absmax / mpose_weights_absmax.  A value below the true maximum overflows fp16 (inf / NaN results). */
+  /* MPOSE_CONV_F16X3: largest magnitudes of the tensors as the K loop sees them -- `in` AFTER the in_scale / in_shift / ReLU
+   * prologue and `in1` as activation amax SLOTS (see mpose_absmax), the torch-layout weights behind w0 / w1 as one float each
+   * (mpose_weights_absmax).  A value below the true maximum overflows fp16 (inf / NaN results). */
   const float* in_amax;
   const float* in1_amax;
   const float* w0_amax;
@@ -202,8 +202,8 @@ typedef struct {
   const float* gout1;
   float* dw0;                          /* (n_split, n_widx0, Cin/4, Npad0, 4) partial sums */
   float* dw1;
-  /* When in_amax != NULL (all groups alike) the launch runs the three-product fp16 form (see MPOSE_CONV_F16X3): largest
-   * magnitudes of `in` (after the prologue), gout0 and gout1 as written by mpose_absmax. */
+  /* When in_amax != NULL (all groups alike) the launch runs the three-product fp16 form (see MPOSE_CONV_F16X3): amax slots
+   * (see mpose_absmax) of `in` (after the prologue), gout0 and gout1. */
   const float* in_amax;
   const float* gout0_amax;
   const float* gout1_amax;
@@ -234,8 +234,14 @@ typedef struct {
 int mpose_weights_absmax(const mpose_pack_job* jobs_dev, int n_jobs, void* stream);
 
 /* Largest magnitude of up to MPOSE_ABSMAX_MAX activation tensors (npix x C fp32, NHWC dense) as a convolution's K loop will
- * see them: *dst = max(*dst, max |[relu](scale[c] * src + shift[c])|), scale NULL = identity.  dst is accumulated with an
- * atomic max on the float's bit pattern: zero it before the first launch that targets it. */
+ * see them: max |[relu](scale[c] * src + shift[c])|, scale NULL = identity.
+ * An activation amax SLOT is MPOSE_AMAX_SUBSLOTS floats spaced MPOSE_AMAX_STRIDE floats apart (4 KiB per slot); the tensor's
+ * largest magnitude is the maximum over the sub-slots (consumers take it).  Producers accumulate with an atomic max on the
+ * float's bit pattern, workgroup b into sub-slot b % MPOSE_AMAX_SUBSLOTS (thousands of same-address atomics serialise in L2):
+ * zero the slot before the first launch that targets it.  The *_amax outputs of mpose_bn_add_fwd / mpose_bn_bwd_apply are such
+ * slots too. */
+#define MPOSE_AMAX_SUBSLOTS 16
+#define MPOSE_AMAX_STRIDE 64
 #define MPOSE_ABSMAX_MAX 6
 typedef struct {
   const float* src;
@@ -306,6 +312,7 @@ typedef struct {
   const float* a; const float* a_scale; const float* a_shift;
   const float* b; const float* b_scale; const float* b_shift;
   float* out;
+  float* out_amax;                     /* optional (layouts 0 and 2): amax slot (see mpose_absmax) accumulating max |out|, for MPOSE_CONV_F16X3 */
 } mpose_bn_add_operands;
 
 int mpose_bn_add_fwd(const mpose_bn_add_operands* ops, int n_groups, int pixels_per_image, int B,
@@ -345,6 +352,7 @@ typedef struct {
   const float* a_scale;                /* optional ReLU mask of branch a, as in the reduce step */
   const float* a_shift;
   float* da; float* db;
+  float* da_amax; float* db_amax;      /* optional: amax slots (see mpose_absmax) accumulating max |da| / |db|, for MPOSE_CONV_F16X3 */
 } mpose_bn_bwd_apply_operands;
 
 int mpose_bn_bwd_apply(const mpose_bn_bwd_apply_operands* ops, int n_groups, int pixels_per_image,

@@ -117,7 +117,7 @@ class AbsmaxOperands(ctypes.Structure):
 
 class BnAddOperands(ctypes.Structure):
     _fields_ = [('a', c_void_p), ('a_scale', c_void_p), ('a_shift', c_void_p),
-                ('b', c_void_p), ('b_scale', c_void_p), ('b_shift', c_void_p), ('out', c_void_p)]
+                ('b', c_void_p), ('b_scale', c_void_p), ('b_shift', c_void_p), ('out', c_void_p), ('out_amax', c_void_p)]
 
 
 class SplitOperands(ctypes.Structure):
@@ -131,7 +131,8 @@ class BnBwdReduceOperands(ctypes.Structure):
 
 class BnBwdApplyOperands(ctypes.Structure):
     _fields_ = [('g', c_void_p), ('a', c_void_p), ('b', c_void_p), ('coef_a', c_void_p), ('coef_b', c_void_p),
-                ('a_scale', c_void_p), ('a_shift', c_void_p), ('da', c_void_p), ('db', c_void_p)]
+                ('a_scale', c_void_p), ('a_shift', c_void_p), ('da', c_void_p), ('db', c_void_p),
+                ('da_amax', c_void_p), ('db_amax', c_void_p)]
 
 
 # Host-side mirrors of the device-resident job tables (filled into int64 tensors, see engine.py).

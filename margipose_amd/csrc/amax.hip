@@ -40,32 +40,23 @@ __global__ __launch_bounds__(256) void absmax_k(AbsmaxArgs a) {
     c4 = step(c3);
   }
   for (; e < a.total4; e += stride) { take(src[e], c4); c4 = step(c4); }
-  m = wave_max(m);
-  __shared__ float sm[4];
-  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    m = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
-    if (!(m == m)) m = __uint_as_float(0x7f800000u);          // NaN anywhere -> +inf (ordered above everything)
-    atomicMax(reinterpret_cast<unsigned*>(op.dst), __float_as_uint(m));
-  }
+  block_amax_commit(m, op.dst);
 }
 
-// one workgroup per weight tensor (at most ~330k elements): plain store, no atomics
+// weight tensors (at most ~330k elements each): blockIdx.y = job, up to 16 workgroups per job, atomic max into the job's slot
+// (zeroed by weights_amax_zero_k: the slots are re-measured on every pack)
+__global__ __launch_bounds__(256) void weights_amax_zero_k(const mpose_pack_job* __restrict__ jobs, int n_jobs) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n_jobs && jobs[i].amax != nullptr) *jobs[i].amax = 0.f;
+}
 __global__ __launch_bounds__(256) void weights_absmax_k(const mpose_pack_job* __restrict__ jobs) {
-  const mpose_pack_job j = jobs[blockIdx.x];
+  const mpose_pack_job j = jobs[blockIdx.y];
   if (j.amax == nullptr) return;
   const long n = (long)j.N * j.K * j.T;
+  if ((long)blockIdx.x * 256 >= n) return;
   float m = 0.f;
-  for (long e = threadIdx.x; e < n; e += 256) m = fmaxf(m, fabsf(j.src[e]));
-  m = wave_max(m);
-  __shared__ float sm[4];
-  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    m = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
-    *j.amax = (m == m) ? m : __uint_as_float(0x7f800000u);
-  }
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) m = fmaxf(m, fabsf(j.src[e]));
+  block_amax_commit_one(m, j.amax);
 }
 
 }  // namespace
@@ -93,6 +84,7 @@ extern "C" int mpose_absmax(const mpose_absmax_operands* ops, int n_tensors, int
 
 extern "C" int mpose_weights_absmax(const mpose_pack_job* jobs_dev, int n_jobs, void* stream) {
   if (n_jobs <= 0) return 0;
-  weights_absmax_k<<<n_jobs, 256, 0, (hipStream_t)stream>>>(jobs_dev);
+  weights_amax_zero_k<<<(n_jobs + 255) / 256, 256, 0, (hipStream_t)stream>>>(jobs_dev, n_jobs);
+  weights_absmax_k<<<dim3(16, n_jobs), 256, 0, (hipStream_t)stream>>>(jobs_dev);
   return launch_status();
 }

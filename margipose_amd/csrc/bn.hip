@@ -58,6 +58,7 @@ template <bool RELU_A>
 __global__ __launch_bounds__(256) void bn_add_nhwc_k(BnAddArgs a) {
   const mpose_bn_add_operands& op = a.op[blockIdx.y];
   const int c4n = a.C >> 2;
+  float amax = 0.f;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < a.total4; i += (long)gridDim.x * 256) {
     const int c = (int)(i % c4n) * 4;
     const float4 x = reinterpret_cast<const float4*>(op.a)[i];
@@ -70,7 +71,9 @@ __global__ __launch_bounds__(256) void bn_add_nhwc_k(BnAddArgs a) {
     o.z = (RELU_A ? fmaxf(fmaf(x.z, sa.z, ta.z), 0.f) : fmaf(x.z, sa.z, ta.z)) + fmaf(y.z, sb.z, tb.z);
     o.w = (RELU_A ? fmaxf(fmaf(x.w, sa.w, ta.w), 0.f) : fmaf(x.w, sa.w, ta.w)) + fmaf(y.w, sb.w, tb.w);
     reinterpret_cast<float4*>(op.out)[i] = o;
+    amax = fmaxf(fmaxf(amax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
   }
+  if (op.out_amax != nullptr) block_amax_commit(amax, op.out_amax);      // (uniform per workgroup: one operand set per blockIdx.y)
 }
 
 // NHWC (B, P, C) inputs -> NCHW (B, c_keep, P) output: one thread per pixel, writes coalesced over pixels.
@@ -232,6 +235,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_k(BnApplyArgs a) {
   const mpose_bn_bwd_apply_operands& op = a.op[blockIdx.y];
   const int c4n = a.C >> 2;
   const bool has_b = op.b != nullptr;
+  float amax_a = 0.f, amax_b = 0.f;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < a.total4; i += (long)gridDim.x * 256) {
     const int c = (int)(i % c4n) * 4;
     const float4 g = reinterpret_cast<const float4*>(op.g)[i];
@@ -253,6 +257,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_k(BnApplyArgs a) {
       o.x = fmaf(k1.x, x.x - mu.x, fmaf(k0.x, ga.x, k2.x)); o.y = fmaf(k1.y, x.y - mu.y, fmaf(k0.y, ga.y, k2.y));
       o.z = fmaf(k1.z, x.z - mu.z, fmaf(k0.z, ga.z, k2.z)); o.w = fmaf(k1.w, x.w - mu.w, fmaf(k0.w, ga.w, k2.w));
       reinterpret_cast<float4*>(op.da)[i] = o;
+      amax_a = fmaxf(fmaxf(amax_a, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
     }
     if (has_b) {
       const float4 x = reinterpret_cast<const float4*>(op.b)[i];
@@ -264,8 +269,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_k(BnApplyArgs a) {
       o.x = fmaf(k1.x, x.x - mu.x, fmaf(k0.x, g.x, k2.x)); o.y = fmaf(k1.y, x.y - mu.y, fmaf(k0.y, g.y, k2.y));
       o.z = fmaf(k1.z, x.z - mu.z, fmaf(k0.z, g.z, k2.z)); o.w = fmaf(k1.w, x.w - mu.w, fmaf(k0.w, g.w, k2.w));
       reinterpret_cast<float4*>(op.db)[i] = o;
+      amax_b = fmaxf(fmaxf(amax_b, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
     }
   }
+  if (op.da_amax != nullptr) block_amax_commit(amax_a, op.da_amax);
+  if (has_b && op.db_amax != nullptr) { __syncthreads(); block_amax_commit(amax_b, op.db_amax); }
 }
 
 // out = relu(a*scale + shift)  (the stem's BN + ReLU, materialised because the stage input is shared)
@@ -287,6 +295,9 @@ __global__ __launch_bounds__(256) void relu_bwd_k(const float4* __restrict__ g, 
     gm[i] = make_float4(b.x > 0.f ? a.x : 0.f, b.y > 0.f ? a.y : 0.f, b.z > 0.f ? a.z : 0.f, b.w > 0.f ? a.w : 0.f);
   }
 }
+
+// passes that end with one atomic per workgroup (an amax output) run at most 512 workgroups per tensor: 32 per sub-slot
+inline int amax_grid(int blocks, bool amax) { return (amax && blocks > 512) ? 512 : blocks; }
 
 inline int grid_for(long work_items, int per_block) {
   long b = (work_items + per_block - 1) / per_block;
@@ -335,9 +346,9 @@ extern "C" int mpose_bn_add_fwd(const mpose_bn_add_operands* ops, int n_groups, 
   if (a.total4 == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   if (layout == 0) {
-    bn_add_nhwc_k<true><<<dim3(grid_for(a.total4, 256), n_groups), 256, 0, s>>>(a);
+    bn_add_nhwc_k<true><<<dim3(amax_grid(grid_for(a.total4, 256), ops[0].out_amax != nullptr), n_groups), 256, 0, s>>>(a);
   } else if (layout == 2) {             // no ReLU on branch a: bn2(x) + bn_d(shortcut) of a ResNet downsample block
-    bn_add_nhwc_k<false><<<dim3(grid_for(a.total4, 256), n_groups), 256, 0, s>>>(a);
+    bn_add_nhwc_k<false><<<dim3(amax_grid(grid_for(a.total4, 256), ops[0].out_amax != nullptr), n_groups), 256, 0, s>>>(a);
   } else {
     if (c_keep < 1 || c_keep > C) return MPOSE_EINVAL;
     bn_add_nchw_k<<<dim3(grid_for((long)B * pixels_per_image, 256), n_groups), 256, 0, s>>>(a, B);
@@ -412,7 +423,7 @@ extern "C" int mpose_bn_bwd_apply(const mpose_bn_bwd_apply_operands* ops, int n_
   a.C = C;
   a.total4 = (long)B * pixels_per_image * C / 4;
   if (a.total4 == 0) return 0;
-  bn_bwd_apply_k<<<dim3(grid_for(a.total4, 256), n_groups), 256, 0, (hipStream_t)stream>>>(a);
+  bn_bwd_apply_k<<<dim3(amax_grid(grid_for(a.total4, 256), ops[0].da_amax != nullptr), n_groups), 256, 0, (hipStream_t)stream>>>(a);
   return launch_status();
 }
 

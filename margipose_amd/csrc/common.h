@@ -29,6 +29,8 @@ __device__ __forceinline__ float cell_coord(int i, float two_over_l, float first
   return fmaf((float)i, two_over_l, first);
 }
 
+__device__ __forceinline__ void block_amax_commit_one(float m, float* dst);
+
 // MPOSE_CONV_F16X3 (include/margipose_hip.h): exponent k of the power-of-two scale that puts a tensor whose largest magnitude is
 // `amax` into fp16's upper range, amax * 2^k in [2^14, 2^15).  The packer, both convolution kernels and the weight-gradient
 // kernel all derive k from the same float with this function.
@@ -44,6 +46,37 @@ __host__ __device__ __forceinline__ float pow2f(int k) {       // 2^k, -126 <= k
   float f;
   __builtin_memcpy(&f, &bits, 4);
   return f;
+}
+
+// An activation tensor's "amax slot" is MPOSE_AMAX_SUBSLOTS floats, MPOSE_AMAX_STRIDE floats apart (one cache line each); the
+// tensor's largest magnitude is the maximum over them.  Why: every workgroup of a producer pass ends with one atomic max, and
+// same-address atomics serialise in L2 -- 2048 workgroups on ONE float tripled the duration of a 20 us elementwise pass, and
+// looking before the atomic does not help while the first resident workgroups all still see zero.  Workgroup b uses sub-slot b % 16.
+__device__ __forceinline__ float amax_gather(const float* slot) {          // wave-uniform result; call from whole waves
+  const int l = threadIdx.x & 63;
+  const float v = l < MPOSE_AMAX_SUBSLOTS ? slot[l * MPOSE_AMAX_STRIDE] : 0.f;
+  return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(wave_max(v))));     // (the builtin is integer-typed)
+}
+
+// Largest magnitude seen by a 256-thread workgroup -> atomic max on the uint view of its sub-slot (non-negative floats order
+// like their bit patterns).  Every thread of the workgroup must call it (it contains a barrier).
+__device__ __forceinline__ void block_amax_commit(float m, float* slot) {
+  float* dst = slot + (blockIdx.x % MPOSE_AMAX_SUBSLOTS) * MPOSE_AMAX_STRIDE;
+  block_amax_commit_one(m, dst);
+}
+// (single address: the weight tensors' slots, 16 workgroups each)
+__device__ __forceinline__ void block_amax_commit_one(float m, float* dst) {
+  __shared__ float amax_sm[4];
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) amax_sm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(amax_sm[0], amax_sm[1]), fmaxf(amax_sm[2], amax_sm[3]));
+    if (!(m == m)) m = __uint_as_float(0x7f800000u);          // NaN anywhere -> +inf (ordered above everything)
+    // look first: a workgroup that would not raise the value skips the atomic (a stale look costs one extra atomic)
+    const unsigned seen = __hip_atomic_load(reinterpret_cast<unsigned*>(dst), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (__float_as_uint(m) > seen) atomicMax(reinterpret_cast<unsigned*>(dst), __float_as_uint(m));
+  }
 }
 
 struct Ptr3 {

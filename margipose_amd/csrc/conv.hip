@@ -230,8 +230,8 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
   // F16: scale exponents of this launch's tensors (SGPRs).  Pass `set` multiplies input ka[set] with weights kw[set].
   int ka0 = 0, ka1 = 0, kw0 = 0, kw1 = 0;
   if (F16) {
-    ka0 = f16_scale_exp(*op.in_amax);
-    ka1 = SUM2 ? f16_scale_exp(*op.in1_amax) : ka0;
+    ka0 = f16_scale_exp(amax_gather(op.in_amax));
+    ka1 = SUM2 ? f16_scale_exp(amax_gather(op.in1_amax)) : ka0;
     kw0 = f16_scale_exp(*op.w0_amax);
     kw1 = MODE ? f16_scale_exp(*op.w1_amax) : kw0;
   }
@@ -788,8 +788,8 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_k(WgradArgs a) {
   const int x_pix = g.in_mul * in_ld * 4, g_pix = g.out_mul * g_ld * 4;        // byte stride between consecutive slots
   const int x_lane = (k0 + li) * 4, g_lane = (n0 + li) * 4;
   const bool pro = op.in_scale != nullptr;
-  const int kx = F16 ? f16_scale_exp(*op.in_amax) : 0;
-  const int kg = F16 ? f16_scale_exp(*(second ? op.gout1_amax : op.gout0_amax)) : 0;
+  const int kx = F16 ? f16_scale_exp(amax_gather(op.in_amax)) : 0;
+  const int kg = F16 ? f16_scale_exp(amax_gather(second ? op.gout1_amax : op.gout0_amax)) : 0;
   const float x_mul = pow2f(kx), g_mul = pow2f(kg);
   float psc[KB], psh[KB];
 #pragma unroll

@@ -48,6 +48,7 @@ COEF_DT = np.dtype([('sums', 'u8'), ('gamma', 'u8'), ('mean', 'u8'), ('invstd', 
                     ('dbeta', 'u8'), ('sums_stride', 'i4'), ('which', 'i4'), ('C', 'i4'), ('c_stride', 'i4'), ('count', 'i4'),
                     ('sg_col', 'i4'), ('dconv_bias', 'u8')], align=True)
 
+AMAX_SLOT = 16 * 64          # floats per activation amax slot (MPOSE_AMAX_SUBSLOTS * MPOSE_AMAX_STRIDE)
 _SIZES_CHECKED = False
 
 
@@ -215,6 +216,11 @@ class _Ctx(dict):
     __slots__ = ('__weakref__',)
 
 
+def _first_same(tensors, c):
+    """Index of the first tensor that shares tensors[c]'s storage."""
+    return next(k for k in range(len(tensors)) if tensors[k].data_ptr() == tensors[c].data_ptr())
+
+
 def _jobs_to_device(arr, device):
     return torch.from_numpy(arr.view(np.uint8).copy()).to(device)
 
@@ -255,6 +261,11 @@ class Engine:
         # fused into the plane engine's epilogue, no fp32 round trip) and the single-pass bf16 mode run on the plane engine.
         # MPOSE_PLANES=1 / 0 forces one engine everywhere (A/B runs).
         self.planes_mode = os.environ.get('MPOSE_PLANES', 'auto')
+        # conv_igemm_k / conv_wgrad_k multiply as THREE fp16 products of two-way split, per-tensor-scaled operands instead of six
+        # bf16 products of three-way split ones (MPOSE_CONV_F16X3 in include/margipose_hip.h): the same fp32-equivalent accuracy
+        # (tests/test_conv_f16x3_gpu.py) at half the matrix work.  Each operand tensor's largest magnitude is measured by a small
+        # pass (mpose_absmax) before the convolution that reads it.  MPOSE_F16X3=0 keeps the six-product form (A/B runs).
+        self.f16x3 = os.environ.get('MPOSE_F16X3', '1') != '0'
         self.conv_bf16 = False       # single-pass bf16 convolutions in the columns (MargiPoseModel.conv_dtype, configs[4])
         for c in block_convs:
             c.layout = 1             # packed-weight layout when the plane engine runs (layout 0 otherwise; see pack_weights)
@@ -387,11 +398,23 @@ class Engine:
                 j['sn'], j['sk'], j['st'] = sn, sk, st
                 j['layout'] = 0
                 mx = max(mx, int(j['T']) * int(j['Kpad']) * int(j['Npad']))
-        jobs_p = jobs.copy()
+        jobs_p, jobs_h = jobs.copy(), jobs.copy()
+        # largest magnitudes (MPOSE_CONV_F16X3): one float per convolution weight, per block (cur[3], a1[3]) for the forward
+        # operands -- kept until the backward pass, the weight gradients read the same tensors -- and (d_c2[3], d_c1[3], d_sc[3])
+        # for the gradients
+        self.wamax = torch.zeros(len(self._convs), dtype=torch.float32, device=device)
+        # (an activation slot is 16 sub-slots 64 floats apart = 1024 floats: include/margipose_hip.h, mpose_absmax)
+        self.amax_f = torch.zeros(self.T * 10 * 6 * AMAX_SLOT, dtype=torch.float32, device=device)
+        self.amax_b = torch.zeros(self.T * 10 * 9 * AMAX_SLOT, dtype=torch.float32, device=device)
         for i, c in enumerate(self._convs):
-            jobs_p[2 * i]['layout'] = jobs_p[2 * i + 1]['layout'] = c.layout
-        self._pack_jobs = (_jobs_to_device(jobs, device), _jobs_to_device(jobs_p, device))     # [0] igemm engine, [1] plane engine
-        self._packed_for = None      # which of the two the packed arena currently holds
+            c.amax_ptr = self.wamax.data_ptr() + 4 * i
+            if c.layout == 1:                      # a column convolution
+                jobs_p[2 * i]['layout'] = jobs_p[2 * i + 1]['layout'] = 1
+                jobs_h[2 * i]['layout'] = jobs_h[2 * i + 1]['layout'] = 2
+                jobs_h[2 * i]['amax'] = jobs_h[2 * i + 1]['amax'] = c.amax_ptr
+        # [0] conv_igemm_k, six bf16 products; [1] plane engine; [2] conv_igemm_k, three fp16 products
+        self._pack_jobs = tuple(_jobs_to_device(j, device) for j in (jobs, jobs_p, jobs_h))
+        self._packed_for = None      # which of the three the packed arena currently holds
         self._pack_max = mx
         self._tables = {}
         self._arena_key = key
@@ -598,8 +621,39 @@ class Engine:
             return self.planes_mode == '1'
         return self.conv_bf16 or not (train or save)
 
-    def conv_flags(self, planes):
-        return (4 | (8 if self.conv_bf16 else 0)) if planes else 0
+    def conv_mode_for(self, train, save):
+        """0: conv_igemm_k with six bf16 products, 1: plane engine, 2: conv_igemm_k with three fp16 products."""
+        if self.planes_for(train, save):
+            return 1
+        return 2 if self.f16x3 else 0
+
+    def conv_flags(self, cmode):
+        return (4 | (8 if self.conv_bf16 else 0)) if cmode == 1 else (32 if cmode == 2 else 0)
+
+    def absmax(self, tensors, slots, C, scales=None, shifts=None, relu=False):
+        """Largest magnitude of each NHWC tensor (after an optional per-channel affine map + ReLU) into its device slot; tensors
+        that share storage share one pass."""
+        ops, seen = [], set()
+        for i, t in enumerate(tensors):
+            key = (t.data_ptr(), slots[i])
+            if key in seen:
+                continue
+            seen.add(key)
+            ao = AbsmaxOperands()
+            ao.src, ao.dst = t.data_ptr(), slots[i]
+            if scales is not None:
+                ao.scale, ao.shift = scales[i], shifts[i]
+            ops.append(ao)
+        npix = tensors[0].numel() // C
+        check(lib().mpose_absmax((AbsmaxOperands * len(ops))(*ops), len(ops), c_int64(npix), C, int(relu), stream_ptr()), 'mpose_absmax')
+
+    def _amax_f(self, t, i, which, c):
+        """which: 0 block input, 1 relu(bn1(c1))."""
+        return self.amax_f.data_ptr() + 4 * AMAX_SLOT * (((t * 10 + i) * 2 + which) * 3 + c)
+
+    def _amax_b(self, t, i, which, c):
+        """which: 0 d_c2, 1 d_c1, 2 d_sc."""
+        return self.amax_b.data_ptr() + 4 * AMAX_SLOT * (((t * 10 + i) * 3 + which) * 3 + c)
 
     def wgrad(self, g, ops, n_split):
         arr = (WgradOperands * 3)(*ops)
@@ -648,10 +702,12 @@ class Engine:
         check(lib().mpose_bn_finalize(c_void_p(base), n, int(train), ctypes.c_float(BN_EPS), ctypes.c_float(BN_MOMENTUM),
                                       stream_ptr()), 'mpose_bn_finalize')
 
-    def pack_weights(self, planes):
-        check(lib().mpose_pack_weights(ptr(self._pack_jobs[1 if planes else 0]), 2 * len(self._convs), self._pack_max, stream_ptr()),
-              'mpose_pack_weights')
-        self._packed_for = bool(planes)
+    def pack_weights(self, cmode):
+        jobs = self._pack_jobs[cmode]
+        if cmode == 2:
+            check(lib().mpose_weights_absmax(ptr(jobs), 2 * len(self._convs), stream_ptr()), 'mpose_weights_absmax')
+        check(lib().mpose_pack_weights(ptr(jobs), 2 * len(self._convs), self._pack_max, stream_ptr()), 'mpose_pack_weights')
+        self._packed_for = cmode
 
     # ------------------------------------------------------------------ forward
     def forward(self, x, train, save, hm_bf16=False, features=None):
@@ -700,8 +756,12 @@ class Engine:
 
         # (repacked on every forward, 0.33 ms: a cache keyed on the parameters' version counters would miss `p.data` updates and
         #  anything a replayed graph or a raw kernel such as DeviceSGD writes)
-        planes = ctx['planes'] = self.planes_for(train, save)
-        self.pack_weights(planes)
+        cmode = ctx['cmode'] = self.conv_mode_for(train, save)
+        planes = cmode == 1
+        f16 = cmode == 2
+        self.pack_weights(cmode)
+        if f16:
+            self.amax_f.zero_()
         if train:
             self.stat_arena.zero_()
         elif self.stem is None:
@@ -748,7 +808,7 @@ class Engine:
                 inp = new_inp
             ctx['inps'].append(inp)
             cur = [inp, inp, inp]
-            pflags = ctx['pflags'] = self.conv_flags(planes)
+            pflags = ctx['pflags'] = self.conv_flags(cmode)
             if planes:               # the stage input is read by all three columns: split once
                 inp_p = self.split_planes([inp], B * F * F, 128)[0]
                 cur_p = [inp_p, inp_p, inp_p]
@@ -781,11 +841,17 @@ class Engine:
                 sc = [torch.empty(B, Hout, Hout, b0.cout_s, **f32) for _ in range(3)]
                 if fused:
                     a1_p = [self.planes_empty(npix_o, b0.cout_s) for _ in range(3)]
+                if f16:                      # (columns reading one tensor -- the stage input -- share its slot)
+                    cur_slot = [self._amax_f(t, i, 0, _first_same(cur, c)) for c in range(3)]
+                    if i == 0:               # later blocks: the previous block's residual add measured its output as it wrote it
+                        self.absmax(cur, cur_slot, b0.cin_s)
                 ops = []
                 for c, b in enumerate(grp):
                     op = ConvOperands()
                     op.in_ = (cur_p[c] if planes else cur[c]).data_ptr()
                     op.w0, op.w1 = self._wptr(b.conv_in), self._wptr(b.conv_sc)
+                    if f16:
+                        op.in_amax, op.w0_amax, op.w1_amax = cur_slot[c], b.conv_in.amax_ptr, b.conv_sc.amax_ptr
                     op.out1 = sc[c].data_ptr()
                     if fused:
                         op.out0_planes = a1_p[c].data_ptr()
@@ -798,6 +864,9 @@ class Engine:
                 self.conv(g1, ops, pflags | (16 if fused else 0))
                 if train:
                     self.finalize(tb, self.fin_index(t, i, 0), 6, True)
+                if f16:                      # largest relu(bn1(c1)): what the next K loop (and its weight gradient) will split
+                    self.absmax(c1, [self._amax_f(t, i, 1, c) for c in range(3)], b0.cout_s, [self._bnf_ptr(b.bn1, 0) for b in grp],
+                                [self._bnf_ptr(b.bn1, 1) for b in grp], relu=True)
                 if planes and not fused:     # relu(bn1(c1)) is written once, pre-split, instead of being recomputed by every tap
                     a1_p = self.split_planes(c1, npix_o, b0.cout_s, [self._bnf_ptr(b.bn1, 0) for b in grp],
                                              [self._bnf_ptr(b.bn1, 1) for b in grp], relu=True)
@@ -821,6 +890,8 @@ class Engine:
                     else:
                         op.in_ = c1[c].data_ptr()
                         op.in_scale, op.in_shift = self._bnf_ptr(b.bn1, 0), self._bnf_ptr(b.bn1, 1)
+                        if f16:
+                            op.in_amax, op.w0_amax = self._amax_f(t, i, 1, c), b.conv2.amax_ptr
                     if fuse2:
                         op.out0_planes = nxt_p[c].data_ptr()
                         if outs[c] is not None:
@@ -844,6 +915,8 @@ class Engine:
                         ao.a, ao.a_scale, ao.a_shift = c2[c].data_ptr(), self._bnf_ptr(b.bn2, 0), self._bnf_ptr(b.bn2, 1)
                         ao.b, ao.b_scale, ao.b_shift = sc[c].data_ptr(), self._bnf_ptr(b.bns, 0), self._bnf_ptr(b.bns, 1)
                         ao.out = outs[c].data_ptr()
+                        if f16 and not last:
+                            ao.out_amax = self._amax_f(t, i + 1, 0, c)       # (the axis permutation after block 4 keeps the maximum)
                         aops.append(ao)
                     if planes and not last:
                         cur_p = [self.planes_empty(npix_o, b0.cout_s) for _ in range(3)]
@@ -874,7 +947,7 @@ class Engine:
 
     # ------------------------------------------------------------------ several forwards in flight
     def _arena_tensors(self):
-        return [self.bnf] + ([self.stem.f_arena] if self.stem is not None else [])
+        return [self.bnf, self.amax_f] + ([self.stem.f_arena] if self.stem is not None else [])
 
     def _snapshot_pending(self):
         """Called before a forward overwrites the BatchNorm arenas: if the previous saved forward has not run its backward
@@ -917,10 +990,13 @@ class Engine:
         self.stat_arena.zero_()        # forward sums are consumed (mean/invstd live in the float arena)
         goff = dict((id(p), o) for p, o in zip(self.param_list(), self._grad_offsets))
         coef_base = tb['coef'].data_ptr()
-        planes = ctx['planes']
+        cmode = ctx['cmode']
+        planes, f16 = cmode == 1, cmode == 2
         pflags = ctx['pflags']         # (the forward's convolution engine and precision)
-        if self._packed_for != planes:     # a forward on the other engine ran in between: the parameters are unchanged (checked
-            self.pack_weights(planes)      # above), so this restores exactly the packing of this context's forward
+        if self._packed_for != cmode:      # a forward on another engine ran in between: the parameters are unchanged (checked
+            self.pack_weights(cmode)       # above), so this restores exactly the packing of this context's forward
+        if f16:
+            self.amax_b.zero_()
 
         def run_coef(first, n):
             check(L.mpose_bn_bwd_coef(c_void_p(coef_base + first * COEF_DT.itemsize), n, eval_bn, st()), 'mpose_bn_bwd_coef')
@@ -969,6 +1045,8 @@ class Engine:
                     ao.coef_a, ao.coef_b = self._bnf_ptr(b.bn2, 4), self._bnf_ptr(b.bns, 4)
                     ao.a_scale, ao.a_shift = self._bnf_ptr(b.bn2, 0), self._bnf_ptr(b.bn2, 1)
                     ao.da, ao.db = d_c2[c].data_ptr(), d_sc[c].data_ptr()
+                    if f16:
+                        ao.da_amax, ao.db_amax = self._amax_b(t, i, 0, c), self._amax_b(t, i, 2, c)
                     aops.append(ao)
                 if planes:           # the gradients feed a convolution next: written pre-split as well
                     d_c2_p = [self.planes_empty(cnt, Cs) for _ in range(3)]
@@ -984,6 +1062,8 @@ class Engine:
                     op = ConvOperands()
                     op.in_ = (d_c2_p[c] if planes else d_c2[c]).data_ptr()
                     op.w0, op.out0 = self._wptr(b.conv2, True), d_a1[c].data_ptr()
+                    if f16:
+                        op.in_amax, op.w0_amax = self._amax_b(t, i, 0, c), b.conv2.amax_ptr
                     op.mask_src = sv['c1'][c].data_ptr()
                     op.mask_scale, op.mask_shift = self._bnf_ptr(b.bn1, 0), self._bnf_ptr(b.bn1, 1)
                     op.stats0 = self._stats_ptr(b.bn1, True)
@@ -995,6 +1075,8 @@ class Engine:
                     wo = WgradOperands()
                     wo.in_, wo.in_scale, wo.in_shift = sv['c1'][c].data_ptr(), self._bnf_ptr(b.bn1, 0), self._bnf_ptr(b.bn1, 1)
                     wo.gout0, wo.dw0 = d_c2[c].data_ptr(), tb['part_ptr'][id(b.conv2)]
+                    if f16:
+                        wo.in_amax, wo.gout0_amax = self._amax_f(t, i, 1, c), self._amax_b(t, i, 0, c)
                     wops.append(wo)
                 self.wgrad_async(self.geom('f_conv2', B, Hout, b0), wops, self._n_split(cnt, self._wg_tiles(b0, 'conv2')),
                                  sv['c1'] + d_c2)
@@ -1005,6 +1087,8 @@ class Engine:
                 for c, b in enumerate(grp):
                     ao = BnBwdApplyOperands()
                     ao.g, ao.a, ao.coef_a, ao.da = d_a1[c].data_ptr(), sv['c1'][c].data_ptr(), self._bnf_ptr(b.bn1, 4), d_c1[c].data_ptr()
+                    if f16:
+                        ao.da_amax = self._amax_b(t, i, 1, c)
                     aops.append(ao)
                 if planes:
                     d_c1_p = [self.planes_empty(cnt, Cs) for _ in range(3)]
@@ -1021,6 +1105,9 @@ class Engine:
                     wo.in_ = sv['x'][c].data_ptr()
                     wo.gout0, wo.gout1 = d_c1[c].data_ptr(), d_sc[c].data_ptr()
                     wo.dw0, wo.dw1 = tb['part_ptr'][id(b.conv_in)], tb['part_ptr'][id(b.conv_sc)]
+                    if f16:
+                        wo.in_amax = self._amax_f(t, i, 0, _first_same(sv['x'], c))
+                        wo.gout0_amax, wo.gout1_amax = self._amax_b(t, i, 1, c), self._amax_b(t, i, 2, c)
                     wops.append(wo)
                 self.wgrad_async(self.geom(gname, B, Hin, b0), wops, self._n_split(slots, self._wg_tiles(b0, 'in')),
                                  list(sv['x']) + d_c1 + d_sc)
@@ -1034,6 +1121,9 @@ class Engine:
                     op.in1 = (d_sc_p[c] if planes else d_sc[c]).data_ptr()
                     op.w0, op.out0 = self._wptr(b.conv_in, True), d_x[c].data_ptr()
                     op.w1 = self._wptr(b.conv_sc, True)
+                    if f16:
+                        op.in_amax, op.in1_amax = self._amax_b(t, i, 1, c), self._amax_b(t, i, 2, c)
+                        op.w0_amax, op.w1_amax = b.conv_in.amax_ptr, b.conv_sc.amax_ptr
                     ops.append(op)
                 self.conv(self.geom(kd, B, Hout, b0), ops, 2 | pflags)
                 g = d_x
