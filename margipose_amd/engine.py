@@ -410,6 +410,7 @@ class Engine:
             c.amax_ptr = self.wamax.data_ptr() + 4 * i
             if c.layout == 1:                      # a column convolution
                 jobs_p[2 * i]['layout'] = jobs_p[2 * i + 1]['layout'] = 1
+            if c.layout == 1 or getattr(c, 'generic', False):      # columns and the feature extractor's graph (not the patch8 stem)
                 jobs_h[2 * i]['layout'] = jobs_h[2 * i + 1]['layout'] = 2
                 jobs_h[2 * i]['amax'] = jobs_h[2 * i + 1]['amax'] = c.amax_ptr
         # [0] conv_igemm_k, six bf16 products; [1] plane engine; [2] conv_igemm_k, three fp16 products
@@ -619,7 +620,9 @@ class Engine:
         """Which engine a forward (and its backward) runs the columns on: see __init__."""
         if self.planes_mode in ('0', '1'):
             return self.planes_mode == '1'
-        return self.conv_bf16 or not (train or save)
+        # (with the three-product fp16 form conv_igemm_k also wins at inference: 4280 vs 3640 images/s at B=64, one box, against
+        #  the plane engine's six-product bf16 form even with its fused BatchNorm / ReLU / residual epilogue)
+        return self.conv_bf16 or (not self.f16x3 and not (train or save))
 
     def conv_mode_for(self, train, save):
         """0: conv_igemm_k with six bf16 products, 1: plane engine, 2: conv_igemm_k with three fp16 products."""
@@ -773,7 +776,7 @@ class Engine:
             inp = features.permute(0, 2, 3, 1).contiguous()
         elif self.stem is not None:
             # ---- InceptionV4 feature extractor (stem.py) ----
-            inp, ctx['stem_ctx'] = self.stem.forward(x, train, save)
+            inp, ctx['stem_ctx'] = self.stem.forward(x, train, save, f16)
         else:
             # ---- patch8 stem: space-to-depth + 1x1 conv (192->128) + BN + ReLU ----
             if x.dtype == torch.uint8:
@@ -947,7 +950,7 @@ class Engine:
 
     # ------------------------------------------------------------------ several forwards in flight
     def _arena_tensors(self):
-        return [self.bnf, self.amax_f] + ([self.stem.f_arena] if self.stem is not None else [])
+        return [self.bnf, self.amax_f] + ([self.stem.f_arena, self.stem.amax_f] if self.stem is not None else [])
 
     def _snapshot_pending(self):
         """Called before a forward overwrites the BatchNorm arenas: if the previous saved forward has not run its backward

@@ -235,6 +235,14 @@ class _GraphStem:
             soff += 6 * n.C
         self.f_arena = torch.zeros(foff, dtype=torch.float32, device=device)
         self.s_arena = torch.zeros(soff, dtype=torch.float64, device=device)
+        # MPOSE_CONV_F16X3: one amax slot per node for what its consumers read (relu(bn(raw)); the image patches as they are) and
+        # one for the gradient w.r.t. its raw values
+        from .engine import AMAX_SLOT
+        self.amax_f = torch.zeros(len(self.nodes) * AMAX_SLOT, dtype=torch.float32, device=device)
+        self.amax_b = torch.zeros(len(self.nodes) * AMAX_SLOT, dtype=torch.float32, device=device)
+        for i, n in enumerate(self.nodes):
+            n.amax_f = self.amax_f.data_ptr() + 4 * AMAX_SLOT * i
+            n.amax_b = self.amax_b.data_ptr() + 4 * AMAX_SLOT * i
         for n in self.nodes:       # identity parts: scale 1, shift 0, backward coefficient c0 = 1
             for c0, c1, bn, _, _ in n.parts:
                 if bn is None:
@@ -321,7 +329,9 @@ class _GraphStem:
         return g
 
     # ------------------------------------------------------------------ forward
-    def forward(self, x, train, save):
+    def forward(self, x, train, save, f16=False):
+        """f16: the convolutions run the three-product fp16 form (engine.py); every node's largest consumer-side magnitude is
+        measured once, when its BatchNorm vectors are final."""
         eng, L = self.engine, lib()
         B, _, S, _ = x.shape
         dev = x.device
@@ -332,6 +342,9 @@ class _GraphStem:
             self.s_arena.zero_()
         else:
             eng.finalize_table(tb['fin'], 0, tb['n_fin'], False)
+        if f16:
+            self.amax_f.zero_()
+        measured = set()
         raw = {}
         img = self.nodes[0]
         raw[img.name] = torch.empty(B, S // 2, S // 2, self.IMG_C, **f32)
@@ -360,7 +373,13 @@ class _GraphStem:
                 o.out0 = raw[n.name].data_ptr() + 4 * op.c0
                 if train:
                     o.stats0 = self.sptr(n, False, op.c0)
-                eng.conv(self.geom(op, B, S, 'f'), [o])
+                if f16:
+                    if src.name not in measured:       # (all of the node's channels: a bound for any channel slice of it)
+                        eng.absmax([raw[src.name]], [src.amax_f], src.C, None if sc is None else [sc], None if sc is None else [sh],
+                                   relu=sc is not None)
+                        measured.add(src.name)
+                    o.in_amax, o.w0_amax = src.amax_f, op.conv.amax_ptr
+                eng.conv(self.geom(op, B, S, 'f'), [o], 32 if f16 else 0)
             elif isinstance(op, _AddOp):
                 ao = BnAddOperands()
                 ao.a, ao.a_scale, ao.a_shift = raw[op.a.name].data_ptr(), self.fptr(op.a, 0), self.fptr(op.a, 1)
@@ -381,7 +400,7 @@ class _GraphStem:
         out = torch.empty(B, S // n7.div, S // n7.div, n7.C, **f32)
         check(L.mpose_bn_relu_fwd(ptr(raw[n7.name]), c_void_p(self.fptr(n7, 0)), c_void_p(self.fptr(n7, 1)), ptr(out),
                                   c_int64(out.numel()), n7.C, st()), 'mpose_bn_relu_fwd')
-        ctx = {'raw': raw, 'B': B, 'S': S, 'train': train} if save else None
+        ctx = {'raw': raw, 'B': B, 'S': S, 'train': train, 'f16': f16, 'measured': measured} if save else None
         return out, ctx
 
     # ------------------------------------------------------------------ backward
@@ -394,6 +413,9 @@ class _GraphStem:
         f32 = dict(dtype=torch.float32, device=dev)
         tb = self.tables(B, S)
         self.s_arena.zero_()
+        f16 = ctx.get('f16', False)
+        if f16:
+            self.amax_b.zero_()
         dact = {self.out_node.name: D}
         for n in reversed(self.nodes):
             if n.is_image or n.name not in dact:
@@ -414,6 +436,8 @@ class _GraphStem:
             ao.g, ao.a, ao.coef_a, ao.da = g.data_ptr(), raw[n.name].data_ptr(), self.fptr(n, 4), d_raw.data_ptr()
             if n.relu:
                 ao.a_scale, ao.a_shift = self.fptr(n, 0), self.fptr(n, 1)
+            if f16:
+                ao.da_amax = n.amax_b
             check(L.mpose_bn_bwd_apply((BnBwdApplyOperands * 3)(ao), 1, H * H, B, n.C, 0, 0, st()), 'mpose_bn_bwd_apply')
             for op in n.producers:
                 if isinstance(op, _AddOp):     # both addends receive d_raw (w.r.t. their affine / activated values)
@@ -436,12 +460,16 @@ class _GraphStem:
                     wo.in_, wo.in_scale, wo.in_shift = raw[src.name].data_ptr(), sc, sh
                     wo.gout0 = d_raw.data_ptr() + 4 * op.c0
                     wo.dw0 = eng.part_ptr(B, S, op.conv)
+                    if f16:
+                        wo.in_amax, wo.gout0_amax = src.amax_f, n.amax_b
                     eng.wgrad_async(self.geom(op, B, S, 'f'), [wo], eng.stem_n_split(B, S, op), [raw[src.name], d_raw])
                     if want_dsrc:
                         o = ConvOperands()
                         o.in_, o.w0 = d_raw.data_ptr() + 4 * op.c0, eng._wptr(op.conv, True)
                         o.out0 = dact[src.name].data_ptr()
-                        eng.conv(self.geom(op, B, S, 'd'), [o], 1)       # accumulate
+                        if f16:
+                            o.in_amax, o.w0_amax = n.amax_b, op.conv.amax_ptr
+                        eng.conv(self.geom(op, B, S, 'd'), [o], 1 | (32 if f16 else 0))       # accumulate
                 elif want_dsrc and op.kind == 0:
                     ws = torch.empty(B * H * H * src.C, dtype=torch.uint8, device=dev)       # window arg-max positions
                     check(L.mpose_maxpool3_bwd_ws(ptr(raw[src.name]), c_void_p(sc), c_void_p(sh), c_void_p(d_raw.data_ptr() + 4 * op.c0),

@@ -78,11 +78,18 @@ def report(name, errs, tol=TOL):
     assert not bad, 'parity failures (%s): %s' % (name, bad[:10])
 
 
-@pytest.mark.parametrize('T,perm', [(1, True), (2, True), (1, False)])
-def test_eval_forward(T, perm):
+@pytest.mark.parametrize('T,perm,engine', [(1, True, 'auto'), (2, True, 'auto'), (1, False, 'auto'), (2, True, 'planes'), (1, True, 'bf16x6')])
+def test_eval_forward(T, perm, engine):
+    """engine: 'auto' = conv_igemm_k with three fp16 products (the default); 'planes' = the plane engine with BatchNorm, ReLU and
+    the residual sum fused into its epilogues; 'bf16x6' = conv_igemm_k with six bf16 products."""
     seed, B = 400 + T, 2
     x, target, mask = W.seeded_inputs(seed + 1000, B)
     m = build(T, seed, x, perm).eval()
+    if engine == 'planes':
+        m.inner.engine().planes_mode = '1'
+    elif engine == 'bf16x6':
+        m.inner.engine().f16x3 = False
+        m.inner.engine().planes_mode = '0'
     with torch.no_grad():
         out = m(x.cuda())
         l3 = m.forward_3d_losses(out, target.cuda())
@@ -91,7 +98,7 @@ def test_eval_forward(T, perm):
     for p in ('xy', 'zy', 'xz'):
         for t in range(T):
             errs['hm_%s%d' % (p, t)] = rel(getattr(m, p + '_heatmaps')[t].cpu(), ref[p][t].detach())
-    report('eval_T%d_%d' % (T, perm), errs)
+    report('eval_T%d_%d%s' % (T, perm, '' if engine == 'auto' else '_' + engine), errs)
 
 
 def grad_noise_gate(name, gpu, ref64, ref32):
@@ -260,12 +267,21 @@ def test_full_config_shapes_and_properties():
     assert torch.isfinite(loss)
     for k, p in m.named_parameters():
         assert p.grad is not None and torch.isfinite(p.grad).all(), k
-    # batch-shard consistency (data-parallel invariant): eval-mode outputs of a half batch equal the full batch's half
+    # batch-shard consistency (data-parallel invariant): eval-mode outputs of a half batch equal the full batch's half -- to fp32
+    # rounding with the default three-product fp16 convolutions (a tensor's power-of-two scale follows the largest magnitude in
+    # the BATCH, so a sample's roundings depend on its batch mates; this untrained model's peaked heatmaps amplify that to ~2e-5 on
+    # a coordinate), bit for bit with the six-product bf16 form (summation order fixed per sample)
     m.eval()
     with torch.no_grad():
         full = m(x[:8])
         half = m(x[:4])
-    assert (full[:4] - half).abs().max() < 1e-5
+    assert (full[:4] - half).abs().max() < 1e-4
+    eng = m.inner.engine()
+    eng.f16x3, eng.planes_mode = False, '0'
+    with torch.no_grad():
+        full = m(x[:8])
+        half = m(x[:4])
+    assert torch.equal(full[:4], half)
 
 
 @pytest.mark.parametrize('size,T', [(384, 1), (512, 1), (128, 2)])
@@ -392,7 +408,9 @@ def test_uint8_frames_are_normalised_on_device(stem):
     loss_u.backward()
     g_u = m.inner.xy_hm_cnns[0].down_layers[0].module[0].weight.grad
     assert float((out_u - out_f).abs().max()) < 2e-5, float((out_u - out_f).abs().max())     # (x/255 - mean)/std vs fma form: 1 ulp inputs
-    assert float((g_u - g_f).norm() / g_f.norm()) < 5e-3
+    # (inputs that differ in the last bit put a handful of the ~10M ReLU sites of this B=2 step on the other piece: the size of
+    #  the resulting gradient change is that of tests/test_grad_parity_gpu.py's free-running comparison, not an arithmetic error)
+    assert float((g_u - g_f).norm() / g_f.norm()) < 2e-2
 
 
 def test_bf16_heatmap_inference_mode():
