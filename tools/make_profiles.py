@@ -41,20 +41,25 @@ for sub in ('pmc_sq', 'pmc_lds', 'pmc_fetch', 'pmc_write'):
     for f in glob.glob(os.path.join(src, sub, '**', '*counter_collection.csv'), recursive=True):
         for r in csv.DictReader(open(f)):
             ctr[(short(r['Kernel_Name']).split('(')[0], int(r['Grid_Size']))][r['Counter_Name']].append(float(r['Counter_Value']))
-labels = {   # bench.py kernel tag -> (template, threads in the grid) at B = 32, three column groups
-    'conv:f_conv2/32x32/128->128': ('conv_planes_k<2, 2, 2, 2, 3, 0, 3>', 256 * 3 * 256, 3 * 32768 * (128 * 6 + 128 * 4) + 3 * 9 * 128 * 128 * 6),
-    'conv:d_conv2/32x32/128->128': ('conv_planes_k<2, 2, 2, 2, 3, 0, 3>', 256 * 3 * 256, 3 * 32768 * (128 * 6 + 128 * 4 + 128 * 4) + 3 * 9 * 128 * 128 * 6),
-    'conv:f_in_regular/32x32/128->128': ('conv_planes_k<2, 2, 2, 2, 3, 1, 3>', 256 * 3 * 256, 3 * 32768 * (128 * 6 + 2 * 128 * 4) + 3 * 10 * 128 * 128 * 6),
-    'conv:d_in_regular/32x32/128->128': ('conv_planes_k<2, 2, 2, 2, 3, 2, 3>', 256 * 3 * 256, 3 * 32768 * (2 * 128 * 6 + 128 * 4) + 3 * 10 * 128 * 128 * 6),
-    'conv:f_conv2/16x16/192->192': ('conv_planes_k<2, 2, 1, 3, 3, 0, 3>', 128 * 3 * 256, 3 * 8192 * (192 * 6 + 192 * 4) + 3 * 9 * 192 * 192 * 6),
-    'conv:d_conv2/16x16/192->192': ('conv_planes_k<2, 2, 1, 3, 3, 0, 3>', 128 * 3 * 256, 3 * 8192 * (192 * 6 + 192 * 8) + 3 * 9 * 192 * 192 * 6),
-    'wgrad:f_conv2/32x32/128->128': ('conv_wgrad_k<4, 4>', None, 3 * 32768 * 128 * 8),
-    'wgrad:f_conv2/16x16/192->192': ('conv_wgrad_k<3, 3>', None, 3 * 8192 * 192 * 8),
+labels = {   # bench.py kernel tag -> (template, threads in the grid, algorithmic bytes) at B = 32, three column groups; the columns run
+    # conv_igemm_k / conv_wgrad_k in their three-product fp16 form (last template argument 2 / true): fp32 activations in and out
+    'conv:f_conv2/32x32/128->128': ('conv_igemm_k<4, 0, 2, true, 2>', 256 * 3 * 256, 3 * 32768 * (128 * 4 + 128 * 4) + 3 * 9 * 128 * 128 * 4),
+    'conv:d_conv2/32x32/128->128': ('conv_igemm_k<4, 0, 2, false, 2>', 256 * 3 * 256, 3 * 32768 * (128 * 4 + 128 * 4 + 128 * 4) + 3 * 9 * 128 * 128 * 4),
+    'conv:f_in_regular/32x32/128->128': ('conv_igemm_k<4, 1, 2, false, 2>', 256 * 3 * 256, 3 * 32768 * (128 * 4 + 2 * 128 * 4) + 3 * 10 * 128 * 128 * 4),
+    'conv:d_in_regular/32x32/128->128': ('conv_igemm_k<4, 2, 2, false, 2>', 256 * 3 * 256, 3 * 32768 * (2 * 128 * 4 + 128 * 4) + 3 * 10 * 128 * 128 * 4),
+    'conv:f_conv2/16x16/192->192': ('conv_igemm_k<3, 0, 1, true, 2>', None, 3 * 8192 * (192 * 4 + 192 * 4) + 3 * 9 * 192 * 192 * 4),
+    'conv:d_conv2/16x16/192->192': ('conv_igemm_k<3, 0, 1, false, 2>', None, 3 * 8192 * (192 * 4 + 192 * 8) + 3 * 9 * 192 * 192 * 4),
+    'conv:f_in_regular/16x16/192->192': ('conv_igemm_k<3, 1, 1, false, 2>', None, 3 * 8192 * (192 * 4 + 2 * 192 * 4) + 3 * 10 * 192 * 192 * 4),
+    'conv:d_in_regular/16x16/192->192': ('conv_igemm_k<3, 2, 1, false, 2>', None, 3 * 8192 * (2 * 192 * 4 + 192 * 4) + 3 * 10 * 192 * 192 * 4),
+    'wgrad:f_conv2/32x32/128->128': ('conv_wgrad_k<4, 4, true>', None, 3 * 32768 * 128 * 8),
+    'wgrad:f_in_regular/32x32/128->128': ('conv_wgrad_k<4, 4, true>', None, 3 * 32768 * 128 * 12),
+    'wgrad:f_conv2/16x16/192->192': ('conv_wgrad_k<3, 3, true>', None, 3 * 8192 * 192 * 8),
+    'wgrad:f_in_regular/16x16/192->192': ('conv_wgrad_k<3, 3, true>', None, 3 * 8192 * 192 * 12),
 }
 out = {'_source': 'rocprofv3 --kernel-trace --pmc <one counter group per run> of `python bench.py --steps 1 --warmup 1 --no-cpu-baseline '
                   '--no-kernel-timing --no-overlap-wgrad --eager --no-inference` (tools/profile.sh %s): per-dispatch averages of the kernel '
                   'template (and grid) the label launches; hbm_bytes = 2 x FETCH_SIZE (16-byte/lane streams are tallied at half their bytes on '
-                  'gfx950, MI355X_MICROARCH.md) + WRITE_SIZE; mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs)' % tag}
+                  'gfx950, MI355X_MICROARCH.md; 1 x for conv_wgrad_k, whose gathers are dword loads) + WRITE_SIZE; mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs)' % tag}
 for label, (templ, grid, alg) in labels.items():
     keys = [k for k in ctr if k[0] == templ and (grid is None or k[1] == grid)]
     if not keys:
@@ -66,7 +71,8 @@ for label, (templ, grid, alg) in labels.items():
     conf, idx = avg('SQ_LDS_BANK_CONFLICT'), avg('SQ_LDS_IDX_ACTIVE')
     e = {'kernel': templ + (' grid %d' % grid if grid else ''), 'algorithmic_bytes': alg}
     if fe is not None and wr is not None:
-        e.update(fetch_size_kb_reported=fe, write_size_kb_reported=wr, hbm_bytes_per_launch=int(2 * fe * 1024 + wr * 1024))
+        fx = 1 if templ.startswith('conv_wgrad') else 2      # the weight gradient gathers with dword loads: counted in full
+        e.update(fetch_size_kb_reported=fe, write_size_kb_reported=wr, fetch_correction=fx, hbm_bytes_per_launch=int(fx * fe * 1024 + wr * 1024))
     if busy is not None and gui:
         e['mfma_busy_frac'] = busy / (gui / 8 * 1024)
         e['shader_clock_GHz_note'] = 'GRBM_GUI_ACTIVE / 8 = %.0f cycles per launch' % (gui / 8)
