@@ -352,6 +352,24 @@ def main():
     if allreduce is not None:
         res['allreduce_buckets'] = {'buckets': allreduce, 'xgmi_peak_GBps_per_gpu': 7 * 153.0, 'total_bytes': sum(b['bytes'] for b in allreduce),
                                     'total_ms_if_serial': sum(b['ms'] for b in allreduce)}
+    if world == 1 and not args.no_inference and args.conv_dtype == 'f32' and model.inner.engine().conv_mode_for(True, True) == 2:
+        # the same step with the six-product bf16 form of the convolutions (round 1's arithmetic, MPOSE_F16X3=0), for reference
+        eng = model.inner.engine()
+        eng.f16x3 = False
+        for _ in range(2):
+            eager_step()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            eager_step()
+        torch.cuda.synchronize()
+        dt6 = (time.perf_counter() - t1) / 5
+        eng.f16x3 = True
+        res['six_product_bf16_form'] = {'images_per_sec': B / dt6, 'ms_per_step': 1e3 * dt6, 'steps': 5,
+                                        'note': 'same training step with every fp32 multiply-add as six bf16 MFMA products of three-way split '
+                                                'operands instead of three fp16 products of two-way split, per-tensor-scaled ones; both forms '
+                                                'pass the same parity gates (tests/test_conv_gpu.py, tests/test_conv_f16x3_gpu.py, '
+                                                'tests/test_grad_parity_gpu.py)'}
     if world == 1 and not args.no_inference:
         res['inference'] = inference_microbench(model, device, args.size)
     if world == 1 and not args.no_cpu_baseline:
