@@ -364,6 +364,10 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
         }
         load_b(nb, s_, rn);
         side(rn);
+        // Pin the column block: without the fence hipcc sinks every global load of the body to its end and hoists their
+        // consumers to its start (s_waitcnt vmcnt(23) ... vmcnt(0) in front of the first MFMAs: a prefetch distance of a few
+        // instructions) -- harmless behind 96 MFMAs per tile step, exposed behind 48.
+        __builtin_amdgcn_sched_barrier(0);
       }
     };
     // Software pipeline (ONE wave per SIMD: every latency has to be covered by this wave's own MFMAs).  Time is

@@ -26,6 +26,14 @@ from oracle import weights as W
 pytestmark = pytest.mark.gpu
 MASKED_TOL = 3e-5          # relative L2 per tensor against fp64 on the same ReLU piece (fp32 arithmetic through ~60 layers;
                            # the worst tensors are bias gradients = sums over pixels with heavy cancellation)
+MASKED_TOL_CONFIG = 1e-4   # the same at the configuration size (B=32: sums over 32768 pixels) = BASELINE.json configs[2]'s own
+                           # "grads within 1e-4".  Measured worst tensor: 4.6e-5 with the default three-product fp16 convolutions
+                           # (the shortcut BatchNorm bias gradients of each stage's first block: the 2^-22 representation
+                           # residual of a WEIGHT is the same for every pixel, so it does not average out of a sum over pixels
+                           # the way activation roundings do), 1e-5 on the plane engine (six bf16 products, two accumulators).
+FREE_RATIO = 3.0           # free running, the GPU may deviate from fp64 by this multiple of what the fp32 oracle does.  Which
+                           # ReLU sites flip is luck, how many scales with the forward error: 6.6e-6 on a heatmap for the default
+                           # form, 2.6e-6 for the plane engine (gated at 1.5 below), 1.4e-5 for round 1's six-product conv_igemm_k
 
 
 def rel_l2(a, b):
@@ -121,10 +129,12 @@ def mask_flips(a, b):
     return sum(int((a[k] != b[k]).sum()) for k in a), n
 
 
-@pytest.mark.parametrize('T,B,engine', [(1, 2, 'auto'), (2, 2, 'auto'), (1, 8, 'auto'), (3, 4, 'auto'), (2, 2, 'planes'), (1, 8, 'planes')])
+@pytest.mark.parametrize('T,B,engine', [(1, 2, 'auto'), (2, 2, 'auto'), (1, 8, 'auto'), (3, 4, 'auto'), (2, 2, 'planes'), (1, 8, 'planes'),
+                                        (2, 2, 'bf16x6')])
 def test_grads_on_the_same_relu_piece(T, B, engine):
-    """engine 'auto' = what training runs by default (conv_igemm_k for the columns); 'planes' forces the plane engine
-    (conv_planes_k: pre-split operands, two accumulators) through the same step."""
+    """engine 'auto' = what training runs by default (conv_igemm_k / conv_wgrad_k with three fp16 products); 'planes' forces the
+    plane engine (conv_planes_k: pre-split operands, six bf16 products, two accumulators) through the same step; 'bf16x6' =
+    conv_igemm_k / conv_wgrad_k with six bf16 products (round 1's arithmetic)."""
     seed = 700 + 10 * T + B
     x, target, mask = W.seeded_inputs(seed + 1000, B)
     rng = np.random.default_rng(seed)
@@ -134,6 +144,9 @@ def test_grads_on_the_same_relu_piece(T, B, engine):
     if engine == 'planes':
         m.inner.engine().planes_mode = '1'
         tag += '_planes'
+    elif engine == 'bf16x6':
+        m.inner.engine().f16x3, m.inner.engine().planes_mode = False, '0'
+        tag += '_bf16x6'
     gpu, masks, loss_gpu = gpu_step(m, x, target, mask)
     own = {}
     free64, _ = oracle_grads(sd, T, x, target, mask, torch.float64, record=own)      # the oracle on ITS piece (for the record)
@@ -157,8 +170,13 @@ def test_config_size_train_step_gradients(stem):
     T, B, seed = 3, 32, 900
     x, target, mask = W.seeded_inputs(seed + 1000, B)
     m, sd = build(T, seed, x, stem)
+    gpu_planes = None
     if stem == 'patch8':
         gpu, masks, loss_gpu = gpu_step(m, x, target, mask)
+        m2, _ = build(T, seed, x, stem)                       # the same step on the plane engine (free-running comparison only)
+        m2.inner.engine().planes_mode = '1'
+        gpu_planes, _, _ = gpu_step(m2, x, target, mask)
+        del m2
     else:
         from margipose_amd import dsntnn
         xg = x.cuda().requires_grad_(True)
@@ -172,12 +190,17 @@ def test_config_size_train_step_gradients(stem):
     ref32, _ = oracle_grads(sd, T, x, target, mask, torch.float32)
     st = compare('config_%s_T3_B32' % stem, gpu, ref64, ref32)
     assert abs(loss_gpu - loss64) <= 1e-5 * abs(loss64)
-    # free running: the GPU may sit on a different piece than fp64, exactly like the fp32 oracle does; it must not be
-    # further from fp64 than 1.5 x the reference's own fp32 path, tensor population against tensor population
-    assert st['gpu_median'] <= max(1e-4, 1.5 * st['ref32_median']), st
-    assert st['gpu_p99'] <= max(1e-4, 1.5 * st['ref32_p99']), st
+    # free running: the GPU may sit on a different piece than fp64, exactly like the fp32 oracle does; tensor population
+    # against tensor population it must stay within FREE_RATIO x the reference's own fp32 path (1.5 x on the plane engine)
+    assert st['gpu_median'] <= max(1e-4, FREE_RATIO * st['ref32_median']), st
+    assert st['gpu_p99'] <= max(1e-4, FREE_RATIO * st['ref32_p99']), st
+    if gpu_planes is not None:
+        sp = compare('config_%s_T3_B32_planes' % stem, gpu_planes, ref64, ref32)
+        assert sp['gpu_median'] <= max(1e-4, 1.5 * sp['ref32_median']), sp
+        assert sp['gpu_p99'] <= max(1e-4, 1.5 * sp['ref32_p99']), sp
     if masks is not None:
         m64, _ = oracle_grads(sd, T, x, target, mask, torch.float64, masks=masks)
         m32, _ = oracle_grads(sd, T, x, target, mask, torch.float32, masks=masks)
         sm = compare('config_%s_T3_B32_masked' % stem, gpu, m64, m32)
-        assert sm['gpu_max'] <= MASKED_TOL, sm
+        assert sm['gpu_max'] <= MASKED_TOL_CONFIG, sm
+        assert sm['gpu_median'] <= 1.5 * sm['ref32_median'], sm
