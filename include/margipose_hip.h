@@ -142,11 +142,13 @@ typedef struct {
   const float* mask_scale;
   const float* mask_shift;
   const float* in1;                    /* MPOSE_CONV_SUM_INPUTS: input of the taps with acc == 1 (same shape as `in`) */
-  /* Fused output stage of the plane engine (MPOSE_CONV_PLANES_IN only; inference: BatchNorm with running statistics is a
-   * per-channel affine map, so a ResidualBlock needs no elementwise pass at all):
+  /* Fused output stage (inference: BatchNorm with running statistics is a per-channel affine map, so a ResidualBlock needs
+   * no elementwise pass at all):
    *     y0 = [relu](epi_scale0 * conv0 + epi_shift0) [+ add_scale * add_src + add_shift]      (MPOSE_CONV_EPI_RELU0)
-   * y0 is written as fp32 NHWC to out0 (may then be NULL) and/or as pre-split planes P8[Cout0/8][3][B*OH*OW][8] to
-   * out0_planes -- what the next convolution reads.  Not combined with stats / mask_src / MPOSE_CONV_ACCUMULATE. */
+   * y0 is written as fp32 NHWC to out0 and -- plane engine only, out0 may then be NULL -- as pre-split planes
+   * P8[Cout0/8][3][B*OH*OW][8] to out0_planes (what the next plane convolution reads); conv.hip's engine can also accumulate
+   * max |y0| into the amax slot out0_amax (what the next MPOSE_CONV_F16X3 convolution needs).  Not combined with
+   * stats0 / mask_src / MPOSE_CONV_ACCUMULATE. */
   const float* epi_scale0;
   const float* epi_shift0;
   const float* add_src;                /* fp32 NHWC, same shape as out0 (the shortcut branch), or NULL */
@@ -160,6 +162,7 @@ typedef struct {
   const float* in1_amax;
   const float* w0_amax;
   const float* w1_amax;
+  float* out0_amax;                    /* optional, with the fused output stage of conv.hip's engine: amax slot of y0 */
 } mpose_conv_operands;
 
 #define MPOSE_CONV_ACCUMULATE 1   /* out0 += result */

@@ -537,6 +537,11 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
     double* stats = oset ? op.stats1 : op.stats0;
     const bool masked = (oset == 0) && op.mask_src != nullptr;
     const bool accumulate = (oset == 0) && (a.flags & 1);
+    // fused output stage (inference): y = [relu](es * conv + et) [+ as * add_src + at], and max |y| for the next convolution
+    const bool epi = (oset == 0) && op.epi_scale0 != nullptr;
+    const bool epi_add = epi && op.add_src != nullptr;
+    const bool epi_relu = (a.flags & MPOSE_CONV_EPI_RELU0) != 0;
+    float epi_amax = 0.f;
     const int old_ = oset ? g.out_ld1 : g.out_ld0;
     const int out_ld = old_ > 0 ? old_ : cout;
     const unsigned out_bytes = (unsigned)((((long)g.B * g.OH * g.OW - 1) * out_ld + cout) * 4);
@@ -596,6 +601,26 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) v[r] += old[r];
           }
+          if (epi) {
+            const float es = op.epi_scale0[n], et = op.epi_shift0[n];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              v[r] = fmaf(v[r], es, et);
+              if (epi_relu) v[r] = fmaxf(v[r], 0.f);
+            }
+            if (epi_add) {
+              const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(op.add_src), 0, out_bytes, 0x00020000);
+              const float as = op.add_scale[n], at = op.add_shift[n];
+              float ad[16];
+#pragma unroll
+              for (int r = 0; r < 16; ++r) ad[r] = buf_load1(rs_a, voff[r] + (unsigned)(rn * 128), 0);
+#pragma unroll
+              for (int r = 0; r < 16; ++r) v[r] += fmaf(ad[r], as, at);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r)       // (rows beyond M: their stores are dropped, but relu(et) + at need not be zero)
+              epi_amax = fmaxf(epi_amax, voff[r] < 0xFFFFF000u ? fabsf(v[r]) : 0.f);
+          }
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[r]), rs_o, (int)(voff[r] + (unsigned)(rn * 128)), 0, 0);
@@ -604,6 +629,14 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
             if (!masked) csq[rn] = fmaf(v[r], v[r], csq[rn]);
           }
         }
+      }
+    }
+    if (epi && op.out0_amax != nullptr) {      // one look-then-atomic per wave into the workgroup's sub-slot (common.h)
+      float m = wave_max(epi_amax);
+      if (lane == 0) {
+        if (!(m == m)) m = __uint_as_float(0x7f800000u);
+        unsigned* dst = reinterpret_cast<unsigned*>(op.out0_amax + (blockIdx.x % MPOSE_AMAX_SUBSLOTS) * MPOSE_AMAX_STRIDE);
+        if (__float_as_uint(m) > __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(dst, __float_as_uint(m));
       }
     }
     if (stats != nullptr) {
@@ -1150,7 +1183,12 @@ extern "C" int mpose_conv_fwd(const mpose_conv_geom* geom, const mpose_conv_oper
     a.op[i] = ops[i];
     if (!ops[i].in || !ops[i].w0) return MPOSE_EINVAL;
     if (!ops[i].out0 && !((flags & MPOSE_CONV_PLANES_IN) && ops[i].out0_planes)) return MPOSE_EINVAL;
-    if (!(flags & MPOSE_CONV_PLANES_IN) && (ops[i].epi_scale0 || ops[i].add_src || ops[i].out0_planes)) return MPOSE_EINVAL;
+    if (!(flags & MPOSE_CONV_PLANES_IN) && ops[i].out0_planes) return MPOSE_EINVAL;
+    if ((flags & MPOSE_CONV_PLANES_IN) && ops[i].out0_amax) return MPOSE_EINVAL;
+    if (ops[i].epi_scale0 && (!ops[i].epi_shift0 || ops[i].stats0 || ops[i].mask_src || (flags & MPOSE_CONV_ACCUMULATE))) return MPOSE_EINVAL;
+    if (ops[i].add_src && (!ops[i].epi_scale0 || !ops[i].add_scale || !ops[i].add_shift)) return MPOSE_EINVAL;
+    if ((ops[i].epi_scale0 != nullptr) != (ops[0].epi_scale0 != nullptr) || (ops[i].add_src != nullptr) != (ops[0].add_src != nullptr)) return MPOSE_EINVAL;
+    if (ops[i].out0_amax && !ops[i].epi_scale0) return MPOSE_EINVAL;
     if (acc1 && (!ops[i].w1 || !ops[i].out1)) return MPOSE_EINVAL;
     if ((ops[i].in_scale != nullptr) != (ops[0].in_scale != nullptr)) return MPOSE_EINVAL;
     if (ops[i].in_scale && (acc1 || !ops[i].in_shift)) return MPOSE_EINVAL;

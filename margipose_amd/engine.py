@@ -840,6 +840,10 @@ class Engine:
                 # ReLU, and the block's residual sum) run in the convolutions' epilogues, which write the next convolution's
                 # pre-split planes directly -- a ResidualBlock is two launches and no elementwise pass (reference :31-40).
                 fused = planes and not train and not save and not self.conv_bf16
+                # The same on conv_igemm_k (three-product form): its epilogue applies bn1 + ReLU (conv2 then reads a plain
+                # tensor: no prologue) or bn2 + ReLU + the shortcut's BatchNorm + the sum, and measures max |.| for the next
+                # convolution's scale as it stores -- fp32 in and out, two launches per block, no elementwise or amax pass.
+                fused_h = f16 and not train and not save and os.environ.get('MPOSE_FUSED_EVAL', '1') != '0'
                 c1 = None if fused else [torch.empty(B, Hout, Hout, b0.cout_s, **f32) for _ in range(3)]
                 sc = [torch.empty(B, Hout, Hout, b0.cout_s, **f32) for _ in range(3)]
                 if fused:
@@ -861,21 +865,25 @@ class Engine:
                         op.epi_scale0, op.epi_shift0 = self._bnf_ptr(b.bn1, 0), self._bnf_ptr(b.bn1, 1)
                     else:
                         op.out0 = c1[c].data_ptr()
+                        if fused_h:          # c1 holds relu(bn1(conv)) here
+                            op.epi_scale0, op.epi_shift0 = self._bnf_ptr(b.bn1, 0), self._bnf_ptr(b.bn1, 1)
+                            op.out0_amax = self._amax_f(t, i, 1, c)
                     if train:
                         op.stats0, op.stats1 = self._stats_ptr(b.bn1), self._stats_ptr(b.bns)
                     ops.append(op)
-                self.conv(g1, ops, pflags | (16 if fused else 0))
+                self.conv(g1, ops, pflags | (16 if (fused or fused_h) else 0))
                 if train:
                     self.finalize(tb, self.fin_index(t, i, 0), 6, True)
-                if f16:                      # largest relu(bn1(c1)): what the next K loop (and its weight gradient) will split
+                if f16 and not fused_h:      # largest relu(bn1(c1)): what the next K loop (and its weight gradient) will split
                     self.absmax(c1, [self._amax_f(t, i, 1, c) for c in range(3)], b0.cout_s, [self._bnf_ptr(b.bn1, 0) for b in grp],
                                 [self._bnf_ptr(b.bn1, 1) for b in grp], relu=True)
                 if planes and not fused:     # relu(bn1(c1)) is written once, pre-split, instead of being recomputed by every tap
                     a1_p = self.split_planes(c1, npix_o, b0.cout_s, [self._bnf_ptr(b.bn1, 0) for b in grp],
                                              [self._bnf_ptr(b.bn1, 1) for b in grp], relu=True)
                 fuse2 = fused and not last
+                fuse2_h = fused_h and not last
                 need_f32 = (not fuse2) or (i == 4 and any(sp != 0 for sp in self.spaces))     # the axis permutation reads fp32
-                c2 = None if fuse2 else [torch.empty(B, Hout, Hout, b0.cout_s, **f32) for _ in range(3)]
+                c2 = None if (fuse2 or fuse2_h) else [torch.empty(B, Hout, Hout, b0.cout_s, **f32) for _ in range(3)]
                 if last:
                     outs = [torch.empty(B, self.J, F, F, **f32) for _ in range(3)]
                 elif need_f32:
@@ -892,7 +900,8 @@ class Engine:
                         op.in_ = a1_p[c].data_ptr()
                     else:
                         op.in_ = c1[c].data_ptr()
-                        op.in_scale, op.in_shift = self._bnf_ptr(b.bn1, 0), self._bnf_ptr(b.bn1, 1)
+                        if not fused_h:
+                            op.in_scale, op.in_shift = self._bnf_ptr(b.bn1, 0), self._bnf_ptr(b.bn1, 1)
                         if f16:
                             op.in_amax, op.w0_amax = self._amax_f(t, i, 1, c), b.conv2.amax_ptr
                     if fuse2:
@@ -901,16 +910,23 @@ class Engine:
                             op.out0 = outs[c].data_ptr()
                         op.epi_scale0, op.epi_shift0 = self._bnf_ptr(b.bn2, 0), self._bnf_ptr(b.bn2, 1)
                         op.add_src, op.add_scale, op.add_shift = sc[c].data_ptr(), self._bnf_ptr(b.bns, 0), self._bnf_ptr(b.bns, 1)
+                    elif fuse2_h:
+                        op.out0 = outs[c].data_ptr()
+                        op.epi_scale0, op.epi_shift0 = self._bnf_ptr(b.bn2, 0), self._bnf_ptr(b.bn2, 1)
+                        op.add_src, op.add_scale, op.add_shift = sc[c].data_ptr(), self._bnf_ptr(b.bns, 0), self._bnf_ptr(b.bns, 1)
+                        op.out0_amax = self._amax_f(t, i + 1, 0, c)           # (the axis permutation after block 4 keeps the maximum)
                     else:
                         op.out0 = c2[c].data_ptr()
                     if train:
                         op.stats0 = self._stats_ptr(b.bn2)
                     ops.append(op)
-                self.conv(self.geom('f_conv2', B, Hout, b0), ops, pflags | (16 if fuse2 else 0))
+                self.conv(self.geom('f_conv2', B, Hout, b0), ops, pflags | (16 if (fuse2 or fuse2_h) else 0))
                 if train:
                     self.finalize(tb, self.fin_index(t, i, 2), 3, True)
                 if fuse2:
                     cur_p = nxt_p
+                elif fuse2_h:
+                    pass
                 else:
                     aops = []
                     for c, b in enumerate(grp):

@@ -346,3 +346,50 @@ def test_weight_gradient_stride2_with_fused_shortcut():
     dw, dw1 = _wgrad(L, _lib, eng, g, xg, gg, cout, cin, 9, npad, 2, amaxes, gout1=gg1, cout1=cout)
     _check(*_wgrad_errs(dw, x, go, lambda a, w: F.conv2d(a, w, stride=2, padding=1), (cout, cin, 3, 3)))
     _check(*_wgrad_errs(dw1, x, go1, lambda a, w: F.conv2d(a, w, stride=2), (cout, cin, 1, 1)))
+
+
+@pytest.mark.parametrize('B,H,cin,cout,add,f16', [(2, 32, 128, 128, True, True), (4, 16, 192, 192, False, True), (3, 8, 32, 32, True, True),
+                                                 (1, 12, 64, 96, True, False)])
+def test_fused_output_stage(B, H, cin, cout, add, f16):
+    """Inference epilogue of conv_igemm_k: y = relu(es * conv + et) [+ as * add_src + at] stored as fp32, max |y| accumulated
+    into the amax slot the next convolution reads (reference models/margipose_model.py:31-40 with running-statistics BatchNorm)."""
+    from margipose_amd import _lib, engine as eng
+    from margipose_amd._lib import ConvOperands
+    L = _lib.lib()
+    rng = np.random.default_rng(B * 31 + H)
+    x = torch.from_numpy(_data(rng, (B, cin, H, H), 'relu')).float()
+    w = torch.from_numpy(rng.standard_normal((cout, cin, 3, 3)) * (2.0 / (9 * cin)) ** 0.5).float()
+    es, et = torch.from_numpy(rng.uniform(0.5, 1.5, cout)).float(), torch.from_numpy(rng.standard_normal(cout) * 0.3).float()
+    a_s, a_t = torch.from_numpy(rng.uniform(-1.5, 1.5, cout)).float(), torch.from_numpy(rng.standard_normal(cout) * 0.3).float()
+    src = torch.from_numpy(rng.standard_normal((B, cout, H, H))).float()
+    xg = x.permute(0, 2, 3, 1).contiguous().cuda()
+    srcg = src.permute(0, 2, 3, 1).contiguous().cuda()
+    if f16:
+        packed, w_amax, npad = _pack(L, _lib, eng, w.cuda(), cout, cin, 9)
+    else:
+        import tests.test_conv_gpu as T6
+        packed, npad, _ = T6._pack(L, _lib, eng, w.cuda(), cout, cin, 9)
+    x_amax = _amax(L, _lib, [xg], cin)
+    t9 = [(ky - 1, kx - 1, ky * 3 + kx, 0) for ky, kx in eng.TAPS3]
+    g = eng._geom(B, H, cin, H, cout, 0, H, 1, 1, [(0, 0, t9)], npad)
+    out = torch.full((B, H, H, cout), float('nan'), device='cuda')
+    slot = torch.zeros(SLOT, device='cuda')
+    dev = [t.cuda() for t in (es, et, a_s, a_t)]
+    op = ConvOperands()
+    op.in_, op.w0, op.out0 = xg.data_ptr(), packed.data_ptr(), out.data_ptr()
+    if f16:
+        op.in_amax, op.w0_amax = x_amax.data_ptr(), w_amax.data_ptr()
+    op.epi_scale0, op.epi_shift0, op.out0_amax = dev[0].data_ptr(), dev[1].data_ptr(), slot.data_ptr()
+    if add:
+        op.add_src, op.add_scale, op.add_shift = srcg.data_ptr(), dev[2].data_ptr(), dev[3].data_ptr()
+    _lib.check(L.mpose_conv_fwd(ctypes.byref(g), (ConvOperands * 1)(op), 1, (F16X3 if f16 else 0) | 16, _lib.stream_ptr()), 'conv')
+    torch.cuda.synchronize()
+
+    def fn(a, v, dt):
+        y = torch.relu(F.conv2d(a, v, padding=1) * es.to(dt).view(1, -1, 1, 1) + et.to(dt).view(1, -1, 1, 1))
+        return y + (src.to(dt) * a_s.to(dt).view(1, -1, 1, 1) + a_t.to(dt).view(1, -1, 1, 1)) if add else y
+    _check(*_errs(out, fn(x.double(), w.double(), torch.float64), fn(x, w, torch.float32)))
+    assert float(slot.max()) == float(out.abs().max())
+    # stats / mask / accumulate do not combine with the output stage
+    op.stats0 = slot.data_ptr()
+    assert L.mpose_conv_fwd(ctypes.byref(g), (ConvOperands * 1)(op), 1, (F16X3 if f16 else 0) | 16, _lib.stream_ptr()) == -22
