@@ -42,7 +42,12 @@ inline FastDiv make_fastdiv(unsigned d) {
 __device__ __forceinline__ unsigned fdiv(unsigned n, FastDiv f) { return (__umulhi(n, f.mul) + n) >> f.shift; }
 
 constexpr int KC = 32;              // channels per K-chunk = two 16-deep MFMA k-groups
-constexpr int A_ROW_B = 80;         // LDS bytes per pixel row of one bf16 plane: 64 B of data + 16 B pad
+// LDS bytes per pixel row of one 16-bit plane: 64 B of data, no padding.  The four 16-byte chunks of a row are stored XOR-swizzled
+// by row bits 2-3 (physical chunk = chunk ^ ((row >> 2) & 3)): the staging writes (ds_write_b64: 32 lanes = 4 consecutive rows x
+// 8 lanes, the same swizzle for all four) and the fragment reads (ds_read_b128: 16 lanes = 16 consecutive rows of one logical
+// chunk -> (row & 3, chunk ^ (row >> 2)) takes all 16 values) both touch every bank once.  Round 1's 80-byte pitch made the reads
+// conflict-free but let row 3 of a write alias row 0 (20 r mod 64 = 0, 20, 40, 60: SQ_LDS_BANK_CONFLICT 36-40 % of the LDS cycles).
+constexpr int A_ROW_B = 64;
 constexpr int A_PLANE_B = 64 * A_ROW_B;
 constexpr int A_TILE_B = 3 * A_PLANE_B;   // hi / mid / lo planes of one 64-pixel x 32-channel tile
 
@@ -175,6 +180,12 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
       ? *reinterpret_cast<const int*>(&g.cls[cls].taps[(threadIdx.x & 63) < MPOSE_MAX_TAPS ? (threadIdx.x & 63) : 0]) : 0;
   auto tap_word = [&](int t) { return __builtin_amdgcn_readlane(lane_tap, t); };
   unsigned char* sA = sA_all + wave * 2 * A_TILE_B;
+  // swizzled chunk offsets inside a 64-byte row (see A_ROW_B): staging writes 8 bytes of chunk (lane & 7) >> 1, fragment reads
+  // take chunk 2 s + (lane >> 5) of row (lane & 31)
+  const int st_off_even = ((((lane & 7) >> 1) ^ (lane >> 5)) << 4) + ((lane & 1) << 3);
+  const int st_off_odd = ((((lane & 7) >> 1) ^ ((lane >> 5) | 2)) << 4) + ((lane & 1) << 3);
+  const int rd_sw = ((lane & 31) >> 2) & 3;
+  const int rd_off0 = ((0 + (lane >> 5)) ^ rd_sw) << 4, rd_off1 = ((2 + (lane >> 5)) ^ rd_sw) << 4;
 
   // ---- per-lane staging state (loop invariant) ----
   // row_voff[j]: BYTE offset of the slot's anchor pixel + this lane's 16-byte channel column;
@@ -305,7 +316,8 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
         v.x = pad ? 0.f : fmaxf(fmaf(v.x, sc.x, sh.x), 0.f); v.y = pad ? 0.f : fmaxf(fmaf(v.y, sc.y, sh.y), 0.f);
         v.z = pad ? 0.f : fmaxf(fmaf(v.z, sc.z, sh.z), 0.f); v.w = pad ? 0.f : fmaxf(fmaf(v.w, sc.w, sh.w), 0.f);
       }
-      unsigned char* dA = sA + buf * A_TILE_B + ((lane >> 3) + 8 * j) * A_ROW_B + a_col4 * 8;
+      // row (lane >> 3) + 8 j: its swizzle is ((lane >> 5) + 2 j) & 3 -- one of two per-lane values (j is a compile-time constant)
+      unsigned char* dA = sA + buf * A_TILE_B + ((lane >> 3) + 8 * j) * A_ROW_B + ((j & 1) ? st_off_odd : st_off_even);
       if constexpr (F16) {
         if (!pro) { v.x *= a_mul; v.y *= a_mul; v.z *= a_mul; v.w *= a_mul; }
         uint2 h, l;
@@ -325,7 +337,7 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
     auto stage_row = [&](int buf, int j) { stage(buf, j, ra[j], pad_c, rsc_c, rsh_c); };
     auto rotate_stage_state = [&]() { pad_c = pad_n; rsc_c = rsc_n; rsh_c = rsh_n; };
     auto read_frags = [&](int buf, int s_, u32x4 (&af)[2][NPL]) {
-      const unsigned char* cA = sA + buf * A_TILE_B + li * A_ROW_B + s_ * 32 + lh * 16;
+      const unsigned char* cA = sA + buf * A_TILE_B + li * A_ROW_B + (s_ ? rd_off1 : rd_off0);    // (rows li and li + 32 swizzle alike)
 #pragma unroll
       for (int rm = 0; rm < 2; ++rm)
 #pragma unroll
