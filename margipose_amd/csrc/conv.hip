@@ -22,6 +22,7 @@
 // [widx][K/16][plane][Npad][half][8] -- one 16-byte v_mfma_f32_32x32x16_bf16 B fragment per (n, half):
 //   lane (i = l&31, h = l>>5) holds A[pixel i][k = 16 s + 8 h + 0..7] and B[k = 16 s + 8 h + 0..7][n = l&31].
 #include "common.h"
+#include <stdlib.h>
 
 namespace mpose {
 namespace {
@@ -50,6 +51,13 @@ constexpr int KC = 32;              // channels per K-chunk = two 16-deep MFMA k
 constexpr int A_ROW_B = 64;
 constexpr int A_PLANE_B = 64 * A_ROW_B;
 constexpr int A_TILE_B = 3 * A_PLANE_B;   // hi / mid / lo planes of one 64-pixel x 32-channel tile
+// Row-group staging (ROWG; stride-1 3x3, first pass): one staged tile serves the three dx taps of a kernel row.  It holds the
+// 66 consecutive input pixels  m0-1+dy*IW .. m0+64+dy*IW  (rows 0..65) plus an all-zero row that the fragment reads of
+// out-of-image taps are redirected to.
+constexpr int RG_ROWS = 68;
+constexpr int RG_ZERO_ROW = 66;
+constexpr int RG_PLANE_B = RG_ROWS * A_ROW_B;
+constexpr int RG_TILE_B = 3 * RG_PLANE_B;
 
 struct ConvArgs {
   mpose_conv_geom g;
@@ -152,17 +160,20 @@ __device__ __forceinline__ f32x16 mfma_f16(const u32x4 a, const u32x4 b, const f
 // NPL = 3: the six-product bf16 form above.  NPL = 2 (MPOSE_CONV_F16X3): operands split into TWO fp16 planes after a
 // per-tensor power-of-two scale, three products per k-group (al*bh, ah*bl, ah*bh), accumulators scaled back (exactly) after
 // the K loop -- half the matrix work, two thirds of the LDS and L2 fragment traffic, 4 instead of 5.5 VALU per element.
-template <int RN, int MODE, int KS, bool PRO, int NPL>
+// ROWG (stride-1 3x3 first passes, three-product form): the operand split -- all of the loop's VALU work -- runs once per
+// (channel chunk, kernel ROW) instead of once per tap: see the row-group K loop below.
+template <int RN, int MODE, int KS, bool PRO, int NPL, bool ROWG>
 __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
   constexpr bool ACC1 = MODE == 1, SUM2 = MODE == 2;
   constexpr bool F16 = NPL == 2;
+  constexpr int TILE_B = ROWG ? RG_TILE_B : A_TILE_B;      // LDS bytes reserved per staging buffer
   constexpr int NPASS = MODE ? 2 : 1;
   constexpr int BM = 256 / KS;
   constexpr int BN = 32 * RN;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  unsigned char* sA_all = smem_raw;                                               // [4 waves][2][A_TILE_B]
-  float* sRed = reinterpret_cast<float*>(smem_raw + 4 * 2 * A_TILE_B);            // [2 sets][4 waves][BN][2]
-  unsigned* sRow = reinterpret_cast<unsigned*>(smem_raw + 4 * 2 * A_TILE_B + 2 * 4 * BN * 2 * 4);   // [4 waves][64] output row offsets
+  unsigned char* sA_all = smem_raw;                                               // [4 waves][2][TILE_B]
+  float* sRed = reinterpret_cast<float*>(smem_raw + 4 * 2 * TILE_B);              // [2 sets][4 waves][BN][2]
+  unsigned* sRow = reinterpret_cast<unsigned*>(smem_raw + 4 * 2 * TILE_B + 2 * 4 * BN * 2 * 4);   // [4 waves][64] output row offsets
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lh = lane >> 5;
@@ -179,7 +190,7 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
   const int lane_tap = (int)(threadIdx.x & 63) < MPOSE_MAX_TAPS
       ? *reinterpret_cast<const int*>(&g.cls[cls].taps[(threadIdx.x & 63) < MPOSE_MAX_TAPS ? (threadIdx.x & 63) : 0]) : 0;
   auto tap_word = [&](int t) { return __builtin_amdgcn_readlane(lane_tap, t); };
-  unsigned char* sA = sA_all + wave * 2 * A_TILE_B;
+  unsigned char* sA = sA_all + wave * 2 * TILE_B;
   // swizzled chunk offsets inside a 64-byte row (see A_ROW_B): staging writes 8 bytes of chunk (lane & 7) >> 1, fragment reads
   // take chunk 2 s + (lane >> 5) of row (lane & 31)
   const int st_off_even = ((((lane & 7) >> 1) ^ (lane >> 5)) << 4) + ((lane & 1) << 3);
@@ -233,7 +244,7 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
   const unsigned w_voff = (unsigned)(((n0 + li) * 2 + lh) * 16);     // this lane's 16-byte fragment inside a slab
 
   f32x16 acc0[2][RN];
-  float4 ra[8];                          // A rows in flight: global -> registers -> (BN+ReLU, split) -> LDS
+  float4 ra[ROWG ? 9 : 8];               // A rows in flight: global -> registers -> (BN+ReLU, split) -> LDS
   float4 rsc_c = make_float4(1.f, 1.f, 1.f, 1.f), rsh_c = make_float4(0.f, 0.f, 0.f, 0.f), rsc_n = rsc_c, rsh_n = rsh_c;
   unsigned pad_c = 0, pad_n = 0;         // bit j: row j of the tile being staged / being loaded is padding (PRO only)
   u32x4 fb[2][RN][NPL];                  // B-fragment ring: [k-group][column block][plane] of the NEXT use
@@ -389,6 +400,173 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
     //   global loads of tile k               issued row by row as staging frees the registers: one body ahead;
     //   B fragments of (tile k, group s)     loaded right after group s of tile k-1 used the registers.
     // A loop body is { half 2k+1, half 2k+2 } so that all of this is one basic block for the scheduler.
+    const bool use_rowg = ROWG && set == 0;
+    if (use_rowg) {
+      if constexpr (ROWG) {
+        // ---- row-group K loop (first pass of a stride-1 3x3: taps 3*ky .. 3*ky+2 share dy and have dx in {-1,0,1}) ----
+        // One staged tile per (32-channel chunk, kernel row): 66 consecutive input pixels, scaled and split ONCE, serve the
+        // three dx taps -- the fragment read of tap dx starts at staged row 1+dx.  Zero padding moves to the fragment read:
+        // a lane whose (pixel, tap) falls outside the image reads the all-zero row instead (no masking at staging time, so
+        // the BN+ReLU prologue needs no special case either).  Staging work, A loads and LDS writes per MFMA fall ~2.7x.
+        unsigned char* sG = sA;
+        const int ld4 = in_ld * 4;
+        const int q_lane = m0 + (lane >> 3);                   // pixel staged by this lane in piece 0 is q_lane + qs
+        const unsigned rg_voff = (unsigned)q_lane * (unsigned)ld4 + (unsigned)(a_col4 * 16);
+        const unsigned fr_zero = (unsigned)(RG_ZERO_ROW * A_ROW_B);
+        unsigned fr_taps[2] = {0u, 0u};                        // bit t: tap t of output pixel m0 + 32*rm + li is inside the image
+        struct GroupInfo { unsigned a_soff; int qs; int c; int t; };
+        auto group_ck = [&](int c, int ky) {
+          GroupInfo G;
+          G.c = c; G.t = 3 * ky;
+          const int dy = (int)(signed char)(tap_word(G.t) & 0xff);
+          G.qs = dy * g.IW - 1;
+          G.a_soff = (unsigned)((G.qs * in_ld + c * KC) * 4 + a.in_bias);
+          return G;
+        };
+        auto load_piece = [&](const GroupInfo& G, int j) {       // staged rows 8j .. 8j+7, 16 bytes per lane
+          const int q = q_lane + G.qs + 8 * j;
+          const unsigned vo = (unsigned)q < (unsigned)a.M ? rg_voff : kOob;     // never touch memory outside the tensor
+          ra[j] = buf_load4(rs_in, vo, G.a_soff + (unsigned)(j * 8 * ld4));
+        };
+        auto load_scale_c = [&](int c, float4& sc, float4& sh) {
+          if (pro) {
+            sc = *reinterpret_cast<const float4*>(op.in_scale + c * KC + a_col4 * 4);
+            sh = *reinterpret_cast<const float4*>(op.in_shift + c * KC + a_col4 * 4);
+            if (F16) {
+              sc.x *= a_mul; sc.y *= a_mul; sc.z *= a_mul; sc.w *= a_mul;
+              sh.x *= a_mul; sh.y *= a_mul; sh.z *= a_mul; sh.w *= a_mul;
+            }
+          }
+        };
+        auto stage_piece = [&](int buf, int j, const float4& sc, const float4& sh) {
+          float4 v = ra[j];
+          if (pro) {
+            v.x = fmaxf(fmaf(v.x, sc.x, sh.x), 0.f); v.y = fmaxf(fmaf(v.y, sc.y, sh.y), 0.f);
+            v.z = fmaxf(fmaf(v.z, sc.z, sh.z), 0.f); v.w = fmaxf(fmaf(v.w, sc.w, sh.w), 0.f);
+          }
+          unsigned char* dA = sG + buf * RG_TILE_B + ((lane >> 3) + 8 * j) * A_ROW_B + ((j & 1) ? st_off_odd : st_off_even);
+          if (j < 8 || (lane >> 3) < 2) {                        // the last piece is rows 64, 65 only
+            if constexpr (F16) {
+              if (!pro) { v.x *= a_mul; v.y *= a_mul; v.z *= a_mul; v.w *= a_mul; }
+              uint2 h, l;
+              split2h(v.x, v.y, h.x, l.x);
+              split2h(v.z, v.w, h.y, l.y);
+              *reinterpret_cast<uint2*>(dA) = h;
+              *reinterpret_cast<uint2*>(dA + RG_PLANE_B) = l;
+            } else {
+              uint2 h, m, l;
+              split4(v, h, m, l);
+              *reinterpret_cast<uint2*>(dA) = h;
+              *reinterpret_cast<uint2*>(dA + RG_PLANE_B) = m;
+              *reinterpret_cast<uint2*>(dA + 2 * RG_PLANE_B) = l;
+            }
+          }
+        };
+        // LDS offsets of this lane's fragment rows for tap t, and the chunk swizzle of those rows (rows li+1+dx and
+        // li+33+dx swizzle alike; the zero row holds zeros in every chunk)
+        auto frag_addr = [&](int buf, int t, unsigned (&fa)[2], int& fsw) {
+          const int dx = (int)(signed char)((tap_word(t) >> 8) & 0xff);
+          fsw = ((li + 1 + dx) >> 2) & 3;
+#pragma unroll
+          for (int rm = 0; rm < 2; ++rm) {
+            const bool ok = (fr_taps[rm] >> t) & 1u;
+            fa[rm] = (ok ? (unsigned)((li + rm * 32 + 1 + dx) * A_ROW_B) : fr_zero) + (unsigned)(buf * RG_TILE_B);
+          }
+        };
+        auto read_frags_g = [&](int s_, const unsigned (&fa)[2], int fsw, u32x4 (&af)[2][NPL]) {
+          const unsigned chunk = (unsigned)(((s_ * 2 + lh) ^ fsw) << 4);
+#pragma unroll
+          for (int rm = 0; rm < 2; ++rm)
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl)
+              af[rm][pl] = *reinterpret_cast<const u32x4*>(sG + fa[rm] + chunk + pl * RG_PLANE_B);
+        };
+        const int n_grp = n_chunks * 3;
+        const int g_begin = (KS == 1) ? 0 : (n_grp * kh) / KS;
+        const int g_end = (KS == 1) ? n_grp : (n_grp * (kh + 1)) / KS;
+        if (g_begin < g_end) {
+          int c2 = g_begin / 3, ky2 = g_begin - 3 * c2, idx2 = g_begin;
+          auto next_group = [&]() {              // advance the cursor (clamped at the last group: repeats are harmless)
+            if (idx2 + 1 < g_end) { ++idx2; if (++ky2 == 3) { ky2 = 0; ++c2; } }
+            return group_ck(c2, ky2);
+          };
+          GroupInfo gc = group_ck(c2, ky2);
+          GroupInfo gn = next_group();
+          float4 sc_n = rsc_c, sh_n = rsh_c, sc_2 = rsc_c, sh_2 = rsh_c;
+          {
+            const TileInfo tb0 = tile_ct(gc.c, gc.t);
+#pragma unroll
+            for (int s_ = 0; s_ < 2; ++s_)
+#pragma unroll
+              for (int rn = 0; rn < RN; ++rn) load_b(tb0, s_, rn);
+            float4 sc0 = rsc_c, sh0 = rsh_c;
+            load_scale_c(gc.c, sc0, sh0);
+#pragma unroll
+            for (int j = 0; j < 9; ++j) load_piece(gc, j);
+            load_scale_c(gn.c, sc_n, sh_n);
+            // while those loads fly: the zero rows and the per-lane tap masks
+            if (lane < 16) {
+#pragma unroll
+              for (int buf = 0; buf < 2; ++buf)
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl)
+                  *reinterpret_cast<unsigned*>(sG + buf * RG_TILE_B + pl * RG_PLANE_B + RG_ZERO_ROW * A_ROW_B + lane * 4) = 0u;
+            }
+#pragma unroll
+            for (int rm = 0; rm < 2; ++rm) {
+              const unsigned m = (unsigned)(m0 + rm * 32 + li);
+              if ((int)m < a.M) {
+                const unsigned b = fdiv(m, a.div_ghw);
+                const unsigned rem = m - b * (unsigned)(g.GH * g.GW);
+                const int gy = (int)fdiv(rem, a.div_gw);
+                const int gx = (int)rem - gy * g.GW;
+                for (int t = 0; t < 9; ++t) {
+                  const int tp = tap_word(t);
+                  const int iy = gy + (int)(signed char)(tp & 0xff), ix = gx + (int)(signed char)((tp >> 8) & 0xff);
+                  if ((unsigned)iy < (unsigned)g.IH && (unsigned)ix < (unsigned)g.IW) fr_taps[rm] |= 1u << t;
+                }
+              }
+            }
+#pragma unroll
+            for (int j = 0; j < 9; ++j) { stage_piece(0, j, sc0, sh0); load_piece(gn, j); }
+          }
+          __builtin_amdgcn_wave_barrier();
+          unsigned fa[2];
+          int fsw;
+          frag_addr(0, gc.t, fa, fsw);
+          read_frags_g(0, fa, fsw, afA);
+          int bcur = 0;
+#pragma unroll 1
+          for (int G = g_begin; G < g_end; ++G) {
+            const GroupInfo g2 = next_group();
+            load_scale_c(g2.c, sc_2, sh_2);
+            const TileInfo tc1 = tile_ct(gc.c, gc.t + 1), tc2 = tile_ct(gc.c, gc.t + 2), tn0 = tile_ct(gn.c, gn.t);
+            const int bnxt = bcur ^ 1;
+            auto side = [&](int h, int rn) {       // staging of the next group, spread over half-steps 0..4
+#pragma unroll
+              for (int j = 2 * h + (rn * 2) / RN; j < 2 * h + ((rn + 1) * 2) / RN; ++j)
+                if (j < 9) { stage_piece(bnxt, j, sc_n, sh_n); load_piece(g2, j); }
+            };
+            read_frags_g(1, fa, fsw, afB);                          // tap 0, k-group 1
+            mfma_group(0, afA, tc1, [&](int rn) { side(0, rn); });
+            frag_addr(bcur, gc.t + 1, fa, fsw);
+            read_frags_g(0, fa, fsw, afA);                          // tap 1, k-group 0
+            mfma_group(1, afB, tc1, [&](int rn) { side(1, rn); });
+            read_frags_g(1, fa, fsw, afB);
+            mfma_group(0, afA, tc2, [&](int rn) { side(2, rn); });
+            frag_addr(bcur, gc.t + 2, fa, fsw);
+            read_frags_g(0, fa, fsw, afA);                          // tap 2, k-group 0
+            mfma_group(1, afB, tc2, [&](int rn) { side(3, rn); });
+            read_frags_g(1, fa, fsw, afB);
+            mfma_group(0, afA, tn0, [&](int rn) { side(4, rn); });
+            frag_addr(bnxt, gn.t, fa, fsw);
+            read_frags_g(0, fa, fsw, afA);                          // next group, tap 0, k-group 0
+            mfma_group(1, afB, tn0, [&](int) {});
+            gc = gn; gn = g2; bcur = bnxt; sc_n = sc_2; sh_n = sh_2;
+          }
+        }
+      }
+    } else {
     const int it_begin = (KS == 1) ? 0 : (n_iter * kh) / KS;
     const int it_end = (KS == 1) ? n_iter : (n_iter * (kh + 1)) / KS;
     if (it_begin < it_end) {
@@ -453,6 +631,7 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
       }
       mfma_group(1, afB, t1, [&](int) {});          // last tile, k-group 1
     }
+    }
 
     if constexpr (F16) {
       // back to the tensors' own units (v_ldexp_f32: exact).  Under SUM2 the first pass is re-expressed in the second pass's
@@ -480,7 +659,7 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
     if (KS > 1) {
       constexpr int BLK = 16 * 64;                       // floats of one accumulator block
       constexpr int STRIDE = (KS == 2 ? RN : 2 * RN - RN / 2) * BLK;    // most blocks a wave can have to park
-      static_assert(4 * STRIDE * 4 <= 4 * 2 * A_TILE_B, "exchange area must fit in the A-tile region");
+      static_assert(4 * STRIDE * 4 <= 4 * 2 * TILE_B, "exchange area must fit in the A-tile region");
       __syncthreads();                                   // every wave is done with its A tiles
       float* ex_all = reinterpret_cast<float*>(sA_all);  // [wave][parked blocks, in (rm, rn) order][16][64]
       auto owned_by = [&](int k, int rm, int rn) {       // ownership rule for the wave with K part k
@@ -684,13 +863,13 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
   }
 }
 
-template <int RN, int MODE, int KS, bool PRO, int NPL>
+template <int RN, int MODE, int KS, bool PRO, int NPL, bool ROWG>
 int launch_conv(const ConvArgs& a0, int n_groups, hipStream_t s) {
   constexpr int BN = 32 * RN;
-  constexpr int lds = 4 * 2 * A_TILE_B + 2 * 4 * BN * 2 * 4 + 4 * 64 * 4;
+  constexpr int lds = 4 * 2 * (ROWG ? RG_TILE_B : A_TILE_B) + 2 * 4 * BN * 2 * 4 + 4 * 64 * 4;
   static bool attr_set = false;          // > 64 KiB of dynamic LDS has to be requested once per kernel
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_k<RN, MODE, KS, PRO, NPL>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_k<RN, MODE, KS, PRO, NPL, ROWG>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
       return MPOSE_EINVAL;
     attr_set = true;
   }
@@ -698,7 +877,7 @@ int launch_conv(const ConvArgs& a0, int n_groups, hipStream_t s) {
   a.n_mtiles = (a.M + 256 / KS - 1) / (256 / KS);
   const int cmax = a.g.Cout1 > a.g.Cout0 ? a.g.Cout1 : a.g.Cout0;
   dim3 grid(a.n_mtiles * a.g.n_classes, (cmax + BN - 1) / BN, n_groups);
-  conv_igemm_k<RN, MODE, KS, PRO, NPL><<<grid, 256, lds, s>>>(a);
+  conv_igemm_k<RN, MODE, KS, PRO, NPL, ROWG><<<grid, 256, lds, s>>>(a);
   return launch_status();
 }
 
@@ -728,26 +907,53 @@ inline int pick_ks(const ConvArgs& a, int cmax, int n_groups) {
   return best;
 }
 
-template <int RN, int MODE, bool PRO, int NPL>
+// Row-group staging applies to the first pass of a stride-1 3x3 over an input of the output's size: one class,
+// nine acc == 0 taps first, each consecutive triple sharing dy (|dy| <= 1) with dx in {-1, 0, 1}.
+inline bool rowg_eligible(const mpose_conv_geom& g) {
+  if (g.n_classes != 1 || g.in_mul != 1 || g.IH != g.GH || g.IW != g.GW || (g.Cin % KC)) return false;
+  const mpose_tap_class& c = g.cls[0];
+  int n0 = 0;
+  for (int t = 0; t < c.n_taps; ++t) {
+    if (c.taps[t].acc == 0) { if (n0 != t) return false; ++n0; }
+  }
+  if (n0 != 9) return false;
+  for (int t = 0; t < 9; ++t) {
+    if (c.taps[t].dy != c.taps[3 * (t / 3)].dy || c.taps[t].dy < -1 || c.taps[t].dy > 1) return false;
+    if (c.taps[t].dx < -1 || c.taps[t].dx > 1) return false;
+  }
+  return true;
+}
+
+template <int RN, int MODE, bool PRO, int NPL, bool ROWG>
 int launch_conv_kp(const ConvArgs& a, int cmax, int n_groups, hipStream_t s) {
   const int ks = pick_ks<RN, NPL>(a, cmax, n_groups);
   if constexpr (RN > 1) {                  // (32-wide tiles never profit from a 4-way split)
-    if (ks == 4) return launch_conv<RN, MODE, 4, PRO, NPL>(a, n_groups, s);
+    if (ks == 4) return launch_conv<RN, MODE, 4, PRO, NPL, ROWG>(a, n_groups, s);
   }
-  if (ks >= 2) return launch_conv<RN, MODE, 2, PRO, NPL>(a, n_groups, s);
-  return launch_conv<RN, MODE, 1, PRO, NPL>(a, n_groups, s);
+  if (ks >= 2) return launch_conv<RN, MODE, 2, PRO, NPL, ROWG>(a, n_groups, s);
+  return launch_conv<RN, MODE, 1, PRO, NPL, ROWG>(a, n_groups, s);
 }
-template <int RN, int NPL>
+template <int RN, int NPL, bool ROWG>
 int launch_conv_ks_p(const ConvArgs& a, int mode, int cmax, int n_groups, hipStream_t s) {
-  if (mode == 1) return launch_conv_kp<RN, 1, false, NPL>(a, cmax, n_groups, s);
-  if (mode == 2) return launch_conv_kp<RN, 2, false, NPL>(a, cmax, n_groups, s);
-  if (a.op[0].in_scale != nullptr) return launch_conv_kp<RN, 0, true, NPL>(a, cmax, n_groups, s);
-  return launch_conv_kp<RN, 0, false, NPL>(a, cmax, n_groups, s);
+  if (mode == 1) return launch_conv_kp<RN, 1, false, NPL, ROWG>(a, cmax, n_groups, s);
+  if (mode == 2) return launch_conv_kp<RN, 2, false, NPL, ROWG>(a, cmax, n_groups, s);
+  if (a.op[0].in_scale != nullptr) return launch_conv_kp<RN, 0, true, NPL, ROWG>(a, cmax, n_groups, s);
+  return launch_conv_kp<RN, 0, false, NPL, ROWG>(a, cmax, n_groups, s);
+}
+static int rowg_env() {                    // MPOSE_CONV_ROWG=0 disables the row-group loop (A/B runs)
+  static int v = -2;
+  if (v == -2) { const char* e = getenv("MPOSE_CONV_ROWG"); v = e ? atoi(e) : 1; }
+  return v;
 }
 template <int RN>
 int launch_conv_ks(const ConvArgs& a, int mode, int cmax, int n_groups, hipStream_t s) {
-  if (a.flags & MPOSE_CONV_F16X3) return launch_conv_ks_p<RN, 2>(a, mode, cmax, n_groups, s);
-  return launch_conv_ks_p<RN, 3>(a, mode, cmax, n_groups, s);
+  if (a.flags & MPOSE_CONV_F16X3) {
+    if constexpr (RN > 1) {
+      if (rowg_env() && rowg_eligible(a.g)) return launch_conv_ks_p<RN, 2, true>(a, mode, cmax, n_groups, s);
+    }
+    return launch_conv_ks_p<RN, 2, false>(a, mode, cmax, n_groups, s);
+  }
+  return launch_conv_ks_p<RN, 3, false>(a, mode, cmax, n_groups, s);
 }
 
 // ---------------------------------------------------------------------------------------------
