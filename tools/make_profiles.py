@@ -42,15 +42,15 @@ for sub in ('pmc_sq', 'pmc_lds', 'pmc_fetch', 'pmc_write'):
         for r in csv.DictReader(open(f)):
             ctr[(short(r['Kernel_Name']).split('(')[0], int(r['Grid_Size']))][r['Counter_Name']].append(float(r['Counter_Value']))
 labels = {   # bench.py kernel tag -> (template, threads in the grid, algorithmic bytes) at B = 32, three column groups; the columns run
-    # conv_igemm_k / conv_wgrad_k in their three-product fp16 form (last template argument 2 / true): fp32 activations in and out
-    'conv:f_conv2/32x32/128->128': ('conv_igemm_k<4, 0, 2, true, 2>', 256 * 3 * 256, 3 * 32768 * (128 * 4 + 128 * 4) + 3 * 9 * 128 * 128 * 4),
-    'conv:d_conv2/32x32/128->128': ('conv_igemm_k<4, 0, 2, false, 2>', 256 * 3 * 256, 3 * 32768 * (128 * 4 + 128 * 4 + 128 * 4) + 3 * 9 * 128 * 128 * 4),
-    'conv:f_in_regular/32x32/128->128': ('conv_igemm_k<4, 1, 2, false, 2>', 256 * 3 * 256, 3 * 32768 * (128 * 4 + 2 * 128 * 4) + 3 * 10 * 128 * 128 * 4),
-    'conv:d_in_regular/32x32/128->128': ('conv_igemm_k<4, 2, 2, false, 2>', 256 * 3 * 256, 3 * 32768 * (2 * 128 * 4 + 128 * 4) + 3 * 10 * 128 * 128 * 4),
-    'conv:f_conv2/16x16/192->192': ('conv_igemm_k<3, 0, 1, true, 2>', None, 3 * 8192 * (192 * 4 + 192 * 4) + 3 * 9 * 192 * 192 * 4),
-    'conv:d_conv2/16x16/192->192': ('conv_igemm_k<3, 0, 1, false, 2>', None, 3 * 8192 * (192 * 4 + 192 * 8) + 3 * 9 * 192 * 192 * 4),
-    'conv:f_in_regular/16x16/192->192': ('conv_igemm_k<3, 1, 1, false, 2>', None, 3 * 8192 * (192 * 4 + 2 * 192 * 4) + 3 * 10 * 192 * 192 * 4),
-    'conv:d_in_regular/16x16/192->192': ('conv_igemm_k<3, 2, 1, false, 2>', None, 3 * 8192 * (2 * 192 * 4 + 192 * 4) + 3 * 10 * 192 * 192 * 4),
+    # conv_igemm_k / conv_wgrad_k in their three-product fp16 form with row-group staging (template arguments ..., 2, true): fp32 activations in and out
+    'conv:f_conv2/32x32/128->128': ('conv_igemm_k<4, 0, 2, true, 2, true>', 256 * 3 * 256, 3 * 32768 * (128 * 4 + 128 * 4) + 3 * 9 * 128 * 128 * 4),
+    'conv:d_conv2/32x32/128->128': ('conv_igemm_k<4, 0, 2, false, 2, true>', 256 * 3 * 256, 3 * 32768 * (128 * 4 + 128 * 4 + 128 * 4) + 3 * 9 * 128 * 128 * 4),
+    'conv:f_in_regular/32x32/128->128': ('conv_igemm_k<4, 1, 2, false, 2, true>', 256 * 3 * 256, 3 * 32768 * (128 * 4 + 2 * 128 * 4) + 3 * 10 * 128 * 128 * 4),
+    'conv:d_in_regular/32x32/128->128': ('conv_igemm_k<4, 2, 2, false, 2, true>', 256 * 3 * 256, 3 * 32768 * (2 * 128 * 4 + 128 * 4) + 3 * 10 * 128 * 128 * 4),
+    'conv:f_conv2/16x16/192->192': ('conv_igemm_k<3, 0, 1, true, 2, true>', None, 3 * 8192 * (192 * 4 + 192 * 4) + 3 * 9 * 192 * 192 * 4),
+    'conv:d_conv2/16x16/192->192': ('conv_igemm_k<3, 0, 1, false, 2, true>', None, 3 * 8192 * (192 * 4 + 192 * 8) + 3 * 9 * 192 * 192 * 4),
+    'conv:f_in_regular/16x16/192->192': ('conv_igemm_k<3, 1, 1, false, 2, true>', None, 3 * 8192 * (192 * 4 + 2 * 192 * 4) + 3 * 10 * 192 * 192 * 4),
+    'conv:d_in_regular/16x16/192->192': ('conv_igemm_k<3, 2, 1, false, 2, true>', None, 3 * 8192 * (2 * 192 * 4 + 192 * 4) + 3 * 10 * 192 * 192 * 4),
     'wgrad:f_conv2/32x32/128->128': ('conv_wgrad_k<4, 4, true>', None, 3 * 32768 * 128 * 8),
     'wgrad:f_in_regular/32x32/128->128': ('conv_wgrad_k<4, 4, true>', None, 3 * 32768 * 128 * 12),
     'wgrad:f_conv2/16x16/192->192': ('conv_wgrad_k<3, 3, true>', None, 3 * 8192 * 192 * 8),
