@@ -52,12 +52,15 @@ constexpr int A_ROW_B = 64;
 constexpr int A_PLANE_B = 64 * A_ROW_B;
 constexpr int A_TILE_B = 3 * A_PLANE_B;   // hi / mid / lo planes of one 64-pixel x 32-channel tile
 // Row-group staging (ROWG; stride-1 3x3, first pass): one staged tile serves the three dx taps of a kernel row.  It holds the
-// 66 consecutive input pixels  m0-1+dy*IW .. m0+64+dy*IW  (rows 0..65) plus an all-zero row that the fragment reads of
-// out-of-image taps are redirected to.
-constexpr int RG_ROWS = 68;
-constexpr int RG_ZERO_ROW = 66;
+// 66 consecutive input pixels  m0-1+dy*IW .. m0+64+dy*IW  (rows 0..65) plus SIXTEEN all-zero rows (80..95) that the fragment
+// reads of out-of-image taps are redirected to: a redirected lane takes zero row 80 + (its row & 15), i.e. the banks (and the
+// chunk swizzle) of the row it would have read, so the 16 lanes of a ds_read_b128 still touch every bank once (one shared zero
+// row cost a two-way conflict wherever a 16-lane group held an image-border pixel: 0.09-0.27 of the LDS cycles).
+// Two planes per tile: the row-group loop exists in the three-product form only.
+constexpr int RG_ROWS = 96;
+constexpr int RG_ZERO_ROW = 80;
 constexpr int RG_PLANE_B = RG_ROWS * A_ROW_B;
-constexpr int RG_TILE_B = 3 * RG_PLANE_B;
+constexpr int RG_TILE_B = 2 * RG_PLANE_B;
 
 struct ConvArgs {
   mpose_conv_geom g;
@@ -167,6 +170,7 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
   constexpr bool ACC1 = MODE == 1, SUM2 = MODE == 2;
   constexpr bool F16 = NPL == 2;
   constexpr int TILE_B = ROWG ? RG_TILE_B : A_TILE_B;      // LDS bytes reserved per staging buffer
+  static_assert(!ROWG || NPL == 2, "row-group tiles hold two planes");
   constexpr int NPASS = MODE ? 2 : 1;
   constexpr int BM = 256 / KS;
   constexpr int BN = 32 * RN;
@@ -412,7 +416,6 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
         const int ld4 = in_ld * 4;
         const int q_lane = m0 + (lane >> 3);                   // pixel staged by this lane in piece 0 is q_lane + qs
         const unsigned rg_voff = (unsigned)q_lane * (unsigned)ld4 + (unsigned)(a_col4 * 16);
-        const unsigned fr_zero = (unsigned)(RG_ZERO_ROW * A_ROW_B);
         unsigned fr_taps[2] = {0u, 0u};                        // bit t: tap t of output pixel m0 + 32*rm + li is inside the image
         struct GroupInfo { unsigned a_soff; int qs; int c; int t; };
         auto group_ck = [&](int c, int ky) {
@@ -470,7 +473,8 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
 #pragma unroll
           for (int rm = 0; rm < 2; ++rm) {
             const bool ok = (fr_taps[rm] >> t) & 1u;
-            fa[rm] = (ok ? (unsigned)((li + rm * 32 + 1 + dx) * A_ROW_B) : fr_zero) + (unsigned)(buf * RG_TILE_B);
+            const int row = li + rm * 32 + 1 + dx;
+            fa[rm] = (unsigned)((ok ? row : RG_ZERO_ROW + (row & 15)) * A_ROW_B) + (unsigned)(buf * RG_TILE_B);
           }
         };
         auto read_frags_g = [&](int s_, const unsigned (&fa)[2], int fsw, u32x4 (&af)[2][NPL]) {
@@ -505,13 +509,11 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
             for (int j = 0; j < 9; ++j) load_piece(gc, j);
             load_scale_c(gn.c, sc_n, sh_n);
             // while those loads fly: the zero rows and the per-lane tap masks
-            if (lane < 16) {
 #pragma unroll
-              for (int buf = 0; buf < 2; ++buf)
+            for (int buf = 0; buf < 2; ++buf)
 #pragma unroll
-                for (int pl = 0; pl < NPL; ++pl)
-                  *reinterpret_cast<unsigned*>(sG + buf * RG_TILE_B + pl * RG_PLANE_B + RG_ZERO_ROW * A_ROW_B + lane * 4) = 0u;
-            }
+              for (int pl = 0; pl < NPL; ++pl)       // 16 rows x 64 bytes = 64 lanes x 16 bytes
+                *reinterpret_cast<u32x4*>(sG + buf * RG_TILE_B + pl * RG_PLANE_B + RG_ZERO_ROW * A_ROW_B + lane * 16) = u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
             for (int rm = 0; rm < 2; ++rm) {
               const unsigned m = (unsigned)(m0 + rm * 32 + li);
