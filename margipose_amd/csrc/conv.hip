@@ -891,7 +891,7 @@ int launch_conv(const ConvArgs& a0, int n_groups, hipStream_t s) {
 // predicted, 98/108/103 measured (same order).  The choice is made for a NOMINAL batch of 32 images, not the actual
 // one: the summation order of a sample then does not depend on how many other samples share its launch, so a
 // data-parallel shard reproduces the full batch's per-sample results bit for bit.
-template <int RN, int NPL>
+template <int RN, int NPL, bool ROWG>
 inline int pick_ks(const ConvArgs& a, int cmax, int n_groups) {
   const int n_iter = (a.g.Cin / KC) * a.g.cls[0].n_taps;
   const long m_nominal = 32l * a.g.GH * a.g.GW;
@@ -902,8 +902,13 @@ inline int pick_ks(const ConvArgs& a, int cmax, int n_groups) {
     const long wgs = ((m_nominal + 256 / ks - 1) / (256 / ks)) * a.g.n_classes * ((cmax + 32 * RN - 1) / (32 * RN)) * n_groups;
     const long rounds = (wgs + 255) / 256;
     const double exchange = ks == 1 ? 0.0 : (ks == 2 ? 1.5 : 2.5);
-    const double per_iter = NPL == 2 ? 0.55 + 0.27 * RN : 0.65 + 0.49 * RN;      // (three instead of six products per k-group)
-    const double cost = (double)rounds * (9.5 + exchange + (double)((n_iter + ks - 1) / ks) * per_iter);
+    // (three instead of six products per k-group; with row-group staging a tap costs ~0.3 us per 32 output channels -- the
+    //  192-channel layers: 2.7 us per row group of three taps at RN = 3 -- and the 128-channel launch measured FASTER with 384
+    //  workgroups of twelve row groups than with 768 of six (25.5 vs 26.2-27.1 ms per training step), which puts the fixed
+    //  cost of a round at >= 17 us there: nine staged pieces and the tap masks before the first MFMA)
+    const double per_iter = ROWG ? 0.05 + 0.29 * RN : (NPL == 2 ? 0.55 + 0.27 * RN : 0.65 + 0.49 * RN);
+    const double fixed = ROWG ? 18.0 : 9.5;
+    const double cost = (double)rounds * (fixed + exchange + (double)((n_iter + ks - 1) / ks) * per_iter);
     if (ks == 1 || cost < 0.97 * best_cost) { best = ks; best_cost = cost; }     // ties go to the smaller split
   }
   return best;
@@ -928,7 +933,7 @@ inline bool rowg_eligible(const mpose_conv_geom& g) {
 
 template <int RN, int MODE, bool PRO, int NPL, bool ROWG>
 int launch_conv_kp(const ConvArgs& a, int cmax, int n_groups, hipStream_t s) {
-  const int ks = pick_ks<RN, NPL>(a, cmax, n_groups);
+  const int ks = pick_ks<RN, NPL, ROWG>(a, cmax, n_groups);
   if constexpr (RN > 1) {                  // (32-wide tiles never profit from a 4-way split)
     if (ks == 4) return launch_conv<RN, MODE, 4, PRO, NPL, ROWG>(a, n_groups, s);
   }
