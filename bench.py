@@ -62,8 +62,8 @@ def traffic_fields(label):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=40)
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=32, help='per-GPU batch (weak scaling)')
     ap.add_argument('--stages', type=int, default=3)
     ap.add_argument('--size', type=int, default=256)
@@ -237,8 +237,9 @@ def main():
 
     for _ in range(args.warmup):
         loss = step()
-    # Per-kernel HIP events (for the roofline block) bracket every conv / tail launch of EVERY TENTH timed step (steps 0, 10, ...),
-    # which runs eagerly: an event is a barrier packet between two kernels, and ~800 of them per step cost ~5 % of the step.
+    # Per-kernel HIP events (for the roofline block) bracket every conv / tail launch of EVERY FORTIETH timed step (steps 0, 40, ...: one per default run),
+    # which runs eagerly with the serial stream schedule: an event is a barrier packet between two kernels, and such a step takes
+    # ~45 ms instead of ~26 -- at one in ten (the earlier cadence, with 10 default steps) that was +1.9 ms on the reported step time.
     timer = KernelTimer() if (rank == 0 and not args.no_kernel_timing) else None
     if timer is not None:
         timer.calibrate()
@@ -246,7 +247,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        on = timer is not None and i % 10 == 0
+        on = timer is not None and i % 40 == 0
         if on:
             model.inner.engine().timer = timer
             timed_steps += 1
