@@ -163,6 +163,15 @@ typedef struct {
   const float* w0_amax;
   const float* w1_amax;
   float* out0_amax;                    /* optional, with the fused output stage of conv.hip's engine: amax slot of y0 */
+  /* BatchNorm-backward sums of the CONSUMER of out0, taken while out0 is stored (conv.hip's engine; out0 = g is the gradient
+   * w.r.t. relu(bn_a(red_a)) + bn_b(red_b), models/margipose_model.py:34-40): red_sums[n][4] += (sum g*m, sum g*m*red_a, sum g,
+   * sum g*red_b) over the launch's pixels, m = [red_scale[n] * red_a + red_shift[n] > 0] -- what mpose_bn_bwd_reduce computes in
+   * a pass of its own.  red_a / red_b: fp32 NHWC tensors of out0's shape.  Not combined with stats0 / stats1. */
+  const float* red_a;
+  const float* red_b;
+  const float* red_scale;
+  const float* red_shift;
+  double* red_sums;
 } mpose_conv_operands;
 
 #define MPOSE_CONV_ACCUMULATE 1   /* out0 += result */

@@ -102,7 +102,8 @@ class ConvOperands(ctypes.Structure):
                 ('mask_src', c_void_p), ('mask_scale', c_void_p), ('mask_shift', c_void_p), ('in1', c_void_p),
                 ('epi_scale0', c_void_p), ('epi_shift0', c_void_p), ('add_src', c_void_p), ('add_scale', c_void_p),
                 ('add_shift', c_void_p), ('out0_planes', c_void_p),
-                ('in_amax', c_void_p), ('in1_amax', c_void_p), ('w0_amax', c_void_p), ('w1_amax', c_void_p), ('out0_amax', c_void_p)]
+                ('in_amax', c_void_p), ('in1_amax', c_void_p), ('w0_amax', c_void_p), ('w1_amax', c_void_p), ('out0_amax', c_void_p),
+                ('red_a', c_void_p), ('red_b', c_void_p), ('red_scale', c_void_p), ('red_shift', c_void_p), ('red_sums', c_void_p)]
 
 
 class WgradOperands(ctypes.Structure):

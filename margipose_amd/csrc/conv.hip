@@ -735,6 +735,11 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
     const bool epi_add = epi && op.add_src != nullptr;
     const bool epi_relu = (a.flags & MPOSE_CONV_EPI_RELU0) != 0;
     float epi_amax = 0.f;
+    // BatchNorm-backward sums of the tensor's consumer, taken from the values as they are stored (see mpose_conv_operands.red_*)
+    const bool red = (oset == 0) && op.red_sums != nullptr;
+    float rs0[RN], rs1[RN], rs2[RN], rs3[RN];
+#pragma unroll
+    for (int rn = 0; rn < RN; ++rn) rs0[rn] = rs1[rn] = rs2[rn] = rs3[rn] = 0.f;
     const int old_ = oset ? g.out_ld1 : g.out_ld0;
     const int out_ld = old_ > 0 ? old_ : cout;
     const unsigned out_bytes = (unsigned)((((long)g.B * g.OH * g.OW - 1) * out_ld + cout) * 4);
@@ -814,6 +819,25 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
             for (int r = 0; r < 16; ++r)       // (rows beyond M: their stores are dropped, but relu(et) + at need not be zero)
               epi_amax = fmaxf(epi_amax, voff[r] < 0xFFFFF000u ? fabsf(v[r]) : 0.f);
           }
+          if (red) {
+            const __amdgpu_buffer_rsrc_t rs_ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(op.red_a), 0, out_bytes, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rs_rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(op.red_b), 0, out_bytes, 0x00020000);
+            const float ms = op.red_scale[n], mt = op.red_shift[n];
+            float xa[16], xb[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              xa[r] = buf_load1(rs_ra, voff[r] + (unsigned)(rn * 128), 0);
+              xb[r] = buf_load1(rs_rb, voff[r] + (unsigned)(rn * 128), 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {       // (rows beyond M hold v = 0 and read 0: they add nothing)
+              const float ga = fmaf(xa[r], ms, mt) > 0.f ? v[r] : 0.f;
+              rs0[rn] += ga;
+              rs1[rn] = fmaf(ga, xa[r], rs1[rn]);
+              rs2[rn] += v[r];
+              rs3[rn] = fmaf(v[r], xb[r], rs3[rn]);
+            }
+          }
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[r]), rs_o, (int)(voff[r] + (unsigned)(rn * 128)), 0, 0);
@@ -830,6 +854,14 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
         if (!(m == m)) m = __uint_as_float(0x7f800000u);
         unsigned* dst = reinterpret_cast<unsigned*>(op.out0_amax + (blockIdx.x % MPOSE_AMAX_SUBSLOTS) * MPOSE_AMAX_STRIDE);
         if (__float_as_uint(m) > __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(dst, __float_as_uint(m));
+      }
+    }
+    if (red) {       // (sRed is free: red_* and stats* exclude each other) [4 waves][BN][4]
+#pragma unroll
+      for (int rn = 0; rn < RN; ++rn) {
+        const float t0 = rs0[rn] + __shfl_xor(rs0[rn], 32, 64), t1 = rs1[rn] + __shfl_xor(rs1[rn], 32, 64);
+        const float t2 = rs2[rn] + __shfl_xor(rs2[rn], 32, 64), t3 = rs3[rn] + __shfl_xor(rs3[rn], 32, 64);
+        if (lh == 0) *reinterpret_cast<float4*>(sRed + (wave * BN + rn * 32 + li) * 4) = make_float4(t0, t1, t2, t3);
       }
     }
     if (stats != nullptr) {
@@ -862,6 +894,16 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
         atomicAdd(stats + (size_t)n * 2 + 1, (double)q);
       }
     }
+  }
+  if (op.red_sums != nullptr && tid < BN && n0 + tid < g.Cout0) {
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float4 d = *reinterpret_cast<const float4*>(sRed + (w * BN + tid) * 4);
+      t.x += d.x; t.y += d.y; t.z += d.z; t.w += d.w;
+    }
+    double* d = op.red_sums + (size_t)(n0 + tid) * 4;
+    atomicAdd(d, (double)t.x); atomicAdd(d + 1, (double)t.y); atomicAdd(d + 2, (double)t.z); atomicAdd(d + 3, (double)t.w);
   }
 }
 
@@ -1418,6 +1460,10 @@ extern "C" int mpose_conv_fwd(const mpose_conv_geom* geom, const mpose_conv_oper
     if (ops[i].add_src && (!ops[i].epi_scale0 || !ops[i].add_scale || !ops[i].add_shift)) return MPOSE_EINVAL;
     if ((ops[i].epi_scale0 != nullptr) != (ops[0].epi_scale0 != nullptr) || (ops[i].add_src != nullptr) != (ops[0].add_src != nullptr)) return MPOSE_EINVAL;
     if (ops[i].out0_amax && !ops[i].epi_scale0) return MPOSE_EINVAL;
+    if (ops[i].red_sums && ((flags & MPOSE_CONV_PLANES_IN) || !ops[i].red_a || !ops[i].red_b || !ops[i].red_scale || !ops[i].red_shift ||
+                            ops[i].stats0 || ops[i].stats1 || ops[i].epi_scale0 || (acc1 && !sum_inputs)))
+      return MPOSE_EINVAL;
+    if ((ops[i].red_sums != nullptr) != (ops[0].red_sums != nullptr)) return MPOSE_EINVAL;
     if (acc1 && (!ops[i].w1 || !ops[i].out1)) return MPOSE_EINVAL;
     if ((ops[i].in_scale != nullptr) != (ops[0].in_scale != nullptr)) return MPOSE_EINVAL;
     if (ops[i].in_scale && (acc1 || !ops[i].in_shift)) return MPOSE_EINVAL;

@@ -1045,15 +1045,23 @@ class Engine:
                 cnt = B * Hout * Hout
                 Cs = b0.cout_s
                 jb = (t * 10 + i) * 9
-                # (1) sums of g, g*c2, g*sc -> BN2 / BN_shortcut backward coefficients, dgamma, dbeta
-                rops = []
-                for c, b in enumerate(grp):
-                    ro = BnBwdReduceOperands()
-                    ro.g, ro.a, ro.b = g[c].data_ptr(), sv['c2'][c].data_ptr(), sv['sc'][c].data_ptr()
-                    ro.a_scale, ro.a_shift = self._bnf_ptr(b.bn2, 0), self._bnf_ptr(b.bn2, 1)     # ReLU after the second BN
-                    ro.sums = self._stats_ptr(b.bn2, True)
-                    rops.append(ro)
-                self.bn_bwd_reduce(rops, Hout * Hout, B, Cs)
+                if i == 9:
+                    sums_done = False        # (g comes from the tail)
+                # this block's data-gradient can take block i-1's sums unless the axis permutation sits between them (after
+                # block 4: it mixes channels and pixels) or the plane engine runs; MPOSE_FUSE_BN_SUMS=0 for A/B runs
+                fuse_sums = (not planes) and i >= 1 and not (i == 5 and any(sp != 0 for sp in self.spaces)) and \
+                    os.environ.get('MPOSE_FUSE_BN_SUMS', '1') != '0'
+                # (1) sums of g, g*c2, g*sc -> BN2 / BN_shortcut backward coefficients, dgamma, dbeta -- already taken by the
+                #     data-gradient that produced g (the epilogue of the next block's step (6)) where that was possible
+                if not sums_done:
+                    rops = []
+                    for c, b in enumerate(grp):
+                        ro = BnBwdReduceOperands()
+                        ro.g, ro.a, ro.b = g[c].data_ptr(), sv['c2'][c].data_ptr(), sv['sc'][c].data_ptr()
+                        ro.a_scale, ro.a_shift = self._bnf_ptr(b.bn2, 0), self._bnf_ptr(b.bn2, 1)     # ReLU after the second BN
+                        ro.sums = self._stats_ptr(b.bn2, True)
+                        rops.append(ro)
+                    self.bn_bwd_reduce(rops, Hout * Hout, B, Cs)
                 run_coef(jb, 6)
                 d_c2 = [torch.empty(B, Hout, Hout, Cs, **f32) for _ in range(3)]
                 d_sc = [torch.empty(B, Hout, Hout, Cs, **f32) for _ in range(3)]
@@ -1143,8 +1151,14 @@ class Engine:
                     if f16:
                         op.in_amax, op.in1_amax = self._amax_b(t, i, 1, c), self._amax_b(t, i, 2, c)
                         op.w0_amax, op.w1_amax = b.conv_in.amax_ptr, b.conv_sc.amax_ptr
+                    if fuse_sums:            # d_x is the previous block's g: its BatchNorm-backward sums while it is stored
+                        pb, psv = self.stage_blocks[t][i - 1][c], saved[i - 1]
+                        op.red_a, op.red_b = psv['c2'][c].data_ptr(), psv['sc'][c].data_ptr()
+                        op.red_scale, op.red_shift = self._bnf_ptr(pb.bn2, 0), self._bnf_ptr(pb.bn2, 1)
+                        op.red_sums = self._stats_ptr(pb.bn2, True)
                     ops.append(op)
                 self.conv(self.geom(kd, B, Hout, b0), ops, 2 | pflags)
+                sums_done = fuse_sums
                 g = d_x
                 if i == 5 and any(sp != 0 for sp in self.spaces):     # the permutation is an involution
                     outs = [g[c] if self.spaces[c] == 0 else torch.empty_like(g[c]) for c in range(3)]

@@ -393,3 +393,54 @@ def test_fused_output_stage(B, H, cin, cout, add, f16):
     # stats / mask / accumulate do not combine with the output stage
     op.stats0 = slot.data_ptr()
     assert L.mpose_conv_fwd(ctypes.byref(g), (ConvOperands * 1)(op), 1, (F16X3 if f16 else 0) | 16, _lib.stream_ptr()) == -22
+
+
+@pytest.mark.parametrize('B,H,cin,cout,f16', [(2, 32, 128, 128, True), (4, 16, 192, 192, True), (3, 8, 32, 64, False)])
+def test_consumer_bn_sums_in_epilogue(B, H, cin, cout, f16):
+    """mpose_conv_operands.red_*: while the two-input data-gradient stores g = conv3x3(in, w0) + conv1x1(in1, w1), its epilogue
+    accumulates the BatchNorm-backward sums of g's consumer -- (sum g*m, sum g*m*a, sum g, sum g*b) per channel with
+    m = [scale*a + shift > 0] -- what mpose_bn_bwd_reduce computes in a pass of its own (reference: autograd through
+    models/margipose_model.py:34-40)."""
+    from margipose_amd import _lib, engine as eng
+    from margipose_amd._lib import ConvOperands
+    L = _lib.lib()
+    rng = np.random.default_rng(B * 7 + H)
+    x0 = torch.from_numpy(rng.standard_normal((B, cin, H, H))).float()
+    x1 = torch.from_numpy(rng.standard_normal((B, cin, H, H)) * 0.1).float()
+    w0 = torch.from_numpy(rng.standard_normal((cout, cin, 3, 3)) * (2.0 / (9 * cin)) ** 0.5).float()
+    w1 = torch.from_numpy(rng.standard_normal((cout, cin, 1, 1)) * (2.0 / cin) ** 0.5).float()
+    a = torch.from_numpy(rng.standard_normal((B, cout, H, H))).float()
+    b = torch.from_numpy(rng.standard_normal((B, cout, H, H))).float()
+    sc = torch.from_numpy(rng.uniform(-1.5, 1.5, cout)).float()
+    sh = torch.from_numpy(rng.standard_normal(cout) * 0.3).float()
+    if f16:
+        p0, wa0, npad = _pack(L, _lib, eng, w0.cuda(), cout, cin, 9)
+        p1, wa1, _ = _pack(L, _lib, eng, w1.cuda(), cout, cin, 1)
+    else:
+        import tests.test_conv_gpu as T6
+        p0, npad, _ = T6._pack(L, _lib, eng, w0.cuda(), cout, cin, 9)
+        p1, _, _ = T6._pack(L, _lib, eng, w1.cuda(), cout, cin, 1)
+    t9 = [(ky - 1, kx - 1, ky * 3 + kx, 0) for ky, kx in eng.TAPS3]
+    g = eng._geom(B, H, cin, H, cout, cout, H, 1, 1, [(0, 0, t9 + [(0, 0, 0, 1)])], npad, npad)
+    to = lambda t: t.permute(0, 2, 3, 1).contiguous().cuda()
+    x0g, x1g, ag, bg = to(x0), to(x1), to(a), to(b)
+    xa = _amax(L, _lib, [x0g, x1g], cin)
+    out = torch.full((B, H, H, cout), float('nan'), device='cuda')
+    sums = torch.zeros(cout, 4, dtype=torch.float64, device='cuda')
+    scg, shg = sc.cuda(), sh.cuda()
+    op = ConvOperands()
+    op.in_, op.in1, op.w0, op.w1, op.out0 = x0g.data_ptr(), x1g.data_ptr(), p0.data_ptr(), p1.data_ptr(), out.data_ptr()
+    if f16:
+        op.in_amax, op.in1_amax, op.w0_amax, op.w1_amax = xa[0].data_ptr(), xa[1].data_ptr(), wa0.data_ptr(), wa1.data_ptr()
+    op.red_a, op.red_b, op.red_scale, op.red_shift, op.red_sums = ag.data_ptr(), bg.data_ptr(), scg.data_ptr(), shg.data_ptr(), sums.data_ptr()
+    _lib.check(L.mpose_conv_fwd(ctypes.byref(g), (ConvOperands * 1)(op), 1, 2 | (F16X3 if f16 else 0), _lib.stream_ptr()), 'conv')
+    torch.cuda.synchronize()
+    gout = out.cpu().double().permute(0, 3, 1, 2)                      # the sums are defined on the values the kernel stored
+    m = (torch.addcmul(sh.view(1, -1, 1, 1), a, sc.view(1, -1, 1, 1)) > 0).double()
+    ref = torch.stack([(gout * m).sum((0, 2, 3)), (gout * m * a.double()).sum((0, 2, 3)), gout.sum((0, 2, 3)),
+                       (gout * b.double()).sum((0, 2, 3))], 1)
+    scale = torch.stack([gout.abs().sum((0, 2, 3)), (gout * a.double()).abs().sum((0, 2, 3)), gout.abs().sum((0, 2, 3)),
+                         (gout * b.double()).abs().sum((0, 2, 3))], 1)
+    assert float(((sums.cpu() - ref).abs() / scale).max()) < 2e-6      # fp32 partial sums over <= 256 rows, fp64 across workgroups
+    op.stats0 = sums.data_ptr()                                       # forward statistics and consumer sums exclude each other
+    assert L.mpose_conv_fwd(ctypes.byref(g), (ConvOperands * 1)(op), 1, 2 | (F16X3 if f16 else 0), _lib.stream_ptr()) == -22
