@@ -7,6 +7,7 @@ import subprocess
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, 'csrc')
 LIB_PATH = os.path.join(PKG_DIR, 'libmargipose_hip.so')
+LOG_PATH = os.path.join(CSRC, 'build.log')      # hipcc's output of the last build, kernel-resource-usage remarks included
 HIPCC_FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function',
                '-Wno-unused-variable', '-Wno-unused-but-set-variable', '-fno-slp-vectorize']
 
@@ -38,17 +39,22 @@ def build(force=False, verbose=False):
     procs = []
     for src in sources():
         obj = os.path.splitext(src)[0] + '.o'
-        cmd = [_hipcc()] + HIPCC_FLAGS + ['-c', src, '-o', obj]
+        cmd = [_hipcc()] + HIPCC_FLAGS + ['-Rpass-analysis=kernel-resource-usage', '-c', src, '-o', obj]
         if verbose:
             print(' '.join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
         objs.append(obj)
+    log = []
     for src, p in procs:
         out, _ = p.communicate()
+        text = out.decode(errors='replace')
         if p.returncode != 0:
-            raise RuntimeError('hipcc failed on %s:\n%s' % (src, out.decode(errors='replace')))
-        if verbose and out:
-            print(out.decode(errors='replace'))
+            raise RuntimeError('hipcc failed on %s:\n%s' % (src, '\n'.join(l for l in text.splitlines() if 'remark:' not in l)))
+        log.append('==== %s\n%s' % (os.path.basename(src), text))
+        if verbose:
+            print('\n'.join(l for l in text.splitlines() if 'remark:' not in l))
+    with open(LOG_PATH, 'w') as f:
+        f.write('\n'.join(log))
     cmd = [_hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB_PATH] + objs
     subprocess.run(cmd, check=True)
     return LIB_PATH
