@@ -301,7 +301,7 @@ def main():
                             'unpinned, random init)' if args.stem == 'inceptionv4' else
                             '%s (reference option, models/margipose_model.py:119-137; torchvision layers restated, unpinned, '
                             'random init)' % args.stem if args.stem.startswith('resnet') else
-                            'patch8 (in-repo deterministic stem; the InceptionV4 stem is available with --stem inceptionv4)'), 'parallelism': 'dp%d' % world, 'overlap_wgrad': (not args.no_overlap_wgrad) and world == 1,
+                            'patch8 (in-repo deterministic stem; the InceptionV4 stem is available with --stem inceptionv4)'), 'parallelism': 'dp%d' % world, 'overlap_wgrad': (not args.no_overlap_wgrad) and (world == 1 or model.inner.engine().dp_overlap()),
                    'step_dispatch': 'hip graph replay (train_helpers.GraphedTrainStep)' if use_graph else 'eager launches',
                    'conv_engine': {0: 'conv_igemm_k / conv_wgrad_k (conv.hip), six bf16 products per fp32 multiply-add',
                                    1: 'plane engine (conv_p.hip)',

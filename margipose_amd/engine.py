@@ -665,14 +665,25 @@ class Engine:
         if t0 is not None:
             self.timer.stop('wgrad:' + g._name, t0, g._flops * len(ops))
 
+    def dp_overlap(self):
+        e = os.environ.get('MPOSE_DP_OVERLAP')
+        if e is not None:
+            return e != '0'
+        try:
+            return torch.distributed.get_backend(self.dp[0]) == 'nccl'
+        except Exception:
+            return False
+
     def wgrad_async(self, g, ops, n_split, tensors):
         """Weight-gradient launch on the side stream: it only feeds the final unpack, so it overlaps the next
         block's data-gradient chain and the small BatchNorm kernels.  `tensors` are the buffers it reads: their
         memory must not be recycled by the caching allocator before the side stream is done with them."""
-        # Serial when a KernelTimer brackets the launches (clean durations) and under data parallelism: with a gloo process
-        # group on a shared GPU the side stream made the step 2-6x slower (188-568 vs 95 ms), and the RCCL path cannot be tried
-        # on the single-GPU boxes of this round -- MPOSE_DP_OVERLAP=1 enables it for a measurement on a multi-GPU node.
-        if not self.overlap_wgrad or self.timer is not None or (self.dp is not None and not os.environ.get('MPOSE_DP_OVERLAP')):
+        # Serial when a KernelTimer brackets the launches (clean durations).  Under data parallelism the side stream stays on
+        # with the RCCL backend (same stream logic as single-GPU: the bucket's all-reduce is issued after the main stream has
+        # waited for the side stream and unpacked the partials) and off with gloo, whose host-staged collectives made a shared-GPU
+        # step 2-6x slower with it (188-568 vs 95 ms); MPOSE_DP_OVERLAP=0/1 overrides.  (The RCCL combination has not run on
+        # hardware: the pool has no multi-GPU node.  tests/test_model_gpu.py runs the schedule under gloo, functionally.)
+        if not self.overlap_wgrad or self.timer is not None or (self.dp is not None and not self.dp_overlap()):
             self.wgrad(g, ops, n_split)
             return
         main = torch.cuda.current_stream()
