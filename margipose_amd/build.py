@@ -8,7 +8,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, 'csrc')
 LIB_PATH = os.path.join(PKG_DIR, 'libmargipose_hip.so')
 LOG_PATH = os.path.join(CSRC, 'build.log')      # hipcc's output of the last build, kernel-resource-usage remarks included
-HIPCC_FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function',
+HIPCC_FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++20', '-fPIC', '-Wall', '-Wno-unused-function',
                '-Wno-unused-variable', '-Wno-unused-but-set-variable', '-fno-slp-vectorize']
 
 

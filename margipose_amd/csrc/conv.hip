@@ -1422,6 +1422,8 @@ using namespace mpose;
 
 int mpose_conv_planes_launch(const mpose_conv_geom* geom, const mpose_conv_operands* ops, int n_groups, int flags, int mode,
                              int cmax, void* stream);      // conv_p.hip
+int mpose_wgrad_rows_units(const mpose_conv_geom* geom);                                                                       // wgrad.hip
+int mpose_wgrad_rows_launch(const mpose_conv_geom* geom, const mpose_wgrad_operands* ops, int n_groups, int n_split, void* stream);
 
 static int check_geom(const mpose_conv_geom* g) {
   if (!g || g->Cin <= 0 || (g->Cin % KC) || g->n_classes < 1 || g->n_classes > MPOSE_MAX_CLASSES) return MPOSE_EINVAL;
@@ -1523,6 +1525,7 @@ extern "C" int mpose_conv_fwd(const mpose_conv_geom* geom, const mpose_conv_oper
 
 extern "C" int mpose_conv_wgrad_tiles(const mpose_conv_geom* geom) {
   if (check_geom(geom)) return -1;
+  if (const int rows = mpose_wgrad_rows_units(geom)) return rows;      // the row-of-taps kernel (wgrad.hip) takes this geometry
   int entries = 0;
   for (int c = 0; c < geom->n_classes; ++c) entries += geom->cls[c].n_taps;
   return entries * (geom->Cin / (32 * wgrad_blocks(geom->Cin))) * (geom->Cout0 / (32 * wgrad_blocks(geom->Cout0)));
@@ -1563,6 +1566,9 @@ extern "C" int mpose_conv_wgrad(const mpose_conv_geom* geom, const mpose_wgrad_o
   const long in_bytes = (long)geom->B * geom->IH * geom->IW * (geom->in_ld > 0 ? geom->in_ld : geom->Cin) * 4;
   const long g_bytes = (long)geom->B * geom->OH * geom->OW * (geom->out_ld0 > geom->Cout0 ? geom->out_ld0 : geom->Cout0) * 4;
   if (in_bytes >= 0x7FFFFF00l || g_bytes >= 0x7FFFFF00l) return MPOSE_EINVAL;        // signed 32-bit byte offsets
+  // stride-1 geometries in the three-product form: one staged operand pair per kernel ROW of taps (wgrad.hip)
+  rc = mpose_wgrad_rows_launch(geom, ops, n_groups, n_split, stream);
+  if (rc != MPOSE_ENOSYS) return rc;
   a.div_gh = make_fastdiv((unsigned)geom->GH);
   a.n_split = n_split;
   a.rows_per_split = (n_rows + n_split - 1) / n_split;
