@@ -30,6 +30,10 @@
 #include <utility>
 #include "common.h"
 
+#ifndef WG_EXP
+#define WG_EXP 0      // timing experiments (tools/wgrad_exp.sh; wrong results): 1 no fragment reads, 2 no staging, 4 no barrier, 8 no MFMA
+#endif
+
 namespace mpose {
 namespace {
 
@@ -76,6 +80,7 @@ struct WgRowsArgs {
   int n_ktiles, n_ntiles;
   int n_split, rows_per_split;
   int n_groups, chunk, total;
+  int exp_flags;                   // timing experiments (MPOSE_EXP): 1 = no operand traffic, 2 = no partial-sum stores, 4 = operands re-read from one place (wrong results)
   FastDiv div_h;
 };
 
@@ -109,25 +114,27 @@ constexpr int lds_pitch(int C) {
 
 template <int WK, int WN, int KB, int NB>
 struct Cfg {
+  static constexpr int NW = WK * WN, NTH = 64 * NW;              // waves / threads per workgroup
   static constexpr int KT = 32 * KB * WK, NT = 32 * NB * WN;
   static constexpr int QX = KT / 4, QG = NT / 4;                 // float4 items per pixel
-  static constexpr int NXB = (2 * KT + 255) / 256;               // body items (8 pixels x QX) per octet and thread
-  static constexpr int NGB = (2 * NT + 255) / 256;
+  static constexpr int NXI = (16 * QX + NTH - 1) / NTH;          // body items (2 octets x 8 pixels x QX) per thread
+  static constexpr int NGI = (16 * QG + NTH - 1) / NTH;
+  static constexpr bool X_OSTATIC = (8 * QX) % NTH == 0, G_OSTATIC = (8 * QG) % NTH == 0;     // an item's octet is the same for all threads
   static constexpr int NPX = 10;                                 // staged input pixels per octet: halo, 8, halo
   static constexpr int PX = lds_pitch(KT), PG = lds_pitch(NT);
   static constexpr int HW = KT % 128 == 0 ? 2 : 4;               // floats of a halo pixel per thread
   static constexpr int XPL_DATA = 2 * NPX * PX, GPL_DATA = 2 * 8 * PG;       // bytes of one fp16 plane (two octets) ...
-  // ... + a dump area: 8 bytes per thread for stores that must go nowhere (+ the octet offset that is added to every store)
-  static constexpr int XPL = XPL_DATA + 2048 + NPX * PX, GPL = GPL_DATA + 2048 + 8 * PG;
+  static constexpr int XPL = XPL_DATA + 8 * NTH, GPL = GPL_DATA + 8 * NTH;   // ... + a dump area: 8 bytes per thread for stores that must go nowhere
   static constexpr int BUF = 2 * XPL + 2 * GPL;                  // h and l planes of both operands
   static constexpr int LDS = 2 * BUF;
+  static_assert(4 * KT / HW <= NTH, "one halo item per thread at most");
 };
 
-template <int WK, int WN, int KB, int NB, bool PRO>
-__global__ __launch_bounds__(256, 1) void conv_wgrad_rows_k(WgRowsArgs a) {
+template <int WK, int WN, int KB, int NB, bool PRO, bool PAIR>
+__global__ __launch_bounds__(64 * WK * WN, WK * WN / 4) void conv_wgrad_rows_k(WgRowsArgs a) {
   using C = Cfg<WK, WN, KB, NB>;
-  static_assert(WK * WN == 4, "four waves");
-  constexpr int KT = C::KT, NT = C::NT, QX = C::QX, QG = C::QG, NXB = C::NXB, NGB = C::NGB, NPX = C::NPX, PX = C::PX, PG = C::PG;
+  static_assert(C::NW == 4 || C::NW == 8, "one or two waves per SIMD");
+  constexpr int KT = C::KT, NT = C::NT, QX = C::QX, QG = C::QG, NXI = C::NXI, NGI = C::NGI, NPX = C::NPX, PX = C::PX, PG = C::PG, NTH = C::NTH;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lh = lane >> 5;
@@ -163,16 +170,20 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_rows_k(WgRowsArgs a) {
   const int kg = f16_scale_exp(amax_gather(second ? op.gout1_amax : op.gout0_amax));
   const float x_mul = pow2f(kx), g_mul = pow2f(kg);
 
-  // ---- per-thread staging items (loop invariant): global byte offset inside an octet, LDS byte offset inside a plane ----
-  unsigned xb_voff[NXB], xb_lds[NXB], g_voff[NGB], g_lds[NGB];
-  float4 xb_sc[NXB], xb_sh[NXB];
+  // ---- per-thread staging items (loop invariant).  The body pixels of both octets are one list of 16 * QX float4 items handed out
+  //      thread by thread: item -> (octet, pixel j, channel quad q); kept per item: the global byte offset relative to the octet,
+  //      which octet, and the LDS byte offset inside a plane (threads without an item: out-of-range offset, dump area). ----
+  unsigned xb_voff[NXI], xb_lds[NXI], g_voff[NGI], g_lds[NGI];
+  bool xb_o[NXI], g_o[NGI];
+  float4 xb_sc[NXI], xb_sh[NXI];
 #pragma unroll
-  for (int i = 0; i < NXB; ++i) {
-    const int it = tid + 256 * i;
-    const int j = it / QX, q = it - j * QX;
-    const bool ok = it < 8 * QX && k0 + 4 * q < a.Cin;
-    xb_voff[i] = ok ? (unsigned)(j * x_pix + (k0 + 4 * q) * 4) : kBig;
-    xb_lds[i] = it < 8 * QX ? (unsigned)((j + 1) * PX + q * 8) : (unsigned)(C::XPL_DATA + tid * 8);      // (surplus threads: dump area)
+  for (int i = 0; i < NXI; ++i) {
+    const int it = tid + NTH * i;
+    const int o = it / (8 * QX), r = it - o * (8 * QX), j = r / QX, q = r - j * QX;
+    const bool ok = it < 16 * QX && k0 + 4 * q < a.Cin;
+    xb_o[i] = o != 0;
+    xb_voff[i] = ok && !(a.exp_flags & 1) ? (unsigned)(j * x_pix + (k0 + 4 * q) * 4) : kBig;
+    xb_lds[i] = it < 16 * QX ? (unsigned)((o * NPX + j + 1) * PX + q * 8) : (unsigned)(C::XPL_DATA + tid * 8);
     xb_sc[i] = make_float4(x_mul, x_mul, x_mul, x_mul);
     xb_sh[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (pro && ok) {
@@ -182,12 +193,13 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_rows_k(WgRowsArgs a) {
     }
   }
 #pragma unroll
-  for (int i = 0; i < NGB; ++i) {
-    const int it = tid + 256 * i;
-    const int j = it / QG, q = it - j * QG;
-    const bool ok = it < 8 * QG && n0 + 4 * q < a.Cout;
-    g_voff[i] = ok ? (unsigned)(j * g_pix + (n0 + 4 * q) * 4) : kBig;
-    g_lds[i] = it < 8 * QG ? (unsigned)(j * PG + q * 8) : (unsigned)(C::GPL_DATA + tid * 8);
+  for (int i = 0; i < NGI; ++i) {
+    const int it = tid + NTH * i;
+    const int o = it / (8 * QG), r = it - o * (8 * QG), j = r / QG, q = r - j * QG;
+    const bool ok = it < 16 * QG && n0 + 4 * q < a.Cout;
+    g_o[i] = o != 0;
+    g_voff[i] = ok && !(a.exp_flags & 1) ? (unsigned)(j * g_pix + (n0 + 4 * q) * 4) : kBig;
+    g_lds[i] = it < 16 * QG ? (unsigned)((o * 8 + j) * PG + q * 8) : (unsigned)(C::GPL_DATA + tid * 8);
   }
   // halo pixels of the two octets (three-tap units), HW floats per thread: thread t takes (octet, side) = t / TPS, channels
   // (t % TPS) * HW .. + HW-1.  Threads beyond 4 * TPS read nothing (out-of-range offset) and store into the dump area.
@@ -228,8 +240,9 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_rows_k(WgRowsArgs a) {
   const int v_begin = Hv > 0 ? valid_before(r_split0) : 0, v_end = Hv > 0 ? valid_before(r_end) : 0;
   const int n_octets = (v_end - v_begin) * n_oct;
   const int n_steps = (n_octets + 1) >> 1;
-  const unsigned x_step = (unsigned)(8 * x_pix), g_step = (unsigned)(8 * g_pix);
-  const unsigned x_jump = (unsigned)(ady * a.W * x_pix), g_jump = (unsigned)(ady * a.W * g_pix);
+  const bool exp_still = (a.exp_flags & 4) != 0;          // (timing experiment: every step re-reads the first octets -> cache-resident operands)
+  const unsigned x_step = exp_still ? 0u : (unsigned)(8 * x_pix), g_step = exp_still ? 0u : (unsigned)(8 * g_pix);
+  const unsigned x_jump = exp_still ? 0u : (unsigned)(ady * a.W * x_pix), g_jump = exp_still ? 0u : (unsigned)(ady * a.W * g_pix);
   struct Cursor { unsigned xs, gs; int vy, o, left; };    // left = octets still to hand out (<= 0: dummy octets, gradient reads 0)
   Cursor cur;
   {
@@ -256,23 +269,51 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_rows_k(WgRowsArgs a) {
     return o;
   };
 
+  struct Oct2 { Oct o[2]; };
+  // The two octets of a step.  PAIR (an even number of octets per row): they are neighbours in one row, which halves the
+  // scalar work -- the inner halo pixels are each other's border pixels, and there is no odd tail.
+  auto take2 = [&](Cursor& c, Oct2& oo) {
+    if constexpr (PAIR) {
+      const unsigned xs1 = c.xs + x_step, pen = c.left > 0 ? 0u : kBig;
+      oo.o[0].xs = c.xs; oo.o[0].gs = c.gs; oo.o[1].xs = xs1; oo.o[1].gs = c.gs + g_step;
+      oo.o[0].hl = c.o > 0 ? c.xs - (unsigned)x_pix : kBig;
+      oo.o[0].hr = xs1;
+      oo.o[1].hl = xs1 - (unsigned)x_pix;
+      oo.o[1].hr = c.o + 2 < n_oct ? xs1 + x_step : kBig;
+      oo.o[0].gpen = pen; oo.o[1].gpen = pen;
+      const bool row_done = c.o + 2 == n_oct;
+      const bool img_done = row_done && c.vy + 1 == Hv;
+      c.xs = xs1 + x_step + (img_done ? x_jump : 0u);
+      c.gs += 2 * g_step + (img_done ? g_jump : 0u);
+      c.left -= 2;
+      c.o = row_done ? 0 : c.o + 2;
+      c.vy = img_done ? 0 : c.vy + (row_done ? 1 : 0);
+    } else {
+      oo.o[0] = take(c); oo.o[1] = take(c);
+    }
+  };
+
   // ---- staging: global -> registers -> (BN + ReLU prologue, scale, split) -> LDS.  The operands of a step are a list of ITEMS
   //      (one load per thread each): X body of octet 0 / 1 (NXB each), G of octet 0 / 1 (NGB each), the X halos (three-tap units).
   //      Item i of step s+1 is staged, and its registers refilled with item i of step s+2, between two MFMAs of step s.  All of
   //      it is branch-free (threads without an item read out of range and store into the dump area), so that a step is ONE basic
   //      block and the staging instructions can be interleaved with the MFMAs one by one. ----
-  constexpr int I_G = 2 * NXB, I_HALO = 2 * NXB + 2 * NGB;
+  constexpr int I_G = NXI, I_HALO = NXI + NGI;
   float4 raw[I_HALO + 1];
-  struct Oct2 { Oct o[2]; };
   unsigned h_base_prev = kBig;          // offset the halo registers were loaded from (HW == 4; HW == 2 keeps it in raw[].z)
   auto load_item = [&](auto ic, const Oct2& oo) {
     constexpr int I = decltype(ic)::value;
     if constexpr (I < I_G) {
-      constexpr int o = I / NXB, i = I % NXB;
-      raw[I] = buf_load4(rs_x, xb_voff[i], oo.o[o].xs);
+      if constexpr (C::X_OSTATIC) raw[I] = buf_load4(rs_x, xb_voff[I], oo.o[(I * NTH) / (8 * QX)].xs);
+      else raw[I] = buf_load4(rs_x, xb_voff[I] + (xb_o[I] ? oo.o[1].xs : oo.o[0].xs), 0);
     } else if constexpr (I < I_HALO) {
-      constexpr int o = (I - I_G) / NGB, i = (I - I_G) % NGB;
-      raw[I] = buf_load4(rs_g, g_voff[i] + oo.o[o].gpen, oo.o[o].gs);
+      constexpr int i = I - I_G;
+      if constexpr (C::G_OSTATIC) {
+        constexpr int o = (i * NTH) / (8 * QG);
+        raw[I] = buf_load4(rs_g, g_voff[i] + oo.o[o].gpen, oo.o[o].gs);
+      } else {
+        raw[I] = buf_load4(rs_g, g_voff[i] + (g_o[i] ? oo.o[1].gs + oo.o[1].gpen : oo.o[0].gs + oo.o[0].gpen), 0);
+      }
     } else {
       const unsigned s0 = h_side ? oo.o[0].hr : oo.o[0].hl, s1 = h_side ? oo.o[1].hr : oo.o[1].hl;
       const unsigned base = h_ok ? (h_oct ? s1 : s0) : kBig;
@@ -304,13 +345,11 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_rows_k(WgRowsArgs a) {
   auto stage_item = [&](auto ic, unsigned char* buf) {
     constexpr int I = decltype(ic)::value;
     if constexpr (I < I_G) {
-      constexpr int o = I / NXB, i = I % NXB;
-      split_store4(buf, C::XPL, (unsigned)(o * NPX * PX) + xb_lds[i], prologue4(raw[I], xb_sc[i], xb_sh[i]));
+      split_store4(buf, C::XPL, xb_lds[I], prologue4(raw[I], xb_sc[I], xb_sh[I]));
     } else if constexpr (I < I_HALO) {
-      constexpr int o = (I - I_G) / NGB, i = (I - I_G) % NGB;
       float4 v = raw[I];
       v.x *= g_mul; v.y *= g_mul; v.z *= g_mul; v.w *= g_mul;
-      split_store4(buf + 2 * C::XPL, C::GPL, (unsigned)(o * 8 * PG) + g_lds[i], v);
+      split_store4(buf + 2 * C::XPL, C::GPL, g_lds[I - I_G], v);
     } else {
       // (a padding pixel under the prologue: relu(shift) need not be zero -> the pieces are cleared)
       if constexpr (HW == 4) {
@@ -371,11 +410,11 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_rows_k(WgRowsArgs a) {
           l[kb] = read_tr8(cb + C::XPL + fa_x + (t + TOFF) * PX + kb * 64, PX);
         }
       };
-      oo.o[0] = take(cur); oo.o[1] = take(cur);
+      take2(cur, oo);
       for_items([&](auto ic) { load_item(ic, oo); });
-      oo.o[0] = take(cur); oo.o[1] = take(cur);
+      take2(cur, oo);
       for_items([&](auto ic) { stage_item(ic, smem); load_item(ic, oo); });       // step 0 -> LDS, step 1 -> registers
-      oo.o[0] = take(cur); oo.o[1] = take(cur);                                    // step 2
+      take2(cur, oo);                                                              // step 2
       lds_barrier();
       read_b(smem, bh[0], bl[0]);
       read_a(smem, 0, ah[0], al[0]);
@@ -383,45 +422,50 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_rows_k(WgRowsArgs a) {
         constexpr int BUFI = decltype(buf_c)::value;
         const unsigned char* cb = smem + BUFI * C::BUF;
         unsigned char* nb_ = smem + (BUFI ^ 1) * C::BUF;
+        // One phase = the KB*NB MFMAs of one (tap, product) + the other work that belongs beside them.  The phases before the
+        // barrier form one scheduling region, the phases after it another: inside a region the MFMAs are spread evenly and
+        // every gap between two of them gets a few of the other instructions (at most five hide behind an MFMA when a SIMD
+        // holds one wave: MI355X_MICROARCH.md).
+        auto phase = [&](auto ph_c) {
+          constexpr int PH = decltype(ph_c)::value, t = PH / 3, p = PH % 3;
+          constexpr int aset = (t + BUFI) & 1;
+          constexpr int i_lo = PH < NSP ? (PH * NI + NSP - 1) / NSP : NI, i_hi = PH < NSP ? ((PH + 1) * NI + NSP - 1) / NSP : NI;
+          if constexpr (p == 0 && t + 1 < NTAP && !(WG_EXP & 1)) read_a(cb, t + 1, ah[aset ^ 1], al[aset ^ 1]);      // the next tap, three phases ahead
+          if constexpr (PH == PB && !(WG_EXP & 1)) {     // the next step's first fragments
+            read_b(nb_, bh[BUFI ^ 1], bl[BUFI ^ 1]);
+            read_a(nb_, 0, ah[BUFI ^ 1], al[BUFI ^ 1]);
+          }
+#pragma unroll
+          for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+              if constexpr (!(WG_EXP & 8)) acc[t][kb][nb] = mfma_f16(p == 0 ? al[aset][kb] : ah[aset][kb], p == 1 ? bl[BUFI][nb] : bh[BUFI][nb], acc[t][kb][nb]);
+              else asm volatile("" :: "v"(al[aset][kb]), "v"(ah[aset][kb]), "v"(bl[BUFI][nb]), "v"(bh[BUFI][nb]));
+          [&]<int... Js>(std::integer_sequence<int, Js...>) {
+            (((WG_EXP & 2) ? (void)0 : stage_item(std::integral_constant<int, i_lo + Js>{}, nb_), load_item(std::integral_constant<int, i_lo + Js>{}, oo)), ...);
+          }(std::make_integer_sequence<int, i_hi - i_lo>{});
+          if constexpr (PH == PB) take2(cur, oo);        // octets of the next step's loads
+        };
         __builtin_amdgcn_sched_barrier(0);
-        [&]<int... Ps>(std::integer_sequence<int, Ps...>) {
-          ([&] {
-            constexpr int PH = Ps, t = PH / 3, p = PH % 3;
-            constexpr int aset = (t + BUFI) & 1;
-            constexpr int i_lo = PH < NSP ? (PH * NI + NSP - 1) / NSP : NI, i_hi = PH < NSP ? ((PH + 1) * NI + NSP - 1) / NSP : NI;
-            if constexpr (PH == PB) lds_barrier();
-            if constexpr (p == 0 && t + 1 < NTAP) read_a(cb, t + 1, ah[aset ^ 1], al[aset ^ 1]);      // the next tap, three phases ahead
-            if constexpr (PH == PB) {                      // the next step's first fragments
-              read_b(nb_, bh[BUFI ^ 1], bl[BUFI ^ 1]);
-              read_a(nb_, 0, ah[BUFI ^ 1], al[BUFI ^ 1]);
-            }
+        [&]<int... Ps>(std::integer_sequence<int, Ps...>) { (phase(std::integral_constant<int, Ps>{}), ...); }(std::make_integer_sequence<int, PB>{});
 #pragma unroll
-            for (int kb = 0; kb < KB; ++kb)
+        for (int m = 0; m < PB * KB * NB; ++m) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+          __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+          if (m % 4 == 3) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (!(WG_EXP & 4)) lds_barrier();
+        [&]<int... Ps>(std::integer_sequence<int, Ps...>) { (phase(std::integral_constant<int, PB + Ps>{}), ...); }(std::make_integer_sequence<int, NPH - PB>{});
 #pragma unroll
-              for (int nb = 0; nb < NB; ++nb)
-                acc[t][kb][nb] = mfma_f16(p == 0 ? al[aset][kb] : ah[aset][kb], p == 1 ? bl[BUFI][nb] : bh[BUFI][nb], acc[t][kb][nb]);
-            [&]<int... Js>(std::integer_sequence<int, Js...>) {
-              ((stage_item(std::integral_constant<int, i_lo + Js>{}, nb_), load_item(std::integral_constant<int, i_lo + Js>{}, oo)), ...);
-            }(std::make_integer_sequence<int, i_hi - i_lo>{});
-            // octets of the next step's loads (scalar work, spread over the phases without staging)
-            if constexpr (PH == PB) oo.o[0] = take(cur);
-            if constexpr (PH == (PB + 1 < NPH ? PB + 1 : PB)) oo.o[1] = take(cur);
-            // issue order inside the phase: the LDS reads first, then one MFMA followed by a slice of the other work
-            if constexpr (PH == PB) __builtin_amdgcn_sched_group_barrier(0x100, 4 * (KB + NB), 0);
-            else if constexpr (p == 0 && t + 1 < NTAP) __builtin_amdgcn_sched_group_barrier(0x100, 4 * KB, 0);
-#pragma unroll
-            for (int m = 0; m < KB * NB; ++m) {
-              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-              if constexpr (PH >= PB) {
-                __builtin_amdgcn_sched_group_barrier(0x004, 7, 0);
-              } else {
-                __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
-                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-              }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-          }(), ...);
-        }(std::make_integer_sequence<int, NPH>{});
+        for (int m = 0; m < (NPH - PB) * KB * NB; ++m) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x004, 2, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
       };
       int s = 0;
 #pragma unroll 1
@@ -446,7 +490,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_rows_k(WgRowsArgs a) {
 #pragma unroll
           for (int rg = 0; rg < 4; ++rg) {
             const int k4 = (k0 + (wk * KB + kb) * 32) / 4 + 2 * rg + lh;
-            if (k4 < k4_total && n < a.npad && n0 + (wn * NB + nb) * 32 < a.Cout) {
+            if (k4 < k4_total && n < a.npad && n0 + (wn * NB + nb) * 32 < a.Cout && !(a.exp_flags & 2)) {
               const float4 v = make_float4(__builtin_ldexpf(acc[t][kb][nb][4 * rg], -(kx + kg)), __builtin_ldexpf(acc[t][kb][nb][4 * rg + 1], -(kx + kg)),
                                            __builtin_ldexpf(acc[t][kb][nb][4 * rg + 2], -(kx + kg)), __builtin_ldexpf(acc[t][kb][nb][4 * rg + 3], -(kx + kg)));
               *reinterpret_cast<float4*>(base + ((long)k4 * a.npad + n) * 4) = v;
@@ -459,12 +503,12 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_rows_k(WgRowsArgs a) {
   else body(std::integral_constant<int, 1>{});
 }
 
-template <int WK, int WN, int KB, int NB, bool PRO>
-int launch_rows_p(WgRowsArgs& a, hipStream_t s) {
+template <int WK, int WN, int KB, int NB, bool PRO, bool PAIR>
+int launch_rows_pp(WgRowsArgs& a, hipStream_t s) {
   using C = Cfg<WK, WN, KB, NB>;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_rows_k<WK, WN, KB, NB, PRO>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_rows_k<WK, WN, KB, NB, PRO, PAIR>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS) != hipSuccess)
       return MPOSE_EINVAL;
     attr_set = true;
   }
@@ -472,8 +516,12 @@ int launch_rows_p(WgRowsArgs& a, hipStream_t s) {
   a.n_ntiles = (a.Cout + C::NT - 1) / C::NT;
   a.total = a.n_units * a.n_ktiles * a.n_ntiles * a.n_split * a.n_groups;
   a.chunk = (a.total + 7) / 8;
-  conv_wgrad_rows_k<WK, WN, KB, NB, PRO><<<dim3(8 * a.chunk), 256, C::LDS, s>>>(a);
+  conv_wgrad_rows_k<WK, WN, KB, NB, PRO, PAIR><<<dim3(8 * a.chunk), C::NTH, C::LDS, s>>>(a);
   return launch_status();
+}
+template <int WK, int WN, int KB, int NB, bool PRO>
+int launch_rows_p(WgRowsArgs& a, hipStream_t s) {
+  return (a.W & 15) == 0 ? launch_rows_pp<WK, WN, KB, NB, PRO, true>(a, s) : launch_rows_pp<WK, WN, KB, NB, PRO, false>(a, s);
 }
 template <int WK, int WN, int KB, int NB>
 int launch_rows(WgRowsArgs& a, hipStream_t s) {
@@ -481,20 +529,33 @@ int launch_rows(WgRowsArgs& a, hipStream_t s) {
 }
 
 // tile shape per (Cin, Cout): 0 = 128 x 128 (2x2 waves of 64 x 64), 1 = 192 x 64 (2x2 waves of 96 x 32), 2 = 128 x 32 (4x1 waves of
-// 32 x 32), 3 = 64 x 64 (2x2 waves of 32 x 32)
+// 32 x 32), 3 = 64 x 64 (2x2 waves of 32 x 32).  MPOSE_WGRAD_192=1 (experiments) runs shapes 0 / 1 with EIGHT waves per workgroup
+// (two per SIMD; 2x4 waves of 64 x 32 / 96 x 32, tiles 128 x 128 / 192 x 128): measured slower -- 95 vs 88 us on the 128-channel
+// layers -- because eight waves read 1.75x the fragment bytes from LDS for the same MFMAs (profiles/r3_wgrad_loop_parts.txt).
 inline int rows_shape(int cin, int cout) {
   if (cin % 192 == 0 && cout % 64 == 0) return 1;
   if (cout <= 32) return cin > 64 ? 2 : 3;
   if (cin <= 64 && cout <= 64) return 3;
   return 0;
 }
+inline bool wide192() {
+  static int v = -2;
+  if (v == -2) { const char* e = getenv("MPOSE_WGRAD_192"); v = e ? atoi(e) : 0; }
+  return v != 0;
+}
 inline void shape_tiles(int shape, int& kt, int& nt) {
   switch (shape) {
-    case 1: kt = 192; nt = 64; break;
+    case 1: kt = 192; nt = wide192() ? 128 : 64; break;
     case 2: kt = 128; nt = 32; break;
     case 3: kt = 64; nt = 64; break;
     default: kt = 128; nt = 128; break;
   }
+}
+
+int rows_env() {               // MPOSE_WGRAD_ROWS=0: conv_wgrad_k everywhere (A/B runs); 2: the row form also for launches of single taps
+  static int v = -2;
+  if (v == -2) { const char* e = getenv("MPOSE_WGRAD_ROWS"); v = e ? atoi(e) : 1; }
+  return v;
 }
 
 // Kernel rows / single taps of a geometry, or -1 when the row form does not apply (then conv.hip's conv_wgrad_k runs).
@@ -530,13 +591,12 @@ int build_units(const mpose_conv_geom* g, RowUnit* units, int* n_widx0, int* n_w
   }
   *n_widx0 = max0 + 1;
   *n_widx1 = max1 + 1;
+  // a launch of single taps only (1x1 convolutions, k x 1 columns) stages as much per step as a kernel row for a third of the
+  // MFMAs: conv_wgrad_k keeps those unless MPOSE_WGRAD_ROWS=2
+  bool any3 = false;
+  for (int i = 0; i < n_units; ++i) any3 |= units[i].ntap == 3;
+  if (!any3 && rows_env() < 2) return -1;
   return n_units;
-}
-
-int rows_env() {               // MPOSE_WGRAD_ROWS=0: conv_wgrad_k everywhere (A/B runs)
-  static int v = -2;
-  if (v == -2) { const char* e = getenv("MPOSE_WGRAD_ROWS"); v = e ? atoi(e) : 1; }
-  return v;
 }
 
 }  // namespace
@@ -583,11 +643,12 @@ int mpose_wgrad_rows_launch(const mpose_conv_geom* geom, const mpose_wgrad_opera
   a.rows_per_split = (a.n_rows + n_split - 1) / n_split;
   a.n_groups = n_groups;
   a.div_h = make_fastdiv((unsigned)geom->GH);
+  if (const char* e = getenv("MPOSE_EXP")) a.exp_flags = atoi(e);
   hipStream_t s = (hipStream_t)stream;
   switch (rows_shape(geom->Cin, geom->Cout0)) {
-    case 1: return launch_rows<2, 2, 3, 1>(a, s);
+    case 1: return wide192() ? launch_rows<2, 4, 3, 1>(a, s) : launch_rows<2, 2, 3, 1>(a, s);
     case 2: return launch_rows<4, 1, 1, 1>(a, s);
     case 3: return launch_rows<2, 2, 1, 1>(a, s);
-    default: return launch_rows<2, 2, 2, 2>(a, s);
+    default: return wide192() ? launch_rows<2, 4, 2, 1>(a, s) : launch_rows<2, 2, 2, 2>(a, s);
   }
 }

@@ -503,9 +503,11 @@ class Engine:
                     coef_job(cj[base + 3 + c], b.bns, b.bn2, 4, 2, 3, cnt)
                     coef_job(cj[base + 6 + c], b.bn1, b.bn1, 2, 0, 1, cnt)
                     slots_in = B * (hw_in(i) if b.kind == 'up' else hw_out(i)) ** 2
-                    unpack_job(uj[base + 3 * c], b.conv2, self._n_split(cnt, self._wg_tiles(b, 'conv2')))
-                    unpack_job(uj[base + 3 * c + 1], b.conv_in, self._n_split(slots_in, self._wg_tiles(b, 'in')))
-                    unpack_job(uj[base + 3 * c + 2], b.conv_sc, self._n_split(slots_in, self._wg_tiles(b, 'in')))
+                    gname = {'regular': 'f_in_regular', 'down': 'f_in_down', 'up': 'f_in_up'}[b.kind]
+                    nsp_in = self.wg_n_split(self.geom(gname, B, hw_in(i), b))
+                    unpack_job(uj[base + 3 * c], b.conv2, self.wg_n_split(self.geom('f_conv2', B, hw_out(i), b)))
+                    unpack_job(uj[base + 3 * c + 1], b.conv_in, nsp_in)
+                    unpack_job(uj[base + 3 * c + 2], b.conv_sc, nsp_in)
         if self.stem is None:
             coef_job(cj[self.T * 90], self.stem_bn, self.stem_bn, 4, 0, 1, B * F * F)
             unpack_job(uj[self.T * 90], self.stem_conv, self._n_split(B * F * F, 2, 1))
@@ -706,10 +708,19 @@ class Engine:
         return self._tables_for(B, S // 8)['part_ptr'][id(conv)]
 
     def stem_n_split(self, B, S, op):
-        H = S // op.dst.div
-        cin_s = op.conv.cin_s
-        tiles = op.kh * op.kw * (cin_s // (32 * self._wg_blocks(cin_s))) * (op.cout // (32 * self._wg_blocks(op.cout)))
-        return self._n_split(B * H * 32, tiles, 1)
+        return self.wg_n_split(self.stem.geom(op, B, S, 'f'), 1, width32=True)
+
+    def wg_n_split(self, g, groups=3, width32=False):
+        """Split-K factor of one weight-gradient launch: the library says how many workgroups one pixel split of one column
+        takes for this geometry (mpose_conv_wgrad_tiles: it knows which kernel will run), _n_split fills the chip with them."""
+        nsp = getattr(g, '_n_split', None)
+        if nsp is None:
+            tiles = int(lib().mpose_conv_wgrad_tiles(ctypes.byref(g)))
+            if tiles <= 0:
+                raise _lib.MposeError('mpose_conv_wgrad_tiles rejected the geometry %s' % getattr(g, '_name', '?'))
+            slots = g.B * g.GH * (32 if width32 else g.GW)
+            nsp = g._n_split = self._n_split(slots, tiles, groups)
+        return nsp
 
     def finalize(self, tb, first, n, train):
         base = tb['fin'].data_ptr() + first * BN_DT.itemsize
@@ -1116,8 +1127,8 @@ class Engine:
                     if f16:
                         wo.in_amax, wo.gout0_amax = self._amax_f(t, i, 1, c), self._amax_b(t, i, 0, c)
                     wops.append(wo)
-                self.wgrad_async(self.geom('f_conv2', B, Hout, b0), wops, self._n_split(cnt, self._wg_tiles(b0, 'conv2')),
-                                 sv['c1'] + d_c2)
+                g_w2 = self.geom('f_conv2', B, Hout, b0)
+                self.wgrad_async(g_w2, wops, self.wg_n_split(g_w2), sv['c1'] + d_c2)
                 # (4) BN1 backward
                 run_coef(jb + 6, 3)
                 d_c1 = [torch.empty(B, Hout, Hout, Cs, **f32) for _ in range(3)]
@@ -1147,8 +1158,8 @@ class Engine:
                         wo.in_amax = self._amax_f(t, i, 0, _first_same(sv['x'], c))
                         wo.gout0_amax, wo.gout1_amax = self._amax_b(t, i, 1, c), self._amax_b(t, i, 2, c)
                     wops.append(wo)
-                self.wgrad_async(self.geom(gname, B, Hin, b0), wops, self._n_split(slots, self._wg_tiles(b0, 'in')),
-                                 list(sv['x']) + d_c1 + d_sc)
+                g_w1 = self.geom(gname, B, Hin, b0)
+                self.wgrad_async(g_w1, wops, self.wg_n_split(g_w1), list(sv['x']) + d_c1 + d_sc)
                 # (6) dgrad of conv_in + the shortcut's dgrad: one launch, the shortcut as a tap on a second input
                 d_x = [torch.empty(B, Hin, Hin, b0.cin_s, **f32) for _ in range(3)]
                 kd = {'regular': 'd_in_regular', 'down': 'd_in_down', 'up': 'd_in_up'}[b0.kind]
@@ -1268,15 +1279,6 @@ class Engine:
     @staticmethod
     def _wg_blocks(c):
         return 4 if c % 128 == 0 else (3 if c % 96 == 0 else (2 if c % 64 == 0 else 1))
-
-    @staticmethod
-    def _wg_tiles(blk, which):
-        """Work units of one column's weight-gradient launch (mirrors mpose_conv_wgrad_tiles)."""
-        cs = blk.cout_s
-        n_ct = cs // (32 * Engine._wg_blocks(cs))
-        if which == 'conv2':
-            return 9 * n_ct * n_ct
-        return 10 * (blk.cin_s // (32 * Engine._wg_blocks(blk.cin_s))) * n_ct
 
     def grads_from_flat(self, flat):
         out = []
