@@ -172,6 +172,11 @@ typedef struct {
   const float* red_scale;
   const float* red_shift;
   double* red_sums;
+  /* Per-channel extremes of out0 (conv.hip's engine, with stats0): mm0[2n] / mm0[2n+1] accumulate (atomic max) the sortable
+   * keys (mpose_float_key) of max out0[.., n] and of max -out0[.., n] over the launch's pixels; zero the array first (key 0 is
+   * below every float).  mpose_bn_finalize turns them into the EXACT largest magnitude of relu(scale * out0 + shift) -- the
+   * operand of the next MPOSE_CONV_F16X3 convolution -- without a measuring pass (an affine map followed by ReLU is monotone). */
+  unsigned* mm0;
 } mpose_conv_operands;
 
 #define MPOSE_CONV_ACCUMULATE 1   /* out0 += result */
@@ -310,6 +315,9 @@ typedef struct {
   const float* conv_bias;              /* optional bias of the producing conv (folded: the conv kernels are bias-free) */
   float eps;                           /* 0 = the launch-wide default */
   int pad_;
+  const unsigned* minmax;              /* optional (C, 2) extremes of the normalised tensor (mpose_conv_operands.mm0) ...           */
+  float* amax_out;                     /* ... -> max over channels of max(0, scale*max + shift, scale*min + shift), accumulated     */
+                                       /*     (atomic max) into sub-slot 0 of this activation amax slot (see mpose_absmax)          */
 } mpose_bn_job;
 
 /* For every job: derive scale/shift (+ mean/invstd); train != 0 also updates the running stats. */

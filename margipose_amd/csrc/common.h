@@ -79,6 +79,18 @@ __device__ __forceinline__ void block_amax_commit_one(float m, float* dst) {
   }
 }
 
+// Sortable key of a float: keys order like the floats (negative numbers included), and 0 is below the key of every float, so a
+// zero-filled word is the identity of an atomic max over keys.  NaN -> the key of +inf (ordered above everything: the scale
+// derived from it makes the convolution's result non-finite, like the NaN would).
+__device__ __forceinline__ unsigned float_key(float x) {
+  if (!(x == x)) x = __uint_as_float(0x7f800000u);
+  const unsigned b = __float_as_uint(x);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float key_float(unsigned k) {
+  return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+
 struct Ptr3 {
   const float* p[MPOSE_MAX_GROUP];
 };

@@ -178,6 +178,7 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
   unsigned char* sA_all = smem_raw;                                               // [4 waves][2][TILE_B]
   float* sRed = reinterpret_cast<float*>(smem_raw + 4 * 2 * TILE_B);              // [2 sets][4 waves][BN][2]
   unsigned* sRow = reinterpret_cast<unsigned*>(smem_raw + 4 * 2 * TILE_B + 2 * 4 * BN * 2 * 4);   // [4 waves][64] output row offsets
+  float* sMM = reinterpret_cast<float*>(smem_raw + 4 * 2 * TILE_B + 2 * 4 * BN * 2 * 4 + 4 * 64 * 4);   // [4 waves][BN][2] channel extremes of out0
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lh = lane >> 5;
@@ -748,6 +749,12 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
     float csum[RN], csq[RN];
 #pragma unroll
     for (int rn = 0; rn < RN; ++rn) csum[rn] = csq[rn] = 0.f;
+    // per-channel extremes of out0 as stored (mpose_conv_operands.mm0): max v and max -v over the rows that exist
+    const bool want_mm = (oset == 0) && op.mm0 != nullptr;
+    const float kNegInf = __uint_as_float(0xff800000u);
+    float vmx[RN], vng[RN];
+#pragma unroll
+    for (int rn = 0; rn < RN; ++rn) vmx[rn] = vng[rn] = kNegInf;
     // Output row table: lane l works out the byte offset of output pixel m0 + l ONCE (two divisions per lane
     // instead of two per accumulator row); rows beyond M, and every row of a non-writing wave, get an offset the
     // buffer unit rejects (stores dropped, loads return 0).  Accumulator register group rg of lane half h holds
@@ -845,7 +852,22 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
             csum[rn] += v[r];
             if (!masked) csq[rn] = fmaf(v[r], v[r], csq[rn]);
           }
+          if (want_mm) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const bool ok = voff[r] < 0xFFFFF000u;
+              vmx[rn] = fmaxf(vmx[rn], ok ? v[r] : kNegInf);
+              vng[rn] = fmaxf(vng[rn], ok ? -v[r] : kNegInf);
+            }
+          }
         }
+      }
+    }
+    if (want_mm) {       // (waves that own no block of a column group contribute the identity)
+#pragma unroll
+      for (int rn = 0; rn < RN; ++rn) {
+        const float a_ = fmaxf(vmx[rn], __shfl_xor(vmx[rn], 32, 64)), b_ = fmaxf(vng[rn], __shfl_xor(vng[rn], 32, 64));
+        if (lh == 0) { sMM[(wave * BN + rn * 32 + li) * 2] = a_; sMM[(wave * BN + rn * 32 + li) * 2 + 1] = b_; }
       }
     }
     if (epi && op.out0_amax != nullptr) {      // one look-then-atomic per wave into the workgroup's sub-slot (common.h)
@@ -895,6 +917,13 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
       }
     }
   }
+  if (op.mm0 != nullptr && tid < BN && n0 + tid < g.Cout0) {
+    float a_ = sMM[tid * 2], b_ = sMM[tid * 2 + 1];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) { a_ = fmaxf(a_, sMM[(w * BN + tid) * 2]); b_ = fmaxf(b_, sMM[(w * BN + tid) * 2 + 1]); }
+    atomicMax(op.mm0 + (size_t)(n0 + tid) * 2, float_key(a_));
+    atomicMax(op.mm0 + (size_t)(n0 + tid) * 2 + 1, float_key(b_));
+  }
   if (op.red_sums != nullptr && tid < BN && n0 + tid < g.Cout0) {
     float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -910,7 +939,7 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
 template <int RN, int MODE, int KS, bool PRO, int NPL, bool ROWG>
 int launch_conv(const ConvArgs& a0, int n_groups, hipStream_t s) {
   constexpr int BN = 32 * RN;
-  constexpr int lds = 4 * 2 * (ROWG ? RG_TILE_B : A_TILE_B) + 2 * 4 * BN * 2 * 4 + 4 * 64 * 4;
+  constexpr int lds = 4 * 2 * (ROWG ? RG_TILE_B : A_TILE_B) + 2 * 4 * BN * 2 * 4 + 4 * 64 * 4 + 4 * BN * 2 * 4;
   static bool attr_set = false;          // > 64 KiB of dynamic LDS has to be requested once per kernel
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_k<RN, MODE, KS, PRO, NPL, ROWG>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
@@ -1466,6 +1495,7 @@ extern "C" int mpose_conv_fwd(const mpose_conv_geom* geom, const mpose_conv_oper
                             ops[i].stats0 || ops[i].stats1 || ops[i].epi_scale0 || (acc1 && !sum_inputs)))
       return MPOSE_EINVAL;
     if ((ops[i].red_sums != nullptr) != (ops[0].red_sums != nullptr)) return MPOSE_EINVAL;
+    if (ops[i].mm0 && ((flags & MPOSE_CONV_PLANES_IN) || !ops[i].stats0)) return MPOSE_EINVAL;
     if (acc1 && (!ops[i].w1 || !ops[i].out1)) return MPOSE_EINVAL;
     if ((ops[i].in_scale != nullptr) != (ops[0].in_scale != nullptr)) return MPOSE_EINVAL;
     if (ops[i].in_scale && (acc1 || !ops[i].in_shift)) return MPOSE_EINVAL;

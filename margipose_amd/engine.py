@@ -43,7 +43,7 @@ UNPACK_DT = np.dtype([('src', 'u8'), ('dst', 'u8'), ('N', 'i4'), ('K', 'i4'), ('
                       ('n_split', 'i4'), ('sn', 'i8'), ('sk', 'i8'), ('st', 'i8'), ('accumulate', 'i4')], align=True)
 BN_DT = np.dtype([('stats', 'u8'), ('gamma', 'u8'), ('beta', 'u8'), ('running_mean', 'u8'), ('running_var', 'u8'),
                   ('scale', 'u8'), ('shift', 'u8'), ('mean', 'u8'), ('invstd', 'u8'), ('C', 'i4'), ('count', 'i4'),
-                  ('conv_bias', 'u8'), ('eps', 'f4'), ('pad_', 'i4')], align=True)
+                  ('conv_bias', 'u8'), ('eps', 'f4'), ('pad_', 'i4'), ('minmax', 'u8'), ('amax_out', 'u8')], align=True)
 COEF_DT = np.dtype([('sums', 'u8'), ('gamma', 'u8'), ('mean', 'u8'), ('invstd', 'u8'), ('coef', 'u8'), ('dgamma', 'u8'),
                     ('dbeta', 'u8'), ('sums_stride', 'i4'), ('which', 'i4'), ('C', 'i4'), ('c_stride', 'i4'), ('count', 'i4'),
                     ('sg_col', 'i4'), ('dconv_bias', 'u8')], align=True)
@@ -286,6 +286,8 @@ class Engine:
         self._geoms = {}
         self._tables = {}
         self._arena_key = None
+        self._plist = None
+        self._key_tensors = None
         self.timer = None            # optional KernelTimer (bench.py)
         self.side_stream = None      # weight-gradient GEMMs run here, off the data-gradient critical path
         self._side_keep = []         # tensors the side stream still reads (released at the next bucket boundary)
@@ -303,6 +305,8 @@ class Engine:
     # ------------------------------------------------------------------ parameters / arenas
     def param_list(self):
         """Every learnable tensor, in the order grads are returned by the autograd Function."""
+        if self._plist is not None:
+            return self._plist
         ps = []
         for c in self._convs:
             ps.append(c.param)
@@ -313,10 +317,14 @@ class Engine:
                 ps += [m.weight, m.bias]
             ps += self.stem.extra_params
         ps += self.combiners
+        if self._arena_key is not None:          # (the stem adds its parameters while the engine is being built: cache afterwards)
+            self._plist = ps
         return ps
 
     def invalidate(self):
         self._arena_key = None
+        self._plist = None
+        self._key_tensors = None
         self._tables = {}
 
     def _bn_buffers(self):
@@ -326,9 +334,12 @@ class Engine:
     def _ensure_arenas(self, device):
         # every address baked into the device-resident job tables takes part in the key: a parameter or buffer that was
         # re-bound outside Module._apply (load_state_dict(assign=True), p.data = ..., swap_tensors) rebuilds the tables
-        key = (str(device), hash(tuple(t.data_ptr() for t in self.param_list() + self._bn_buffers())))
+        if self._key_tensors is None:
+            self._key_tensors = self.param_list() + self._bn_buffers()
+        key = (str(device), hash(tuple([t.data_ptr() for t in self._key_tensors])))
         if self._arena_key == key:
             return
+        self._plist = None
         _check_struct_sizes()
         for p in self.param_list():
             _lib.dev_f32(p.data, 'parameter')
@@ -343,7 +354,7 @@ class Engine:
         foff = soff = 0
         for n in self._bns:
             n.f_off = foff; foff += 8 * n.Cs
-            n.s_off = soff; soff += 6 * n.Cs
+            n.s_off = soff; soff += 7 * n.Cs         # (+ Cs doubles = 2*Cs sortable keys: the channel extremes of the forward)
         self.bnf = torch.zeros(foff, dtype=torch.float32, device=device)
         self.stat_arena = torch.zeros(soff, dtype=torch.float64, device=device)
         # grad layout: offsets of every parameter in the flat gradient buffer
@@ -428,6 +439,10 @@ class Engine:
     def _stats_ptr(self, n, bwd=False):
         return self.stat_arena.data_ptr() + 8 * (n.s_off + (2 * n.Cs if bwd else 0))
 
+    def _mm_ptr(self, n):
+        """(Cs, 2) sortable keys of max / max(-x) per channel of the tensor this BatchNorm normalises (mpose_conv_operands.mm0)."""
+        return self.stat_arena.data_ptr() + 8 * (n.s_off + 6 * n.Cs)
+
     # ------------------------------------------------------------------ job tables per batch size
     def _tables_for(self, B, F):
         """Device-resident job tables + persistent workspaces for one (batch, heatmap size).  Everything they
@@ -497,6 +512,8 @@ class Engine:
                 base = (t * 10 + i) * 9
                 for c, b in enumerate(grp):
                     bn_job(fj[1 + base + c], b.bn1, cnt)
+                    # largest relu(bn1(c1)) -- the operand of the block's second convolution -- from c1's channel extremes
+                    fj[1 + base + c]['minmax'], fj[1 + base + c]['amax_out'] = self._mm_ptr(b.bn1), self._amax_f(t, i, 1, c)
                     bn_job(fj[1 + base + 3 + c], b.bns, cnt)
                     bn_job(fj[1 + base + 6 + c], b.bn2, cnt)
                     coef_job(cj[base + c], b.bn2, b.bn2, 4, 0, 1, cnt)
@@ -892,11 +909,15 @@ class Engine:
                             op.out0_amax = self._amax_f(t, i, 1, c)
                     if train:
                         op.stats0, op.stats1 = self._stats_ptr(b.bn1), self._stats_ptr(b.bns)
+                        if f16:
+                            op.mm0 = self._mm_ptr(b.bn1)
                     ops.append(op)
                 self.conv(g1, ops, pflags | (16 if (fused or fused_h) else 0))
                 if train:
                     self.finalize(tb, self.fin_index(t, i, 0), 6, True)
-                if f16 and not fused_h:      # largest relu(bn1(c1)): what the next K loop (and its weight gradient) will split
+                # largest relu(bn1(c1)): what the next K loop (and its weight gradient) will split.  In training bn_finalize just
+                # derived it from c1's channel extremes (the convolution's epilogue took them); otherwise it is measured
+                if f16 and not fused_h and not train:
                     self.absmax(c1, [self._amax_f(t, i, 1, c) for c in range(3)], b0.cout_s, [self._bnf_ptr(b.bn1, 0) for b in grp],
                                 [self._bnf_ptr(b.bn1, 1) for b in grp], relu=True)
                 if planes and not fused:     # relu(bn1(c1)) is written once, pre-split, instead of being recomputed by every tap

@@ -131,6 +131,7 @@ class DeviceSGD:
         self._np = np
         self._eager_table = torch.zeros(len(self.params) * _sgd_job_dtype().itemsize, dtype=torch.uint8, device=dev)
         self._uploaded = {}          # id(table) -> bytes it holds
+        self._table_key = {}         # id(table) -> gradient addresses it was built from (alignment / contiguity checked then)
         self._graph_table = torch.zeros_like(self._eager_table)                  # filled by finish_capture() (allocated HERE: an
         #   allocation inside the capture would come from the graph's pool and its zero-fill would be replayed before every step)
 
@@ -142,6 +143,13 @@ class DeviceSGD:
                 p.grad.zero_()
 
     def _fill_table(self, table):
+        # (the gradients are usually where they were one or two steps ago: compare their addresses before rebuilding the table)
+        try:
+            gptrs = tuple([p.grad.data_ptr() for p in self.params])
+        except AttributeError:
+            raise RuntimeError('DeviceSGD.step(): a parameter has no gradient')
+        if self._table_key.get(id(table)) == gptrs:
+            return
         jobs = self._np.zeros(len(self.params), dtype=_sgd_job_dtype())
         for i, p in enumerate(self.params):
             if p.grad is None:
@@ -158,6 +166,7 @@ class DeviceSGD:
             staged = torch.from_numpy(jobs.view(self._np.uint8)).pin_memory()
             table.copy_(staged, non_blocking=True)
             self._uploaded[id(table)] = raw
+        self._table_key[id(table)] = gptrs
 
     def upload_hyper(self):
         """Hand {lr, momentum, first-step flag} of the next step() to the device (values travel as kernel arguments)."""
