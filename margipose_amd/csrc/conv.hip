@@ -24,6 +24,10 @@
 #include "common.h"
 #include <stdlib.h>
 
+#ifndef CV_EXP
+#define CV_EXP 0      // timing experiments (tools/igemm_exp.sh; wrong results): 1 no epilogue, 2 no K loop, 4 no split-K exchange
+#endif
+
 namespace mpose {
 namespace {
 
@@ -406,7 +410,8 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
     //   B fragments of (tile k, group s)     loaded right after group s of tile k-1 used the registers.
     // A loop body is { half 2k+1, half 2k+2 } so that all of this is one basic block for the scheduler.
     const bool use_rowg = ROWG && set == 0;
-    if (use_rowg) {
+    if constexpr (CV_EXP & 2) {
+    } else if (use_rowg) {
       if constexpr (ROWG) {
         // ---- row-group K loop (first pass of a stride-1 3x3: taps 3*ky .. 3*ky+2 share dy and have dx in {-1,0,1}) ----
         // One staged tile per (32-channel chunk, kernel row): 66 consecutive input pixels, scaled and split ONCE, serve the
@@ -659,7 +664,7 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
       if (KS == 2) return rm == kh;
       return rm == (kh & 1) && ((rn * 2) / RN) == (kh >> 1);
     };
-    if (KS > 1) {
+    if (KS > 1 && !(CV_EXP & 4)) {
       constexpr int BLK = 16 * 64;                       // floats of one accumulator block
       constexpr int STRIDE = (KS == 2 ? RN : 2 * RN - RN / 2) * BLK;    // most blocks a wave can have to park
       static_assert(4 * STRIDE * 4 <= 4 * 2 * TILE_B, "exchange area must fit in the A-tile region");
@@ -773,7 +778,7 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
     }
     const unsigned col_off = (unsigned)((n0 + li) * 4);
 #pragma unroll
-    for (int rm = 0; rm < 2; ++rm) {
+    for (int rm = 0; rm < ((CV_EXP & 1) ? 0 : 2); ++rm) {
       unsigned voff[16];
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
