@@ -12,8 +12,9 @@ JS-reg + pixelwise loss on"): the config the metric "images/sec fwd+bwd at 256x2
 with the 3-stage model of configs[1].  fp32 arithmetic throughout (the reference's precision).
 
 Rank 0 prints ONE JSON line.  `roofline` describes the dominant kernel (an implicit-GEMM convolution or its
-weight gradient: fp32 arithmetic carried out as six bf16 MFMAs per multiply-add, so the bound is the dense bf16
-MFMA peak / 6; algorithmic fp32 FLOPs / HIP-event launch duration measured inside the timed region);
+weight gradient: fp32 arithmetic carried out as THREE fp16 MFMA products per multiply-add of two-way split,
+per-tensor-scaled operands, so the bound is the dense 16-bit MFMA peak / 3; algorithmic fp32 FLOPs / HIP-event
+launch duration measured inside the timed region, nothing subtracted);
 `tail_roofline` is the soft-argmax kernel the metric also names (algorithmic bytes / launch duration, HBM
 bound); `cpu_baseline` times the oracle (the stock-PyTorch CPU restatement of the reference, oracle/model_ref.py)
 on the host cores on a bounded sample of the same workload.
@@ -80,8 +81,10 @@ def parse():
                     'of enqueueing ~1000 launches per step from Python.  Bit-identical results; the step is GPU-bound, and a replay '
                     'measured ~1 %% SLOWER than eager launches (37.2 vs 36.8 ms, one box), so the benchmark default is eager')
     ap.add_argument('--eager', action='store_true', help='(default) kept for scripts')
-    ap.add_argument('--conv-dtype', default='f32', choices=['f32', 'bf16'], help="'bf16' = BASELINE configs[4]'s reduced-precision "
-                    'convolutions (model.conv_dtype = torch.bfloat16): a DIFFERENT workload, reported with dtype bf16, never the headline')
+    ap.add_argument('--conv-dtype', default='f32', choices=['f32', 'f16', 'bf16'], help="BASELINE configs[4]'s reduced-precision "
+                    "convolutions -- 'f16': every convolution on fp16-rounded operands, one MFMA product (model.conv_dtype = "
+                    "torch.float16; with --stages 5 --size 384 that is configs[4]'s workload); 'bf16': round 2's variant (columns' "
+                    'forward / data-gradient only).  A DIFFERENT workload, reported with its own dtype, never the headline')
     return ap.parse_args()
 
 
@@ -197,6 +200,8 @@ def main():
     model.inner.engine().overlap_wgrad = not args.no_overlap_wgrad
     if args.conv_dtype == 'bf16':
         model.conv_dtype = torch.bfloat16
+    elif args.conv_dtype == 'f16':
+        model.conv_dtype = torch.float16
     # the reference's optimiser, SGD(lr, momentum) (bin/train_3d.py:339), as one launch with device-resident hyper-parameters
     opt = DeviceSGD(model.parameters(), lr=0.01, momentum=0.9)
     g = torch.Generator(device='cpu').manual_seed(12345 + rank)
@@ -293,9 +298,12 @@ def main():
         'metric': 'images/sec fwd+bwd at 256x256, 17 joints (training step: forward + JS/Euclidean loss + backward + SGD)',
         'value': images / dt, 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': 'f32' if args.conv_dtype == 'f32' else 'bf16', 'data': 'synthetic',
-        'config': {'workload': 'BASELINE configs[2]: training step, per-GPU batch %d, %d-stage MargiPose, %dx%d input, 17 joints, '
-                               '32x32 heatmaps, JS + Euclidean loss, SGD(momentum 0.9)' % (B, args.stages, args.size, args.size),
+        'dtype': {'f32': 'f32 (3xfp16 split operands, fp32 accumulate)', 'f16': 'f16 (operands rounded to fp16, fp32 accumulate; BatchNorm / loss fp32)',
+                  'bf16': 'bf16'}[args.conv_dtype], 'data': 'synthetic',
+        'config': {'workload': '%s: training step, per-GPU batch %d, %d-stage MargiPose, %dx%d input, 17 joints, '
+                               '%dx%d heatmaps, JS + Euclidean loss, SGD(momentum 0.9)' % (
+                                   'BASELINE configs[4] (reduced-precision convolutions)' if args.conv_dtype != 'f32' and args.stages == 5 and args.size == 384
+                                   else 'BASELINE configs[2]', B, args.stages, args.size, args.size, args.size // 8, args.size // 8),
                    'global_batch': world * B, 'n_stages': args.stages,
                    'stem': ('inceptionv4 (reference default; restated from SURVEY Appendix B, third-party original unavailable: '
                             'unpinned, random init)' if args.stem == 'inceptionv4' else
@@ -311,6 +319,8 @@ def main():
                    'final_loss': loss_value},
     }
     products = 3.0 if model.inner.engine().conv_mode_for(True, True) == 2 else 6.0
+    if args.conv_dtype == 'f16':
+        products = 1.0                 # one MFMA product per multiply-add: priced against the full dense 16-bit MFMA peak
     peak_equiv = PEAK_BF16_MFMA_TFLOPS / products
     if timer is not None:
         summ = timer.summary()
@@ -326,7 +336,7 @@ def main():
                                'frac': tf / peak_equiv, 'traffic': tr_bytes, 'traffic_detail': tr_detail, 'kernel': top[0],
                                'mfma_busy_frac_pmc': (tr_detail or {}).get('mfma_busy_frac'),
                                'avg_launch_us': top[1]['avg_us'], 'launches': top[1]['n'],
-                               'event_bracket_overhead_us_subtracted': 1e3 * timer.bracket_ms,
+                               'event_bracket_overhead_us_not_subtracted': 1e3 * timer.bracket_cal_ms,
                                'flops_per_launch': top[1]['work_per_launch'],
                                'note': 'achieved = algorithmic fp32 FLOPs / launch duration; the kernel executes %d 16-bit MFMA FLOPs '
                                        'per algorithmic FLOP (split operands), so peak = dense 16-bit MFMA peak 2500 / %d (fp16 and bf16 '
@@ -334,8 +344,8 @@ def main():
                                        % (products, products, PEAK_FP32_MFMA_TFLOPS),
                                'mfma_tflops_executed': products * tf,
                                'all_conv_kernels_tflops': all_flops / (all_ms * 1e-3) / 1e12,
-                               'all_conv_kernels_frac_note': 'column convolutions over their own peak; the feature extractor still runs '
-                                                             'the six-product form and is priced as if it did not (understates)',
+                               'all_conv_kernels_frac_note': 'every convolution of the step (columns and feature extractor, forward, data- and '
+                                                             'weight-gradient: all in the three-product form) over the same peak',
                                'all_conv_kernels_frac': all_flops / (all_ms * 1e-3) / 1e12 / peak_equiv,
                                'conv_share_of_step_gpu_time': (all_ms / max(1, timed_steps)) / (1e3 * dt / args.steps),
                                'kernel_timed_steps': timed_steps}

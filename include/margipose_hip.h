@@ -198,6 +198,10 @@ typedef struct {
                                    * result is as close as the six-product bf16 form (tests/test_conv_gpu.py) at half the matrix
                                    * work.  Needs ops[i].in_amax / w0_amax (+ in1_amax / w1_amax with a second input / weight set)
                                    * and weights packed with layout 2. */
+#define MPOSE_CONV_F16X1 64       /* with MPOSE_CONV_F16X3 (same operands, amax slots, packed weights and scales): multiply the h pieces
+                                   * only -- operands ROUNDED to fp16 (11 significant bits) after the per-tensor power-of-two scale,
+                                   * one MFMA product per multiply-add, fp32 accumulation.  The reduced-precision mode of BASELINE
+                                   * configs[4] ("fp16 convs with MFMA"), NOT fp32-equivalent; BatchNorm, losses, soft-argmax stay fp32. */
 #define MPOSE_CONV_SUM_INPUTS 2   /* taps with acc == 1 read `in1` through `w1` and add into out0 (one pass, one
                                    * output): the data-gradient of a ResidualBlock's input, dX = conv_in^T(dC1) +
                                    * shortcut^T(dSC), models/margipose_model.py:39 */
@@ -224,6 +228,8 @@ typedef struct {
   const float* in_amax;
   const float* gout0_amax;
   const float* gout1_amax;
+  int single_product;                  /* with in_amax (all groups alike): MPOSE_CONV_F16X1's arithmetic -- the h x h product only */
+  int pad_;
 } mpose_wgrad_operands;
 
 /* Number of (tap, input-channel tile, output-channel tile) work units of one group's weight-gradient launch;

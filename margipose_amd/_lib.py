@@ -111,7 +111,7 @@ class ConvOperands(ctypes.Structure):
 class WgradOperands(ctypes.Structure):
     _fields_ = [('in_', c_void_p), ('in_scale', c_void_p), ('in_shift', c_void_p),
                 ('gout0', c_void_p), ('gout1', c_void_p), ('dw0', c_void_p), ('dw1', c_void_p),
-                ('in_amax', c_void_p), ('gout0_amax', c_void_p), ('gout1_amax', c_void_p)]
+                ('in_amax', c_void_p), ('gout0_amax', c_void_p), ('gout1_amax', c_void_p), ('single_product', c_int), ('pad_', c_int)]
 
 
 class AbsmaxOperands(ctypes.Structure):

@@ -8,10 +8,21 @@ namespace mpose {
 
 constexpr int kWave = 64;
 
+// Wave-wide reductions with DPP row operations (no LDS crossbar: __shfl_xor compiles to ds_bpermute_b32, ~60 cycles of latency per
+// step in a dependent chain of six; the soft-argmax kernels are four such chains long).  quad_perm + row_half_mirror + row_mirror
+// leave every 16-lane row holding its total; row_bcast:15 / row_bcast:31 carry the totals up to lane 63; v_readlane broadcasts.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f32(float old, float v) {
+  return __uint_as_float((unsigned)__builtin_amdgcn_update_dpp((int)__float_as_uint(old), (int)__float_as_uint(v), CTRL, ROW_MASK, 0xf, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += dpp_f32<0xB1, 0xf>(0.f, v);        // quad_perm [1,0,3,2]
+  v += dpp_f32<0x4E, 0xf>(0.f, v);        // quad_perm [2,3,0,1]
+  v += dpp_f32<0x141, 0xf>(0.f, v);       // row_half_mirror
+  v += dpp_f32<0x140, 0xf>(0.f, v);       // row_mirror
+  v += dpp_f32<0x142, 0xa>(0.f, v);       // row_bcast:15 into rows 1 and 3
+  v += dpp_f32<0x143, 0xc>(0.f, v);       // row_bcast:31 into rows 2 and 3
+  return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), 63));
 }
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -19,9 +30,14 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  const float ninf = __uint_as_float(0xff800000u);
+  v = fmaxf(v, dpp_f32<0xB1, 0xf>(ninf, v));
+  v = fmaxf(v, dpp_f32<0x4E, 0xf>(ninf, v));
+  v = fmaxf(v, dpp_f32<0x141, 0xf>(ninf, v));
+  v = fmaxf(v, dpp_f32<0x140, 0xf>(ninf, v));
+  v = fmaxf(v, dpp_f32<0x142, 0xa>(ninf, v));
+  v = fmaxf(v, dpp_f32<0x143, 0xc>(ninf, v));
+  return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), 63));
 }
 
 // Cell-centre coordinate i*(2/L) - (L-1)/L  (reference dsntnn.py:35-36).

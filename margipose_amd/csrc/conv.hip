@@ -1,6 +1,7 @@
-// Implicit-GEMM convolution engine for gfx950: fp32 convolutions computed on the bf16 matrix cores with
-// 3-way split operands ("bf16x6", fp32-equivalent accuracy; see conv_igemm_k), forward, data-gradient and
-// weight-gradient alike.  (conv_p.hip holds the round-2 engine that reads PRE-SPLIT activations.)
+// Implicit-GEMM convolution engine for gfx950: fp32 convolutions computed on the 16-bit matrix cores with split operands --
+// by default THREE fp16 products per multiply-add of two-way split, per-tensor-scaled operands (MPOSE_CONV_F16X3, NPL = 2
+// below), on request six bf16 products of three-way split ones ("bf16x6", NPL = 3) -- forward, data-gradient and weight-gradient
+// alike.  (conv_p.hip: the engine that reads PRE-SPLIT activations; wgrad.hip: the row-of-taps weight gradient, round 3.)
 //
 // Replaces every Conv2d / ConvTranspose2d of reference src/margipose/models/margipose_model.py
 // (:33, :67-68, :73-74, :79-82), their data-gradients and their weight-gradients.  One kernel
@@ -137,7 +138,8 @@ __device__ __forceinline__ f32x16 mfma_f16(const u32x4 a, const u32x4 b, const f
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 
-// Forward / data-gradient kernel: fp32 convolution on the bf16 matrix cores ("bf16x6").
+// Forward / data-gradient kernel: fp32 convolution on the 16-bit matrix cores (NPL = 2: three fp16 products, the default;
+// NPL = 3: six bf16 products -- the form the next paragraph derives; the fp16 form's own argument is at MPOSE_CONV_F16X3 in the header).
 //
 // Why: gfx950's fp32 MFMA (v_mfma_f32_32x32x2_f32) runs on the SIMD's 32 fp32 FMA lanes -- measured 147 TFLOP/s
 // for the whole chip (tools/probe/mfma_probe.hip) -- while v_mfma_f32_32x32x16_bf16 sustains 1.9 PFLOP/s.  An fp32
@@ -172,9 +174,10 @@ __device__ __forceinline__ f32x16 mfma_f16(const u32x4 a, const u32x4 b, const f
 template <int RN, int MODE, int KS, bool PRO, int NPL, bool ROWG>
 __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
   constexpr bool ACC1 = MODE == 1, SUM2 = MODE == 2;
-  constexpr bool F16 = NPL == 2;
+  constexpr bool F16 = NPL <= 2;          // NPL == 1: the h planes only (MPOSE_CONV_F16X1: operands rounded to fp16, one product)
+  constexpr int NPM = F16 ? 2 : 3;        // planes of the packed weights in memory
   constexpr int TILE_B = ROWG ? RG_TILE_B : A_TILE_B;      // LDS bytes reserved per staging buffer
-  static_assert(!ROWG || NPL == 2, "row-group tiles hold two planes");
+  static_assert(!ROWG || F16, "row-group tiles hold two planes");
   constexpr int NPASS = MODE ? 2 : 1;
   constexpr int BM = 256 / KS;
   constexpr int BN = 32 * RN;
@@ -265,6 +268,14 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
     ka1 = SUM2 ? f16_scale_exp(amax_gather(op.in1_amax)) : ka0;
     kw0 = f16_scale_exp(*op.w0_amax);
     kw1 = MODE ? f16_scale_exp(*op.w1_amax) : kw0;
+    if (SUM2) {
+      // The first pass's accumulators are re-expressed in the second pass's units (2^((ka1 + kw1) - (ka0 + kw0))) before the second
+      // input accumulates on top.  A second input that is all zeros (a shortcut BatchNorm with gamma == 0) or 2^60 times smaller
+      // than the first would make that factor overflow fp32: cap it -- the second input is then scaled less than its own maximum
+      // allows, which costs it precision it cannot contribute anyway (its whole sum is below the first's rounding error).
+      const int excess = (ka1 + kw1) - (ka0 + kw0) - 60;
+      if (excess > 0) ka1 -= excess;
+    }
   }
   const int oyc = g.cls[cls].oy, oxc = g.cls[cls].ox;
 
@@ -302,12 +313,12 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
       const int dy = (int)(signed char)(tp & 0xff), dx = (int)(signed char)((tp >> 8) & 0xff);
       const int widx = (tp >> 16) & 0xff;
       ti.a_soff = (unsigned)(((dy * g.IW + dx) * in_ld + ti.c * KC) * 4 + a.in_bias);
-      ti.w_soff = (unsigned)(widx * k16_total + ti.c * (KC / 16)) * (unsigned)NPL * plane_b;
+      ti.w_soff = (unsigned)(widx * k16_total + ti.c * (KC / 16)) * (unsigned)NPM * plane_b;
       return ti;
     };
     auto tile_info = [&](int it) { const int c = it / nt; return tile_ct(c, it - c * nt); };
     auto load_b = [&](const TileInfo& ti, int s_, int rn) {
-      const unsigned so = ti.w_soff + (unsigned)s_ * (unsigned)NPL * plane_b;
+      const unsigned so = ti.w_soff + (unsigned)s_ * (unsigned)NPM * plane_b;
 #pragma unroll
       for (int pl = 0; pl < NPL; ++pl)
         fb[s_][rn][pl] = buf_load4u(rs_w, w_voff + (unsigned)(rn * 1024), so + (unsigned)pl * plane_b);
@@ -338,7 +349,13 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
       }
       // row (lane >> 3) + 8 j: its swizzle is ((lane >> 5) + 2 j) & 3 -- one of two per-lane values (j is a compile-time constant)
       unsigned char* dA = sA + buf * A_TILE_B + ((lane >> 3) + 8 * j) * A_ROW_B + ((j & 1) ? st_off_odd : st_off_even);
-      if constexpr (F16) {
+      if constexpr (NPL == 1) {
+        if (!pro) { v.x *= a_mul; v.y *= a_mul; v.z *= a_mul; v.w *= a_mul; }
+        uint2 h;
+        h.x = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v.x, v.y}, f16x2));
+        h.y = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v.z, v.w}, f16x2));
+        *reinterpret_cast<uint2*>(dA) = h;
+      } else if constexpr (F16) {
         if (!pro) { v.x *= a_mul; v.y *= a_mul; v.z *= a_mul; v.w *= a_mul; }
         uint2 h, l;
         split2h(v.x, v.y, h.x, l.x);
@@ -370,7 +387,10 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
     auto mfma_group = [&](int s_, const u32x4 (&af)[2][NPL], const TileInfo& nb, auto&& side) {
 #pragma unroll
       for (int rn = 0; rn < RN; ++rn) {
-        if constexpr (F16) {
+        if constexpr (NPL == 1) {
+#pragma unroll
+          for (int rm = 0; rm < 2; ++rm) acc0[rm][rn] = mfma_f16(af[rm][0], fb[s_][rn][0], acc0[rm][rn]);
+        } else if constexpr (F16) {
           const u32x4 bh = fb[s_][rn][0], bl = fb[s_][rn][1];
 #pragma unroll
           for (int rm = 0; rm < 2; ++rm) {
@@ -455,7 +475,13 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
           }
           unsigned char* dA = sG + buf * RG_TILE_B + ((lane >> 3) + 8 * j) * A_ROW_B + ((j & 1) ? st_off_odd : st_off_even);
           if (j < 8 || (lane >> 3) < 2) {                        // the last piece is rows 64, 65 only
-            if constexpr (F16) {
+            if constexpr (NPL == 1) {
+              if (!pro) { v.x *= a_mul; v.y *= a_mul; v.z *= a_mul; v.w *= a_mul; }
+              uint2 h;
+              h.x = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v.x, v.y}, f16x2));
+              h.y = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v.z, v.w}, f16x2));
+              *reinterpret_cast<uint2*>(dA) = h;
+            } else if constexpr (F16) {
               if (!pro) { v.x *= a_mul; v.y *= a_mul; v.z *= a_mul; v.w *= a_mul; }
               uint2 h, l;
               split2h(v.x, v.y, h.x, l.x);
@@ -966,7 +992,8 @@ int launch_conv(const ConvArgs& a0, int n_groups, hipStream_t s) {
 // -- e.g. 128->128 @32^2: KS 1/2/4 = 207/174/213 predicted, 195/175/202 measured; 192->192 @16^2: 124/136/125
 // predicted, 98/108/103 measured (same order).  The choice is made for a NOMINAL batch of 32 images, not the actual
 // one: the summation order of a sample then does not depend on how many other samples share its launch, so a
-// data-parallel shard reproduces the full batch's per-sample results bit for bit.
+// data-parallel shard reproduces the full batch's per-sample results bit for bit in the six-product form (MPOSE_F16X3=0); in the
+// default three-product form a tensor's scale follows the largest magnitude in the LOCAL batch, so shards agree to fp32 rounding.
 template <int RN, int NPL, bool ROWG>
 inline int pick_ks(const ConvArgs& a, int cmax, int n_groups) {
   const int n_iter = (a.g.Cin / KC) * a.g.cls[0].n_taps;
@@ -986,7 +1013,7 @@ inline int pick_ks(const ConvArgs& a, int cmax, int n_groups) {
     //  faster constants are used for INFERENCE launches only -- those with the fused output stage -- where the forward error
     //  stays at ~1e-5 of the 1e-4 gate; training keeps the split that bounds the chain.)
     const bool fast = ROWG && a.op[0].epi_scale0 != nullptr;
-    const double per_iter = fast ? 0.05 + 0.29 * RN : (NPL == 2 ? 0.55 + 0.27 * RN : 0.65 + 0.49 * RN);
+    const double per_iter = fast ? 0.05 + 0.29 * RN : (NPL <= 2 ? 0.55 + 0.27 * RN : 0.65 + 0.49 * RN);
     const double fixed = fast ? 18.0 : 9.5;
     const double cost = (double)rounds * (fixed + exchange + (double)((n_iter + ks - 1) / ks) * per_iter);
     if (ks == 1 || cost < 0.97 * best_cost) { best = ks; best_cost = cost; }     // ties go to the smaller split
@@ -1034,6 +1061,12 @@ static int rowg_env() {                    // MPOSE_CONV_ROWG=0 disables the row
 }
 template <int RN>
 int launch_conv_ks(const ConvArgs& a, int mode, int cmax, int n_groups, hipStream_t s) {
+  if (a.flags & MPOSE_CONV_F16X1) {          // (with MPOSE_CONV_F16X3: same operands and scales, the h x h product only)
+    if constexpr (RN > 1) {
+      if (rowg_env() && rowg_eligible(a.g)) return launch_conv_ks_p<RN, 1, true>(a, mode, cmax, n_groups, s);
+    }
+    return launch_conv_ks_p<RN, 1, false>(a, mode, cmax, n_groups, s);
+  }
   if (a.flags & MPOSE_CONV_F16X3) {
     if constexpr (RN > 1) {
       if (rowg_env() && rowg_eligible(a.g)) return launch_conv_ks_p<RN, 2, true>(a, mode, cmax, n_groups, s);
@@ -1133,6 +1166,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_k(WgradArgs a) {
   const int kx = F16 ? f16_scale_exp(amax_gather(op.in_amax)) : 0;
   const int kg = F16 ? f16_scale_exp(amax_gather(second ? op.gout1_amax : op.gout0_amax)) : 0;
   const float x_mul = pow2f(kx), g_mul = pow2f(kg);
+  const bool x1 = F16 && a.op[0].single_product != 0;
   float psc[KB], psh[KB];
 #pragma unroll
   for (int kb = 0; kb < KB; ++kb) {
@@ -1273,8 +1307,10 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_k(WgradArgs a) {
         for (int nb = 0; nb < NB; ++nb) {
           f32x16 c = acc[kb][nb];
           if constexpr (F16) {
-            c = mfma_f16(ac.l, bc[nb].h, c);
-            c = mfma_f16(ac.h, bc[nb].l, c);
+            if (!x1) {                             // (wave-uniform: MPOSE_CONV_F16X1 keeps the h x h product only)
+              c = mfma_f16(ac.l, bc[nb].h, c);
+              c = mfma_f16(ac.h, bc[nb].l, c);
+            }
             c = mfma_f16(ac.h, bc[nb].h, c);
           } else {
             c = mfma_bf16(as_bf16x8(ac.l), as_bf16x8(bc[nb].h), c);
@@ -1518,6 +1554,7 @@ extern "C" int mpose_conv_fwd(const mpose_conv_geom* geom, const mpose_conv_oper
     return mpose_conv_planes_launch(geom, ops, n_groups, flags, sum_inputs ? 2 : (acc1 ? 1 : 0), cm, stream);
   }
   if (flags & MPOSE_CONV_BF16) return MPOSE_EINVAL;
+  if ((flags & MPOSE_CONV_F16X1) && !(flags & MPOSE_CONV_F16X3)) return MPOSE_EINVAL;
   if (flags & MPOSE_CONV_F16X3) {
     for (int i = 0; i < n_groups; ++i) {
       if (!ops[i].in_amax || !ops[i].w0_amax) return MPOSE_EINVAL;
@@ -1595,6 +1632,7 @@ extern "C" int mpose_conv_wgrad(const mpose_conv_geom* geom, const mpose_wgrad_o
     if (ops[i].in_scale && !ops[i].in_shift) return MPOSE_EINVAL;
     if ((ops[i].in_amax != nullptr) != (ops[0].in_amax != nullptr)) return MPOSE_EINVAL;
     if (ops[i].in_amax && (!ops[i].gout0_amax || (acc1 && !ops[i].gout1_amax))) return MPOSE_EINVAL;
+    if ((ops[i].single_product != 0) != (ops[0].single_product != 0) || (ops[i].single_product && !ops[i].in_amax)) return MPOSE_EINVAL;
   }
   const int n_rows = geom->B * geom->GH;
   if (n_rows == 0 || a.n_entries == 0) return 0;

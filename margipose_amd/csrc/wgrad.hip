@@ -130,7 +130,7 @@ struct Cfg {
   static_assert(4 * KT / HW <= NTH, "one halo item per thread at most");
 };
 
-template <int WK, int WN, int KB, int NB, bool PRO, bool PAIR>
+template <int WK, int WN, int KB, int NB, bool PRO, bool PAIR, bool X1>
 __global__ __launch_bounds__(64 * WK * WN, WK * WN / 4) void conv_wgrad_rows_k(WgRowsArgs a) {
   using C = Cfg<WK, WN, KB, NB>;
   static_assert(C::NW == 4 || C::NW == 8, "one or two waves per SIMD");
@@ -327,11 +327,18 @@ __global__ __launch_bounds__(64 * WK * WN, WK * WN / 4) void conv_wgrad_rows_k(W
     }
   };
   auto split_store4 = [&](unsigned char* plane_h, int plane_b, unsigned off, const float4& v) {
-    uint2 h, l;
-    split2h(v.x, v.y, h.x, l.x);
-    split2h(v.z, v.w, h.y, l.y);
-    *reinterpret_cast<uint2*>(plane_h + off) = h;
-    *reinterpret_cast<uint2*>(plane_h + plane_b + off) = l;
+    if constexpr (X1) {                 // MPOSE_CONV_F16X1: the operands are ROUNDED to fp16 (the h pieces alone)
+      uint2 h;
+      h.x = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v.x, v.y}, f16x2));
+      h.y = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v.z, v.w}, f16x2));
+      *reinterpret_cast<uint2*>(plane_h + off) = h;
+    } else {
+      uint2 h, l;
+      split2h(v.x, v.y, h.x, l.x);
+      split2h(v.z, v.w, h.y, l.y);
+      *reinterpret_cast<uint2*>(plane_h + off) = h;
+      *reinterpret_cast<uint2*>(plane_h + plane_b + off) = l;
+    }
   };
   auto prologue4 = [&](float4 v, const float4& sc, const float4& sh) {
     if (pro) {
@@ -362,7 +369,7 @@ __global__ __launch_bounds__(64 * WK * WN, WK * WN / 4) void conv_wgrad_rows_k(W
         unsigned h, l;
         split2h(v.x, v.y, h, l);
         *reinterpret_cast<unsigned*>(buf + h_lds) = h;
-        *reinterpret_cast<unsigned*>(buf + C::XPL + h_lds) = l;
+        if constexpr (!X1) *reinterpret_cast<unsigned*>(buf + C::XPL + h_lds) = l;
       }
     }
   };
@@ -370,7 +377,8 @@ __global__ __launch_bounds__(64 * WK * WN, WK * WN / 4) void conv_wgrad_rows_k(W
 
   auto body = [&](auto ntap_c) {
     constexpr int NTAP = decltype(ntap_c)::value;
-    constexpr int NPH = 3 * NTAP;                      // phases of a step: (tap, product), KB*NB MFMAs each
+    constexpr int NPROD = X1 ? 1 : 3;                  // products per multiply-add
+    constexpr int NPH = NPROD * NTAP;                  // phases of a step: (tap, product), KB*NB MFMAs each
     constexpr int TOFF = NTAP == 3 ? 0 : 1;            // single tap: dx = 0 = staged pixel 1
     constexpr int NI = I_HALO + (NTAP == 3 ? 1 : 0);   // (no halo for a single tap)
     auto for_items = [&](auto&& f) {                   // f(integral_constant<int, I>) for I = 0 .. NI-1
@@ -393,21 +401,21 @@ __global__ __launch_bounds__(64 * WK * WN, WK * WN / 4) void conv_wgrad_rows_k(W
       //   barrier            every wave's stores of step s+1 have landed; nobody reads buffer s & 1 through LDS any more
       //   phases PB .. NPH-1 MFMAs of the last tap | fragment reads of step s+1's gradient and first tap | cursor of step s+3
       constexpr int PB = NPH - NPH / 3;
-      constexpr int NSP = NTAP == 3 ? PB - 1 : PB;     // phases that carry staging items
+      constexpr int NSP = (NTAP == 3 && PB > 1) ? PB - 1 : PB;     // phases that carry staging items
       Oct2 oo;
       f16x8 bh[2][NB], bl[2][NB], ah[2][KB], al[2][KB];
       auto read_b = [&](const unsigned char* cb, f16x8 (&h)[NB], f16x8 (&l)[NB]) {
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
           h[nb] = read_tr8(cb + 2 * C::XPL + fa_g + nb * 64, PG);
-          l[nb] = read_tr8(cb + 2 * C::XPL + C::GPL + fa_g + nb * 64, PG);
+          if constexpr (!X1) l[nb] = read_tr8(cb + 2 * C::XPL + C::GPL + fa_g + nb * 64, PG);
         }
       };
       auto read_a = [&](const unsigned char* cb, int t, f16x8 (&h)[KB], f16x8 (&l)[KB]) {
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) {
           h[kb] = read_tr8(cb + fa_x + (t + TOFF) * PX + kb * 64, PX);
-          l[kb] = read_tr8(cb + C::XPL + fa_x + (t + TOFF) * PX + kb * 64, PX);
+          if constexpr (!X1) l[kb] = read_tr8(cb + C::XPL + fa_x + (t + TOFF) * PX + kb * 64, PX);
         }
       };
       take2(cur, oo);
@@ -427,14 +435,10 @@ __global__ __launch_bounds__(64 * WK * WN, WK * WN / 4) void conv_wgrad_rows_k(W
         // every gap between two of them gets a few of the other instructions (at most five hide behind an MFMA when a SIMD
         // holds one wave: MI355X_MICROARCH.md).
         auto phase = [&](auto ph_c) {
-          constexpr int PH = decltype(ph_c)::value, t = PH / 3, p = PH % 3;
+          constexpr int PH = decltype(ph_c)::value, t = PH / NPROD, p = X1 ? 2 : PH % NPROD;      // (p == 2: the h x h product)
           constexpr int aset = (t + BUFI) & 1;
           constexpr int i_lo = PH < NSP ? (PH * NI + NSP - 1) / NSP : NI, i_hi = PH < NSP ? ((PH + 1) * NI + NSP - 1) / NSP : NI;
-          if constexpr (p == 0 && t + 1 < NTAP && !(WG_EXP & 1)) read_a(cb, t + 1, ah[aset ^ 1], al[aset ^ 1]);      // the next tap, three phases ahead
-          if constexpr (PH == PB && !(WG_EXP & 1)) {     // the next step's first fragments
-            read_b(nb_, bh[BUFI ^ 1], bl[BUFI ^ 1]);
-            read_a(nb_, 0, ah[BUFI ^ 1], al[BUFI ^ 1]);
-          }
+          if constexpr (PH % NPROD == 0 && t + 1 < NTAP && !(WG_EXP & 1)) read_a(cb, t + 1, ah[aset ^ 1], al[aset ^ 1]);      // the next tap, a tap's phases ahead
 #pragma unroll
           for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
@@ -444,7 +448,6 @@ __global__ __launch_bounds__(64 * WK * WN, WK * WN / 4) void conv_wgrad_rows_k(W
           [&]<int... Js>(std::integer_sequence<int, Js...>) {
             (((WG_EXP & 2) ? (void)0 : stage_item(std::integral_constant<int, i_lo + Js>{}, nb_), load_item(std::integral_constant<int, i_lo + Js>{}, oo)), ...);
           }(std::make_integer_sequence<int, i_hi - i_lo>{});
-          if constexpr (PH == PB) take2(cur, oo);        // octets of the next step's loads
         };
         __builtin_amdgcn_sched_barrier(0);
         [&]<int... Ps>(std::integer_sequence<int, Ps...>) { (phase(std::integral_constant<int, Ps>{}), ...); }(std::make_integer_sequence<int, PB>{});
@@ -458,6 +461,11 @@ __global__ __launch_bounds__(64 * WK * WN, WK * WN / 4) void conv_wgrad_rows_k(W
         }
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (!(WG_EXP & 4)) lds_barrier();
+        if constexpr (!(WG_EXP & 1)) {                  // the next step's first fragments
+          read_b(nb_, bh[BUFI ^ 1], bl[BUFI ^ 1]);
+          read_a(nb_, 0, ah[BUFI ^ 1], al[BUFI ^ 1]);
+        }
+        take2(cur, oo);                                 // octets of the next step's loads
         [&]<int... Ps>(std::integer_sequence<int, Ps...>) { (phase(std::integral_constant<int, PB + Ps>{}), ...); }(std::make_integer_sequence<int, NPH - PB>{});
 #pragma unroll
         for (int m = 0; m < (NPH - PB) * KB * NB; ++m) {
@@ -503,12 +511,12 @@ __global__ __launch_bounds__(64 * WK * WN, WK * WN / 4) void conv_wgrad_rows_k(W
   else body(std::integral_constant<int, 1>{});
 }
 
-template <int WK, int WN, int KB, int NB, bool PRO, bool PAIR>
-int launch_rows_pp(WgRowsArgs& a, hipStream_t s) {
+template <int WK, int WN, int KB, int NB, bool PRO, bool PAIR, bool X1>
+int launch_rows_ppx(WgRowsArgs& a, hipStream_t s) {
   using C = Cfg<WK, WN, KB, NB>;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_rows_k<WK, WN, KB, NB, PRO, PAIR>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_rows_k<WK, WN, KB, NB, PRO, PAIR, X1>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS) != hipSuccess)
       return MPOSE_EINVAL;
     attr_set = true;
   }
@@ -516,8 +524,12 @@ int launch_rows_pp(WgRowsArgs& a, hipStream_t s) {
   a.n_ntiles = (a.Cout + C::NT - 1) / C::NT;
   a.total = a.n_units * a.n_ktiles * a.n_ntiles * a.n_split * a.n_groups;
   a.chunk = (a.total + 7) / 8;
-  conv_wgrad_rows_k<WK, WN, KB, NB, PRO, PAIR><<<dim3(8 * a.chunk), C::NTH, C::LDS, s>>>(a);
+  conv_wgrad_rows_k<WK, WN, KB, NB, PRO, PAIR, X1><<<dim3(8 * a.chunk), C::NTH, C::LDS, s>>>(a);
   return launch_status();
+}
+template <int WK, int WN, int KB, int NB, bool PRO, bool PAIR>
+int launch_rows_pp(WgRowsArgs& a, hipStream_t s) {
+  return a.op[0].single_product ? launch_rows_ppx<WK, WN, KB, NB, PRO, PAIR, true>(a, s) : launch_rows_ppx<WK, WN, KB, NB, PRO, PAIR, false>(a, s);
 }
 template <int WK, int WN, int KB, int NB, bool PRO>
 int launch_rows_p(WgRowsArgs& a, hipStream_t s) {

@@ -115,7 +115,8 @@ class _Conv:
         self.stem = stem
         self.npad_f = _rup(cout, 64)             # forward pack: N = cout, K = cin_s
         self.npad_d = _rup(cin, 64)              # dgrad pack:   N = cin,  K = cout_s
-        # packed as three bf16 planes (hi, mid, lo) = 6 bytes per element = 1.5 floats of arena
+        # arena sized for the largest packing: three bf16 planes (hi, mid, lo; the six-product form) = 6 bytes per element = 1.5
+        # floats; the default three-product form packs two fp16 planes (4 bytes per element) into the same slot
         self.size_f = self.T * cin_s * self.npad_f * 3 // 2
         self.size_d = self.T * cout_s * self.npad_d * 3 // 2
         self.size_g = self.T * cin_s * self.npad_f          # one split-K partial of the weight gradient (fp32)
@@ -172,8 +173,8 @@ class KernelTimer:
         self.records.append((tag, start, ev, work))
 
     def calibrate(self, n=64):
-        """Cost of an empty start/stop bracket (two event packets back to back on a busy stream), in ms: subtracted
-        from every measured launch so that the averages agree with rocprofv3's kernel durations."""
+        """Cost of an empty start/stop bracket (two event packets back to back on a busy stream), in ms.  REPORTED beside the
+        averages (bench.py), not subtracted from them: a launch's duration is what the events say."""
         evs = []
         busy = torch.zeros(1 << 20, device='cuda')
         for _ in range(n):
@@ -183,13 +184,13 @@ class KernelTimer:
             evs.append((a, b))
         torch.cuda.synchronize()
         ts = sorted(a.elapsed_time(b) for a, b in evs)
-        self.bracket_ms = ts[len(ts) // 2]
-        return self.bracket_ms
+        self.bracket_cal_ms = ts[len(ts) // 2]
+        return self.bracket_cal_ms
 
     def summary(self):
         """tag -> dict(n, total_ms, avg_us, work_per_launch).  Call after torch.cuda.synchronize()."""
         out = {}
-        off = getattr(self, 'bracket_ms', 0.0)
+        off = 0.0
         for tag, a, b, work in self.records:
             d = out.setdefault(tag, {'n': 0, 'total_ms': 0.0, 'work': 0.0})
             d['n'] += 1
@@ -267,6 +268,7 @@ class Engine:
         # pass (mpose_absmax) before the convolution that reads it.  MPOSE_F16X3=0 keeps the six-product form (A/B runs).
         self.f16x3 = os.environ.get('MPOSE_F16X3', '1') != '0'
         self.conv_bf16 = False       # single-pass bf16 convolutions in the columns (MargiPoseModel.conv_dtype, configs[4])
+        self.conv_f16x1 = False      # every convolution on fp16-ROUNDED operands, one product (MPOSE_CONV_F16X1; conv_dtype = float16)
         for c in block_convs:
             c.layout = 1             # packed-weight layout when the plane engine runs (layout 0 otherwise; see pack_weights)
         block_bns = [n for b in self._all_blocks for n in (b.bn1, b.bn2, b.bns)]
@@ -650,7 +652,7 @@ class Engine:
         return 2 if self.f16x3 else 0
 
     def conv_flags(self, cmode):
-        return (4 | (8 if self.conv_bf16 else 0)) if cmode == 1 else (32 if cmode == 2 else 0)
+        return (4 | (8 if self.conv_bf16 else 0)) if cmode == 1 else ((32 | (64 if self.conv_f16x1 else 0)) if cmode == 2 else 0)
 
     def absmax(self, tensors, slots, C, scales=None, shifts=None, relu=False):
         """Largest magnitude of each NHWC tensor (after an optional per-channel affine map + ReLU) into its device slot; tensors
@@ -1055,6 +1057,7 @@ class Engine:
         cmode = ctx['cmode']
         planes, f16 = cmode == 1, cmode == 2
         pflags = ctx['pflags']         # (the forward's convolution engine and precision)
+        x1 = f16 and bool(pflags & 64)
         if self._packed_for != cmode:      # a forward on another engine ran in between: the parameters are unchanged (checked
             self.pack_weights(cmode)       # above), so this restores exactly the packing of this context's forward
         if f16:
@@ -1147,6 +1150,7 @@ class Engine:
                     wo.gout0, wo.dw0 = d_c2[c].data_ptr(), tb['part_ptr'][id(b.conv2)]
                     if f16:
                         wo.in_amax, wo.gout0_amax = self._amax_f(t, i, 1, c), self._amax_b(t, i, 0, c)
+                        wo.single_product = int(x1)
                     wops.append(wo)
                 g_w2 = self.geom('f_conv2', B, Hout, b0)
                 self.wgrad_async(g_w2, wops, self.wg_n_split(g_w2), sv['c1'] + d_c2)
@@ -1178,6 +1182,7 @@ class Engine:
                     if f16:
                         wo.in_amax = self._amax_f(t, i, 0, _first_same(sv['x'], c))
                         wo.gout0_amax, wo.gout1_amax = self._amax_b(t, i, 1, c), self._amax_b(t, i, 2, c)
+                        wo.single_product = int(x1)
                     wops.append(wo)
                 g_w1 = self.geom(gname, B, Hin, b0)
                 self.wgrad_async(g_w1, wops, self.wg_n_split(g_w1), list(sv['x']) + d_c1 + d_sc)

@@ -344,6 +344,7 @@ class _GraphStem:
             eng.finalize_table(tb['fin'], 0, tb['n_fin'], False)
         if f16:
             self.amax_f.zero_()
+        cflags = eng.conv_flags(2) if f16 else 0       # (three-product form, or its single-product reduced-precision variant)
         measured = set()
         raw = {}
         img = self.nodes[0]
@@ -379,7 +380,7 @@ class _GraphStem:
                                    relu=sc is not None)
                         measured.add(src.name)
                     o.in_amax, o.w0_amax = src.amax_f, op.conv.amax_ptr
-                eng.conv(self.geom(op, B, S, 'f'), [o], 32 if f16 else 0)
+                eng.conv(self.geom(op, B, S, 'f'), [o], cflags)
             elif isinstance(op, _AddOp):
                 ao = BnAddOperands()
                 ao.a, ao.a_scale, ao.a_shift = raw[op.a.name].data_ptr(), self.fptr(op.a, 0), self.fptr(op.a, 1)
@@ -400,7 +401,7 @@ class _GraphStem:
         out = torch.empty(B, S // n7.div, S // n7.div, n7.C, **f32)
         check(L.mpose_bn_relu_fwd(ptr(raw[n7.name]), c_void_p(self.fptr(n7, 0)), c_void_p(self.fptr(n7, 1)), ptr(out),
                                   c_int64(out.numel()), n7.C, st()), 'mpose_bn_relu_fwd')
-        ctx = {'raw': raw, 'B': B, 'S': S, 'train': train, 'f16': f16, 'measured': measured} if save else None
+        ctx = {'raw': raw, 'B': B, 'S': S, 'train': train, 'f16': f16, 'cflags': cflags, 'measured': measured} if save else None
         return out, ctx
 
     # ------------------------------------------------------------------ backward
@@ -414,6 +415,7 @@ class _GraphStem:
         tb = self.tables(B, S)
         self.s_arena.zero_()
         f16 = ctx.get('f16', False)
+        cflags = ctx.get('cflags', 32 if f16 else 0)
         if f16:
             self.amax_b.zero_()
         dact = {self.out_node.name: D}
@@ -462,6 +464,7 @@ class _GraphStem:
                     wo.dw0 = eng.part_ptr(B, S, op.conv)
                     if f16:
                         wo.in_amax, wo.gout0_amax = src.amax_f, n.amax_b
+                        wo.single_product = int(bool(cflags & 64))
                     eng.wgrad_async(self.geom(op, B, S, 'f'), [wo], eng.stem_n_split(B, S, op), [raw[src.name], d_raw])
                     if want_dsrc:
                         o = ConvOperands()
@@ -469,7 +472,7 @@ class _GraphStem:
                         o.out0 = dact[src.name].data_ptr()
                         if f16:
                             o.in_amax, o.w0_amax = n.amax_b, op.conv.amax_ptr
-                        eng.conv(self.geom(op, B, S, 'd'), [o], 1 | (32 if f16 else 0))       # accumulate
+                        eng.conv(self.geom(op, B, S, 'd'), [o], 1 | cflags)       # accumulate
                 elif want_dsrc and op.kind == 0:
                     ws = torch.empty(B * H * H * src.C, dtype=torch.uint8, device=dev)       # window arg-max positions
                     check(L.mpose_maxpool3_bwd_ws(ptr(raw[src.name]), c_void_p(sc), c_void_p(sh), c_void_p(d_raw.data_ptr() + 4 * op.c0),

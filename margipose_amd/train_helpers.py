@@ -68,16 +68,55 @@ def forward_loss(model, out_var, target_var, mask_var, valid_depth):
     return dsntnn.average_loss(losses, mask_var)
 
 
-def training_step(model, scheduler, in_var, target_var, mask_var, valid_depth):
-    """One iteration of do_training_pass (train_3d.py:154-186) without data loading / metrics."""
+class StepTimes:
+    """The reference's wall-clock meters around one iteration (train_3d.py:44-49: `forward_time`, `backward_time`, `optim_time`,
+    each a mean over the epoch's batches; tele's MeanValueMeter): .add(name, seconds), .mean(name), .reset().
+    The reference times host-side `perf_counter` intervals around asynchronous launches -- its `forward_time` ends with
+    `loss.sum().item()`, a device synchronisation, the other two do not wait for the GPU -- and so does training_step when it is
+    given a StepTimes: the forward bucket ends with the same `.item()`, nothing else synchronises."""
+    NAMES = ('forward_time', 'backward_time', 'optim_time')
+
+    def __init__(self):
+        self.reset()
+
+    def reset(self):
+        self.total = {k: 0.0 for k in self.NAMES}
+        self.count = {k: 0 for k in self.NAMES}
+        self.train_loss = 0.0
+
+    def add(self, name, seconds):
+        self.total[name] += seconds
+        self.count[name] += 1
+
+    def mean(self, name):
+        return self.total[name] / self.count[name] if self.count[name] else 0.0
+
+
+def training_step(model, scheduler, in_var, target_var, mask_var, valid_depth, times=None):
+    """One iteration of do_training_pass (train_3d.py:154-186) without data loading / metrics.
+    times: an optional StepTimes that receives the reference's three timing buckets (and, like the reference's
+    `tel['train_loss'].add(loss.sum().item())`, the loss value -- which is what makes `forward_time` include the GPU's work)."""
+    import time
     if hasattr(scheduler, 'batch_step'):
         scheduler.batch_step()
     optimiser = scheduler.optimizer
+    t0 = time.perf_counter()
     out_var = model(in_var)
     loss = forward_loss(model, out_var, target_var, mask_var, valid_depth)
+    if times is not None:
+        times.train_loss += loss.sum().item()
+        t1 = time.perf_counter()
+        times.add('forward_time', t1 - t0)
+        t0 = t1
     optimiser.zero_grad()
     loss.backward()
+    if times is not None:
+        t1 = time.perf_counter()
+        times.add('backward_time', t1 - t0)
+        t0 = t1
     optimiser.step()
+    if times is not None:
+        times.add('optim_time', time.perf_counter() - t0)
     return out_var, loss
 
 
@@ -117,6 +156,10 @@ class DeviceSGD:
         self.params = [p for p in params]
         if not self.params or not all(p.is_cuda and p.dtype == torch.float32 for p in self.params):
             raise _lib.MposeError('DeviceSGD needs float32 parameters on a ROCm device')
+        if not all(p.is_contiguous() and p.data_ptr() % 16 == 0 for p in self.params):       # (sgd_step_k reads and writes float4)
+            raise _lib.MposeError('DeviceSGD needs contiguous, 16-byte aligned parameters')
+        if _lib.lib().mpose_sizeof(11) != _sgd_job_dtype().itemsize:
+            raise _lib.MposeError('ABI struct 11 (mpose_sgd_job): library and binding disagree')
         self.param_groups = [{'params': self.params, 'lr': float(lr), 'momentum': float(momentum)}]
         dev = self.params[0].device
         offs, tot = [], 0
@@ -158,8 +201,9 @@ class DeviceSGD:
             if not g.is_contiguous() or g.data_ptr() % 16:
                 raise RuntimeError('DeviceSGD needs contiguous, 16-byte aligned gradients')
             jobs[i] = (p.data_ptr(), g.data_ptr(), self._buf_ptr[i], p.numel())
-        # The engine hands out views of one persistent flat gradient buffer, so the table is the same every step: upload it only
-        # when an address moved, and then from pinned memory, stream-ordered.  (A copy from pageable memory every step was a
+        # The engine hands out views of a per-step clone of its flat gradient buffer; the caching allocator usually returns the same
+        # one or two blocks, so the table mostly repeats: upload it only when an address moved, and then from pinned memory,
+        # stream-ordered.  (A copy from pageable memory every step was a
         # host-device synchronisation per iteration: the eager loop lost 1.1 ms of a 34 ms step to the bubble behind it.)
         raw = jobs.tobytes()
         if self._uploaded.get(id(table)) != raw:
@@ -222,7 +266,13 @@ class GraphedTrainStep:
 
     `optimiser`: DeviceSGD (hyper-parameters may change every step, e.g. driven by make_1cycle(...).batch_step()) or any torch
     optimiser whose step() is capturable with FIXED hyper-parameters (torch.optim.SGD(..., fused=True)).
-    `valid_depth` (3D vs 2D loss per sample, train_3d.py:126-142) is fixed at capture time."""
+    `valid_depth` (3D vs 2D loss per sample, train_3d.py:126-142) is fixed at capture time.
+
+    Side effects of the constructor (torch's capture rule needs eager warm-up runs): it executes `warmup` REAL iterations on the
+    example batch and the capture pass itself records one more -- optimiser steps that move the weights, the momentum buffers,
+    the BatchNorm running statistics and num_batches_tracked, and consume DeviceSGD's first-step flag.  Construct it before
+    training starts (or on a throw-away copy of the batch with lr = 0); a non-DeviceSGD optimiser's hyper-parameters are frozen
+    into the graph."""
 
     def __init__(self, model, optimiser, x, target, mask, valid_depth=None, warmup=2):
         self.model, self.opt = model, optimiser
@@ -267,7 +317,9 @@ class BatchStager:
     """Host -> device staging of training batches (reference bin/train_3d.py:158-161: `batch['input'].to(device, float32)`,
     `batch['target']...`, `batch['joint_mask']...`, synchronous and from pageable memory), done the way the device wants it:
     pinned double buffers, one asynchronous copy per tensor on a dedicated copy stream, overlapped with the previous
-    iteration's kernels; the consumer stream waits on an event, never on the host.  Frames may stay uint8 across PCIe (a
+    iteration's kernels (the copy stream only waits for the consumer's position at the PREVIOUS stage() call -- by then the
+    last reader of this slot's device buffers, two iterations back, had been enqueued -- not for the work enqueued since);
+    the consumer stream waits on an event, never on the host.  Frames may stay uint8 across PCIe (a
     quarter of the bytes: 6.3 MB instead of 25 MB per 32 frames): MargiPoseModel normalises them on the device
     (`ImageSpecs.convert` fused into the feature extractor's first load).
 
@@ -283,6 +335,7 @@ class BatchStager:
         self.stream = torch.cuda.Stream(device=self.device)
         self._slots = [dict() for _ in range(depth)]          # key -> (pinned host tensor, device tensor)
         self._events = [None] * depth
+        self._consumer_mark = None                             # the consumer stream's position at the previous stage() call
         self._i = 0
 
     def _buffers(self, slot, key, t, dtype):
@@ -300,7 +353,14 @@ class BatchStager:
             self._events[i].synchronize()                      # the copy that last read this slot's pinned buffers is done
         out = dict(batch)
         consumer = torch.cuda.current_stream(self.device)
-        self.stream.wait_stream(consumer)                      # the device buffers of this slot are free again (2 iterations old)
+        # The device buffers of this slot were last read by the iteration staged `depth` calls ago; everything up to the previous
+        # call is covered by the mark taken then.  (Waiting for the whole consumer stream here would put the copy BEHIND the
+        # iteration that was just enqueued: no overlap at all.)
+        if self._consumer_mark is not None:
+            self.stream.wait_event(self._consumer_mark)
+        mark = torch.cuda.Event()
+        mark.record(consumer)
+        self._consumer_mark = mark
         with torch.cuda.stream(self.stream):
             for key in self.keys:
                 if key not in batch:

@@ -234,10 +234,12 @@ def test_conv_prologue_and_bn_statistics(B, H, C):
     assert float(err.max()) < 1e-4, float(err.max())
 
 
-@pytest.mark.parametrize('B,H,cin,cout,ratio', [(2, 32, 128, 128, 1.0), (8, 16, 192, 192, 1e-9), (1, 12, 64, 96, 1e6), (4, 32, 32, 128, 1e-3)])
+@pytest.mark.parametrize('B,H,cin,cout,ratio', [(2, 32, 128, 128, 1.0), (8, 16, 192, 192, 1e-9), (1, 12, 64, 96, 1e6), (4, 32, 32, 128, 1e-3),
+                                               (2, 16, 64, 64, 0.0), (2, 16, 64, 64, 1e-30)])
 def test_conv_sum_of_two_inputs(B, H, cin, cout, ratio):
     """MPOSE_CONV_SUM_INPUTS with the two inputs at very different magnitudes: each has its own scale, the first pass is
-    re-expressed in the second pass's units (a power of two) before the second accumulates on top."""
+    re-expressed in the second pass's units (a power of two) before the second accumulates on top.  ratio 0 / 1e-30: a second input
+    that is all zeros (a shortcut BatchNorm frozen at gamma = 0) or negligible must not overflow that re-expression."""
     from margipose_amd import _lib, engine as eng
     from margipose_amd._lib import ConvOperands
     L = _lib.lib()

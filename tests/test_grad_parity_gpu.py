@@ -129,12 +129,13 @@ def mask_flips(a, b):
     return sum(int((a[k] != b[k]).sum()) for k in a), n
 
 
-@pytest.mark.parametrize('T,B,engine', [(1, 2, 'auto'), (2, 2, 'auto'), (1, 8, 'auto'), (3, 4, 'auto'), (2, 2, 'planes'), (1, 8, 'planes'),
-                                        (2, 2, 'bf16x6')])
+@pytest.mark.parametrize('T,B,engine', [(1, 2, 'auto'), (2, 2, 'auto'), (1, 8, 'auto'), (2, 2, 'planes'), (1, 2, 'bf16x6')])
 def test_grads_on_the_same_relu_piece(T, B, engine):
-    """engine 'auto' = what training runs by default (conv_igemm_k / conv_wgrad_k with three fp16 products); 'planes' forces the
-    plane engine (conv_planes_k: pre-split operands, six bf16 products, two accumulators) through the same step; 'bf16x6' =
-    conv_igemm_k / conv_wgrad_k with six bf16 products (round 1's arithmetic)."""
+    """engine 'auto' = what training runs by default (conv_igemm_k + the row-of-taps weight gradient, three fp16 products); 'planes'
+    forces the plane engine (conv_planes_k: pre-split operands, six bf16 products, two accumulators) through the same step;
+    'bf16x6' = conv_igemm_k / conv_wgrad_k with six bf16 products (round 1's arithmetic).  (Three stages on a common piece: the
+    configuration-size test below.  The free-running fp64 pass -- how many ReLU sites sit on another piece, and what that alone
+    does to the gradients -- runs for ONE case: it is a CPU fp64 backward pass per case and the suite has a time budget.)"""
     seed = 700 + 10 * T + B
     x, target, mask = W.seeded_inputs(seed + 1000, B)
     rng = np.random.default_rng(seed)
@@ -148,15 +149,17 @@ def test_grads_on_the_same_relu_piece(T, B, engine):
         m.inner.engine().f16x3, m.inner.engine().planes_mode = False, '0'
         tag += '_bf16x6'
     gpu, masks, loss_gpu = gpu_step(m, x, target, mask)
-    own = {}
-    free64, _ = oracle_grads(sd, T, x, target, mask, torch.float64, record=own)      # the oracle on ITS piece (for the record)
     ref64, loss64 = oracle_grads(sd, T, x, target, mask, torch.float64, masks=masks)
     ref32, _ = oracle_grads(sd, T, x, target, mask, torch.float32, masks=masks)
-    flips, total = mask_flips(masks, own)
-    free = compare('free_' + tag, gpu, free64, ref32)
-    st = compare('masked_' + tag, gpu, ref64, ref32,
-                 {'relu_sites_flipped_vs_fp64': flips, 'relu_sites': total, 'free_running_gpu_median': free['gpu_median'],
-                  'free_running_gpu_max': free['gpu_max']})
+    extra = {}
+    if (T, B, engine) == (2, 2, 'auto'):
+        own = {}
+        free64, _ = oracle_grads(sd, T, x, target, mask, torch.float64, record=own)      # the oracle on ITS piece (for the record)
+        flips, total = mask_flips(masks, own)
+        free = compare('free_' + tag, gpu, free64, ref32)
+        extra = {'relu_sites_flipped_vs_fp64': flips, 'relu_sites': total, 'free_running_gpu_median': free['gpu_median'],
+                 'free_running_gpu_max': free['gpu_max']}
+    st = compare('masked_' + tag, gpu, ref64, ref32, extra)
     assert abs(loss_gpu - loss64) <= 1e-5 * abs(loss64)
     assert st['gpu_max'] <= MASKED_TOL, st
     assert st['gpu_median'] <= max(1.5 * st['ref32_median'], 2e-6), st
@@ -166,17 +169,25 @@ def test_grads_on_the_same_relu_piece(T, B, engine):
 @pytest.mark.parametrize('stem', ['patch8', 'inceptionv4'])
 def test_config_size_train_step_gradients(stem):
     """BASELINE.json configs[2]: batch 32, three stages, JS + Euclidean loss -- every gradient against the fp64 and the fp32
-    oracle, free running (each implementation on its own ReLU / max-pool piece)."""
+    oracle.  patch8: on a COMMON ReLU piece (the oracle forced onto the masks the GPU used): pure arithmetic error at the
+    configuration's size.  inceptionv4 (the reference's default stem; no mask control for its ReLU / max-pool sites): free
+    running, each implementation on its own piece.  (Round 2 also ran patch8 free and on the plane engine here: two more CPU
+    fp64 / fp32 backward passes at B=32, dropped for the suite's time budget -- profiles/r2_gradient_parity.json has them.)"""
     T, B, seed = 3, 32, 900
     x, target, mask = W.seeded_inputs(seed + 1000, B)
     m, sd = build(T, seed, x, stem)
-    gpu_planes = None
     if stem == 'patch8':
         gpu, masks, loss_gpu = gpu_step(m, x, target, mask)
-        m2, _ = build(T, seed, x, stem)                       # the same step on the plane engine (free-running comparison only)
-        m2.inner.engine().planes_mode = '1'
-        gpu_planes, _, _ = gpu_step(m2, x, target, mask)
-        del m2
+        m64, loss64 = oracle_grads(sd, T, x, target, mask, torch.float64, masks=masks)
+        m32, _ = oracle_grads(sd, T, x, target, mask, torch.float32, masks=masks)
+        sm = compare('config_%s_T3_B32_masked' % stem, gpu, m64, m32)
+        assert abs(loss_gpu - loss64) <= 1e-5 * abs(loss64)
+        assert sm['gpu_max'] <= MASKED_TOL_CONFIG, sm
+        assert sm['gpu_median'] <= 1.5 * sm['ref32_median'], sm
+        # the tail, not only the median: the worst percentile sits 3.4x above the fp32 oracle's (the weight-residual bias of the
+        # first blocks' shortcut BatchNorm bias gradients, see MASKED_TOL_CONFIG) -- gated so that it cannot grow unnoticed
+        assert sm['gpu_p99'] <= 4.0 * sm['ref32_p99'], sm
+        return
     else:
         from margipose_amd import dsntnn
         xg = x.cuda().requires_grad_(True)
@@ -194,13 +205,4 @@ def test_config_size_train_step_gradients(stem):
     # against tensor population it must stay within FREE_RATIO x the reference's own fp32 path (1.5 x on the plane engine)
     assert st['gpu_median'] <= max(1e-4, FREE_RATIO * st['ref32_median']), st
     assert st['gpu_p99'] <= max(1e-4, FREE_RATIO * st['ref32_p99']), st
-    if gpu_planes is not None:
-        sp = compare('config_%s_T3_B32_planes' % stem, gpu_planes, ref64, ref32)
-        assert sp['gpu_median'] <= max(1e-4, 1.5 * sp['ref32_median']), sp
-        assert sp['gpu_p99'] <= max(1e-4, 1.5 * sp['ref32_p99']), sp
-    if masks is not None:
-        m64, _ = oracle_grads(sd, T, x, target, mask, torch.float64, masks=masks)
-        m32, _ = oracle_grads(sd, T, x, target, mask, torch.float32, masks=masks)
-        sm = compare('config_%s_T3_B32_masked' % stem, gpu, m64, m32)
-        assert sm['gpu_max'] <= MASKED_TOL_CONFIG, sm
-        assert sm['gpu_median'] <= 1.5 * sm['ref32_median'], sm
+

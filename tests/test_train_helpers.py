@@ -42,7 +42,7 @@ def test_five_step_training_curve_vs_reference(golden_dir):
     run drifts from its fp64 run (1e-7 at step 1, 1e-3 at step 5), so each step is gated on 3x that drift."""
     from oracle import weights as W
     from margipose_amd.models import CanonicalSkeletonDesc, MargiPoseModel
-    from margipose_amd.train_helpers import make_1cycle, training_step
+    from margipose_amd.train_helpers import StepTimes, make_1cycle, training_step
     g = np.load(os.path.join(golden_dir, 'train_curve.npz'))
     T, seed, B = 1, int(g['seed']), 2
     x, target, _ = W.seeded_inputs(seed + 1000, B)
@@ -53,8 +53,9 @@ def test_five_step_training_curve_vs_reference(golden_dir):
     sched = make_1cycle(opt, 10, lr_max=0.05, momentum=0.9)
     mask = torch.ones(B, 17, device='cuda')
     losses = []
+    times = StepTimes()                  # the reference's forward_time / backward_time / optim_time meters (train_3d.py:44-49,167-186)
     for it in range(5):
-        out, loss = training_step(m, sched, x.cuda(), target.cuda(), mask, [1, 1])
+        out, loss = training_step(m, sched, x.cuda(), target.cuda(), mask, [1, 1], times=times)
         assert abs(opt.param_groups[0]['lr'] - g['lr'][it]) < 1e-12 and abs(opt.param_groups[0]['momentum'] - g['momentum'][it]) < 1e-12
         losses.append(float(loss))
     drift = np.abs(g['losses_f32'] - g['losses_f64'])
@@ -62,3 +63,5 @@ def test_five_step_training_curve_vs_reference(golden_dir):
     print('loss curve', losses, 'ours-vs-fp64', err, 'reference fp32-vs-fp64', drift)
     assert np.all(err <= np.maximum(1e-5 * g['losses_f64'], 3 * drift)), (err, drift)
     assert err[0] < 1e-5 * g['losses_f64'][0]
+    assert all(times.count[k] == 5 and times.mean(k) > 0 for k in StepTimes.NAMES), (times.count, times.total)
+    assert abs(times.train_loss - sum(losses)) < 1e-4 * sum(losses)       # (`tel['train_loss'].add(loss.sum().item())`)
