@@ -25,8 +25,12 @@
 #include "common.h"
 #include <stdlib.h>
 
+#ifndef MFMA_SPREAD
+#define MFMA_SPREAD 1      // 0: round 2's rm-major MFMA chains (A/B builds)
+#endif
 #ifndef CV_EXP
-#define CV_EXP 0      // timing experiments (tools/igemm_exp.sh; wrong results): 1 no epilogue, 2 no K loop, 4 no split-K exchange
+#define CV_EXP 0      // timing experiments (tools/igemm_exp.sh; wrong results): 1 no epilogue, 2 no K loop, 4 no split-K exchange,
+                      // 8 every B fragment from one place (L1-resident weights), 16 every A row from one place
 #endif
 
 namespace mpose {
@@ -312,8 +316,8 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
       const int tp = tap_word(ti.t);
       const int dy = (int)(signed char)(tp & 0xff), dx = (int)(signed char)((tp >> 8) & 0xff);
       const int widx = (tp >> 16) & 0xff;
-      ti.a_soff = (unsigned)(((dy * g.IW + dx) * in_ld + ti.c * KC) * 4 + a.in_bias);
-      ti.w_soff = (unsigned)(widx * k16_total + ti.c * (KC / 16)) * (unsigned)NPM * plane_b;
+      ti.a_soff = (CV_EXP & 16) ? (unsigned)a.in_bias : (unsigned)(((dy * g.IW + dx) * in_ld + ti.c * KC) * 4 + a.in_bias);
+      ti.w_soff = (CV_EXP & 8) ? 0u : (unsigned)(widx * k16_total + ti.c * (KC / 16)) * (unsigned)NPM * plane_b;
       return ti;
     };
     auto tile_info = [&](int it) { const int c = it / nt; return tile_ct(c, it - c * nt); };
@@ -385,6 +389,41 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
     // each column block followed by the refill of its B fragments with the same k-group of tile `nb`.  `side(rn)`
     // is the staging work the caller wants issued between the MFMAs of column block rn.
     auto mfma_group = [&](int s_, const u32x4 (&af)[2][NPL], const TileInfo& nb, auto&& side) {
+      if constexpr (NPL == 2 && MFMA_SPREAD) {
+        // Three-product form, column blocks in PAIRS, products outermost: al*bh over the pair's four accumulators, then ah*bl,
+        // then ah*bh -- the accumulation order of every accumulator is what it was (results bit-identical), but two consecutive
+        // MFMAs never share an accumulator.  Why: an instruction issued between two MFMAs on the SAME accumulator costs ~43
+        // cycles, between MFMAs on different ones ~6 and up to five of them hide (MI355X_MICROARCH.md, "one wave per SIMD"), so
+        // with rm-major chains of three the staging work could only sit behind the chains -- exposed.  The pattern below hands
+        // every gap between two MFMAs a share of the block pair's other instructions.
+        constexpr int STEP = RN >= 2 ? 2 : 1;
+#pragma unroll
+        for (int rn0 = 0; rn0 < RN; rn0 += STEP) {
+          constexpr int dummy = 0;
+          const int nblk = (rn0 + STEP <= RN) ? STEP : RN - rn0;
+#pragma unroll
+          for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int j = 0; j < STEP; ++j)
+              if (j < nblk) {
+#pragma unroll
+                for (int rm = 0; rm < 2; ++rm)
+                  acc0[rm][rn0 + j] = mfma_f16(af[rm][p == 0 ? 1 : 0], fb[s_][rn0 + j][p == 1 ? 1 : 0], acc0[rm][rn0 + j]);
+              }
+#pragma unroll
+          for (int j = 0; j < STEP; ++j)
+            if (j < nblk) { load_b(nb, s_, rn0 + j); side(rn0 + j); }
+#pragma unroll
+          for (int m = 0; m < 6 * STEP; ++m) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x030, 1, 0);
+            if (m % 3 == 2) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        return;
+      }
 #pragma unroll
       for (int rn = 0; rn < RN; ++rn) {
         if constexpr (NPL == 1) {
@@ -449,7 +488,7 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
           G.c = c; G.t = 3 * ky;
           const int dy = (int)(signed char)(tap_word(G.t) & 0xff);
           G.qs = dy * g.IW - 1;
-          G.a_soff = (unsigned)((G.qs * in_ld + c * KC) * 4 + a.in_bias);
+          G.a_soff = (CV_EXP & 16) ? (unsigned)(a.in_bias + in_ld * 4 * (g.IW + 1)) : (unsigned)((G.qs * in_ld + c * KC) * 4 + a.in_bias);
           return G;
         };
         auto load_piece = [&](const GroupInfo& G, int j) {       // staged rows 8j .. 8j+7, 16 bytes per lane

@@ -78,7 +78,7 @@ def report(name, errs, tol=TOL):
     assert not bad, 'parity failures (%s): %s' % (name, bad[:10])
 
 
-@pytest.mark.parametrize('T,perm,engine', [(1, True, 'auto'), (2, True, 'auto'), (1, False, 'auto'), (2, True, 'planes'), (1, True, 'bf16x6')])
+@pytest.mark.parametrize('T,perm,engine', [(1, True, 'auto'), (2, True, 'auto'), (1, False, 'auto'), (1, True, 'planes'), (1, True, 'bf16x6')])
 def test_eval_forward(T, perm, engine):
     """engine: 'auto' = conv_igemm_k with three fp16 products (the default); 'planes' = the plane engine with BatchNorm, ReLU and
     the residual sum fused into its epilogues; 'bf16x6' = conv_igemm_k with six bf16 products."""
@@ -99,6 +99,35 @@ def test_eval_forward(T, perm, engine):
         for t in range(T):
             errs['hm_%s%d' % (p, t)] = rel(getattr(m, p + '_heatmaps')[t].cpu(), ref[p][t].detach())
     report('eval_T%d_%d%s' % (T, perm, '' if engine == 'auto' else '_' + engine), errs)
+
+
+def test_inference_config_batch64_vs_oracle():
+    """BASELINE configs[1] at its own size -- batch 64, 3 stages, 256x256, eval mode, bf16 heatmap storage + fp32 soft-argmax --
+    against the fp64 oracle with the same rounding points (tests' test_bf16_heatmap_inference_mode explains them).  At B=64 the
+    split-K cost model picks the unsplit 128-channel launches with the fused output stage (conv.hip::pick_ks, inference
+    constants): the launch plan bench.py's inference leg times, checked here at full size (the small-batch eval tests run other
+    plans).  Coordinates 1e-4; stored heatmaps one bf16 ulp where the fp32 values straddle a rounding boundary."""
+    T, seed, B = 3, 460, 64
+    x, target, mask = W.seeded_inputs(seed + 1000, B)
+    m = build(T, seed, x).eval()
+    m.heatmap_dtype = torch.bfloat16
+    with torch.no_grad():
+        out = m(x.cuda())
+        assert out.shape == (B, 17, 3) and m.xy_heatmaps[-1].dtype == torch.bfloat16
+        sd = weights(T, seed, x, True)
+        sd = OrderedDict((k, v.double() if v.is_floating_point() else v) for k, v in sd.items())
+        un = {}
+        xy, zy, xz = R.inner_forward(sd, x.double(), T, False, True, heatmap_dtype=torch.bfloat16, unrounded=un)
+        ref = R.heatmaps_to_coords(un['xy'], un['zy'], un['xz'])
+    err = rel(out.cpu(), ref)
+    worst = 0.0
+    for got, want in ((m.xy_heatmaps, xy), (m.zy_heatmaps, zy), (m.xz_heatmaps, xz)):
+        for t in range(T):
+            g, w = got[t].float().cpu().double(), want[t]
+            worst = max(worst, float(((g - w).abs() / w.abs().clamp_min(1e-30)).max()))
+            assert float((g != w).double().mean()) < 5e-3
+    print('configs[1] B=64 T=3: coords %.2e, worst heatmap element %.2e' % (err, worst))
+    assert err < TOL and worst <= 2.0 ** -7, (err, worst)
 
 
 def grad_noise_gate(name, gpu, ref64, ref32):
@@ -142,7 +171,7 @@ def grad_noise_gate(name, gpu, ref64, ref32):
     assert stats['zero_grad_abs_max'] < 1e-4, stats
 
 
-@pytest.mark.parametrize('T,B,planes', [(1, 2, False), (2, 2, False), (1, 3, False), (1, 2, True)])
+@pytest.mark.parametrize('T,B,planes', [(1, 2, False), (2, 2, False), (1, 2, True)])
 def test_train_step_vs_oracle(T, B, planes):
     """planes=True forces the plane convolution engine (inference's and the bf16 mode's) through an fp32 training step."""
     seed = 500 + T
@@ -596,41 +625,34 @@ def test_default_model_single_frame_vs_oracle():
 
 def test_five_stage_model_at_384_vs_oracle():
     """BASELINE configs[4]'s shape: 5 stages at 384x384 input (48x48 heatmaps, 24x24 mid resolution; the size constraint of
-    models/margipose_model.py:87-97), one training step against the fp64 oracle; gradients by whole-model norm and the
-    same-population bar as tests/test_grad_parity_gpu.py."""
+    models/margipose_model.py:87-97), one training step against the fp64 oracle: forward quantities free running, gradients on
+    the ReLU piece the GPU took (tests/test_grad_parity_gpu.py's mask control: at B=1 a free-running comparison measures which
+    handful of the ~100 M ReLU sites flipped -- 1.5e-4 ... 1e-3 on the median from one build to the next -- not arithmetic)."""
     from margipose_amd import dsntnn
+    import tests.test_grad_parity_gpu as G
     T, seed, B, size = 5, 820, 1, 384
     x, target, mask = W.seeded_inputs(seed, B, size)
     m, sd = _build_stem(T, seed, x, 'patch8')
     m.train()
-    out = m(x.cuda())
+    xg = x.cuda().requires_grad_(True)
+    out = m(xg)
     assert m.xy_heatmaps[-1].shape == (B, 17, 48, 48) and len(m.zy_heatmaps) == 5
+    masks = G.gpu_relu_masks(m.inner.engine(), m.xy_heatmaps[0].grad_fn.ectx)
     l3 = m.forward_3d_losses(out, target.cuda())
     loss = dsntnn.average_loss(l3, mask.cuda())
     loss.backward()
     gpu = OrderedDict((k, p.grad.detach().cpu()) for k, p in m.named_parameters())
-
-    def oracle(dtype):
-        s = OrderedDict((k, v.detach().clone().to(dtype) if v.is_floating_point() else v.clone()) for k, v in sd.items())
-        params = OrderedDict((k, v.requires_grad_(True)) for k, v in s.items() if v.is_floating_point() and 'running' not in k)
-        xy, zy, xz = R.inner_forward(s, x.to(dtype), T, True)
-        ls = R.forward_3d_losses(xy, zy, xz, target.to(dtype))
-        R.average_loss(ls, mask.to(dtype)).backward()
-        return (xy, zy, xz), ls, OrderedDict((k, p.grad) for k, p in params.items())
-    (xy, zy, xz), ref_l3, g64 = oracle(torch.float64)
-    _, _, g32 = oracle(torch.float32)
+    gpu['__dx__'] = xg.grad.cpu()
+    with torch.no_grad():                      # forward quantities: the oracle on its own piece
+        xy, zy, xz = R.inner_forward(OrderedDict((k, v.double() if v.is_floating_point() else v) for k, v in sd.items()), x.double(), T, True)
+        ref_l3 = R.forward_3d_losses(xy, zy, xz, target.double())
     errs = {'coords': rel(out.detach().cpu(), R.heatmaps_to_coords(xy[-1], zy[-1], xz[-1]).detach()), 'l3': rel(l3.detach().cpu(), ref_l3.detach())}
     for t in range(T):
         errs['hm_zy%d' % t] = rel(m.zy_heatmaps[t].detach().cpu(), zy[t].detach())
     report('T5_384', errs)
-    typical = float(np.median([float(v.norm()) for v in g64.values()]))
-    e_gpu = np.array([rel_l2(gpu[k], g64[k]) for k in g64 if float(g64[k].norm()) > 1e-9 * typical])
-    e_ref = np.array([rel_l2(g32[k].double(), g64[k]) for k in g64 if float(g64[k].norm()) > 1e-9 * typical])
-    print('T5@384 grads: gpu median %.2e p99 %.2e | fp32 oracle median %.2e p99 %.2e' % (np.median(e_gpu), np.quantile(e_gpu, 0.99),
-                                                                                       np.median(e_ref), np.quantile(e_ref, 0.99)))
-    # free running at B=1 (each implementation on its own ReLU piece; which sites flip is luck: tests/test_grad_parity_gpu.py,
-    # FREE_RATIO); the arithmetic itself is gated on a common piece there
-    assert np.median(e_gpu) <= max(1e-4, 3.0 * np.median(e_ref)) and np.quantile(e_gpu, 0.99) <= max(1e-4, 3.0 * np.quantile(e_ref, 0.99))
+    g64, _, g32 = G.oracle_grads_pair(sd, T, x, target, mask, masks=masks)
+    st = G.compare('masked_T5_384', gpu, g64, g32)
+    assert st['gpu_max'] <= G.MASKED_TOL_CONFIG and st['gpu_median'] <= max(1.5 * st['ref32_median'], 2e-6), st
 
 
 def _oracle_step(sd, x, target, mask, T, dtype=torch.float64):

@@ -3,7 +3,7 @@
    python tools/make_profiles.py r2"""
 import collections, csv, glob, json, os, re, shutil, statistics, sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else 'r2'
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r3'
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(ROOT, 'gpurun_out', 'prof_' + tag)
 dst = os.path.join(ROOT, 'profiles')
@@ -51,15 +51,17 @@ labels = {   # bench.py kernel tag -> (template, threads in the grid, algorithmi
     'conv:d_conv2/16x16/192->192': ('conv_igemm_k<3, 0, 1, false, 2, true>', None, 3 * 8192 * (192 * 4 + 192 * 8) + 3 * 9 * 192 * 192 * 4),
     'conv:f_in_regular/16x16/192->192': ('conv_igemm_k<3, 1, 1, false, 2, true>', None, 3 * 8192 * (192 * 4 + 2 * 192 * 4) + 3 * 10 * 192 * 192 * 4),
     'conv:d_in_regular/16x16/192->192': ('conv_igemm_k<3, 2, 1, false, 2, true>', None, 3 * 8192 * (2 * 192 * 4 + 192 * 4) + 3 * 10 * 192 * 192 * 4),
-    'wgrad:f_conv2/32x32/128->128': ('conv_wgrad_k<4, 4, true>', None, 3 * 32768 * 128 * 8),
-    'wgrad:f_in_regular/32x32/128->128': ('conv_wgrad_k<4, 4, true>', None, 3 * 32768 * 128 * 12),
-    'wgrad:f_conv2/16x16/192->192': ('conv_wgrad_k<3, 3, true>', None, 3 * 8192 * 192 * 8),
-    'wgrad:f_in_regular/16x16/192->192': ('conv_wgrad_k<3, 3, true>', None, 3 * 8192 * 192 * 12),
+    # round 3: the row-of-taps weight gradient (wgrad.hip), template <WK, WN, KB, NB, PRO, PAIR, X1>; algorithmic bytes = the input and the
+    # gradient(s) read once + the split-K partial sums written once (n_split x taps x Cin x Cout x 4: 28 / 21 / 9 / 7 splits at B = 32)
+    'wgrad:f_conv2/32x32/128->128': ('conv_wgrad_rows_k<2, 2, 2, 2, true, true, false>', None, 3 * 32768 * 128 * 8 + 3 * 28 * 9 * 128 * 128 * 4),
+    'wgrad:f_in_regular/32x32/128->128': ('conv_wgrad_rows_k<2, 2, 2, 2, false, true, false>', None, 3 * 32768 * 128 * 12 + 3 * 21 * 10 * 128 * 128 * 4),
+    'wgrad:f_conv2/16x16/192->192': ('conv_wgrad_rows_k<2, 2, 3, 1, true, true, false>', None, 3 * 8192 * 192 * 8 + 3 * 9 * 9 * 192 * 192 * 4),
+    'wgrad:f_in_regular/16x16/192->192': ('conv_wgrad_rows_k<2, 2, 3, 1, false, true, false>', None, 3 * 8192 * 192 * 12 + 3 * 7 * 10 * 192 * 192 * 4),
 }
 out = {'_source': 'rocprofv3 --kernel-trace --pmc <one counter group per run> of `python bench.py --steps 1 --warmup 1 --no-cpu-baseline '
                   '--no-kernel-timing --no-overlap-wgrad --eager --no-inference` (tools/profile.sh %s): per-dispatch averages of the kernel '
                   'template (and grid) the label launches; hbm_bytes = 2 x FETCH_SIZE (16-byte/lane streams are tallied at half their bytes on '
-                  'gfx950, MI355X_MICROARCH.md; 1 x for conv_wgrad_k, whose gathers are dword loads) + WRITE_SIZE; mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs)' % tag}
+                  'gfx950, MI355X_MICROARCH.md; 1 x for conv.hip\'s conv_wgrad_k, whose gathers are dword loads) + WRITE_SIZE; mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs)' % tag}
 for label, (templ, grid, alg) in labels.items():
     keys = [k for k in ctr if k[0] == templ and (grid is None or k[1] == grid)]
     if not keys:
@@ -71,7 +73,7 @@ for label, (templ, grid, alg) in labels.items():
     conf, idx = avg('SQ_LDS_BANK_CONFLICT'), avg('SQ_LDS_IDX_ACTIVE')
     e = {'kernel': templ + (' grid %d' % grid if grid else ''), 'algorithmic_bytes': alg}
     if fe is not None and wr is not None:
-        fx = 1 if templ.startswith('conv_wgrad') else 2      # the weight gradient gathers with dword loads: counted in full
+        fx = 1 if templ.startswith('conv_wgrad_k') else 2    # conv_wgrad_k gathers with dword loads: counted in full; everything else streams 16 bytes per lane
         e.update(fetch_size_kb_reported=fe, write_size_kb_reported=wr, fetch_correction=fx, hbm_bytes_per_launch=int(fx * fe * 1024 + wr * 1024))
     if busy is not None and gui:
         e['mfma_busy_frac'] = busy / (gui / 8 * 1024)

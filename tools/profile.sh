@@ -1,7 +1,7 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun): kernel-trace stats of bench.py + PMC passes on the dominant kernels + the tail loop.
 # Outputs under gpurun_out/prof_$1/ ; copy the summaries you want judged into profiles/.
-TAG=${1:-r2}
+TAG=${1:-r3}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
