@@ -30,7 +30,7 @@ extern "C" {
 
 #define MPOSE_MAX_GROUP 3   /* the xy / zy / xz columns of one stage run as one grouped launch */
 #define MPOSE_MAX_TAPS 12
-#define MPOSE_MAX_CLASSES 4
+#define MPOSE_MAX_CLASSES 8
 
 int mpose_abi_version(void);
 /* sizeof() of the ABI structs, for binding self-checks: which = 0 geom, 1 conv operands, 2 wgrad
@@ -100,8 +100,10 @@ int mpose_average_loss_fwd(const float* losses, const float* mask, float* out2, 
 /* Geometry of one implicit-GEMM convolution launch (all Conv2d / ConvTranspose2d of
  * models/margipose_model.py:33,67-82 and their data-gradients are instances):
  * the launch enumerates a grid of GH x GW "slots" per image and per class; slot (gy,gx) of class
- * c reads input pixels (gy*in_mul + dy_t, gx*in_mul + dx_t) for every tap t of the class and
- * writes output pixel (gy*out_mul + oy_c, gx*out_mul + ox_c). */
+ * c reads input pixels (gy*in_mul + dy_t, gx*in_mul_x + dx_t) for every tap t of the class and
+ * writes output pixel (gy*out_mul + oy_c, gx*out_mul_x + ox_c).  in_mul_x / out_mul_x = 0 mean "as along y" (the
+ * square strides of margipose_model.py); the dilated, one-axis-strided Conv2d / ConvTranspose2d of
+ * models/chatterbox_model.py:88-125 set them. */
 typedef struct {
   int8_t dy, dx;      /* input offset of the tap */
   int8_t widx;        /* which packed weight slice the tap multiplies with */
@@ -118,11 +120,12 @@ typedef struct {
   int B, IH, IW, Cin;                  /* input  (B, IH, IW, Cin) NHWC, Cin % 32 == 0 */
   int OH, OW, Cout0, Cout1;            /* outputs (B, OH, OW, CoutX) NHWC (storage channel counts) */
   int GH, GW;                          /* slot grid per image and class */
-  int in_mul, out_mul;                 /* 1 or 2 */
+  int in_mul, out_mul;                 /* 1 .. 8 */
   int n_classes;
   int Npad0, Npad1;                    /* padded N of the packed weights for acc 0 / acc 1 */
   int in_ld;                           /* pixel stride (floats) of the input tensor, 0 = Cin (dense); a larger value */
   int out_ld0, out_ld1;                /*   reads/writes a channel slice of a wider (concatenated) NHWC tensor       */
+  int in_mul_x, out_mul_x;             /* 0: in_mul / out_mul along x too */
   mpose_tap_class cls[MPOSE_MAX_CLASSES];
 } mpose_conv_geom;
 

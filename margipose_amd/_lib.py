@@ -17,10 +17,10 @@ c_int = ctypes.c_int
 c_float = ctypes.c_float
 c_int64 = ctypes.c_int64
 
-ABI_VERSION = 10         # must equal mpose_abi_version() of the library (csrc/tail.hip)
+ABI_VERSION = 11         # must equal mpose_abi_version() of the library (csrc/tail.hip)
 MAX_GROUP = 3
 MAX_TAPS = 12
-MAX_CLASSES = 4
+MAX_CLASSES = 8
 
 
 class MposeError(RuntimeError):
@@ -92,7 +92,7 @@ class ConvGeom(ctypes.Structure):
                 ('OH', c_int), ('OW', c_int), ('Cout0', c_int), ('Cout1', c_int),
                 ('GH', c_int), ('GW', c_int), ('in_mul', c_int), ('out_mul', c_int),
                 ('n_classes', c_int), ('Npad0', c_int), ('Npad1', c_int),
-                ('in_ld', c_int), ('out_ld0', c_int), ('out_ld1', c_int),
+                ('in_ld', c_int), ('out_ld0', c_int), ('out_ld1', c_int), ('in_mul_x', c_int), ('out_mul_x', c_int),
                 ('cls', TapClass * MAX_CLASSES)]
 
 

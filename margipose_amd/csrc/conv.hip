@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
       const unsigned rem = m - b * (unsigned)(g.GH * g.GW);
       const unsigned gy = fdiv(rem, a.div_gw);
       const unsigned gx = rem - gy * (unsigned)g.GW;
-      const int iy0 = (int)gy * g.in_mul, ix0 = (int)gx * g.in_mul;
+      const int iy0 = (int)gy * g.in_mul, ix0 = (int)gx * g.in_mul_x;
       row_voff[j] = (((b * (unsigned)g.IH + (unsigned)iy0) * (unsigned)g.IW + (unsigned)ix0) * (unsigned)in_ld + (unsigned)(a_col4 * 4)) * 4u;
       row_yx[j] = iy0 | (ix0 << 16);
     }
@@ -836,7 +836,7 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
       const unsigned rem = mm - b * (unsigned)(g.GH * g.GW);
       const unsigned gy = fdiv(rem, a.div_gw);
       const unsigned gx = rem - gy * (unsigned)g.GW;
-      const unsigned pix = (b * (unsigned)g.OH + (gy * g.out_mul + oyc)) * (unsigned)g.OW + (gx * g.out_mul + oxc);
+      const unsigned pix = (b * (unsigned)g.OH + (gy * g.out_mul + oyc)) * (unsigned)g.OW + (gx * g.out_mul_x + oxc);
       const bool ok = (int)m < a.M;
       sRow[wave * 64 + lane] = ok ? pix * (unsigned)out_ld * 4u : 0xFFFFF000u;
       __builtin_amdgcn_wave_barrier();
@@ -1063,7 +1063,7 @@ inline int pick_ks(const ConvArgs& a, int cmax, int n_groups) {
 // Row-group staging applies to the first pass of a stride-1 3x3 over an input of the output's size: one class,
 // nine acc == 0 taps first, each consecutive triple sharing dy (|dy| <= 1) with dx in {-1, 0, 1}.
 inline bool rowg_eligible(const mpose_conv_geom& g) {
-  if (g.n_classes != 1 || g.in_mul != 1 || g.IH != g.GH || g.IW != g.GW || (g.Cin % KC)) return false;
+  if (g.n_classes != 1 || g.in_mul != 1 || g.in_mul_x != 1 || g.IH != g.GH || g.IW != g.GW || (g.Cin % KC)) return false;
   const mpose_tap_class& c = g.cls[0];
   int n0 = 0;
   for (int t = 0; t < c.n_taps; ++t) {
@@ -1185,10 +1185,10 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_k(WgradArgs a) {
   const int rpw = (a.rows_per_split + 3) >> 2;
   const int r_begin = min(r_split1, r_split0 + wave * rpw);
   const int r_end = min(r_split1, r_begin + rpw);
-  // valid slot columns for this tap: 0 <= gx*in_mul + dx < IW
+  // valid slot columns for this tap: 0 <= gx*in_mul_x + dx < IW
   int gx_lo = 0, gx_hi = g.GW;
-  while (gx_lo < g.GW && gx_lo * g.in_mul + dx < 0) ++gx_lo;
-  while (gx_hi > gx_lo && (gx_hi - 1) * g.in_mul + dx >= g.IW) --gx_hi;
+  while (gx_lo < g.GW && gx_lo * g.in_mul_x + dx < 0) ++gx_lo;
+  while (gx_hi > gx_lo && (gx_hi - 1) * g.in_mul_x + dx >= g.IW) --gx_hi;
   const int n_oct = g.GW >> 3;
 
   const int in_ld = g.in_ld > 0 ? g.in_ld : g.Cin;
@@ -1199,7 +1199,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_k(WgradArgs a) {
   const unsigned g_bytes = (unsigned)(((long)g.B * g.OH * g.OW - 1) * g_ld * 4 + (long)cout * 4);
   const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(op.in), 0, x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gout), 0, g_bytes, 0x00020000);
-  const int x_pix = g.in_mul * in_ld * 4, g_pix = g.out_mul * g_ld * 4;        // byte stride between consecutive slots
+  const int x_pix = g.in_mul_x * in_ld * 4, g_pix = g.out_mul_x * g_ld * 4;        // byte stride between consecutive slots
   const int x_lane = (k0 + li) * 4, g_lane = (n0 + li) * 4;
   const bool pro = op.in_scale != nullptr;
   const int kx = F16 ? f16_scale_exp(amax_gather(op.in_amax)) : 0;
@@ -1534,20 +1534,31 @@ int mpose_conv_planes_launch(const mpose_conv_geom* geom, const mpose_conv_opera
 int mpose_wgrad_rows_units(const mpose_conv_geom* geom);                                                                       // wgrad.hip
 int mpose_wgrad_rows_launch(const mpose_conv_geom* geom, const mpose_wgrad_operands* ops, int n_groups, int n_split, void* stream);
 
+// in_mul_x / out_mul_x = 0 ("as along y") filled in: what the kernels and the checks below read
+static mpose_conv_geom normalised(const mpose_conv_geom* g) {
+  mpose_conv_geom n = *g;
+  if (!n.in_mul_x) n.in_mul_x = n.in_mul;
+  if (!n.out_mul_x) n.out_mul_x = n.out_mul;
+  return n;
+}
+
 static int check_geom(const mpose_conv_geom* g) {
   if (!g || g->Cin <= 0 || (g->Cin % KC) || g->n_classes < 1 || g->n_classes > MPOSE_MAX_CLASSES) return MPOSE_EINVAL;
   if (g->Npad0 <= 0 || (g->Npad0 % 32)) return MPOSE_EINVAL;
-  if ((g->in_mul != 1 && g->in_mul != 2) || (g->out_mul != 1 && g->out_mul != 2)) return MPOSE_EINVAL;
+  if (g->in_mul < 1 || g->in_mul > 8 || g->out_mul < 1 || g->out_mul > 8) return MPOSE_EINVAL;
+  if (g->in_mul_x < 0 || g->in_mul_x > 8 || g->out_mul_x < 0 || g->out_mul_x > 8) return MPOSE_EINVAL;
   for (int c = 0; c < g->n_classes; ++c)
     if (g->cls[c].n_taps < 0 || g->cls[c].n_taps > MPOSE_MAX_TAPS) return MPOSE_EINVAL;
   if ((long)g->B * g->GH * g->GW >= (1l << 26)) return MPOSE_EINVAL;
   return 0;
 }
 
-extern "C" int mpose_conv_fwd(const mpose_conv_geom* geom, const mpose_conv_operands* ops, int n_groups, int flags,
+extern "C" int mpose_conv_fwd(const mpose_conv_geom* geom_, const mpose_conv_operands* ops, int n_groups, int flags,
                               void* stream) {
-  int rc = check_geom(geom);
+  int rc = check_geom(geom_);
   if (rc) return rc;
+  const mpose_conv_geom gn = normalised(geom_);
+  const mpose_conv_geom* geom = &gn;
   if (n_groups < 1 || n_groups > MPOSE_MAX_GROUP) return MPOSE_EINVAL;
   ConvArgs a{};
   a.g = *geom;
@@ -1634,18 +1645,22 @@ extern "C" int mpose_conv_fwd(const mpose_conv_geom* geom, const mpose_conv_oper
   return launch_conv_ks<2>(a, mode, cmax, n_groups, s);
 }
 
-extern "C" int mpose_conv_wgrad_tiles(const mpose_conv_geom* geom) {
-  if (check_geom(geom)) return -1;
+extern "C" int mpose_conv_wgrad_tiles(const mpose_conv_geom* geom_) {
+  if (check_geom(geom_)) return -1;
+  const mpose_conv_geom gn = normalised(geom_);
+  const mpose_conv_geom* geom = &gn;
   if (const int rows = mpose_wgrad_rows_units(geom)) return rows;      // the row-of-taps kernel (wgrad.hip) takes this geometry
   int entries = 0;
   for (int c = 0; c < geom->n_classes; ++c) entries += geom->cls[c].n_taps;
   return entries * (geom->Cin / (32 * wgrad_blocks(geom->Cin))) * (geom->Cout0 / (32 * wgrad_blocks(geom->Cout0)));
 }
 
-extern "C" int mpose_conv_wgrad(const mpose_conv_geom* geom, const mpose_wgrad_operands* ops, int n_groups, int n_split,
+extern "C" int mpose_conv_wgrad(const mpose_conv_geom* geom_, const mpose_wgrad_operands* ops, int n_groups, int n_split,
                                 void* stream) {
-  int rc = check_geom(geom);
+  int rc = check_geom(geom_);
   if (rc) return rc;
+  const mpose_conv_geom gn = normalised(geom_);
+  const mpose_conv_geom* geom = &gn;
   if (n_groups < 1 || n_groups > MPOSE_MAX_GROUP || n_split < 1) return MPOSE_EINVAL;
   if ((geom->Npad0 % 64) || (geom->Cout0 % 32) || (geom->GW & 7)) return MPOSE_EINVAL;
   WgradArgs a{};

@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256, 2) void conv_planes_k(ConvPArgs a) {
     const unsigned rem = mm - b * (unsigned)(g.GH * g.GW);
     const unsigned gy = fdiv(rem, a.div_gw);
     const unsigned gx = rem - gy * (unsigned)g.GW;
-    const int iy0 = (int)gy * g.in_mul, ix0 = (int)gx * g.in_mul;
+    const int iy0 = (int)gy * g.in_mul, ix0 = (int)gx * g.in_mul_x;
     pix_off = ((b * (unsigned)g.IH + (unsigned)iy0) * (unsigned)g.IW + (unsigned)ix0) * 16u;
     for (int t = 0; t < n_taps; ++t) {
       const int tp = tap_word(t);
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256, 2) void conv_planes_k(ConvPArgs a) {
       const unsigned rem = mm - b * (unsigned)(g.GH * g.GW);
       const unsigned gy = fdiv(rem, a.div_gw);
       const unsigned gx = rem - gy * (unsigned)g.GW;
-      const unsigned pix = (b * (unsigned)g.OH + (gy * g.out_mul + oyc)) * (unsigned)g.OW + (gx * g.out_mul + oxc);
+      const unsigned pix = (b * (unsigned)g.OH + (gy * g.out_mul + oyc)) * (unsigned)g.OW + (gx * g.out_mul_x + oxc);
       sRow[tid] = (int)m < a.M ? pix * (unsigned)out_ld * 4u : 0xFFFFF000u;
       sPix[tid] = (int)m < a.M ? pix : 0xFFFFFFFFu;
     }

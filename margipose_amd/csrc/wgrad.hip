@@ -572,7 +572,7 @@ int rows_env() {               // MPOSE_WGRAD_ROWS=0: conv_wgrad_k everywhere (A
 
 // Kernel rows / single taps of a geometry, or -1 when the row form does not apply (then conv.hip's conv_wgrad_k runs).
 int build_units(const mpose_conv_geom* g, RowUnit* units, int* n_widx0, int* n_widx1) {
-  if (g->n_classes != 1 || g->in_mul != 1 || g->out_mul != 1 || g->IH != g->GH || g->IW != g->GW || g->OH != g->GH || g->OW != g->GW)
+  if (g->n_classes != 1 || g->in_mul != 1 || g->out_mul != 1 || g->in_mul_x != 1 || g->out_mul_x != 1 || g->IH != g->GH || g->IW != g->GW || g->OH != g->GH || g->OW != g->GW)
     return -1;
   if ((g->GW & 7) || (g->Cin & 3) || g->cls[0].oy || g->cls[0].ox) return -1;
   const mpose_tap_class& c = g->cls[0];

@@ -72,10 +72,17 @@ def _check_struct_sizes():
 # geometry builders (see include/margipose_hip.h: mpose_conv_geom)
 # ---------------------------------------------------------------------------------------------
 def _geom(B, IH, Cin, OH, Cout0, Cout1, GH, in_mul, out_mul, classes, Npad0, Npad1=0):
+    return _geom2(B, (IH, IH), Cin, (OH, OH), Cout0, Cout1, (GH, GH), (in_mul, in_mul), (out_mul, out_mul), classes, Npad0, Npad1)
+
+
+def _geom2(B, in_hw, Cin, out_hw, Cout0, Cout1, grid_hw, in_mul, out_mul, classes, Npad0, Npad1=0):
+    """mpose_conv_geom with separate (y, x) sizes and slot strides (include/margipose_hip.h)."""
     g = ConvGeom()
-    g.B, g.IH, g.IW, g.Cin = B, IH, IH, Cin
-    g.OH, g.OW, g.Cout0, g.Cout1 = OH, OH, Cout0, Cout1
-    g.GH, g.GW, g.in_mul, g.out_mul = GH, GH, in_mul, out_mul
+    g.B, g.IH, g.IW, g.Cin = B, in_hw[0], in_hw[1], Cin
+    g.OH, g.OW, g.Cout0, g.Cout1 = out_hw[0], out_hw[1], Cout0, Cout1
+    g.GH, g.GW = grid_hw
+    g.in_mul, g.in_mul_x = in_mul
+    g.out_mul, g.out_mul_x = out_mul
     g.n_classes = len(classes)
     g.Npad0, g.Npad1 = Npad0, Npad1
     for ci, (oy, ox, taps) in enumerate(classes):
@@ -84,6 +91,28 @@ def _geom(B, IH, Cin, OH, Cout0, Cout1, GH, in_mul, out_mul, classes, Npad0, Npa
         for ti, (dy, dx, widx, acc) in enumerate(taps):
             c.taps[ti].dy, c.taps[ti].dx, c.taps[ti].widx, c.taps[ti].acc = dy, dx, widx, acc
     return g
+
+
+def axis_taps(gather, k, stride, dilation, padding):
+    """One axis of a convolution as slot classes: (in_mul, out_mul, [(output phase, [(input offset, kernel index), ...]), ...]).
+    gather=True: the slots are the outputs of a strided Conv (out[o] = sum_k in[o*stride + k*dilation - padding] w[k]);
+    gather=False: the slots are output positions of one phase of its transpose (ConvTranspose forward / Conv data-gradient):
+    out[stride*q + r] = sum over the k with (r + padding - k*dilation) % stride == 0 of in[q + (r + padding - k*dilation)/stride] w[k]."""
+    if gather:
+        return stride, 1, [(0, [(i * dilation - padding, i) for i in range(k)])]
+    classes = []
+    for r in range(stride):
+        classes.append((r, [((r + padding - i * dilation) // stride, i) for i in range(k) if (r + padding - i * dilation) % stride == 0]))
+    return 1, stride, classes
+
+
+def conv_classes(gather, kernel, stride, dilation, padding):
+    """2-D product of axis_taps: ((in_mul_y, in_mul_x), (out_mul_y, out_mul_x), classes in mpose_conv_geom form).  Kernel index
+    ky*kw + kx is the packed weight slice in both directions (a ConvTranspose2d's weight is stored (Cin, Cout, kh, kw))."""
+    imy, omy, cy = axis_taps(gather, kernel[0], stride[0], dilation[0], padding[0])
+    imx, omx, cx = axis_taps(gather, kernel[1], stride[1], dilation[1], padding[1])
+    classes = [(py, px, [(dy, dx, iy * kernel[1] + ix, 0) for dy, iy in ty for dx, ix in tx]) for py, ty in cy for px, tx in cx]
+    return (imy, imx), (omy, omx), classes
 
 
 def _up_classes(with_shortcut, single_tap=False):
@@ -275,10 +304,13 @@ class Engine:
         self.stem = None
         fe_name = getattr(inner, 'feature_extractor_name', 'patch8')
         if fe_name != 'patch8':
-            from .stem import InceptionV4Stem, ResNetStem
+            from .stem import ChatterboxGraph, InceptionV4Stem, ResNetStem
             self.stem_conv = self.stem_bn = None
             self._convs, self._bns = [], block_bns           # filled right below (the stem needs `self` first)
-            self.stem = (InceptionV4Stem if fe_name == 'inceptionv4' else ResNetStem)(self, inner.in_cnn)
+            if fe_name == 'chatterbox':                      # the whole ChatterboxModel is one graph (no stages)
+                self.stem = ChatterboxGraph(self, inner)
+            else:
+                self.stem = (InceptionV4Stem if fe_name == 'inceptionv4' else ResNetStem)(self, inner.in_cnn)
             self._convs = self.stem.convs + block_convs
         else:
             self.stem_conv = _Conv(inner.in_cnn[0].weight, False, 1, 192, 128, 192, 128, stem=True)
@@ -1010,6 +1042,52 @@ class Engine:
         return hms, xyz, ctx
 
     # ------------------------------------------------------------------ several forwards in flight
+    # ------------------------------------------------------------------ graph-only models (ChatterboxModel)
+    def graph_forward(self, x, train, save):
+        """A model that is ONE stem.py graph with several raw outputs (no stages): returns (list of NHWC outputs, ctx)."""
+        if isinstance(x, torch.Tensor) and x.dtype == torch.uint8 and x.is_cuda:
+            x = x.contiguous()
+        else:
+            x = _lib.dev_f32(x.contiguous(), 'input')
+        B, C3, S, S2 = x.shape
+        if C3 != 3 or S != S2 or S != self.stem.INPUT_SIZE:
+            raise _lib.MposeError('expected a (B, 3, %d, %d) input, got %s' % (self.stem.INPUT_SIZE, self.stem.INPUT_SIZE, tuple(x.shape)))
+        self._ensure_arenas(x.device)
+        ctx = _Ctx({'B': B, 'F': S // 8, 'train': train, 'x_shape': tuple(x.shape)})
+        self._snapshot_pending()
+        self._gen += 1
+        self._arena_gen = ctx['gen'] = self._gen
+        if save:
+            self._pending = weakref.ref(ctx)
+            ctx['param_versions'] = [p._version for p in self.param_list()]
+        cmode = ctx['cmode'] = self.conv_mode_for(train, save)
+        if cmode == 1:
+            raise _lib.MposeError('graph models run on conv_igemm_k (MPOSE_PLANES=1 is set)')
+        self.pack_weights(cmode)
+        outs, ctx['stem_ctx'] = self.stem.forward(x, train, save, cmode == 2)
+        if train:
+            self._nbt += 1
+        return outs, ctx
+
+    def graph_backward(self, ctx, grads, need_dx):
+        """grads: gradient w.r.t. each raw output (or None).  Returns (flat gradient buffer, dx or None)."""
+        for p, v in zip(self.param_list(), ctx['param_versions']):
+            if p._version != v:
+                raise RuntimeError('one of the variables needed for gradient computation has been modified by an inplace '
+                                   'operation: a parameter of the model changed between forward and backward')
+        self._restore_arenas(ctx)
+        tb = self._tables_for(ctx['B'], ctx['F'])
+        self.gflat.zero_()
+        if self._packed_for != ctx['cmode']:
+            self.pack_weights(ctx['cmode'])
+        works = []
+        dx = self.stem.backward(ctx['stem_ctx'], grads, need_dx)
+        self._finish_bucket(tb, 0, 0, tb['n_unpack'], works)
+        for w in works:
+            w.wait()
+        ctx['done'] = True
+        return self.gflat, dx
+
     def _arena_tensors(self):
         return [self.bnf, self.amax_f] + ([self.stem.f_arena, self.stem.amax_f] if self.stem is not None else [])
 

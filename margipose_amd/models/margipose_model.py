@@ -278,8 +278,11 @@ class MargiPoseModel(nn.Module):
 
 
 def create_model(model_desc):
-    """Registry entry point of reference models/__init__.py:16-27 for type 'margipose' (^6.0.0)."""
+    """Registry entry point of reference models/__init__.py:16-27: types 'margipose' (^6.0.0) and 'chatterbox' (^1.3.0)."""
     type_name, version = model_desc['type'], str(model_desc['version'])
+    if type_name == 'chatterbox' and version.split('.')[:2] == ['1', '3']:       # ChatterboxModelFactory ('chatterbox', '^1.3.0')
+        from .chatterbox_model import create_chatterbox_model
+        return create_chatterbox_model(model_desc)
     if type_name != 'margipose' or version.split('.')[0] != '6':
         raise Exception('unrecognised model {} v{}'.format(type_name, version))
     s = model_desc['settings']

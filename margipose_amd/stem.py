@@ -142,22 +142,43 @@ def make_resnet_stem_modules(name):
 # ---------------------------------------------------------------------------------------------
 class _Node:
     def __init__(self, name, C, div, relu=True):
-        self.name, self.C, self.div = name, C, div      # spatial size = input size // div
+        self.name, self.C, self.div = name, C, div      # spatial size = input size // div; div = (div_y, div_x) when they differ
         self.relu = relu                                 # consumers see relu(scale*x+shift) (False: scale*x+shift)
         self.parts = []                                  # (c0, c1, bn_module or None, eps, conv_bias)
         self.producers = []
         self.f_off = self.s_off = -1
         self.is_image = False
 
+    def hw(self, S):
+        dy, dx = self.div if isinstance(self.div, tuple) else (self.div, self.div)
+        assert S % dy == 0 and S % dx == 0
+        return S // dy, S // dx
+
+
+def _pair(v):
+    return tuple(v) if isinstance(v, (tuple, list)) else (v, v)
+
 
 class _ConvOp:
-    def __init__(self, src, dst, c0, basic, stride=1, bn=None, eps=None, bias=None):
-        self.src, self.dst, self.c0, self.stride = src, dst, c0, stride
-        if isinstance(basic, nn.Conv2d):                  # plain Conv2d: the BatchNorm that follows is given explicitly
+    """Conv2d (padding k//2 * dilation unless given) or ConvTranspose2d; stride / dilation / padding may differ per axis.
+    flat=True relabels a (1, k) kernel that spans the whole width of its input (models/chatterbox_model.py:104,112): the
+    NHWC tensors are read as one row of H*W pixels, the kernel walks it with stride k (a one-pixel-wide slot grid would not
+    satisfy the weight-gradient kernel's GW % 8 == 0)."""
+
+    def __init__(self, src, dst, c0, basic, stride=1, bn=None, eps=None, bias=None, dilation=1, padding=None, flat=False):
+        self.src, self.dst, self.c0 = src, dst, c0
+        self.stride, self.dilation, self.flat = _pair(stride), _pair(dilation), flat
+        if isinstance(basic, (nn.Conv2d, nn.ConvTranspose2d)):   # plain convolution: the BatchNorm that follows is given explicitly
             self.weight, self.bn, self.eps, self.bias = basic.weight, bn, (0.0 if eps is None else eps), bias
         else:                                             # pretrainedmodels' BasicConv2d
             self.weight, self.bn, self.eps, self.bias = basic.conv.weight, basic.bn, BN_EPS_STEM, None
-        self.cout, self.cin, self.kh, self.kw = self.weight.shape
+        self.transposed = isinstance(basic, nn.ConvTranspose2d)
+        if self.transposed:
+            self.cin, self.cout, self.kh, self.kw = self.weight.shape
+        else:
+            self.cout, self.cin, self.kh, self.kw = self.weight.shape
+        self.padding = _pair(padding) if padding is not None else (self.kh // 2 * self.dilation[0], self.kw // 2 * self.dilation[1])
+        self.cout_s = -(-self.cout // 32) * 32            # storage channels of the output slice (heatmap convolutions: 17 -> 32)
         self.conv = None                                  # engine._Conv (packing slots)
 
 
@@ -170,6 +191,7 @@ class _FirstConvOp(_ConvOp):
         k = self.weight.shape[2]
         assert tuple(self.weight.shape[1:]) == (3, k, k)
         self.cin, self.kh, self.kw = 3 * k * k, 1, 1
+        self.padding = (0, 0)
 
 
 class _AddOp:
@@ -198,20 +220,25 @@ class _GraphStem:
         for op in ops:
             op.dst.producers.append(op)
             if isinstance(op, _ConvOp):
-                op.dst.parts.append((op.c0, op.c0 + op.cout, op.bn, op.eps, op.bias))
+                op.dst.parts.append((op.c0, op.c0 + (op.cout if op.bn is not None else op.cout_s), op.bn, op.eps, op.bias))
                 cin_s = self.IMG_C if op.src.is_image else op.cin
-                op.conv = _Conv(op.weight, False, 1, op.cin, op.cout, cin_s, op.cout)
+                op.conv = _Conv(op.weight, op.transposed, 1, op.cin, op.cout, cin_s, op.cout_s)
                 op.conv.T = op.kh * op.kw
                 op.conv.kk = op.kh * op.kw
                 op.conv.size_g = op.conv.T * cin_s * op.conv.npad_f
                 op.conv.size_f = op.conv.size_g * 3 // 2
-                op.conv.size_d = op.conv.T * op.cout * op.conv.npad_d * 3 // 2
+                op.conv.size_d = op.conv.T * op.cout_s * op.conv.npad_d * 3 // 2
                 op.conv.generic = True
             elif isinstance(op, _AddOp):
                 op.dst.parts.append((0, op.dst.C, None, 0.0, None))
             else:
                 op.dst.parts.append((op.c0, op.c0 + op.src.C, None, 0.0, None))
+        order = dict((id(n), i) for i, n in enumerate(nodes))
+        for op in ops:                                     # the backward pass walks `nodes` in reverse: sources before destinations
+            for t in ([op.a, op.b] if isinstance(op, _AddOp) else [op.src]):
+                assert order[id(t)] < order[id(op.dst)], 'nodes must be created in topological order (%s -> %s)' % (t.name, op.dst.name)
         self.convs = [op.conv for op in ops if isinstance(op, _ConvOp)]
+        self.out_nodes = None                              # several RAW outputs instead of one activated one (ChatterboxGraph)
         self.bn_modules = [p[2] for n in self.nodes for p in n.parts if p[2] is not None]
         self.extra_params = extra_params
         self._tables = {}
@@ -272,14 +299,14 @@ class _GraphStem:
             for (a, b, bn, eps, bias) in n.parts:
                 if bn is None:
                     continue
-                H = S // n.div
+                H, W = n.hw(S)
                 j = np.zeros(1, dtype=BN_DT)[0]
                 j['stats'] = self.sptr(n, False, a)
                 j['gamma'] = bn.weight.data_ptr(); j['beta'] = bn.bias.data_ptr()
                 j['running_mean'] = bn.running_mean.data_ptr(); j['running_var'] = bn.running_var.data_ptr()
                 j['scale'] = self.fptr(n, 0, a); j['shift'] = self.fptr(n, 1, a)
                 j['mean'] = self.fptr(n, 2, a); j['invstd'] = self.fptr(n, 3, a)
-                j['C'] = b - a; j['count'] = B * H * H
+                j['C'] = b - a; j['count'] = B * H * W
                 j['conv_bias'] = bias.data_ptr() if bias is not None else 0
                 j['eps'] = eps
                 fin.append(j)
@@ -288,7 +315,7 @@ class _GraphStem:
                 k['gamma'] = bn.weight.data_ptr(); k['mean'] = self.fptr(n, 2, a); k['invstd'] = self.fptr(n, 3, a)
                 k['coef'] = self.fptr(n, 4, a)
                 k['dgamma'] = gbase + 4 * goff[id(bn.weight)]; k['dbeta'] = gbase + 4 * goff[id(bn.bias)]
-                k['sums_stride'], k['which'], k['C'], k['c_stride'], k['count'], k['sg_col'] = 4, 1, b - a, n.C, B * H * H, 0
+                k['sums_stride'], k['which'], k['C'], k['c_stride'], k['count'], k['sg_col'] = 4, 1, b - a, n.C, B * H * W, 0
                 k['dconv_bias'] = gbase + 4 * goff[id(bias)] if bias is not None else 0
                 coef.append(k)
             tb['fin_range'][n.name] = (f0, len(fin) - f0)
@@ -302,28 +329,30 @@ class _GraphStem:
     # ------------------------------------------------------------------ geometries
     def geom(self, op, B, S, kind):
         """kind: 'f' forward (also the weight-gradient geometry), 'd' data-gradient."""
-        from .engine import _geom, _up_classes
+        from .engine import _geom2, _geom_flops, conv_classes
         key = (id(op), B, S, kind)
         g = self._geoms.get(key)
         if g is not None:
             return g
-        Hin, Hout = S // op.src.div, S // op.dst.div
+        src_hw, dst_hw = op.src.hw(S), op.dst.hw(S)
+        if op.flat:
+            src_hw, dst_hw = (1, src_hw[0] * src_hw[1]), (1, dst_hw[0] * dst_hw[1])
         cin_s = self.IMG_C if op.src.is_image else op.cin
-        taps = [(ky - op.kh // 2, kx - op.kw // 2, ky * op.kw + kx) for ky in range(op.kh) for kx in range(op.kw)]
+        k = (op.kh, op.kw)
+        # the slots of a Conv2d's forward and of a ConvTranspose2d's data-gradient are the SMALL side's pixels, gathering
+        # stride-spaced pixels of the large side; the other two launches enumerate the large side by output phase
+        gather = (kind == 'f') != op.transposed
+        in_mul, out_mul, classes = conv_classes(gather, k, op.stride, op.dilation, op.padding)
+        small = dst_hw if not op.transposed else src_hw
+        large = src_hw if not op.transposed else dst_hw
+        assert all(large[a] == small[a] * op.stride[a] for a in (0, 1)), 'unsupported convolution extent %s -> %s' % (src_hw, dst_hw)
         if kind == 'f':
-            g = _geom(B, Hin, cin_s, Hout, op.cout, 0, Hout, op.stride, 1, [(0, 0, [(dy, dx, w, 0) for dy, dx, w in taps])],
-                      op.conv.npad_f)
+            g = _geom2(B, src_hw, cin_s, dst_hw, op.cout_s, 0, small, in_mul, out_mul, classes, op.conv.npad_f)
             g.in_ld, g.out_ld0 = op.src.C, op.dst.C
         else:
-            if op.stride == 1:
-                g = _geom(B, Hout, op.cout, Hin, cin_s, 0, Hin, 1, 1, [(0, 0, [(-dy, -dx, w, 0) for dy, dx, w in taps])],
-                          op.conv.npad_d)
-            else:       # gradient of a stride-2 3x3 (pad 1) / 1x1: the transposed-conv parity classes
-                assert (op.kh, op.kw, op.stride) in ((3, 3, 2), (1, 1, 2))
-                g = _geom(B, Hout, op.cout, Hin, cin_s, 0, Hout, 1, 2, _up_classes(False, single_tap=op.kh == 1), op.conv.npad_d)
+            g = _geom2(B, dst_hw, op.cout_s, src_hw, cin_s, 0, small, in_mul, out_mul, classes, op.conv.npad_d)
             g.in_ld, g.out_ld0 = op.dst.C, op.src.C
         g._name = 'stem_%s/%s->%s/%dx%d' % (kind, op.src.name, op.dst.name, op.kh, op.kw)
-        from .engine import _geom_flops
         g._flops = _geom_flops(g)
         self._geoms[key] = g
         return g
@@ -362,8 +391,8 @@ class _GraphStem:
         for op in self.ops:
             n = op.dst
             if n.name not in raw:
-                H = S // n.div
-                raw[n.name] = torch.empty(B, H, H, n.C, **f32)
+                H, W = n.hw(S)
+                raw[n.name] = torch.empty(B, H, W, n.C, **f32)
             src = op.src
             sc = None if src.is_image else self.fptr(src, 0)
             sh = None if src.is_image else self.fptr(src, 1)
@@ -386,10 +415,10 @@ class _GraphStem:
                 ao.a, ao.a_scale, ao.a_shift = raw[op.a.name].data_ptr(), self.fptr(op.a, 0), self.fptr(op.a, 1)
                 ao.b, ao.b_scale, ao.b_shift = raw[op.b.name].data_ptr(), self.fptr(op.b, 0), self.fptr(op.b, 1)
                 ao.out = raw[n.name].data_ptr()
-                H = S // n.div
-                check(L.mpose_bn_add_fwd((BnAddOperands * 3)(ao), 1, H * H, B, n.C, 0 if op.relu_a else 2, 0, st()), 'mpose_bn_add_fwd')
+                H, W = n.hw(S)
+                check(L.mpose_bn_add_fwd((BnAddOperands * 3)(ao), 1, H * W, B, n.C, 0 if op.relu_a else 2, 0, st()), 'mpose_bn_add_fwd')
             else:
-                Hs = S // src.div
+                Hs = src.hw(S)[0]       # (pools: square maps only)
                 check(L.mpose_pool3_fwd(ptr(raw[src.name]), c_void_p(sc), c_void_p(sh), c_void_p(raw[n.name].data_ptr() + 4 * op.c0),
                                         B, Hs, Hs, src.C, n.C, op.kind, st()), 'mpose_pool3_fwd')
             done.add(id(op))
@@ -397,19 +426,23 @@ class _GraphStem:
                 f0, nf = tb['fin_range'][n.name]
                 if nf:
                     eng.finalize_table(tb['fin'], f0, nf, True)
-        n7 = self.out_node
-        out = torch.empty(B, S // n7.div, S // n7.div, n7.C, **f32)
-        check(L.mpose_bn_relu_fwd(ptr(raw[n7.name]), c_void_p(self.fptr(n7, 0)), c_void_p(self.fptr(n7, 1)), ptr(out),
-                                  c_int64(out.numel()), n7.C, st()), 'mpose_bn_relu_fwd')
+        if self.out_nodes is not None:
+            out = [raw[n.name] for n in self.out_nodes]
+        else:
+            n7 = self.out_node
+            out = torch.empty(B, S // n7.div, S // n7.div, n7.C, **f32)
+            check(L.mpose_bn_relu_fwd(ptr(raw[n7.name]), c_void_p(self.fptr(n7, 0)), c_void_p(self.fptr(n7, 1)), ptr(out),
+                                      c_int64(out.numel()), n7.C, st()), 'mpose_bn_relu_fwd')
         ctx = {'raw': raw, 'B': B, 'S': S, 'train': train, 'f16': f16, 'cflags': cflags, 'measured': measured} if save else None
         return out, ctx
 
     # ------------------------------------------------------------------ backward
     def backward(self, ctx, D, need_dx):
-        """D: gradient w.r.t. the activated stem output (B, F, F, 128).  Returns dx (NCHW) or None."""
+        """D: gradient w.r.t. the activated stem output (B, F, F, 128) -- or, with `out_nodes`, the list of gradients w.r.t.
+        the raw output nodes (None where an output took no part in the loss).  Returns dx (NCHW) or None."""
         eng, L = self.engine, lib()
         B, S, raw = ctx['B'], ctx['S'], ctx['raw']
-        dev = D.device
+        dev = next(iter(raw.values())).device
         st = stream_ptr
         f32 = dict(dtype=torch.float32, device=dev)
         tb = self.tables(B, S)
@@ -418,29 +451,32 @@ class _GraphStem:
         cflags = ctx.get('cflags', 32 if f16 else 0)
         if f16:
             self.amax_b.zero_()
-        dact = {self.out_node.name: D}
+        if self.out_nodes is not None:
+            dact = dict((n.name, g) for n, g in zip(self.out_nodes, D) if g is not None)
+        else:
+            dact = {self.out_node.name: D}
         for n in reversed(self.nodes):
             if n.is_image or n.name not in dact:
                 continue
-            H = S // n.div
+            H, W = n.hw(S)
             g = dact[n.name]
             # masked BatchNorm backward over the whole node (identity channel ranges: plain ReLU mask)
             ro = BnBwdReduceOperands()
             ro.g, ro.a, ro.sums = g.data_ptr(), raw[n.name].data_ptr(), self.sptr(n, True)
             if n.relu:
                 ro.a_scale, ro.a_shift = self.fptr(n, 0), self.fptr(n, 1)
-            eng.bn_bwd_reduce([ro], H * H, B, n.C)
+            eng.bn_bwd_reduce([ro], H * W, B, n.C)
             c0_, nc = tb['coef_range'][n.name]
             if nc:
                 check(L.mpose_bn_bwd_coef(c_void_p(tb['coef'].data_ptr() + c0_ * eng.COEF_ITEMSIZE), nc, 0 if ctx.get('train', True) else 1, st()), 'mpose_bn_bwd_coef')
-            d_raw = torch.empty(B, H, H, n.C, **f32)
+            d_raw = torch.empty(B, H, W, n.C, **f32)
             ao = BnBwdApplyOperands()
             ao.g, ao.a, ao.coef_a, ao.da = g.data_ptr(), raw[n.name].data_ptr(), self.fptr(n, 4), d_raw.data_ptr()
             if n.relu:
                 ao.a_scale, ao.a_shift = self.fptr(n, 0), self.fptr(n, 1)
             if f16:
                 ao.da_amax = n.amax_b
-            check(L.mpose_bn_bwd_apply((BnBwdApplyOperands * 3)(ao), 1, H * H, B, n.C, 0, 0, st()), 'mpose_bn_bwd_apply')
+            check(L.mpose_bn_bwd_apply((BnBwdApplyOperands * 3)(ao), 1, H * W, B, n.C, 0, 0, st()), 'mpose_bn_bwd_apply')
             for op in n.producers:
                 if isinstance(op, _AddOp):     # both addends receive d_raw (w.r.t. their affine / activated values)
                     for t in (op.a, op.b):
@@ -451,10 +487,10 @@ class _GraphStem:
                             check(L.mpose_add(ptr(acc), ptr(d_raw), ptr(acc), c_int64(acc.numel()), st()), 'mpose_add')
                     continue
                 src = op.src
-                Hs = S // src.div
+                Hs, Ws = src.hw(S)
                 want_dsrc = (not src.is_image) or need_dx
                 if want_dsrc and src.name not in dact:
-                    dact[src.name] = torch.zeros(B, Hs, Hs, src.C, **f32)
+                    dact[src.name] = torch.zeros(B, Hs, Ws, src.C, **f32)
                 sc = None if src.is_image else self.fptr(src, 0)
                 sh = None if src.is_image else self.fptr(src, 1)
                 if isinstance(op, _ConvOp):
@@ -566,3 +602,152 @@ class ResNetStem(_GraphStem):
             extra = [seq[6].bias]
             cur = out
         self._finish(engine, seq, ops, nodes, cur, extra)
+
+
+# ---------------------------------------------------------------------------------------------
+# ChatterboxModel (reference models/chatterbox_model.py): the whole network as one graph
+# ---------------------------------------------------------------------------------------------
+class ChatterboxBlock(nn.Module):
+    """Parameters of _ChatterboxCnn._DownBlock / _UpBlock (models/chatterbox_model.py:132-214): conv1, bn1, conv2, bn2 and,
+    when the block changes stride or width, resample.{0,1}.  `up`: conv1 / resample.0 are ConvTranspose2d."""
+
+    def __init__(self, up, cin, cout, stride=(1, 1), dilation=(1, 1), dilation_in=None, output_padding=(0, 0)):
+        super().__init__()
+        dilation_in = dilation if dilation_in is None else dilation_in
+        self.up, self.stride, self.dilation, self.dilation_in = up, tuple(stride), tuple(dilation), tuple(dilation_in)
+        if self.stride != (1, 1) or cin != cout:
+            if up:
+                rs = nn.ConvTranspose2d(cin, cout, kernel_size=1, stride=stride, output_padding=output_padding, bias=False)
+            else:
+                rs = nn.Conv2d(cin, cout, kernel_size=1, stride=stride, bias=False)
+            self.resample = nn.Sequential(rs, nn.BatchNorm2d(cout))
+        else:
+            self.resample = None
+        if up:
+            self.conv1 = nn.ConvTranspose2d(cin, cout, 3, stride=stride, padding=dilation_in, dilation=dilation_in,
+                                            output_padding=output_padding, bias=False)
+        else:
+            self.conv1 = nn.Conv2d(cin, cout, 3, stride=stride, padding=dilation_in, dilation=dilation_in, bias=False)
+        self.bn1 = nn.BatchNorm2d(cout)
+        self.conv2 = nn.Conv2d(cout, cout, 3, padding=dilation, dilation=dilation, bias=False)
+        self.bn2 = nn.BatchNorm2d(cout)
+
+
+def make_chatterbox_cnn_modules(n_joints, shrink_width):
+    """(down_convs, up_convs) of _ChatterboxCnn (models/chatterbox_model.py:87-126), same module indices."""
+    def f(a, b):
+        return (a, b) if shrink_width else (b, a)
+    D, U = (lambda *a, **k: ChatterboxBlock(False, *a, **k)), (lambda *a, **k: ChatterboxBlock(True, *a, **k))
+    down = nn.Sequential(
+        D(128, 256, stride=f(1, 2), dilation=f(2, 1), dilation_in=f(1, 1)), D(256, 256, dilation=f(2, 1)),
+        D(256, 512, stride=f(1, 2), dilation=f(4, 1), dilation_in=f(2, 1)), D(512, 512, dilation=f(4, 1)),
+        nn.Conv2d(512, 1024, kernel_size=f(1, 8), bias=False), nn.BatchNorm2d(1024), nn.Identity())
+    up = nn.Sequential(
+        nn.ConvTranspose2d(1024, 512, kernel_size=f(1, 8), bias=False), nn.BatchNorm2d(512), nn.Identity(),
+        U(512, 512, dilation=f(4, 1)),
+        U(512, 256, stride=f(1, 2), dilation=f(2, 1), dilation_in=f(4, 1), output_padding=f(0, 1)),
+        U(256, 256, dilation=f(2, 1)),
+        U(256, 128, stride=f(1, 2), dilation=f(1, 1), dilation_in=f(2, 1), output_padding=f(0, 1)),
+        nn.Conv2d(128, n_joints, kernel_size=1, bias=False))
+    return down, up
+
+
+class ChatterboxGraph(_GraphStem):
+    """in_cnn (ResNet-34 conv1 .. layer2, :37-54) -> three heads on its 128 x 32 x 32 output:
+      xy_hm_cnn (:57-84): ResNet-34 layer3 / layer4 with their strides removed and the 3x3 convolutions dilated 2 / 4 (not the
+                 first one of each layer: the reference's `elif` leaves the formerly strided convolution undilated), then a 1x1;
+      zy_hm_cnn / xz_hm_cnn (:87-221): residual blocks that halve ONE axis twice (stride (1,2) / (2,1), the other axis dilated
+                 instead), a kernel over the remaining 8 pixels of that axis, and the mirror-image ConvTranspose2d path back.
+    Outputs: the three heads' RAW heatmap logits (B, 32, 32, 32-channel storage of which n_joints are used), NHWC."""
+
+    IMG_C = 160
+    IMG_K = 7
+    INPUT_SIZE = 256         # ImageSpecs(256) (:227): the heads' fixed 32 -> 16 -> 8 -> 1 ladder needs a 32 x 32 feature map
+
+    def __init__(self, engine, model):
+        nodes, node = self._node_factory()
+        fe = model.in_cnn
+        img = node('img', self.IMG_C, 2); img.is_image = True
+        c1 = node('c1', 64, 2)
+        ops = [_FirstConvOp(img, c1, 0, fe.conv1, bn=fe.bn1)]
+        cur = node('p1', 64, 4)
+        ops.append(_PoolOp(c1, cur, 0, 0))
+
+        def basic(tag, cur, blk, div, stride, dil1, dil2):
+            """torchvision BasicBlock (conv1 may be strided, conv2 never is)."""
+            planes = blk.conv1.weight.shape[0]
+            a = node(tag + '_c1', planes, div)
+            b = node(tag + '_c2', planes, div, relu=False)
+            ops.extend([_ConvOp(cur, a, 0, blk.conv1, stride, bn=blk.bn1, dilation=dil1),
+                        _ConvOp(a, b, 0, blk.conv2, 1, bn=blk.bn2, dilation=dil2)])
+            if hasattr(blk, 'downsample'):                  # (nodes in topological order: the backward pass walks them in reverse)
+                d = node(tag + '_d', planes, div, relu=False)
+                ops.append(_ConvOp(cur, d, 0, blk.downsample[0], stride, bn=blk.downsample[1]))
+                s_ = node(tag + '_s', planes, div)
+                ops.append(_AddOp(d, b, s_, False))
+            else:
+                s_ = node(tag + '_s', planes, div)
+                ops.append(_AddOp(cur, b, s_, True))
+            return s_
+
+        div = 4
+        for li, layer in ((1, fe.layer1), (2, fe.layer2)):
+            for bi, blk in enumerate(layer):
+                div *= blk.stride
+                cur = basic('l%db%d' % (li, bi), cur, blk, div, blk.stride, 1, 1)
+        feat = cur                                          # 128 x 32 x 32
+        # ---- xy head ----
+        cur = feat
+        for li, (layer, dil) in enumerate(((model.xy_hm_cnn.layer1, 2), (model.xy_hm_cnn.layer2, 4))):
+            for bi, blk in enumerate(layer):
+                cur = basic('xy%db%d' % (li, bi), cur, blk, 8, 1, 1 if bi == 0 else dil, dil)
+        xy = node('xy_hm', 32, 8, relu=False)
+        ops.append(_ConvOp(cur, xy, 0, model.xy_hm_cnn.hm_conv, 1))
+        outs = [xy]
+        # ---- zy / xz heads ----
+        for name, cnn, sw in (('zy', model.zy_hm_cnn, True), ('xz', model.xz_hm_cnn, False)):
+            cur, div = feat, (8, 8)
+            mods = list(cnn.down_convs) + list(cnn.up_convs)
+            i = 0
+            while i < len(mods):
+                m = mods[i]
+                tag = '%s%d' % (name, i)
+                if isinstance(m, ChatterboxBlock):
+                    if m.up:
+                        assert all(div[a] % m.stride[a] == 0 for a in (0, 1))
+                        odiv = (div[0] // m.stride[0], div[1] // m.stride[1])
+                    else:
+                        odiv = (div[0] * m.stride[0], div[1] * m.stride[1])
+                    planes = m.bn1.weight.shape[0]
+                    a = node(tag + '_c1', planes, odiv)
+                    b = node(tag + '_c2', planes, odiv, relu=False)
+                    ops.append(_ConvOp(cur, a, 0, m.conv1, m.stride, bn=m.bn1, dilation=m.dilation_in, padding=m.dilation_in))
+                    ops.append(_ConvOp(a, b, 0, m.conv2, 1, bn=m.bn2, dilation=m.dilation, padding=m.dilation))
+                    if m.resample is not None:
+                        d = node(tag + '_d', planes, odiv, relu=False)
+                        ops.append(_ConvOp(cur, d, 0, m.resample[0], m.stride, bn=m.resample[1], padding=0))
+                        s_ = node(tag + '_s', planes, odiv)
+                        ops.append(_AddOp(d, b, s_, False))
+                    else:
+                        s_ = node(tag + '_s', planes, odiv)
+                        ops.append(_AddOp(cur, b, s_, True))
+                    cur, div = s_, odiv
+                    i += 1
+                elif isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)) and m.kernel_size != (1, 1):
+                    # the kernel over the whole short axis (8 pixels): stride = kernel describes the same single position
+                    k = m.kernel_size
+                    if isinstance(m, nn.ConvTranspose2d):
+                        odiv = (div[0] // k[0], div[1] // k[1])
+                    else:
+                        odiv = (div[0] * k[0], div[1] * k[1])
+                    n_ = node(tag + '_k8', m.weight.shape[1] if isinstance(m, nn.ConvTranspose2d) else m.weight.shape[0], odiv)
+                    ops.append(_ConvOp(cur, n_, 0, m, k, bn=mods[i + 1], padding=0, flat=sw))
+                    cur, div = n_, odiv
+                    i += 3                                  # (BatchNorm2d, ReLU)
+                else:                                       # the final 1x1 to the heatmaps
+                    h = node(name + '_hm', 32, div, relu=False)
+                    ops.append(_ConvOp(cur, h, 0, m, 1))
+                    outs.append(h)
+                    i += 1
+        self._finish(engine, model, ops, nodes, None, [])
+        self.out_nodes = outs

@@ -97,6 +97,52 @@ def resnet_stem_entries(name, p='inner.in_cnn.'):
     return e
 
 
+def chatterbox_cnn_entries(p, shrink_width, n_joints=17):
+    """_ChatterboxCnn (models/chatterbox_model.py:87-214) in state_dict order: a block registers resample.{0,1} (when it has
+    one) BEFORE conv1, bn1, conv2, bn2.  Pinned by tests/golden/chatterbox_keys.json (dumped from the imported reference)."""
+    def f(a, b):
+        return (a, b) if shrink_width else (b, a)
+
+    def block(q, cin, cout, resample, up):
+        w1 = (cin, cout, 3, 3) if up else (cout, cin, 3, 3)
+        e = []
+        if resample:
+            e += [(q + 'resample.0.weight', (cin, cout, 1, 1) if up else (cout, cin, 1, 1))] + _bn_entries(q + 'resample.1', cout)
+        e += [(q + 'conv1.weight', w1)] + _bn_entries(q + 'bn1', cout)
+        e += [(q + 'conv2.weight', (cout, cout, 3, 3))] + _bn_entries(q + 'bn2', cout)
+        return e
+    d, u = p + 'down_convs.', p + 'up_convs.'
+    e = block(d + '0.', 128, 256, True, False) + block(d + '1.', 256, 256, False, False)
+    e += block(d + '2.', 256, 512, True, False) + block(d + '3.', 512, 512, False, False)
+    e += [(d + '4.weight', (1024, 512) + f(1, 8))] + _bn_entries(d + '5', 1024)
+    e += [(u + '0.weight', (1024, 512) + f(1, 8))] + _bn_entries(u + '1', 512)
+    e += block(u + '3.', 512, 512, False, True) + block(u + '4.', 512, 256, True, True)
+    e += block(u + '5.', 256, 256, False, True) + block(u + '6.', 256, 128, True, True)
+    e += [(u + '7.weight', (n_joints, 128, 1, 1))]
+    return e
+
+
+def _basic_block_entries(q, cin, planes, downsample):
+    e = [(q + 'conv1.weight', (planes, cin, 3, 3))] + _bn_entries(q + 'bn1', planes)
+    e += [(q + 'conv2.weight', (planes, planes, 3, 3))] + _bn_entries(q + 'bn2', planes)
+    if downsample:
+        e += [(q + 'downsample.0.weight', (planes, cin, 1, 1))] + _bn_entries(q + 'downsample.1', planes)
+    return e
+
+
+def chatterbox_schema(n_joints=17):
+    """ChatterboxModel (models/chatterbox_model.py:223-244): in_cnn (resnet34 conv1, bn1, layer1, layer2), xy_hm_cnn (resnet34
+    layer3 / layer4 as layer1 / layer2, hm_conv), zy_hm_cnn, xz_hm_cnn.  The resnet34 part restates torchvision (unpinned)."""
+    e = [('in_cnn.conv1.weight', (64, 3, 7, 7))] + _bn_entries('in_cnn.bn1', 64)
+    for name, cin, planes, n in (('in_cnn.layer1.', 64, 64, 3), ('in_cnn.layer2.', 64, 128, 4),
+                                 ('xy_hm_cnn.layer1.', 128, 256, 6), ('xy_hm_cnn.layer2.', 256, 512, 3)):
+        for b in range(n):
+            e += _basic_block_entries('%s%d.' % (name, b), cin if b == 0 else planes, planes, b == 0 and cin != planes)
+    e += [('xy_hm_cnn.hm_conv.weight', (n_joints, 512, 1, 1))]
+    e += chatterbox_cnn_entries('zy_hm_cnn.', True, n_joints) + chatterbox_cnn_entries('xz_hm_cnn.', False, n_joints)
+    return OrderedDict(e)
+
+
 def schema(n_stages, n_joints=17, stem='patch8'):
     """Ordered key -> shape map of MargiPoseModel(n_stages) with the given stem."""
     if stem == 'inceptionv4':
@@ -134,7 +180,7 @@ def fill_like(shapes, seed, dtype=torch.float32):
         elif len(shape) == 1:
             v = rng.standard_normal(shape) * 0.1
         else:
-            fan_out = shape[0] * shape[2] * shape[3]          # kaiming_normal_(mode='fan_out')
+            fan_out = shape[0] * shape[2] * shape[3]          # kaiming_normal_(mode='fan_out'): the LEADING dimension
             v = rng.standard_normal(shape) * np.sqrt(2.0 / fan_out)
         sd[key] = torch.from_numpy(np.asarray(v)).to(dtype)
     return sd

@@ -169,3 +169,46 @@ def test_frames_normalisation_fixture(golden_dir):
     want = (x - g['mean'].reshape(1, 3, 1, 1)) / g['stddev'].reshape(1, 3, 1, 1)
     assert np.abs(want - g['expected_f64']).max() < 1e-12
     assert np.abs(want - g['expected_f32']).max() < 5e-7
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# ChatterboxModel's two dilated heads (reference models/chatterbox_model.py:87-221): oracle/chatterbox_ref.py against
+# the imported reference class (tools/make_golden_chatterbox.py)
+# ---------------------------------------------------------------------------------------------------------------
+def test_chatterbox_schema(golden_dir):
+    with open(os.path.join(golden_dir, 'chatterbox_keys.json')) as f:
+        ref = json.load(f)
+    for tag, sw in (('w', True), ('h', False)):
+        assert [[k, list(s)] for k, s in W.chatterbox_cnn_entries('', sw)] == ref[tag]
+    full = W.chatterbox_schema()
+    for head, tag in (('zy_hm_cnn.', 'w'), ('xz_hm_cnn.', 'h')):      # (:241-242: zy shrinks the width, xz the height)
+        assert [[k[len(head):], list(s)] for k, s in full.items() if k.startswith(head)] == ref[tag]
+
+
+@pytest.mark.parametrize('tag', ['w', 'h'])
+def test_chatterbox_cnn_vs_reference(golden_dir, tag):
+    from oracle import chatterbox_ref as C
+    g = _load(golden_dir, 'chatterbox_cnn.npz')
+    with open(os.path.join(golden_dir, 'chatterbox_keys.json')) as f:
+        pnames = json.load(f)['params_' + tag]
+    sw = tag == 'w'
+    seed_w, seed_x = (int(v) for v in g['seeds'])
+    rng = np.random.default_rng(seed_x)
+    x = torch.from_numpy(rng.standard_normal((1, 128, 32, 32))).float().requires_grad_(True)
+    probe = torch.from_numpy(rng.standard_normal((1, 17, 32, 32))).float()
+    sd = W.fill_like(OrderedDict(W.chatterbox_cnn_entries('', sw)), seed_w)
+    with torch.no_grad():
+        y_eval = C.chatterbox_cnn(sd, '', x, sw, False)
+    np.testing.assert_allclose(y_eval.numpy(), g['eval_out_' + tag], rtol=1e-4, atol=1e-4)
+    for n in pnames:
+        sd[n].requires_grad_(True)
+    y = C.chatterbox_cnn(sd, '', x, sw, True)
+    (y * probe).sum().backward()
+    # same ATen kernels on the same machine; the tolerance leaves room for a different summation order in another build
+    np.testing.assert_allclose(y.detach().numpy(), g['train_out_' + tag], rtol=1e-4, atol=1e-4)
+    ref_dx = g['train_dx_' + tag]
+    assert np.abs(x.grad.numpy() - ref_dx).max() <= 1e-4 * np.abs(ref_dx).max()
+    gn = np.array([float(sd[n].grad.double().norm()) for n in pnames])
+    np.testing.assert_allclose(gn, g['train_gnorm_' + tag], rtol=1e-3)
+    np.testing.assert_allclose(sd['down_convs.5.running_mean'].numpy(), g['running_mean_k8_' + tag], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(sd['down_convs.5.running_var'].numpy(), g['running_var_k8_' + tag], rtol=1e-4, atol=1e-6)
