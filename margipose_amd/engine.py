@@ -115,6 +115,22 @@ def conv_classes(gather, kernel, stride, dilation, padding):
     return (imy, imx), (omy, omx), classes
 
 
+def conv_geom(kind, transposed, B, src_hw, cin_s, dst_hw, cout_s, kernel, stride, dilation, padding, npad):
+    """Launch geometry of a Conv2d / ConvTranspose2d (src -> dst) with per-axis kernel, stride, dilation and padding:
+    kind 'f' = forward (also the weight-gradient geometry: it pairs src pixels with dst pixels), 'd' = data-gradient
+    (reads the gradient w.r.t. dst, writes the one w.r.t. src).  The slots of a Conv2d's forward and of a ConvTranspose2d's
+    data-gradient are the SMALL side's pixels, gathering stride-spaced pixels of the large side; the other two launches
+    enumerate the large side by output phase."""
+    gather = (kind == 'f') != transposed
+    in_mul, out_mul, classes = conv_classes(gather, kernel, stride, dilation, padding)
+    small, large = (src_hw, dst_hw) if transposed else (dst_hw, src_hw)
+    if not all(large[a] == small[a] * stride[a] for a in (0, 1)):
+        raise _lib.MposeError('unsupported convolution extent %s -> %s (stride %s)' % (src_hw, dst_hw, stride))
+    if kind == 'f':
+        return _geom2(B, src_hw, cin_s, dst_hw, cout_s, 0, small, in_mul, out_mul, classes, npad)
+    return _geom2(B, dst_hw, cout_s, src_hw, cin_s, 0, small, in_mul, out_mul, classes, npad)
+
+
 def _up_classes(with_shortcut, single_tap=False):
     """Output-parity classes of a stride-2 transposed 3x3 (pad 1, output_padding 1):
     out[2y'+py] receives kernel rows ky with ky = (py+1) mod 2; input row y' + (py+1-ky)/2."""
@@ -1043,15 +1059,23 @@ class Engine:
 
     # ------------------------------------------------------------------ several forwards in flight
     # ------------------------------------------------------------------ graph-only models (ChatterboxModel)
-    def graph_forward(self, x, train, save):
-        """A model that is ONE stem.py graph with several raw outputs (no stages): returns (list of NHWC outputs, ctx)."""
-        if isinstance(x, torch.Tensor) and x.dtype == torch.uint8 and x.is_cuda:
-            x = x.contiguous()
+    def graph_forward(self, x, train, save, features=None):
+        """A model that is ONE stem.py graph with several raw outputs (no stages): returns (list of NHWC outputs, ctx).
+        features (forward only): a (B, 128, 32, 32) tensor in place of the feature extractor's output (`x` is ignored) -- how the
+        reference's _ChatterboxCnn fixtures drive the heads on their own."""
+        if features is not None:
+            if save:
+                raise _lib.MposeError('features= is a forward-only entry')
+            x = features = _lib.dev_f32(features.contiguous(), 'features')
+            B, S = features.shape[0], self.stem.INPUT_SIZE
         else:
-            x = _lib.dev_f32(x.contiguous(), 'input')
-        B, C3, S, S2 = x.shape
-        if C3 != 3 or S != S2 or S != self.stem.INPUT_SIZE:
-            raise _lib.MposeError('expected a (B, 3, %d, %d) input, got %s' % (self.stem.INPUT_SIZE, self.stem.INPUT_SIZE, tuple(x.shape)))
+            if isinstance(x, torch.Tensor) and x.dtype == torch.uint8 and x.is_cuda:
+                x = x.contiguous()
+            else:
+                x = _lib.dev_f32(x.contiguous(), 'input')
+            B, C3, S, S2 = x.shape
+            if C3 != 3 or S != S2 or S != self.stem.INPUT_SIZE:
+                raise _lib.MposeError('expected a (B, 3, %d, %d) input, got %s' % (self.stem.INPUT_SIZE, self.stem.INPUT_SIZE, tuple(x.shape)))
         self._ensure_arenas(x.device)
         ctx = _Ctx({'B': B, 'F': S // 8, 'train': train, 'x_shape': tuple(x.shape)})
         self._snapshot_pending()
@@ -1064,8 +1088,8 @@ class Engine:
         if cmode == 1:
             raise _lib.MposeError('graph models run on conv_igemm_k (MPOSE_PLANES=1 is set)')
         self.pack_weights(cmode)
-        outs, ctx['stem_ctx'] = self.stem.forward(x, train, save, cmode == 2)
-        if train:
+        outs, ctx['stem_ctx'] = self.stem.forward(x, train, save, cmode == 2, features=features)
+        if train and features is None:
             self._nbt += 1
         return outs, ctx
 

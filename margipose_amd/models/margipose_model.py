@@ -277,10 +277,19 @@ class MargiPoseModel(nn.Module):
         return self.heatmaps_to_coords(self.xy_heatmaps[-1], self.zy_heatmaps[-1], self.xz_heatmaps[-1])
 
 
+def _caret_match(version, base):
+    """semantic_version's '^a.b.c' for a >= 1: same major, not older than the base (model_factory.py:10-14)."""
+    try:
+        v = tuple(int(t) for t in version.split('-')[0].split('.')[:3])
+    except ValueError:
+        return False
+    return len(v) == 3 and v[0] == base[0] and v >= base
+
+
 def create_model(model_desc):
     """Registry entry point of reference models/__init__.py:16-27: types 'margipose' (^6.0.0) and 'chatterbox' (^1.3.0)."""
     type_name, version = model_desc['type'], str(model_desc['version'])
-    if type_name == 'chatterbox' and version.split('.')[:2] == ['1', '3']:       # ChatterboxModelFactory ('chatterbox', '^1.3.0')
+    if type_name == 'chatterbox' and _caret_match(version, (1, 3, 0)):          # ChatterboxModelFactory ('chatterbox', '^1.3.0')
         from .chatterbox_model import create_chatterbox_model
         return create_chatterbox_model(model_desc)
     if type_name != 'margipose' or version.split('.')[0] != '6':

@@ -329,7 +329,7 @@ class _GraphStem:
     # ------------------------------------------------------------------ geometries
     def geom(self, op, B, S, kind):
         """kind: 'f' forward (also the weight-gradient geometry), 'd' data-gradient."""
-        from .engine import _geom2, _geom_flops, conv_classes
+        from .engine import _geom_flops, conv_geom
         key = (id(op), B, S, kind)
         g = self._geoms.get(key)
         if g is not None:
@@ -338,19 +338,11 @@ class _GraphStem:
         if op.flat:
             src_hw, dst_hw = (1, src_hw[0] * src_hw[1]), (1, dst_hw[0] * dst_hw[1])
         cin_s = self.IMG_C if op.src.is_image else op.cin
-        k = (op.kh, op.kw)
-        # the slots of a Conv2d's forward and of a ConvTranspose2d's data-gradient are the SMALL side's pixels, gathering
-        # stride-spaced pixels of the large side; the other two launches enumerate the large side by output phase
-        gather = (kind == 'f') != op.transposed
-        in_mul, out_mul, classes = conv_classes(gather, k, op.stride, op.dilation, op.padding)
-        small = dst_hw if not op.transposed else src_hw
-        large = src_hw if not op.transposed else dst_hw
-        assert all(large[a] == small[a] * op.stride[a] for a in (0, 1)), 'unsupported convolution extent %s -> %s' % (src_hw, dst_hw)
+        g = conv_geom(kind, op.transposed, B, src_hw, cin_s, dst_hw, op.cout_s, (op.kh, op.kw), op.stride, op.dilation, op.padding,
+                      op.conv.npad_f if kind == 'f' else op.conv.npad_d)
         if kind == 'f':
-            g = _geom2(B, src_hw, cin_s, dst_hw, op.cout_s, 0, small, in_mul, out_mul, classes, op.conv.npad_f)
             g.in_ld, g.out_ld0 = op.src.C, op.dst.C
         else:
-            g = _geom2(B, dst_hw, op.cout_s, src_hw, cin_s, 0, small, in_mul, out_mul, classes, op.conv.npad_d)
             g.in_ld, g.out_ld0 = op.dst.C, op.src.C
         g._name = 'stem_%s/%s->%s/%dx%d' % (kind, op.src.name, op.dst.name, op.kh, op.kw)
         g._flops = _geom_flops(g)
@@ -358,12 +350,17 @@ class _GraphStem:
         return g
 
     # ------------------------------------------------------------------ forward
-    def forward(self, x, train, save, f16=False):
+    def forward(self, x, train, save, f16=False, features=None):
         """f16: the convolutions run the three-product fp16 form (engine.py); every node's largest consumer-side magnitude is
-        measured once, when its BatchNorm vectors are final."""
+        measured once, when its BatchNorm vectors are final.
+        features (forward only, graphs that name a `feat_node`): a (B, C, H, W) tensor that takes the place of that node -- what
+        its consumers read through their ReLU -- so that the heads can be driven on their own (`x` is not read)."""
         eng, L = self.engine, lib()
-        B, _, S, _ = x.shape
-        dev = x.device
+        if features is not None:
+            B, S = features.shape[0], self.INPUT_SIZE
+        else:
+            B, _, S, _ = x.shape
+        dev = (x if features is None else features).device
         st = stream_ptr
         f32 = dict(dtype=torch.float32, device=dev)
         tb = self.tables(B, S)
@@ -376,6 +373,13 @@ class _GraphStem:
         cflags = eng.conv_flags(2) if f16 else 0       # (three-product form, or its single-product reduced-precision variant)
         measured = set()
         raw = {}
+        first_op = 0
+        if features is not None:
+            fn_ = self.feat_node
+            assert not save and tuple(features.shape[1:]) == (fn_.C,) + fn_.hw(S)
+            raw[fn_.name] = features.permute(0, 2, 3, 1).contiguous()
+            first_op = 1 + max(i for i, op in enumerate(self.ops) if op.dst is fn_)
+            return self._run_ops(raw, first_op, B, S, train, save, f16, cflags, measured, tb)
         img = self.nodes[0]
         raw[img.name] = torch.empty(B, S // 2, S // 2, self.IMG_C, **f32)
         is_u8 = x.dtype == torch.uint8     # raw RGB frames: to_tensor + normalisation fused into the gather
@@ -387,8 +391,14 @@ class _GraphStem:
         else:
             check(L.mpose_im2col_s2(ctypes.c_void_p(x.data_ptr()), int(is_u8), mean3, std3, ptr(raw[img.name]), B, S, S, self.IMG_K,
                                     self.IMG_C, st()), 'mpose_im2col_s2')
-        done = set()
-        for op in self.ops:
+        return self._run_ops(raw, first_op, B, S, train, save, f16, cflags, measured, tb)
+
+    def _run_ops(self, raw, first_op, B, S, train, save, f16, cflags, measured, tb):
+        eng, L = self.engine, lib()
+        st = stream_ptr
+        f32 = dict(dtype=torch.float32, device=next(iter(raw.values())).device)
+        done = set(id(op) for op in self.ops[:first_op])
+        for op in self.ops[first_op:]:
             n = op.dst
             if n.name not in raw:
                 H, W = n.hw(S)
@@ -751,3 +761,4 @@ class ChatterboxGraph(_GraphStem):
                     i += 1
         self._finish(engine, model, ops, nodes, None, [])
         self.out_nodes = outs
+        self.feat_node = feat

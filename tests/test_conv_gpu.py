@@ -282,3 +282,86 @@ def test_weight_gradient_stride2_with_fused_shortcut():
     dw, dw1 = _wgrad(L, _lib, eng, g, to(x), to(go), cout, cin, 9, npad, 2, gout1=to(go1), cout1=cout)
     _check(*_wgrad_errs(dw, x, go, lambda a, w: F.conv2d(a, w, stride=2, padding=1), (cout, cin, 3, 3)))
     _check(*_wgrad_errs(dw1, x, go1, lambda a, w: F.conv2d(a, w, stride=2), (cout, cin, 1, 1)))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Per-axis kernel / stride / dilation / padding (mpose_conv_geom.in_mul_x / out_mul_x): the layer shapes of the reference's
+# ChatterboxModel (models/chatterbox_model.py:96-126, 143-150, 189-198), each one forward, data-gradient and weight-gradient
+# ---------------------------------------------------------------------------------------------------------------
+CHATTERBOX_LAYERS = [
+    # (transposed, kernel, stride, dilation, padding, output_padding, src (H, W), flat)
+    (False, (3, 3), (1, 2), (1, 1), (1, 1), (0, 0), (16, 16), False),      # _DownBlock conv1, width halved
+    (False, (3, 3), (2, 1), (1, 2), (1, 2), (0, 0), (16, 16), False),      # ... height halved, width dilated
+    (False, (3, 3), (1, 1), (4, 1), (4, 1), (0, 0), (16, 8), False),       # conv2, dilation (4, 1)
+    (False, (1, 1), (1, 2), (1, 1), (0, 0), (0, 0), (16, 16), False),      # resample
+    (True, (3, 3), (1, 2), (4, 1), (4, 1), (0, 1), (16, 8), False),        # _UpBlock conv1
+    (True, (3, 3), (1, 1), (1, 4), (1, 4), (0, 0), (8, 16), False),        # ... stride 1
+    (True, (1, 1), (2, 1), (1, 1), (0, 0), (1, 0), (8, 16), False),        # _UpBlock resample (every other row is zero)
+    (False, (1, 8), (1, 8), (1, 1), (0, 0), (0, 0), (16, 8), True),        # Conv2d(512, 1024, (1, 8)) on the 8-wide map
+    (True, (1, 8), (1, 8), (1, 1), (0, 0), (0, 0), (16, 1), True),         # ConvTranspose2d(1024, 512, (1, 8))
+    (False, (8, 1), (8, 1), (1, 1), (0, 0), (0, 0), (8, 16), False),       # the same pair along the height
+    (True, (8, 1), (8, 1), (1, 1), (0, 0), (0, 0), (1, 16), False),
+]
+
+
+@pytest.mark.parametrize('case', range(len(CHATTERBOX_LAYERS)))
+def test_per_axis_convolution_geometries(case):
+    import torch.nn.functional as F
+    from margipose_amd import _lib, engine as eng
+    L = _lib.lib()
+    tr, k, stride, dil, pad, opad, src_hw, flat = CHATTERBOX_LAYERS[case]
+    B, cin, cout = 3, 64, 96
+    T = k[0] * k[1]
+    rng = np.random.default_rng(300 + case)
+    x = torch.from_numpy(rng.standard_normal((B, cin) + src_hw)).float()
+    wshape = (cin, cout) + k if tr else (cout, cin) + k
+    w = torch.from_numpy(rng.standard_normal(wshape) * (2.0 / (T * cin)) ** 0.5).float()
+    # (a full-extent kernel is described with stride = kernel: the same single output position)
+    real_stride = (1, 1) if k in ((1, 8), (8, 1)) else stride
+
+    def fn(a, b):
+        if tr:
+            return F.conv_transpose2d(a, b, None, stride=real_stride, padding=pad, output_padding=opad, dilation=dil)
+        return F.conv2d(a, b, None, stride=real_stride, padding=pad, dilation=dil)
+    ref = fn(x.double(), w.double())
+    dst_hw = tuple(ref.shape[2:])
+    go = torch.from_numpy(rng.standard_normal((B, cout) + dst_hw)).float()
+    s_hw, d_hw = ((1, src_hw[0] * src_hw[1]), (1, dst_hw[0] * dst_hw[1])) if flat else (src_hw, dst_hw)
+    to = lambda t: t.permute(0, 2, 3, 1).contiguous().cuda()
+    wg = w.cuda()
+    # forward
+    packed, npad, _ = _pack(L, _lib, eng, wg, cout, cin, T, transposed_layout=tr)
+    gf = eng.conv_geom('f', tr, B, s_hw, cin, d_hw, cout, k, stride, dil, pad, npad)
+    out = torch.full((B,) + dst_hw + (cout,), float('nan'), device='cuda')
+    _run(L, _lib, gf, to(x), packed, out)
+    _check(*_errs(out, x, w, fn))
+    # data gradient: K = cout, N = cin, the same taps seen from the other side
+    npad_d = (cin + 63) // 64 * 64
+    pd = torch.zeros(T * cout * npad_d * 3 // 2, dtype=torch.float32, device='cuda')
+    jobs = np.zeros(1, dtype=eng.PACK_DT)
+    j = jobs[0]
+    j['src'], j['dst'], j['N'], j['K'], j['T'], j['Npad'], j['Kpad'] = wg.data_ptr(), pd.data_ptr(), cin, cout, T, npad_d, cout
+    j['sn'], j['sk'], j['st'] = (cout * T, T, 1) if tr else (T, cin * T, 1)
+    _lib.check(L.mpose_pack_weights(_lib.ptr(eng._jobs_to_device(jobs, 'cuda')), 1, T * cout * npad_d, _lib.stream_ptr()), 'pack')
+    gd = eng.conv_geom('d', tr, B, s_hw, cin, d_hw, cout, k, stride, dil, pad, npad_d)
+    dx = torch.full((B,) + src_hw + (cin,), float('nan'), device='cuda')
+    _run(L, _lib, gd, to(go), pd, dx)
+
+    def dgrad(dtype):
+        a = x.to(dtype).requires_grad_(True)
+        fn(a, w.to(dtype)).backward(go.to(dtype))
+        return a.grad.double()
+    r64, r32 = dgrad(torch.float64), dgrad(torch.float32)
+    sc = r64.abs().max()
+    _check(float((dx.cpu().double().permute(0, 3, 1, 2) - r64).abs().max() / sc), float((r32 - r64).abs().max() / sc))
+    # weight gradient (unpacked as (Cout, Cin, taps); a ConvTranspose2d stores (Cin, Cout, ...))
+    dw, = _wgrad(L, _lib, eng, gf, to(x), to(go), cout, cin, T, npad, 2)
+
+    def wgradient(dtype):
+        b = w.to(dtype).requires_grad_(True)
+        fn(x.to(dtype), b).backward(go.to(dtype))
+        g_ = b.grad.double().reshape(wshape[0], wshape[1], T)
+        return g_.permute(1, 0, 2) if tr else g_
+    r64, r32 = wgradient(torch.float64), wgradient(torch.float32)
+    sc = r64.abs().max()
+    _check(float((dw.cpu().double() - r64).abs().max() / sc), float((r32 - r64).abs().max() / sc))

@@ -5,7 +5,10 @@
     compared with flat_softmax of the reference's logits;
   * tests/golden/axis_permutation.npz -- the column's axis permutation (:91-99) through mpose_axis_permute;
   * tests/golden/frames_u8.npz -- `ImageSpecs.convert` normalisation (data_specs.py:6-13,38-39) of uint8 frames through
-    mpose_frames_u8 and through the InceptionV4 stem's fused first-layer gather (mpose_im2col_k3s2)."""
+    mpose_frames_u8 and through the InceptionV4 stem's fused first-layer gather (mpose_im2col_k3s2);
+  * tests/golden/chatterbox_cnn.npz (tools/make_golden_chatterbox.py) -- the reference's _ChatterboxCnn
+    (models/chatterbox_model.py:87-221), both orientations, on non-negative features: ChatterboxModel's zy / xz heads are fed the
+    fixture's features (Engine.graph_forward(features=...)) and their logits compared with the reference's."""
 import ctypes
 import os
 from collections import OrderedDict
@@ -89,3 +92,24 @@ def test_uint8_frames_against_the_reference_normalisation(golden_dir):
     _lib.check(L.mpose_im2col_k3s2(ctypes.c_void_p(ref.data_ptr()), 0, None, None, _lib.ptr(pf), B, H, Wd, _lib.stream_ptr()), 'im2col f32')
     torch.cuda.synchronize()
     assert float((pu - pf).abs().max()) < 5e-7
+
+
+@pytest.mark.parametrize('tag', ['w', 'h'])
+def test_chatterbox_head_fixture_through_the_graph(golden_dir, tag):
+    from margipose_amd.models import CanonicalSkeletonDesc, ChatterboxModel
+    g = np.load(os.path.join(golden_dir, 'chatterbox_cnn.npz'))
+    seed_w, seed_x = (int(v) for v in g['seeds'])
+    head, idx = ('zy_hm_cnn.', 1) if tag == 'w' else ('xz_hm_cnn.', 2)        # (:241-242: zy shrinks the width, xz the height)
+    x = torch.from_numpy(np.random.default_rng(seed_x).standard_normal((1, 128, 32, 32))).float().abs().cuda()
+    m = ChatterboxModel(CanonicalSkeletonDesc, 'jsd')
+    sd = m.state_dict()
+    for k, v in W.fill_like(OrderedDict(W.chatterbox_cnn_entries('', tag == 'w')), seed_w).items():
+        sd[head + k] = v
+    m.load_state_dict(sd)
+    eng = m.cuda().engine()
+    for train, key in ((False, 'eval_out_pos_'), (True, 'train_out_pos_')):
+        with torch.no_grad():
+            outs, _ = eng.graph_forward(None, train, False, features=x)
+        got = outs[idx][..., :17].permute(0, 3, 1, 2).cpu()
+        want = g[key + tag]
+        assert rel(got, want) < 1e-4, (tag, train, rel(got, want))

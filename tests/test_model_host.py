@@ -103,3 +103,77 @@ def test_make_gauss_any_dimension_and_js_gradient_to_the_means(golden_dir):
     d, = torch.autograd.grad(js.sum(), mu)
     assert float((js.detach() - torch.tensor(g['js_val'])).abs().max()) < 1e-14
     assert float((d - torch.tensor(g['js_dmu'])).abs().max()) < 1e-13
+
+
+def test_chatterbox_registry_schema_and_graph(golden_dir):
+    """ChatterboxModelFactory ('chatterbox', '^1.3.0') (reference models/chatterbox_model.py:292-303), the state_dict keys of the
+    two dilated heads as dumped from the imported reference, and the launch plan of the whole network (host logic only)."""
+    import ctypes
+    from oracle import weights as W
+    from margipose_amd._lib import lib
+    from margipose_amd.models import ChatterboxModel, Default_Chatterbox_Desc, create_model
+    m = create_model(Default_Chatterbox_Desc)
+    assert isinstance(m, ChatterboxModel) and m.pixelwise_loss == 'jsd' and m.data_specs.input_specs.size == 256
+    assert isinstance(create_model({'type': 'chatterbox', 'version': '1.4.2', 'settings': {'pixelwise_loss': None}}), ChatterboxModel)
+    for v in ('1.2.9', '2.0.0', '1.0.0'):
+        with pytest.raises(Exception, match='unrecognised model'):
+            create_model({'type': 'chatterbox', 'version': v, 'settings': {}})
+    assert [(k, tuple(v.shape)) for k, v in m.state_dict().items()] == [(k, tuple(s)) for k, s in W.chatterbox_schema().items()]
+    with open(os.path.join(golden_dir, 'chatterbox_keys.json')) as f:
+        ref = json.load(f)
+    for head, tag in (('zy_hm_cnn.', 'w'), ('xz_hm_cnn.', 'h')):
+        assert [[k[len(head):], list(v.shape)] for k, v in m.state_dict().items() if k.startswith(head)] == ref[tag]
+    # ResNet-34 without its classifier holds 21,284,672 parameters; conv1 .. layer2 (in_cnn) 1,347,904 of them
+    n_in = sum(p.numel() for k, p in m.named_parameters() if k.startswith('in_cnn.'))
+    n_xy = sum(p.numel() for k, p in m.named_parameters() if k.startswith('xy_hm_cnn.') and 'hm_conv' not in k)
+    assert n_in == 1347904 and n_in + n_xy == 21284672
+    st = m.engine().stem
+    assert [n.name for n in st.out_nodes] == ['xy_hm', 'zy_hm', 'xz_hm']
+    for op in st.ops:
+        if getattr(op, 'conv', None) is None:
+            continue
+        for kind in 'fd':
+            g = st.geom(op, 2, 256, kind)
+            assert g.n_classes <= 8 and all(g.cls[c].n_taps <= 12 for c in range(g.n_classes))
+        gf = st.geom(op, 2, 256, 'f')
+        assert gf.GW % 8 == 0 and lib().mpose_conv_wgrad_tiles(ctypes.byref(gf)) > 0, gf._name
+
+
+@pytest.mark.parametrize('tr,k,stride,dil,pad,opad,src', [
+    (False, (3, 3), (1, 2), (2, 1), (2, 1), (0, 0), (6, 8)), (False, (3, 3), (2, 1), (1, 4), (1, 4), (0, 0), (8, 9)),
+    (True, (3, 3), (1, 2), (4, 1), (4, 1), (0, 1), (9, 4)), (True, (1, 1), (2, 1), (1, 1), (0, 0), (1, 0), (4, 5)),
+    (False, (1, 8), (1, 8), (1, 1), (0, 0), (0, 0), (5, 8)), (True, (8, 1), (8, 1), (1, 1), (0, 0), (0, 0), (1, 5)),
+    (False, (3, 3), (2, 2), (1, 1), (1, 1), (0, 0), (8, 8)), (True, (3, 3), (2, 2), (1, 1), (1, 1), (1, 1), (4, 4))])
+def test_conv_geom_semantics_against_torch(tr, k, stride, dil, pad, opad, src):
+    """engine.conv_geom's slot / class / tap tables, interpreted on the CPU exactly as include/margipose_hip.h defines them
+    (slot (gy, gx) of class c reads input pixel (gy*in_mul + dy, gx*in_mul_x + dx) and writes output pixel (gy*out_mul + oy,
+    gx*out_mul_x + ox)), must reproduce torch's Conv2d / ConvTranspose2d and its data gradient."""
+    import torch.nn.functional as F
+    from margipose_amd.engine import conv_geom
+    g0 = torch.Generator().manual_seed(7)
+    x = torch.randn(1, 1, *src, generator=g0, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(1, 1, *k, generator=g0, dtype=torch.float64)
+    rs = (1, 1) if k in ((1, 8), (8, 1)) else stride
+    y = F.conv_transpose2d(x, w, None, rs, pad, opad, 1, dil) if tr else F.conv2d(x, w, None, rs, pad, dil)
+    dst = tuple(y.shape[2:])
+    go = torch.randn(y.shape, generator=g0, dtype=torch.float64)
+    y.backward(go)
+
+    def interpret(g, inp):
+        out = torch.zeros(g.OH, g.OW, dtype=torch.float64)
+        imx, omx = g.in_mul_x or g.in_mul, g.out_mul_x or g.out_mul
+        for c in range(g.n_classes):
+            cl = g.cls[c]
+            for gy in range(g.GH):
+                for gx in range(g.GW):
+                    acc = 0.0
+                    for t in range(cl.n_taps):
+                        iy, ix = gy * g.in_mul + cl.taps[t].dy, gx * imx + cl.taps[t].dx
+                        if 0 <= iy < g.IH and 0 <= ix < g.IW:
+                            acc += float(inp[iy, ix]) * float(w.reshape(-1)[cl.taps[t].widx])
+                    out[gy * g.out_mul + cl.oy, gx * omx + cl.ox] = acc
+        return out
+    gf = conv_geom('f', tr, 1, src, 32, dst, 32, k, stride, dil, pad, 64)
+    assert torch.allclose(interpret(gf, x.detach()[0, 0]), y.detach()[0, 0], atol=1e-12)
+    gd = conv_geom('d', tr, 1, src, 32, dst, 32, k, stride, dil, pad, 64)
+    assert torch.allclose(interpret(gd, go[0, 0]), x.grad[0, 0], atol=1e-12)

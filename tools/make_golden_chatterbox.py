@@ -51,6 +51,13 @@ def main():
         net.eval()
         with torch.no_grad():
             out['eval_out_' + tag] = net(x).numpy()
+        # the same class on NON-NEGATIVE features (what ResNet's final ReLU hands it): the fixture the HIP heads are compared with
+        # directly (tests/test_golden_direct_gpu.py), since the launch graph's feature node is read through a ReLU
+        xp = x.detach().abs()
+        with torch.no_grad():
+            out['eval_out_pos_' + tag] = net(xp).numpy()
+            net.train()
+            out['train_out_pos_' + tag] = net(xp).numpy()
         keys['params_' + tag] = names
     out['seeds'] = np.array([SEED_W, SEED_X])
     root = os.path.join(os.path.dirname(__file__), '..', 'tests', 'golden')
