@@ -180,6 +180,15 @@ typedef struct {
    * below every float).  mpose_bn_finalize turns them into the EXACT largest magnitude of relu(scale * out0 + shift) -- the
    * operand of the next MPOSE_CONV_F16X3 convolution -- without a measuring pass (an affine map followed by ReLU is monotone). */
   unsigned* mm0;
+  /* Train-mode BatchNorm of out0 / out1 finished by the launch itself (conv.hip's engine, with stats0 / stats1): the LAST
+   * workgroup of this group's launch to pass its statistics on runs the mpose_bn_finalize job(s) fin0 / fin1 point at
+   * (`const mpose_bn_job*` in device memory; scale / shift / mean / invstd, the running-statistics update and, with mm0, the
+   * amax of relu(bn(out0))) -- the next launch finds them done, no mpose_bn_finalize launch in between.  fin_count: one
+   * zero-initialised unsigned per (launch, group) in device memory; it is zero again when the launch ends. */
+  const void* fin0;
+  const void* fin1;
+  unsigned* fin_count;
+  float fin_eps, fin_momentum;
 } mpose_conv_operands;
 
 #define MPOSE_CONV_ACCUMULATE 1   /* out0 += result */
@@ -239,6 +248,12 @@ typedef struct {
  * the launch runs units * n_groups * n_split workgroups, one per CU at a time (the caller sizes n_split so that
  * this is close to a multiple of 256, and the partial-sum buffer as n_split * packed-fp32 weight size). */
 int mpose_conv_wgrad_tiles(const mpose_conv_geom* geom);
+
+/* d > 1: the geometry is a stride-1 convolution dilated by d along x (every tap's dx a multiple of d), whose weight gradient
+ * mpose_conv_wgrad computes as d launches over the residues of x mod d -- IF n_split is a multiple of d; each residue then
+ * writes n_split / d of the n_split partials, and mpose_conv_wgrad_tiles counts the units of ONE residue's launch over
+ * B * GH * GW / d slots.  1: no such decomposition (size n_split as usual). */
+int mpose_conv_wgrad_phases(const mpose_conv_geom* geom);
 
 int mpose_conv_wgrad(const mpose_conv_geom* geom, const mpose_wgrad_operands* ops, int n_groups,
                      int n_split, void* stream);

@@ -17,7 +17,7 @@ c_int = ctypes.c_int
 c_float = ctypes.c_float
 c_int64 = ctypes.c_int64
 
-ABI_VERSION = 11         # must equal mpose_abi_version() of the library (csrc/tail.hip)
+ABI_VERSION = 12         # must equal mpose_abi_version() of the library (csrc/tail.hip)
 MAX_GROUP = 3
 MAX_TAPS = 12
 MAX_CLASSES = 8
@@ -105,7 +105,8 @@ class ConvOperands(ctypes.Structure):
                 ('add_shift', c_void_p), ('out0_planes', c_void_p),
                 ('in_amax', c_void_p), ('in1_amax', c_void_p), ('w0_amax', c_void_p), ('w1_amax', c_void_p), ('out0_amax', c_void_p),
                 ('red_a', c_void_p), ('red_b', c_void_p), ('red_scale', c_void_p), ('red_shift', c_void_p), ('red_sums', c_void_p),
-                ('mm0', c_void_p)]
+                ('mm0', c_void_p), ('fin0', c_void_p), ('fin1', c_void_p), ('fin_count', c_void_p), ('fin_eps', ctypes.c_float),
+                ('fin_momentum', ctypes.c_float)]
 
 
 class WgradOperands(ctypes.Structure):

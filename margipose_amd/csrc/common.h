@@ -107,6 +107,56 @@ __device__ __forceinline__ float key_float(unsigned k) {
   return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
 }
 
+// One mpose_bn_finalize job: BatchNorm statistics -> (scale, shift, mean, invstd), the running-statistics update, and the exact
+// largest relu(scale*x + shift) from the channel extremes.  Run by bn_finalize_k (bn.hip) and -- FRESH -- by the last workgroup
+// of the convolution launch whose epilogues accumulated the statistics (conv.hip): those sums and extremes were written by other
+// workgroups' atomics moments ago, so they are read at device scope.  All 256 threads of the workgroup call it.
+template <bool FRESH>
+__device__ __forceinline__ void bn_finalize_job(const mpose_bn_job& j, int train, float eps, float momentum) {
+  if (j.eps > 0.f) eps = j.eps;
+  const bool want_amax = train && j.minmax != nullptr && j.amax_out != nullptr;
+  float amax = 0.f;
+  auto ld_f64 = [](const double* p) -> double {
+    if (!FRESH) return *p;
+    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  };
+  auto ld_u32 = [](const unsigned* p) -> unsigned {
+    if (!FRESH) return *p;
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  for (int c = threadIdx.x; c < j.C; c += 256) {
+    // The conv kernels are bias-free; a producing conv's bias b only shifts the BN input: batch/running mean
+    // of (y + b) = mean(y) + b, and  scale*(y + b) + beta - (mean + b)*scale  ==  scale*y + beta - mean*scale.
+    const double cb = (j.conv_bias != nullptr) ? (double)j.conv_bias[c] : 0.0;
+    double mean, var;
+    if (train) {
+      const double n = (double)j.count;
+      mean = ld_f64(j.stats + 2 * c) / n;
+      var = ld_f64(j.stats + 2 * c + 1) / n - mean * mean;
+      if (var < 0.0) var = 0.0;
+      if (j.running_mean != nullptr) {
+        const double unbiased = (j.count > 1) ? var * n / (n - 1.0) : var;
+        j.running_mean[c] = (float)((1.0 - momentum) * (double)j.running_mean[c] + momentum * (mean + cb));
+        j.running_var[c] = (float)((1.0 - momentum) * (double)j.running_var[c] + momentum * unbiased);
+      }
+    } else {
+      mean = (double)j.running_mean[c] - cb;
+      var = (double)j.running_var[c];
+    }
+    const double invstd = 1.0 / sqrt(var + (double)eps);
+    const double sc = (double)j.gamma[c] * invstd;
+    const float scf = (float)sc, shf = (float)((double)j.beta[c] - mean * sc);
+    j.scale[c] = scf;
+    j.shift[c] = shf;
+    if (j.mean != nullptr) { j.mean[c] = (float)mean; j.invstd[c] = (float)invstd; }
+    if (want_amax) {       // relu(scale * x + shift) is monotone in x: its largest value sits at one of the channel's two extremes
+      const float vmax = key_float(ld_u32(j.minmax + 2 * c)), vmin = -key_float(ld_u32(j.minmax + 2 * c + 1));
+      amax = fmaxf(amax, fmaxf(fmaf(vmax, scf, shf), fmaf(vmin, scf, shf)));       // (fmaxf drops the NaN of an untouched key)
+    }
+  }
+  if (want_amax) block_amax_commit_one(amax, j.amax_out);       // (uniform: every thread of the workgroup gets here)
+}
+
 struct Ptr3 {
   const float* p[MPOSE_MAX_GROUP];
 };

@@ -1004,6 +1004,23 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
     double* d = op.red_sums + (size_t)(n0 + tid) * 4;
     atomicAdd(d, (double)t.x); atomicAdd(d + 1, (double)t.y); atomicAdd(d + 2, (double)t.z); atomicAdd(d + 3, (double)t.w);
   }
+  // The last workgroup of this group's launch to get here turns the statistics into the BatchNorm vectors (mpose_bn_finalize's
+  // job, common.h).  Every workgroup waits until its device-scope atomics have been ACKNOWLEDGED (vmcnt: they are performed at
+  // the memory side, beyond the XCDs' private L2s) before it draws its ticket there too, so whoever draws the last ticket has
+  // all of them behind it and reads them with device-scope loads.  No workgroup waits for another, and no cache is flushed: a
+  // __threadfence() here -- an agent-scope release writes the XCD's dirty L2 lines back -- cost 2.8 ms per training step.
+  if (op.fin_count != nullptr) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    unsigned* ticket = reinterpret_cast<unsigned*>(sRow);
+    if (tid == 0) *ticket = __hip_atomic_fetch_add(op.fin_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (*ticket == gridDim.x * gridDim.y - 1) {
+      bn_finalize_job<true>(*reinterpret_cast<const mpose_bn_job*>(op.fin0), 1, op.fin_eps, op.fin_momentum);
+      if (ACC1 && op.fin1 != nullptr) bn_finalize_job<true>(*reinterpret_cast<const mpose_bn_job*>(op.fin1), 1, op.fin_eps, op.fin_momentum);
+      if (tid == 0) __hip_atomic_store(op.fin_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 
 template <int RN, int MODE, int KS, bool PRO, int NPL, bool ROWG>
@@ -1587,6 +1604,9 @@ extern "C" int mpose_conv_fwd(const mpose_conv_geom* geom_, const mpose_conv_ope
       return MPOSE_EINVAL;
     if ((ops[i].red_sums != nullptr) != (ops[0].red_sums != nullptr)) return MPOSE_EINVAL;
     if (ops[i].mm0 && ((flags & MPOSE_CONV_PLANES_IN) || !ops[i].stats0)) return MPOSE_EINVAL;
+    if (ops[i].fin_count && ((flags & MPOSE_CONV_PLANES_IN) || !ops[i].fin0 || !ops[i].stats0 || (ops[i].fin1 && (!acc1 || !ops[i].stats1)) ||
+                             sum_inputs)) return MPOSE_EINVAL;
+    if (!ops[i].fin_count && (ops[i].fin0 || ops[i].fin1)) return MPOSE_EINVAL;
     if (acc1 && (!ops[i].w1 || !ops[i].out1)) return MPOSE_EINVAL;
     if ((ops[i].in_scale != nullptr) != (ops[0].in_scale != nullptr)) return MPOSE_EINVAL;
     if (ops[i].in_scale && (acc1 || !ops[i].in_shift)) return MPOSE_EINVAL;
@@ -1645,11 +1665,45 @@ extern "C" int mpose_conv_fwd(const mpose_conv_geom* geom_, const mpose_conv_ope
   return launch_conv_ks<2>(a, mode, cmax, n_groups, s);
 }
 
+// A stride-1 convolution whose taps are all a multiple of d pixels apart along x (dilation d) is d independent undilated
+// convolutions, one per residue of x mod d: pixel x = d*q + r of an NHWC row IS pixel q of a row whose pixels are d*ld floats
+// apart, starting r*ld floats in.  The weight gradient of each residue is a launch of the row-of-taps kernel (wgrad.hip, which
+// wants |dx| <= 1) into its own split-K partials.  Returns d and fills the per-residue geometry, or 1.
+static int x_phases(const mpose_conv_geom& g, mpose_conv_geom* phase) {
+  if (g.n_classes != 1 || g.in_mul != 1 || g.out_mul != 1 || g.in_mul_x != 1 || g.out_mul_x != 1) return 1;
+  if (g.IH != g.GH || g.IW != g.GW || g.OH != g.GH || g.OW != g.GW || g.cls[0].oy || g.cls[0].ox) return 1;
+  int d = 0;
+  for (int t = 0; t < g.cls[0].n_taps; ++t) {
+    if (g.cls[0].taps[t].acc) return 1;
+    int v = g.cls[0].taps[t].dx < 0 ? -g.cls[0].taps[t].dx : g.cls[0].taps[t].dx;
+    while (v) { const int m = d % v; d = v; v = m; }        // gcd
+  }
+  if (d <= 1 || (g.IW % d) || ((g.IW / d) & 7)) return 1;
+  mpose_conv_geom p = g;
+  p.IW = p.OW = p.GW = g.IW / d;
+  p.in_ld = d * (g.in_ld > 0 ? g.in_ld : g.Cin);
+  p.out_ld0 = d * (g.out_ld0 > 0 ? g.out_ld0 : g.Cout0);
+  for (int t = 0; t < p.cls[0].n_taps; ++t) p.cls[0].taps[t].dx = (int8_t)(p.cls[0].taps[t].dx / d);
+  if (mpose_wgrad_rows_units(&p) <= 0) return 1;
+  if (phase) *phase = p;
+  return d;
+}
+
+extern "C" int mpose_conv_wgrad_phases(const mpose_conv_geom* geom_) {
+  if (check_geom(geom_)) return -1;
+  const mpose_conv_geom gn = normalised(geom_);
+  return x_phases(gn, nullptr);
+}
+
 extern "C" int mpose_conv_wgrad_tiles(const mpose_conv_geom* geom_) {
   if (check_geom(geom_)) return -1;
   const mpose_conv_geom gn = normalised(geom_);
   const mpose_conv_geom* geom = &gn;
   if (const int rows = mpose_wgrad_rows_units(geom)) return rows;      // the row-of-taps kernel (wgrad.hip) takes this geometry
+  {
+    mpose_conv_geom pg;
+    if (x_phases(gn, &pg) > 1) return mpose_wgrad_rows_units(&pg);     // ... one residue of x at a time (mpose_conv_wgrad_phases)
+  }
   int entries = 0;
   for (int c = 0; c < geom->n_classes; ++c) entries += geom->cls[c].n_taps;
   return entries * (geom->Cin / (32 * wgrad_blocks(geom->Cin))) * (geom->Cout0 / (32 * wgrad_blocks(geom->Cout0)));
@@ -1696,6 +1750,27 @@ extern "C" int mpose_conv_wgrad(const mpose_conv_geom* geom_, const mpose_wgrad_
   // stride-1 geometries in the three-product form: one staged operand pair per kernel ROW of taps (wgrad.hip)
   rc = mpose_wgrad_rows_launch(geom, ops, n_groups, n_split, stream);
   if (rc != MPOSE_ENOSYS) return rc;
+  {   // x-dilated kernels: one launch of the row form per residue of x, n_split / d partials each (x_phases above)
+    mpose_conv_geom pg;
+    const int d = x_phases(*geom, &pg);
+    if (d > 1 && n_split % d == 0 && ops[0].in_amax) {
+      const long split_stride = (long)a.n_widx0 * geom->Cin * geom->Npad0;       // floats per partial
+      const int in_ld = geom->in_ld > 0 ? geom->in_ld : geom->Cin;
+      const int g_ld = geom->out_ld0 > 0 ? geom->out_ld0 : geom->Cout0;
+      for (int r = 0; r < d; ++r) {
+        mpose_wgrad_operands po[MPOSE_MAX_GROUP];
+        for (int i = 0; i < n_groups; ++i) {
+          po[i] = ops[i];
+          po[i].in = ops[i].in + (long)r * in_ld;
+          po[i].gout0 = ops[i].gout0 + (long)r * g_ld;
+          po[i].dw0 = ops[i].dw0 + (long)r * (n_split / d) * split_stride;
+        }
+        rc = mpose_wgrad_rows_launch(&pg, po, n_groups, n_split / d, stream);
+        if (rc) return rc == MPOSE_ENOSYS ? MPOSE_EINVAL : rc;
+      }
+      return 0;
+    }
+  }
   a.div_gh = make_fastdiv((unsigned)geom->GH);
   a.n_split = n_split;
   a.rows_per_split = (n_rows + n_split - 1) / n_split;

@@ -578,7 +578,7 @@ int build_units(const mpose_conv_geom* g, RowUnit* units, int* n_widx0, int* n_w
   const mpose_tap_class& c = g->cls[0];
   int n_units = 0, max0 = -1, max1 = -1;
   for (int acc = 0; acc < 2; ++acc)
-    for (int dy = -3; dy <= 3; ++dy) {
+    for (int dy = -8; dy <= 8; ++dy) {          // (dilated kernels: rows 2, 4 pixels apart)
       int widx[3] = {-1, -1, -1}, cnt = 0;
       for (int t = 0; t < c.n_taps; ++t) {
         const mpose_tap& tp = c.taps[t];
@@ -598,7 +598,7 @@ int build_units(const mpose_conv_geom* g, RowUnit* units, int* n_widx0, int* n_w
     }
   for (int t = 0; t < c.n_taps; ++t) {
     const mpose_tap& tp = c.taps[t];
-    if (tp.dy < -3 || tp.dy > 3) return -1;
+    if (tp.dy < -8 || tp.dy > 8) return -1;
     if (tp.acc) { if (tp.widx > max1) max1 = tp.widx; } else if (tp.widx > max0) max0 = tp.widx;
   }
   *n_widx0 = max0 + 1;

@@ -341,6 +341,9 @@ class Engine:
         self.timer = None            # optional KernelTimer (bench.py)
         self.side_stream = None      # weight-gradient GEMMs run here, off the data-gradient critical path
         self._side_keep = []         # tensors the side stream still reads (released at the next bucket boundary)
+        # (measured: no faster -- the step is bound by the sum of the heavy kernels' work, not by the main stream's chain of launches -- off)
+        self.fuse_finalize = os.environ.get('MPOSE_FUSE_FINALIZE', '0') != '0'
+        self.inline_unpack = os.environ.get('MPOSE_INLINE_UNPACK', '0') != '0'     # (see unpack_after: measured no faster, off)
         self.overlap_wgrad = True    # +2.3 % step rate, bit-identical results; launches bracketed by a KernelTimer stay serial
         self.dp = None               # optional (process_group, world_size): gradient all-reduce after backward
         self.input_norm = ([0.485, 0.456, 0.406], [0.229, 0.224, 0.225])    # uint8 frames: ImageSpecs mean / stddev
@@ -572,9 +575,10 @@ class Engine:
                     slots_in = B * (hw_in(i) if b.kind == 'up' else hw_out(i)) ** 2
                     gname = {'regular': 'f_in_regular', 'down': 'f_in_down', 'up': 'f_in_up'}[b.kind]
                     nsp_in = self.wg_n_split(self.geom(gname, B, hw_in(i), b))
-                    unpack_job(uj[base + 3 * c], b.conv2, self.wg_n_split(self.geom('f_conv2', B, hw_out(i), b)))
-                    unpack_job(uj[base + 3 * c + 1], b.conv_in, nsp_in)
-                    unpack_job(uj[base + 3 * c + 2], b.conv_sc, nsp_in)
+                    # (the jobs of ONE weight-gradient launch are contiguous: conv2 of the three columns, then conv_in + shortcut)
+                    unpack_job(uj[base + c], b.conv2, self.wg_n_split(self.geom('f_conv2', B, hw_out(i), b)))
+                    unpack_job(uj[base + 3 + c], b.conv_in, nsp_in)
+                    unpack_job(uj[base + 6 + c], b.conv_sc, nsp_in)
         if self.stem is None:
             coef_job(cj[self.T * 90], self.stem_bn, self.stem_bn, 4, 0, 1, B * F * F)
             unpack_job(uj[self.T * 90], self.stem_conv, self._n_split(B * F * F, 2, 1))
@@ -587,9 +591,13 @@ class Engine:
         uj['src'] = pbase + 4 * uj['src']
         tb['part_ptr'] = dict((k_, pbase + 4 * v) for k_, v in part_offs.items())
         tb['fin'] = _jobs_to_device(fj, dev)
+        tb['fin_count'] = torch.zeros(len(fj), dtype=torch.int32, device=dev)     # tickets of the launches that finalise their own BatchNorm
         tb['coef'] = _jobs_to_device(cj, dev)
         tb['unpack'] = _jobs_to_device(uj, dev)
         tb['unpack_max'] = mx
+        # index of every convolution's job: the unpack of a weight-gradient launch follows it on the same stream (wgrad_async)
+        idx = dict((int(uj[k_]['dst']), k_) for k_ in range(len(uj)))
+        tb['unpack_idx'] = dict((id(c), idx[gbase + 4 * goff[id(c.param)]]) for c in self._convs)
         self._tables[key] = tb
         return tb
 
@@ -743,7 +751,21 @@ class Engine:
         except Exception:
             return False
 
-    def wgrad_async(self, g, ops, n_split, tensors):
+    def unpack_after(self, tb, convs):
+        """(table, first job, jobs, largest job) for wgrad_async: the split-K partials of `convs` (one launch's, contiguous jobs)
+        are summed into the flat gradient buffer right behind the launch, on its stream, while they are still in the
+        Infinity Cache -- instead of one pass per stage over 0.7 GB of partials on the main stream at the bucket's end."""
+        if not self.inline_unpack:
+            return None
+        ks = sorted(tb['unpack_idx'][id(c)] for c in convs)
+        assert ks == list(range(ks[0], ks[0] + len(ks)))
+        return tb['unpack'].data_ptr() + ks[0] * UNPACK_DT.itemsize, len(ks), max(c.cout * c.cin * c.T for c in convs)
+
+    def _unpack_now(self, unpack):
+        if unpack is not None:
+            check(lib().mpose_unpack_wgrads(c_void_p(unpack[0]), unpack[1], unpack[2], stream_ptr()), 'mpose_unpack_wgrads')
+
+    def wgrad_async(self, g, ops, n_split, tensors, unpack=None):
         """Weight-gradient launch on the side stream: it only feeds the final unpack, so it overlaps the next
         block's data-gradient chain and the small BatchNorm kernels.  `tensors` are the buffers it reads: their
         memory must not be recycled by the caching allocator before the side stream is done with them."""
@@ -754,6 +776,7 @@ class Engine:
         # hardware: the pool has no multi-GPU node.  tests/test_model_gpu.py runs the schedule under gloo, functionally.)
         if not self.overlap_wgrad or self.timer is not None or (self.dp is not None and not self.dp_overlap()):
             self.wgrad(g, ops, n_split)
+            self._unpack_now(unpack)
             return
         main = torch.cuda.current_stream()
         if self.side_stream is None or self.side_stream.device != main.device:
@@ -762,9 +785,19 @@ class Engine:
         side.wait_stream(main)
         with torch.cuda.stream(side):
             self.wgrad(g, ops, n_split)
+            self._unpack_now(unpack)
         # keep the operands alive until the main stream has waited for the side stream (_finish_bucket): unlike
         # Tensor.record_stream this costs no allocator head-room (reserved memory 8.3 GB instead of 30 GB at B=32)
         self._side_keep.extend(tensors)
+
+    def fuse_fin(self, op, table, counters, job0, job1=None):
+        """The convolution launch finishes the BatchNorm(s) of its output(s) itself (mpose_conv_operands.fin*): job indices into
+        `table` (a device-resident mpose_bn_job array), one ticket counter per first job."""
+        op.fin0 = table.data_ptr() + job0 * BN_DT.itemsize
+        if job1 is not None:
+            op.fin1 = table.data_ptr() + job1 * BN_DT.itemsize
+        op.fin_count = counters.data_ptr() + 4 * job0
+        op.fin_eps, op.fin_momentum = BN_EPS, BN_MOMENTUM
 
     def finalize_table(self, table, first, n, train):
         base = table.data_ptr() + first * BN_DT.itemsize
@@ -786,7 +819,8 @@ class Engine:
             if tiles <= 0:
                 raise _lib.MposeError('mpose_conv_wgrad_tiles rejected the geometry %s' % getattr(g, '_name', '?'))
             slots = g.B * g.GH * (32 if width32 else g.GW)
-            nsp = g._n_split = self._n_split(slots, tiles, groups)
+            d = max(1, int(lib().mpose_conv_wgrad_phases(ctypes.byref(g))))       # x-dilated kernels: d launches, n_split / d each
+            nsp = g._n_split = d * self._n_split(slots // d, tiles, groups)
         return nsp
 
     def finalize(self, tb, first, n, train):
@@ -851,6 +885,8 @@ class Engine:
         cmode = ctx['cmode'] = self.conv_mode_for(train, save)
         planes = cmode == 1
         f16 = cmode == 2
+        # train mode on conv_igemm_k: the convolution launches finalise their own BatchNorms (no mpose_bn_finalize launches)
+        fin_fused = train and not planes and self.fuse_finalize
         self.pack_weights(cmode)
         if f16:
             self.amax_f.zero_()
@@ -961,9 +997,11 @@ class Engine:
                         op.stats0, op.stats1 = self._stats_ptr(b.bn1), self._stats_ptr(b.bns)
                         if f16:
                             op.mm0 = self._mm_ptr(b.bn1)
+                        if fin_fused:        # (the launch's last workgroup per column runs the two finalize jobs)
+                            self.fuse_fin(op, tb['fin'], tb['fin_count'], self.fin_index(t, i, 0) + c, self.fin_index(t, i, 1) + c)
                     ops.append(op)
                 self.conv(g1, ops, pflags | (16 if (fused or fused_h) else 0))
-                if train:
+                if train and not fin_fused:
                     self.finalize(tb, self.fin_index(t, i, 0), 6, True)
                 # largest relu(bn1(c1)): what the next K loop (and its weight gradient) will split.  In training bn_finalize just
                 # derived it from c1's channel extremes (the convolution's epilogue took them); otherwise it is measured
@@ -1012,9 +1050,11 @@ class Engine:
                         op.out0 = c2[c].data_ptr()
                     if train:
                         op.stats0 = self._stats_ptr(b.bn2)
+                        if fin_fused:
+                            self.fuse_fin(op, tb['fin'], tb['fin_count'], self.fin_index(t, i, 2) + c)
                     ops.append(op)
                 self.conv(self.geom('f_conv2', B, Hout, b0), ops, pflags | (16 if (fuse2 or fuse2_h) else 0))
-                if train:
+                if train and not fin_fused:
                     self.finalize(tb, self.fin_index(t, i, 2), 3, True)
                 if fuse2:
                     cur_p = nxt_p
@@ -1255,7 +1295,7 @@ class Engine:
                         wo.single_product = int(x1)
                     wops.append(wo)
                 g_w2 = self.geom('f_conv2', B, Hout, b0)
-                self.wgrad_async(g_w2, wops, self.wg_n_split(g_w2), sv['c1'] + d_c2)
+                self.wgrad_async(g_w2, wops, self.wg_n_split(g_w2), sv['c1'] + d_c2, self.unpack_after(tb, [b.conv2 for b in grp]))
                 # (4) BN1 backward
                 run_coef(jb + 6, 3)
                 d_c1 = [torch.empty(B, Hout, Hout, Cs, **f32) for _ in range(3)]
@@ -1287,7 +1327,8 @@ class Engine:
                         wo.single_product = int(x1)
                     wops.append(wo)
                 g_w1 = self.geom(gname, B, Hin, b0)
-                self.wgrad_async(g_w1, wops, self.wg_n_split(g_w1), list(sv['x']) + d_c1 + d_sc)
+                self.wgrad_async(g_w1, wops, self.wg_n_split(g_w1), list(sv['x']) + d_c1 + d_sc,
+                                 self.unpack_after(tb, [b.conv_in for b in grp] + [b.conv_sc for b in grp]))
                 # (6) dgrad of conv_in + the shortcut's dgrad: one launch, the shortcut as a tap on a second input
                 d_x = [torch.empty(B, Hin, Hin, b0.cin_s, **f32) for _ in range(3)]
                 kd = {'regular': 'd_in_regular', 'down': 'd_in_down', 'up': 'd_in_up'}[b0.kind]
@@ -1355,7 +1396,8 @@ class Engine:
                 check(L.mpose_bn_bwd_apply((BnBwdApplyOperands * 3)(ao), 1, F * F, B, 128, 0, 0, st()), 'mpose_bn_bwd_apply')
                 wo = WgradOperands()
                 wo.in_, wo.gout0, wo.dw0 = ctx['s2d'].data_ptr(), d_raw.data_ptr(), tb['part_ptr'][id(self.stem_conv)]
-                self.wgrad_async(self.geom('f_stem', B, F), [wo], self._n_split(B * F * F, 2, 1), [ctx['s2d'], d_raw])
+                self.wgrad_async(self.geom('f_stem', B, F), [wo], self._n_split(B * F * F, 2, 1), [ctx['s2d'], d_raw],
+                                 self.unpack_after(tb, [self.stem_conv]))
                 if need_dx:
                     d_s2d = torch.empty_like(ctx['s2d'])
                     op = ConvOperands()
@@ -1376,7 +1418,7 @@ class Engine:
         if self.overlap_wgrad and self.side_stream is not None:
             torch.cuda.current_stream().wait_stream(self.side_stream)
         self._side_keep.clear()            # (their memory may now be recycled by main-stream allocations)
-        if n_jobs > 0:
+        if n_jobs > 0 and not self.inline_unpack:
             check(lib().mpose_unpack_wgrads(c_void_p(tb['unpack'].data_ptr() + first_job * UNPACK_DT.itemsize), n_jobs,
                                             tb['unpack_max'], stream_ptr()), 'mpose_unpack_wgrads')
         if self.dp is not None:

@@ -293,7 +293,7 @@ class _GraphStem:
         goff = dict((id(p), o) for p, o in zip(eng.param_list(), eng._grad_offsets))
         gbase = eng.gflat.data_ptr()
         fin, coef = [], []
-        tb = {'fin_range': {}, 'coef_range': {}}
+        tb = {'fin_range': {}, 'coef_range': {}, 'fin_job': {}}
         for n in self.nodes:
             f0, c0_ = len(fin), len(coef)
             for (a, b, bn, eps, bias) in n.parts:
@@ -309,6 +309,7 @@ class _GraphStem:
                 j['C'] = b - a; j['count'] = B * H * W
                 j['conv_bias'] = bias.data_ptr() if bias is not None else 0
                 j['eps'] = eps
+                tb['fin_job'][(n.name, a)] = len(fin)          # (the job of the convolution that writes channels a.. of this node)
                 fin.append(j)
                 k = np.zeros(1, dtype=COEF_DT)[0]
                 k['sums'] = self.sptr(n, True, a)
@@ -323,6 +324,7 @@ class _GraphStem:
         tb['fin'] = _jobs_to_device(np.array(fin, dtype=BN_DT), eng.device)
         tb['coef'] = _jobs_to_device(np.array(coef, dtype=COEF_DT), eng.device)
         tb['n_fin'] = len(fin)
+        tb['fin_count'] = torch.zeros(max(1, len(fin)), dtype=torch.int32, device=eng.device)
         self._tables[key] = tb
         return tb
 
@@ -413,6 +415,9 @@ class _GraphStem:
                 o.out0 = raw[n.name].data_ptr() + 4 * op.c0
                 if train:
                     o.stats0 = self.sptr(n, False, op.c0)
+                    job = tb['fin_job'].get((n.name, op.c0))
+                    if eng.fuse_finalize and job is not None:     # the launch finalises this BatchNorm itself
+                        eng.fuse_fin(o, tb['fin'], tb['fin_count'], job)
                 if f16:
                     if src.name not in measured:       # (all of the node's channels: a bound for any channel slice of it)
                         eng.absmax([raw[src.name]], [src.amax_f], src.C, None if sc is None else [sc], None if sc is None else [sh],
@@ -434,7 +439,7 @@ class _GraphStem:
             done.add(id(op))
             if train and all(id(p) in done for p in n.producers):
                 f0, nf = tb['fin_range'][n.name]
-                if nf:
+                if nf and not eng.fuse_finalize:       # (otherwise the producing launches have finalised their channel ranges)
                     eng.finalize_table(tb['fin'], f0, nf, True)
         if self.out_nodes is not None:
             out = [raw[n.name] for n in self.out_nodes]
@@ -511,7 +516,8 @@ class _GraphStem:
                     if f16:
                         wo.in_amax, wo.gout0_amax = src.amax_f, n.amax_b
                         wo.single_product = int(bool(cflags & 64))
-                    eng.wgrad_async(self.geom(op, B, S, 'f'), [wo], eng.stem_n_split(B, S, op), [raw[src.name], d_raw])
+                    eng.wgrad_async(self.geom(op, B, S, 'f'), [wo], eng.stem_n_split(B, S, op), [raw[src.name], d_raw],
+                                    eng.unpack_after(eng._tables_for(B, S // 8), [op.conv]))
                     if want_dsrc:
                         o = ConvOperands()
                         o.in_, o.w0 = d_raw.data_ptr() + 4 * op.c0, eng._wptr(op.conv, True)

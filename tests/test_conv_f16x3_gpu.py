@@ -446,3 +446,34 @@ def test_consumer_bn_sums_in_epilogue(B, H, cin, cout, f16):
     assert float(((sums.cpu() - ref).abs() / scale).max()) < 2e-6      # fp32 partial sums over <= 256 rows, fp64 across workgroups
     op.stats0 = sums.data_ptr()                                       # forward statistics and consumer sums exclude each other
     assert L.mpose_conv_fwd(ctypes.byref(g), (ConvOperands * 1)(op), 1, 2 | (F16X3 if f16 else 0), _lib.stream_ptr()) == -22
+
+
+@pytest.mark.parametrize('B,hw,cin,cout,dil,n_split,pro', [(2, (16, 32), 128, 128, (2, 2), 4, False), (2, (16, 32), 64, 192, (4, 4), 4, True),
+                                                        (3, (8, 32), 128, 64, (1, 4), 8, False), (2, (32, 16), 128, 128, (4, 1), 3, True),
+                                                        (2, (16, 32), 64, 64, (2, 2), 3, False)])
+def test_weight_gradient_of_dilated_kernels(B, hw, cin, cout, dil, n_split, pro):
+    """Dilated 3x3 (reference models/chatterbox_model.py:62-72, 143-150) in the three-product form: rows 2 / 4 pixels apart go
+    straight to the row-of-taps kernel; a kernel dilated by d ALONG x is computed as d launches over the residues of x mod d
+    (mpose_conv_wgrad_phases), each into n_split / d of the partials -- or, when n_split is not a multiple of d (last case), by
+    conv_wgrad_k.  Same gate as every weight gradient."""
+    from margipose_amd import _lib, engine as eng
+    L = _lib.lib()
+    rng = np.random.default_rng(B * 100 + hw[0] + cin + dil[1])
+    x = torch.from_numpy(rng.standard_normal((B, cin) + hw)).float()
+    go = torch.from_numpy(rng.standard_normal((B, cout) + hw)).float()
+    sc = torch.from_numpy(rng.uniform(0.5, 1.5, cin)).float()
+    sh = torch.from_numpy(rng.standard_normal(cin) * 0.3).float()
+    npad = (cout + 63) // 64 * 64
+    g = eng.conv_geom('f', False, B, hw, cin, hw, cout, (3, 3), (1, 1), dil, dil, npad)
+    d = int(L.mpose_conv_wgrad_phases(ctypes.byref(g)))
+    assert d == (dil[1] if dil[1] > 1 else 1)
+    xg, gg = x.permute(0, 2, 3, 1).contiguous().cuda(), go.permute(0, 2, 3, 1).contiguous().cuda()
+    scg, shg = (sc.cuda(), sh.cuda()) if pro else (None, None)
+    amaxes = torch.cat([_amax(L, _lib, [xg], cin, scg, shg, relu=pro), _amax(L, _lib, [gg], cout)])
+    dw, = _wgrad(L, _lib, eng, g, xg, gg, cout, cin, 9, npad, n_split, amaxes, scg, shg)
+
+    def fn(a, w):
+        if pro:
+            a = F.relu(a * sc.to(a.dtype).view(1, -1, 1, 1) + sh.to(a.dtype).view(1, -1, 1, 1))
+        return F.conv2d(a, w, padding=dil, dilation=dil)
+    _check(*_wgrad_errs(dw, x, go, fn, (cout, cin, 3, 3)))

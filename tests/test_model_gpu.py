@@ -117,13 +117,16 @@ def test_inference_config_batch64_vs_oracle():
         sd = weights(T, seed, x, True)
         sd = OrderedDict((k, v.double() if v.is_floating_point() else v) for k, v in sd.items())
         un = {}
-        xy, zy, xz = R.inner_forward(sd, x.double(), T, False, True, heatmap_dtype=torch.bfloat16, unrounded=un)
+        # eval mode: every frame is independent of its batch mates, so the fp64 oracle checks every fourth frame of the batch
+        # the GPU ran whole (a quarter of the CPU time: the suite's budget)
+        sub = torch.arange(0, B, 4)
+        xy, zy, xz = R.inner_forward(sd, x[sub].double(), T, False, True, heatmap_dtype=torch.bfloat16, unrounded=un)
         ref = R.heatmaps_to_coords(un['xy'], un['zy'], un['xz'])
-    err = rel(out.cpu(), ref)
+    err = rel(out.cpu()[sub], ref)
     worst = 0.0
     for got, want in ((m.xy_heatmaps, xy), (m.zy_heatmaps, zy), (m.xz_heatmaps, xz)):
         for t in range(T):
-            g, w = got[t].float().cpu().double(), want[t]
+            g, w = got[t].float().cpu().double()[sub], want[t]
             worst = max(worst, float(((g - w).abs() / w.abs().clamp_min(1e-30)).max()))
             assert float((g != w).double().mean()) < 5e-3
     print('configs[1] B=64 T=3: coords %.2e, worst heatmap element %.2e' % (err, worst))
