@@ -156,25 +156,39 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_k(BnReduceArgs a) {
 // sums[c][k] = sum over the launch's workgroups of their partial sums, in a fixed order (deterministic).  A workgroup owns 64
 // of the C*4 sums; its four waves each add every fourth workgroup's partial (eight loads in flight per thread), then the four
 // slices are added in order through LDS.  (The first version walked all partials serially per thread: 39 us for a 23 us pass.)
+// EL entries (of a group's C*4 sums) per workgroup, 256 / EL slices of the partial blocks each.  EL = 64: the columns' shape (C <=
+// 192, three groups).  A single wide BatchNorm (C = 256 .. 1024: ChatterboxModel) has 1024 .. 4096 entries: with EL = 64 that is
+// 16 .. 64 workgroups walking 512 partials each (40 us for 8 MB); EL = 16 spreads it over four times as many (and slices).
+template <int EL>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_finish_k(BnReduceArgs a, int n_blocks) {
-  __shared__ double sl[4][64];
-  const int el = threadIdx.x & 63, slice = threadIdx.x >> 6;
-  const int e = blockIdx.x * 64 + el;
+  constexpr int SL = 256 / EL;
+  __shared__ double sl[SL][EL];
+  const int el = threadIdx.x % EL, slice = threadIdx.x / EL;
+  const int e = blockIdx.x * EL + el;
   const int n_e = a.C * 4;
   double t[8] = {0., 0., 0., 0., 0., 0., 0., 0.};
   if (e < n_e) {
     const size_t stride = (size_t)n_e;
     const double* p = a.partials + (size_t)blockIdx.y * n_blocks * stride + e;
     int b = slice;
-    for (; b + 28 < n_blocks; b += 32) {
+    for (; b + 7 * SL < n_blocks; b += 8 * SL) {
 #pragma unroll
-      for (int u = 0; u < 8; ++u) t[u] += p[(size_t)(b + 4 * u) * stride];
+      for (int u = 0; u < 8; ++u) t[u] += p[(size_t)(b + SL * u) * stride];
     }
-    for (; b < n_blocks; b += 4) t[0] += p[(size_t)b * stride];
+    for (; b < n_blocks; b += SL) t[0] += p[(size_t)b * stride];
   }
   sl[slice][el] = ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
   __syncthreads();
-  if (slice == 0 && e < n_e) a.op[blockIdx.y].sums[e] = (sl[0][el] + sl[1][el]) + (sl[2][el] + sl[3][el]);
+  if (slice == 0 && e < n_e) {
+    if constexpr (SL == 4) {
+      a.op[blockIdx.y].sums[e] = (sl[0][el] + sl[1][el]) + (sl[2][el] + sl[3][el]);
+    } else {
+      double s = 0.0;
+#pragma unroll
+      for (int k = 0; k < SL; k += 4) s += (sl[k][el] + sl[k + 1][el]) + (sl[k + 2][el] + sl[k + 3][el]);
+      a.op[blockIdx.y].sums[e] = s;
+    }
+  }
 }
 
 // eval_mode: the forward normalised with the RUNNING statistics (constants), so dx = gamma*invstd*g (c1 = c2 = 0);
@@ -349,16 +363,19 @@ extern "C" int mpose_bn_bwd_reduce(const mpose_bn_bwd_reduce_operands* ops, int 
 
 // workgroups per group of the partial-sum form: enough to fill the chip ~4x over all groups, few enough that the partials stay
 // ~1 MB per group (1024 per group cost more in the finishing pass than it gained in the main one)
-static long reduce_ws_blocks(int n_groups, long npix) {
+static bool reduce_wide(int n_groups, int C) { return n_groups == 1 && C >= 256; }      // one wide BatchNorm (see bn_bwd_reduce_finish_k)
+
+static long reduce_ws_blocks(int n_groups, long npix, int C) {
   const long cap = n_groups >= 3 ? 384 : (n_groups == 2 ? 512 : 1024);
-  long blocks = (npix + 63) / 64;
+  // (wide: a workgroup's pass covers 256 / (C/4) <= 4 pixel rows at a time; 32 pixels each keeps >= 4 workgroups per CU in flight)
+  long blocks = reduce_wide(n_groups, C) ? (npix + 31) / 32 : (npix + 63) / 64;
   if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
   return blocks;
 }
 
 extern "C" int64_t mpose_bn_bwd_reduce_ws_bytes(int n_groups, int pixels_per_image, int B, int C) {
-  return (int64_t)n_groups * reduce_ws_blocks(n_groups, (long)B * pixels_per_image) * C * 4 * 8;
+  return (int64_t)n_groups * reduce_ws_blocks(n_groups, (long)B * pixels_per_image, C) * C * 4 * 8;
 }
 
 // Same sums as mpose_bn_bwd_reduce, WRITTEN (not accumulated), through per-workgroup partial sums in a caller-provided workspace
@@ -372,14 +389,15 @@ extern "C" int mpose_bn_bwd_reduce_ws(const mpose_bn_bwd_reduce_operands* ops, i
   a.npix = (long)B * pixels_per_image;
   if (a.npix == 0) return 0;
   a.C = C;
-  const long blocks = reduce_ws_blocks(n_groups, a.npix);
+  const long blocks = reduce_ws_blocks(n_groups, a.npix, C);
   a.pix_per_block = (int)((a.npix + blocks - 1) / blocks);
   a.partials = reinterpret_cast<double*>(workspace);
   const int rows_per_pass = 256 / (C / 4);
   const int lds = rows_per_pass * C * 4 * 8;
   hipStream_t s = (hipStream_t)stream;
   bn_bwd_reduce_k<<<dim3((unsigned)blocks, n_groups), 256, lds, s>>>(a);
-  bn_bwd_reduce_finish_k<<<dim3((C * 4 + 63) / 64, n_groups), 256, 0, s>>>(a, (int)blocks);
+  if (reduce_wide(n_groups, C)) bn_bwd_reduce_finish_k<16><<<dim3((C * 4 + 15) / 16, n_groups), 256, 0, s>>>(a, (int)blocks);
+  else bn_bwd_reduce_finish_k<64><<<dim3((C * 4 + 63) / 64, n_groups), 256, 0, s>>>(a, (int)blocks);
   return launch_status();
 }
 
