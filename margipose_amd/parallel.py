@@ -49,9 +49,10 @@ def allreduce_mean_(flat, group, world):
 
 
 def attach(model, group=None):
-    """Turn on gradient averaging for a margipose_amd MargiPoseModel (no-op for world size 1)."""
+    """Turn on gradient averaging for a margipose_amd MargiPoseModel / ChatterboxModel (no-op for world size 1)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
-    model.inner.engine().dp = (group, world) if world > 1 else None
+    owner = model.inner if hasattr(model, 'inner') else model        # (ChatterboxModel owns its engine itself)
+    owner.engine().dp = (group, world) if world > 1 else None
     return model
 
 

@@ -135,3 +135,37 @@ def test_chatterbox_2d_losses_and_no_pixelwise():
         m.pixelwise_loss = 'nope'
         with pytest.raises(Exception, match='unrecognised pixelwise loss: nope'):
             m.forward_3d_losses(out, target.cuda())
+
+
+def test_chatterbox_training_harness_eager_and_graphed():
+    """The reference's training iteration (bin/train_3d.py:154-186) on ChatterboxModel through the same harness as MargiPose:
+    training_step + DeviceSGD + 1cycle eagerly, and the iteration captured once as a HIP graph (GraphedTrainStep) -- same
+    losses and weights bit for bit; the loss of a repeated batch goes down."""
+    import copy
+    from margipose_amd.train_helpers import DeviceSGD, GraphedTrainStep, make_1cycle, training_step
+    B, n_iter = 2, 4
+    x, target, mask = W.seeded_inputs(9401, B)
+    sd = calibrated_state(940, x)
+    m_e = build(sd).train()
+    m_g = copy.deepcopy(m_e)
+    opt_e = DeviceSGD(m_e.parameters(), lr=0.02, momentum=0.9)
+    sch_e = make_1cycle(opt_e, 20, 0.02, 0.9)
+    losses_e = []
+    for _ in range(n_iter):
+        _, loss = training_step(m_e, sch_e, x.cuda(), target.cuda(), mask.cuda(), [1] * B)
+        losses_e.append(float(loss.detach()))
+    assert losses_e[-1] < losses_e[0], losses_e
+    opt_g = DeviceSGD(m_g.parameters(), lr=0.02, momentum=0.9)
+    sch_g = make_1cycle(opt_g, 20, 0.02, 0.9)
+    state = copy.deepcopy(m_g.state_dict())
+    step = GraphedTrainStep(m_g, opt_g, x.cuda(), target.cuda(), mask.cuda())
+    m_g.load_state_dict(state)
+    opt_g._bufs.zero_(); opt_g._steps = 0
+    losses_g = []
+    for _ in range(n_iter):
+        sch_g.batch_step()
+        _, loss = step(x.cuda(), target.cuda(), mask.cuda())
+        losses_g.append(float(loss))
+    assert losses_e == losses_g, (losses_e, losses_g)
+    for (k, a), (_, b) in zip(m_e.state_dict().items(), m_g.state_dict().items()):
+        assert torch.equal(a, b), k
