@@ -51,11 +51,12 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--cpu-batch', type=int, default=4)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--graph', action='store_true', help='replay the iteration from one HIP graph (train_helpers.GraphedTrainStep)')
     args = ap.parse_args()
     from margipose_amd import dsntnn
     from margipose_amd.engine import KernelTimer
     from margipose_amd.models import CanonicalSkeletonDesc, ChatterboxModel
-    from margipose_amd.train_helpers import DeviceSGD
+    from margipose_amd.train_helpers import DeviceSGD, GraphedTrainStep
     device = torch.device('cuda', 0)
     torch.manual_seed(12345)
     model = ChatterboxModel(CanonicalSkeletonDesc, 'jsd').to(device).train()
@@ -73,6 +74,10 @@ def main():
         loss.backward()
         opt.step()
         return loss
+    eager_step = step
+    if args.graph:
+        graphed = GraphedTrainStep(model, opt, x, target, mask, warmup=2)
+        step = lambda: graphed()[1]
     for _ in range(args.warmup):
         loss = step()
     timer = KernelTimer()
@@ -82,7 +87,7 @@ def main():
     for i in range(args.steps):
         if i % 40 == 0:
             model.engine().timer = timer
-            loss = step()
+            loss = eager_step()
             model.engine().timer = None
         else:
             loss = step()
@@ -96,7 +101,8 @@ def main():
                                   'step, batch %d, ResNet-34 conv1..layer2 + dilated layer3/4 xy head + two one-axis chatterbox heads, '
                                   '256x256 input, 17 joints, 32x32 heatmaps, JS + Euclidean loss, SGD(momentum 0.9); torchvision layers '
                                   'restated (unpinned), random init' % B,
-                      'global_batch': B, 'final_loss': float(loss.detach())}}
+                      'global_batch': B, 'final_loss': float(loss.detach()),
+                      'step_dispatch': 'hip graph replay (train_helpers.GraphedTrainStep)' if args.graph else 'eager launches'}}
     summ = timer.summary()
     convs = {k: v for k, v in summ.items() if k.startswith('conv:') or k.startswith('wgrad:')}
     top = max(convs.items(), key=lambda kv: kv[1]['total_ms'])
