@@ -1078,7 +1078,8 @@ inline int pick_ks(const ConvArgs& a, int cmax, int n_groups) {
 }
 
 // Row-group staging applies to the first pass of a stride-1 3x3 over an input of the output's size: one class,
-// nine acc == 0 taps first, each consecutive triple sharing dy (|dy| <= 1) with dx in {-1, 0, 1}.
+// nine acc == 0 taps first, each consecutive triple sharing dy with dx in {-1, 0, 1} (any dy: a kernel dilated along y --
+// models/chatterbox_model.py:143-150 -- stages the 66 pixels around m0 + dy * IW like any other row).
 inline bool rowg_eligible(const mpose_conv_geom& g) {
   if (g.n_classes != 1 || g.in_mul != 1 || g.in_mul_x != 1 || g.IH != g.GH || g.IW != g.GW || (g.Cin % KC)) return false;
   const mpose_tap_class& c = g.cls[0];
@@ -1088,7 +1089,7 @@ inline bool rowg_eligible(const mpose_conv_geom& g) {
   }
   if (n0 != 9) return false;
   for (int t = 0; t < 9; ++t) {
-    if (c.taps[t].dy != c.taps[3 * (t / 3)].dy || c.taps[t].dy < -1 || c.taps[t].dy > 1) return false;
+    if (c.taps[t].dy != c.taps[3 * (t / 3)].dy) return false;
     if (c.taps[t].dx < -1 || c.taps[t].dx > 1) return false;
   }
   return true;
@@ -1570,6 +1571,29 @@ static int check_geom(const mpose_conv_geom* g) {
   return 0;
 }
 
+// A stride-1 convolution whose taps are all a multiple of d pixels apart along x (dilation d) is d independent undilated
+// convolutions, one per residue of x mod d: pixel x = d*q + r of an NHWC row IS pixel q of a row whose pixels are d*ld floats
+// apart, starting r*ld floats in.  The kernels that want |dx| <= 1 -- the row-of-taps weight gradient (wgrad.hip), row-group
+// staging in conv_igemm_k -- then take it one residue per launch.  Returns d and fills the per-residue geometry, or 1.
+static int x_phase_geom(const mpose_conv_geom& g, mpose_conv_geom* phase) {
+  if (g.n_classes != 1 || g.in_mul != 1 || g.out_mul != 1 || g.in_mul_x != 1 || g.out_mul_x != 1) return 1;
+  if (g.IH != g.GH || g.IW != g.GW || g.OH != g.GH || g.OW != g.GW || g.cls[0].oy || g.cls[0].ox) return 1;
+  int d = 0;
+  for (int t = 0; t < g.cls[0].n_taps; ++t) {
+    if (g.cls[0].taps[t].acc) return 1;
+    int v = g.cls[0].taps[t].dx < 0 ? -g.cls[0].taps[t].dx : g.cls[0].taps[t].dx;
+    while (v) { const int m = d % v; d = v; v = m; }        // gcd
+  }
+  if (d <= 1 || (g.IW % d) || ((g.IW / d) & 7)) return 1;
+  mpose_conv_geom p = g;
+  p.IW = p.OW = p.GW = g.IW / d;
+  p.in_ld = d * (g.in_ld > 0 ? g.in_ld : g.Cin);
+  p.out_ld0 = d * (g.out_ld0 > 0 ? g.out_ld0 : g.Cout0);
+  for (int t = 0; t < p.cls[0].n_taps; ++t) p.cls[0].taps[t].dx = (int8_t)(p.cls[0].taps[t].dx / d);
+  *phase = p;
+  return d;
+}
+
 extern "C" int mpose_conv_fwd(const mpose_conv_geom* geom_, const mpose_conv_operands* ops, int n_groups, int flags,
                               void* stream) {
   int rc = check_geom(geom_);
@@ -1612,6 +1636,29 @@ extern "C" int mpose_conv_fwd(const mpose_conv_geom* geom_, const mpose_conv_ope
     if (ops[i].in_scale && (acc1 || !ops[i].in_shift)) return MPOSE_EINVAL;
   }
   if (acc1 && geom->Npad1 != geom->Npad0) return MPOSE_EINVAL;
+  // x-dilated 3x3 in the three-product form: one launch per residue of x, each eligible for row-group staging
+  if ((flags & MPOSE_CONV_F16X3) && !(flags & MPOSE_CONV_PLANES_IN) && !acc1 && !sum_inputs && rowg_env()) {
+    mpose_conv_geom pg;
+    const int d = x_phase_geom(*geom, &pg);
+    bool simple = d > 1 && rowg_eligible(pg);
+    for (int i = 0; simple && i < n_groups; ++i)
+      simple = !ops[i].mask_src && !ops[i].epi_scale0 && !ops[i].add_src && !ops[i].out0_planes && !ops[i].out0_amax &&
+               !ops[i].red_sums && !ops[i].fin_count;
+    if (simple) {
+      const int in_ld = geom->in_ld > 0 ? geom->in_ld : geom->Cin, o_ld = geom->out_ld0 > 0 ? geom->out_ld0 : geom->Cout0;
+      for (int r = 0; r < d; ++r) {
+        mpose_conv_operands po[MPOSE_MAX_GROUP];
+        for (int i = 0; i < n_groups; ++i) {
+          po[i] = ops[i];
+          po[i].in = ops[i].in + (long)r * in_ld;
+          po[i].out0 = ops[i].out0 + (long)r * o_ld;
+        }
+        rc = mpose_conv_fwd(&pg, po, n_groups, flags, stream);
+        if (rc) return rc;
+      }
+      return 0;
+    }
+  }
   a.M = geom->B * geom->GH * geom->GW;
   if (a.M == 0) return 0;
   if (flags & MPOSE_CONV_PLANES_IN) {      // pre-split activations: conv_p.hip
@@ -1665,26 +1712,10 @@ extern "C" int mpose_conv_fwd(const mpose_conv_geom* geom_, const mpose_conv_ope
   return launch_conv_ks<2>(a, mode, cmax, n_groups, s);
 }
 
-// A stride-1 convolution whose taps are all a multiple of d pixels apart along x (dilation d) is d independent undilated
-// convolutions, one per residue of x mod d: pixel x = d*q + r of an NHWC row IS pixel q of a row whose pixels are d*ld floats
-// apart, starting r*ld floats in.  The weight gradient of each residue is a launch of the row-of-taps kernel (wgrad.hip, which
-// wants |dx| <= 1) into its own split-K partials.  Returns d and fills the per-residue geometry, or 1.
-static int x_phases(const mpose_conv_geom& g, mpose_conv_geom* phase) {
-  if (g.n_classes != 1 || g.in_mul != 1 || g.out_mul != 1 || g.in_mul_x != 1 || g.out_mul_x != 1) return 1;
-  if (g.IH != g.GH || g.IW != g.GW || g.OH != g.GH || g.OW != g.GW || g.cls[0].oy || g.cls[0].ox) return 1;
-  int d = 0;
-  for (int t = 0; t < g.cls[0].n_taps; ++t) {
-    if (g.cls[0].taps[t].acc) return 1;
-    int v = g.cls[0].taps[t].dx < 0 ? -g.cls[0].taps[t].dx : g.cls[0].taps[t].dx;
-    while (v) { const int m = d % v; d = v; v = m; }        // gcd
-  }
-  if (d <= 1 || (g.IW % d) || ((g.IW / d) & 7)) return 1;
-  mpose_conv_geom p = g;
-  p.IW = p.OW = p.GW = g.IW / d;
-  p.in_ld = d * (g.in_ld > 0 ? g.in_ld : g.Cin);
-  p.out_ld0 = d * (g.out_ld0 > 0 ? g.out_ld0 : g.Cout0);
-  for (int t = 0; t < p.cls[0].n_taps; ++t) p.cls[0].taps[t].dx = (int8_t)(p.cls[0].taps[t].dx / d);
-  if (mpose_wgrad_rows_units(&p) <= 0) return 1;
+static int x_phases(const mpose_conv_geom& g, mpose_conv_geom* phase) {       // ... whose weight gradient the row form takes
+  mpose_conv_geom p;
+  const int d = x_phase_geom(g, &p);
+  if (d <= 1 || mpose_wgrad_rows_units(&p) <= 0) return 1;
   if (phase) *phase = p;
   return d;
 }
