@@ -477,3 +477,69 @@ def test_weight_gradient_of_dilated_kernels(B, hw, cin, cout, dil, n_split, pro)
             a = F.relu(a * sc.to(a.dtype).view(1, -1, 1, 1) + sh.to(a.dtype).view(1, -1, 1, 1))
         return F.conv2d(a, w, padding=dil, dilation=dil)
     _check(*_wgrad_errs(dw, x, go, fn, (cout, cin, 3, 3)))
+
+
+@pytest.mark.parametrize('B,hw,cin,cout,dil,pro', [(2, (16, 32), 128, 128, (2, 2), False), (2, (32, 16), 64, 128, (4, 1), True),
+                                                (3, (8, 32), 128, 64, (1, 4), True), (2, (16, 32), 64, 256, (4, 4), False)])
+def test_dilated_convolution_forward_and_data_gradient(B, hw, cin, cout, dil, pro):
+    """Dilated 3x3 (reference models/chatterbox_model.py:62-72, 143-150) through mpose_conv_fwd in the three-product form: kernel
+    rows 2 / 4 pixels apart run the row-group loop as they are, a kernel dilated ALONG x one residue of x per launch; forward
+    (with the BatchNorm + ReLU prologue and the statistics epilogue) and data-gradient (accumulating), same gate as every
+    convolution."""
+    from margipose_amd import _lib, engine as eng
+    from margipose_amd._lib import ConvOperands
+    L = _lib.lib()
+    rng = np.random.default_rng(B * 10 + hw[0] + cin + dil[0] * 3 + dil[1])
+    x = torch.from_numpy(rng.standard_normal((B, cin) + hw)).float()
+    w = torch.from_numpy(rng.standard_normal((cout, cin, 3, 3)) * (2.0 / (9 * cin)) ** 0.5).float()
+    sc = torch.from_numpy(rng.uniform(0.5, 1.5, cin)).float()
+    sh = torch.from_numpy(rng.standard_normal(cin) * 0.3).float()
+    xg = x.permute(0, 2, 3, 1).contiguous().cuda()
+    scg, shg = (sc.cuda(), sh.cuda()) if pro else (None, None)
+    packed, w_amax, npad = _pack(L, _lib, eng, w.cuda(), cout, cin, 9)
+    x_amax = _amax(L, _lib, [xg], cin, scg, shg, relu=pro)
+    g = eng.conv_geom('f', False, B, hw, cin, hw, cout, (3, 3), (1, 1), dil, dil, npad)
+    out = torch.full((B,) + hw + (cout,), float('nan'), device='cuda')
+    stats = torch.zeros(cout, 2, dtype=torch.float64, device='cuda')
+    op = ConvOperands()
+    op.in_, op.w0, op.out0, op.in_amax, op.w0_amax = xg.data_ptr(), packed.data_ptr(), out.data_ptr(), x_amax.data_ptr(), w_amax.data_ptr()
+    op.stats0 = stats.data_ptr()
+    if pro:
+        op.in_scale, op.in_shift = scg.data_ptr(), shg.data_ptr()
+    _lib.check(L.mpose_conv_fwd(ctypes.byref(g), (ConvOperands * 1)(op), 1, F16X3, _lib.stream_ptr()), 'conv')
+    torch.cuda.synchronize()
+
+    def fn(a, b):
+        if pro:
+            a = F.relu(a * sc.to(a.dtype).view(1, -1, 1, 1) + sh.to(a.dtype).view(1, -1, 1, 1))
+        return F.conv2d(a, b, padding=dil, dilation=dil)
+    ref = fn(x.double(), w.double())
+    _check(*_errs(out, ref, fn(x, w)))
+    want = torch.stack([ref.sum((0, 2, 3)), (ref * ref).sum((0, 2, 3))], 1)
+    assert float((stats.cpu() - want).abs().max() / want.abs().max()) < 1e-5
+    # data gradient: accumulates into a tensor that already holds something
+    go = torch.from_numpy(rng.standard_normal((B, cout) + hw)).float()
+    gg = go.permute(0, 2, 3, 1).contiguous().cuda()
+    npad_d = (cin + 63) // 64 * 64
+    pd = torch.zeros(9 * cout * npad_d * 3 // 2, dtype=torch.float32, device='cuda')
+    jobs = np.zeros(1, dtype=eng.PACK_DT)
+    j = jobs[0]
+    wg = w.cuda()
+    j['src'], j['dst'], j['amax'], j['N'], j['K'], j['T'], j['Npad'], j['Kpad'], j['layout'] = wg.data_ptr(), pd.data_ptr(), w_amax.data_ptr(), cin, cout, 9, npad_d, cout, 2
+    j['sn'], j['sk'], j['st'] = 9, cin * 9, 1
+    _lib.check(L.mpose_pack_weights(_lib.ptr(eng._jobs_to_device(jobs, 'cuda')), 1, 9 * cout * npad_d, _lib.stream_ptr()), 'pack')
+    gd = eng.conv_geom('d', False, B, hw, cin, hw, cout, (3, 3), (1, 1), dil, dil, npad_d)
+    base = torch.from_numpy(rng.standard_normal((B,) + hw + (cin,))).float().cuda()
+    dx = base.clone()
+    g_amax = _amax(L, _lib, [gg], cout)
+    od = ConvOperands()
+    od.in_, od.w0, od.out0, od.in_amax, od.w0_amax = gg.data_ptr(), pd.data_ptr(), dx.data_ptr(), g_amax.data_ptr(), w_amax.data_ptr()
+    _lib.check(L.mpose_conv_fwd(ctypes.byref(gd), (ConvOperands * 1)(od), 1, F16X3 | 1, _lib.stream_ptr()), 'dgrad')
+    torch.cuda.synchronize()
+
+    def dgrad(dtype):
+        a = x.to(dtype).requires_grad_(True)
+        F.conv2d(a, w.to(dtype), padding=dil, dilation=dil).backward(go.to(dtype))
+        return a.grad
+    r64 = dgrad(torch.float64)
+    _check(*_errs(dx - base, r64, dgrad(torch.float32)))
