@@ -29,10 +29,18 @@ def rel_l2(a, b):
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
 
 
+_WEIGHTS = {}
+
+
 def weights(T, seed, x, axis_permutation=True):
-    """fp64 state dict with calibrated BN running statistics (see oracle.model_ref.calibrate_running_stats)."""
-    sd = W.make_state_dict(T, seed, torch.float64)
-    return R.calibrate_running_stats(sd, x.double(), T, axis_permutation)
+    """fp64 state dict with calibrated BN running statistics (see oracle.model_ref.calibrate_running_stats).  The calibration is
+    a train-mode fp64 forward on the CPU; a test asks for the same dict two or three times (model, fp64 oracle, fp32 oracle):
+    computed once per (T, seed, input), handed out as fresh copies."""
+    key = (T, seed, axis_permutation, tuple(x.shape), float(x.double().sum()))
+    if key not in _WEIGHTS:
+        _WEIGHTS.clear()           # (one entry: the tests of a file walk through their configurations one after the other)
+        _WEIGHTS[key] = R.calibrate_running_stats(W.make_state_dict(T, seed, torch.float64), x.double(), T, axis_permutation)
+    return OrderedDict((k, v.clone()) for k, v in _WEIGHTS[key].items())
 
 
 def build(T, seed, x, axis_permutation=True):
