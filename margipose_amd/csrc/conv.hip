@@ -29,7 +29,7 @@
 #define MFMA_SPREAD 1      // 0: round 2's rm-major MFMA chains (A/B builds)
 #endif
 #ifndef CV_EXP
-#define CV_EXP 0      // timing experiments (tools/igemm_exp.sh; wrong results): 1 no epilogue, 2 no K loop, 4 no split-K exchange,
+#define CV_EXP 0      // timing experiments (tools/igemm_exp.sh; wrong results): 32 no scale gathers, 1 no epilogue, 2 no K loop, 4 no split-K exchange,
                       // 8 every B fragment from one place (L1-resident weights), 16 every A row from one place
 #endif
 
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
   u32x4 afA[2][NPL], afB[2][NPL];        // A fragments [row block][plane] of k-group 0 / 1
   // F16: scale exponents of this launch's tensors (SGPRs).  Pass `set` multiplies input ka[set] with weights kw[set].
   int ka0 = 0, ka1 = 0, kw0 = 0, kw1 = 0;
-  if (F16) {
+  if (F16 && !(CV_EXP & 32)) {
     ka0 = f16_scale_exp(amax_gather(op.in_amax));
     ka1 = SUM2 ? f16_scale_exp(amax_gather(op.in1_amax)) : ka0;
     kw0 = f16_scale_exp(*op.w0_amax);
