@@ -1707,7 +1707,9 @@ extern "C" int mpose_conv_fwd(const mpose_conv_geom* geom_, const mpose_conv_ope
   if (cmax <= 32) return launch_conv_ks<1>(a, mode, cmax, n_groups, s);
   if (npad % 64) return MPOSE_EINVAL;
   // widest wave tile that divides the padded N: 128 channels (RN=4), 96 (RN=3) or 64 (RN=2)
-  if (cmax % 128 == 0) return launch_conv_ks<4>(a, mode, cmax, n_groups, s);
+  // (MPOSE_RN2=1, timing probe: 64-channel wave tiles where 128-channel ones would run -- half the MFMAs per staged tile)
+  static const bool rn2 = [] { const char* e = getenv("MPOSE_RN2"); return e && atoi(e) != 0; }();
+  if (cmax % 128 == 0 && !rn2) return launch_conv_ks<4>(a, mode, cmax, n_groups, s);
   if (cmax % 96 == 0 && npad % 96 == 0) return launch_conv_ks<3>(a, mode, cmax, n_groups, s);
   return launch_conv_ks<2>(a, mode, cmax, n_groups, s);
 }
