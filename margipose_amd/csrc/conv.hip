@@ -175,21 +175,33 @@ __device__ __forceinline__ f32x16 mfma_f16(const u32x4 a, const u32x4 b, const f
 // the K loop -- half the matrix work, two thirds of the LDS and L2 fragment traffic, 4 instead of 5.5 VALU per element.
 // ROWG (stride-1 3x3 first passes, three-product form): the operand split -- all of the loop's VALU work -- runs once per
 // (channel chunk, kernel ROW) instead of once per tap: see the row-group K loop below.
+// SLIM (single-pass row-group launches with 64-channel wave tiles, three-product form): TWO workgroups per CU.  A 64-channel
+// wave tile needs <= 256 registers, and a row-group tile of 68 rows (66 are read) with ONE block of zero rows per wave instead of
+// one per plane and buffer brings the workgroup to 79 KB of LDS: the second workgroup's waves issue their MFMAs into the gaps
+// the first one's leave (prologue, exchange, epilogue, every s_waitcnt) -- see slim_tile().
+template <int RN, int MODE, int NPL, bool ROWG>
+constexpr bool slim_tile() { return ROWG && MODE == 0 && RN == 2 && NPL == 2; }
+constexpr int RG_SLIM_ROWS = 68;
+
 template <int RN, int MODE, int KS, bool PRO, int NPL, bool ROWG>
-__global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
+__global__ __launch_bounds__(256, (slim_tile<RN, MODE, NPL, ROWG>() ? 2 : 1)) void conv_igemm_k(ConvArgs a) {
   constexpr bool ACC1 = MODE == 1, SUM2 = MODE == 2;
   constexpr bool F16 = NPL <= 2;          // NPL == 1: the h planes only (MPOSE_CONV_F16X1: operands rounded to fp16, one product)
   constexpr int NPM = F16 ? 2 : 3;        // planes of the packed weights in memory
-  constexpr int TILE_B = ROWG ? RG_TILE_B : A_TILE_B;      // LDS bytes reserved per staging buffer
+  constexpr bool SLIM = slim_tile<RN, MODE, NPL, ROWG>();
+  constexpr int RG_PL = (SLIM ? RG_SLIM_ROWS : RG_ROWS) * A_ROW_B;     // bytes of one plane of a row-group tile
+  constexpr int RG_TL = 2 * RG_PL;
+  constexpr int TILE_B = ROWG ? RG_TL : A_TILE_B;          // LDS bytes reserved per staging buffer
+  constexpr int WAVE_B = 2 * TILE_B + (SLIM ? 16 * A_ROW_B : 0);      // a wave's two buffers (+ its zero rows)
   static_assert(!ROWG || F16, "row-group tiles hold two planes");
   constexpr int NPASS = MODE ? 2 : 1;
   constexpr int BM = 256 / KS;
   constexpr int BN = 32 * RN;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  unsigned char* sA_all = smem_raw;                                               // [4 waves][2][TILE_B]
-  float* sRed = reinterpret_cast<float*>(smem_raw + 4 * 2 * TILE_B);              // [2 sets][4 waves][BN][2]
-  unsigned* sRow = reinterpret_cast<unsigned*>(smem_raw + 4 * 2 * TILE_B + 2 * 4 * BN * 2 * 4);   // [4 waves][64] output row offsets
-  float* sMM = reinterpret_cast<float*>(smem_raw + 4 * 2 * TILE_B + 2 * 4 * BN * 2 * 4 + 4 * 64 * 4);   // [4 waves][BN][2] channel extremes of out0
+  unsigned char* sA_all = smem_raw;                                               // [4 waves][WAVE_B]
+  float* sRed = reinterpret_cast<float*>(smem_raw + 4 * WAVE_B);                  // [2 sets][4 waves][BN][2]
+  unsigned* sRow = reinterpret_cast<unsigned*>(smem_raw + 4 * WAVE_B + 2 * 4 * BN * 2 * 4);   // [4 waves][64] output row offsets
+  float* sMM = reinterpret_cast<float*>(smem_raw + 4 * WAVE_B + 2 * 4 * BN * 2 * 4 + 4 * 64 * 4);   // [4 waves][BN][2] channel extremes of out0
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lh = lane >> 5;
@@ -206,7 +218,7 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
   const int lane_tap = (int)(threadIdx.x & 63) < MPOSE_MAX_TAPS
       ? *reinterpret_cast<const int*>(&g.cls[cls].taps[(threadIdx.x & 63) < MPOSE_MAX_TAPS ? (threadIdx.x & 63) : 0]) : 0;
   auto tap_word = [&](int t) { return __builtin_amdgcn_readlane(lane_tap, t); };
-  unsigned char* sA = sA_all + wave * 2 * TILE_B;
+  unsigned char* sA = sA_all + wave * WAVE_B;
   // swizzled chunk offsets inside a 64-byte row (see A_ROW_B): staging writes 8 bytes of chunk (lane & 7) >> 1, fragment reads
   // take chunk 2 s + (lane >> 5) of row (lane & 31)
   const int st_off_even = ((((lane & 7) >> 1) ^ (lane >> 5)) << 4) + ((lane & 1) << 3);
@@ -512,7 +524,7 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
             v.x = fmaxf(fmaf(v.x, sc.x, sh.x), 0.f); v.y = fmaxf(fmaf(v.y, sc.y, sh.y), 0.f);
             v.z = fmaxf(fmaf(v.z, sc.z, sh.z), 0.f); v.w = fmaxf(fmaf(v.w, sc.w, sh.w), 0.f);
           }
-          unsigned char* dA = sG + buf * RG_TILE_B + ((lane >> 3) + 8 * j) * A_ROW_B + ((j & 1) ? st_off_odd : st_off_even);
+          unsigned char* dA = sG + buf * RG_TL + ((lane >> 3) + 8 * j) * A_ROW_B + ((j & 1) ? st_off_odd : st_off_even);
           if (j < 8 || (lane >> 3) < 2) {                        // the last piece is rows 64, 65 only
             if constexpr (NPL == 1) {
               if (!pro) { v.x *= a_mul; v.y *= a_mul; v.z *= a_mul; v.w *= a_mul; }
@@ -526,35 +538,45 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
               split2h(v.x, v.y, h.x, l.x);
               split2h(v.z, v.w, h.y, l.y);
               *reinterpret_cast<uint2*>(dA) = h;
-              *reinterpret_cast<uint2*>(dA + RG_PLANE_B) = l;
+              *reinterpret_cast<uint2*>(dA + RG_PL) = l;
             } else {
               uint2 h, m, l;
               split4(v, h, m, l);
               *reinterpret_cast<uint2*>(dA) = h;
-              *reinterpret_cast<uint2*>(dA + RG_PLANE_B) = m;
-              *reinterpret_cast<uint2*>(dA + 2 * RG_PLANE_B) = l;
+              *reinterpret_cast<uint2*>(dA + RG_PL) = m;
+              *reinterpret_cast<uint2*>(dA + 2 * RG_PL) = l;
             }
           }
         };
         // LDS offsets of this lane's fragment rows for tap t, and the chunk swizzle of those rows (rows li+1+dx and
         // li+33+dx swizzle alike; the zero row holds zeros in every chunk)
-        auto frag_addr = [&](int buf, int t, unsigned (&fa)[2], int& fsw) {
+        // (fa[rm]: plane 0; fa[2 + rm]: plane 1 -- SLIM keeps one block of zero rows per wave, behind its two buffers, so the
+        //  plane offset of an out-of-image lane is 0 there and cannot be an immediate of the read)
+        auto frag_addr = [&](int buf, int t, unsigned (&fa)[4], int& fsw) {
           const int dx = (int)(signed char)((tap_word(t) >> 8) & 0xff);
           fsw = ((li + 1 + dx) >> 2) & 3;
 #pragma unroll
           for (int rm = 0; rm < 2; ++rm) {
             const bool ok = (fr_taps[rm] >> t) & 1u;
             const int row = li + rm * 32 + 1 + dx;
-            fa[rm] = (unsigned)((ok ? row : RG_ZERO_ROW + (row & 15)) * A_ROW_B) + (unsigned)(buf * RG_TILE_B);
+            if constexpr (SLIM) {
+              fa[rm] = ok ? (unsigned)(row * A_ROW_B + buf * RG_TL) : (unsigned)(2 * RG_TL + (row & 15) * A_ROW_B);
+              fa[2 + rm] = ok ? fa[rm] + (unsigned)RG_PL : fa[rm];
+            } else {
+              fa[rm] = (unsigned)((ok ? row : RG_ZERO_ROW + (row & 15)) * A_ROW_B) + (unsigned)(buf * RG_TL);
+              fa[2 + rm] = fa[rm];
+            }
           }
         };
-        auto read_frags_g = [&](int s_, const unsigned (&fa)[2], int fsw, u32x4 (&af)[2][NPL]) {
+        auto read_frags_g = [&](int s_, const unsigned (&fa)[4], int fsw, u32x4 (&af)[2][NPL]) {
           const unsigned chunk = (unsigned)(((s_ * 2 + lh) ^ fsw) << 4);
 #pragma unroll
           for (int rm = 0; rm < 2; ++rm)
 #pragma unroll
-            for (int pl = 0; pl < NPL; ++pl)
-              af[rm][pl] = *reinterpret_cast<const u32x4*>(sG + fa[rm] + chunk + pl * RG_PLANE_B);
+            for (int pl = 0; pl < NPL; ++pl) {
+              if constexpr (SLIM) af[rm][pl] = *reinterpret_cast<const u32x4*>(sG + fa[pl ? 2 + rm : rm] + chunk);
+              else af[rm][pl] = *reinterpret_cast<const u32x4*>(sG + fa[rm] + chunk + pl * RG_PL);
+            }
         };
         const int n_grp = n_chunks * 3;
         const int g_begin = (KS == 1) ? 0 : (n_grp * kh) / KS;
@@ -580,11 +602,15 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
             for (int j = 0; j < 9; ++j) load_piece(gc, j);
             load_scale_c(gn.c, sc_n, sh_n);
             // while those loads fly: the zero rows and the per-lane tap masks
+            if constexpr (SLIM) {
+              *reinterpret_cast<u32x4*>(sG + 2 * RG_TL + lane * 16) = u32x4{0u, 0u, 0u, 0u};
+            } else {
 #pragma unroll
-            for (int buf = 0; buf < 2; ++buf)
+              for (int buf = 0; buf < 2; ++buf)
 #pragma unroll
-              for (int pl = 0; pl < NPL; ++pl)       // 16 rows x 64 bytes = 64 lanes x 16 bytes
-                *reinterpret_cast<u32x4*>(sG + buf * RG_TILE_B + pl * RG_PLANE_B + RG_ZERO_ROW * A_ROW_B + lane * 16) = u32x4{0u, 0u, 0u, 0u};
+                for (int pl = 0; pl < NPL; ++pl)       // 16 rows x 64 bytes = 64 lanes x 16 bytes
+                  *reinterpret_cast<u32x4*>(sG + buf * RG_TL + pl * RG_PL + RG_ZERO_ROW * A_ROW_B + lane * 16) = u32x4{0u, 0u, 0u, 0u};
+            }
 #pragma unroll
             for (int rm = 0; rm < 2; ++rm) {
               const unsigned m = (unsigned)(m0 + rm * 32 + li);
@@ -604,7 +630,7 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
             for (int j = 0; j < 9; ++j) { stage_piece(0, j, sc0, sh0); load_piece(gn, j); }
           }
           __builtin_amdgcn_wave_barrier();
-          unsigned fa[2];
+          unsigned fa[4];
           int fsw;
           frag_addr(0, gc.t, fa, fsw);
           read_frags_g(0, fa, fsw, afA);
@@ -732,7 +758,7 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
     if (KS > 1 && !(CV_EXP & 4)) {
       constexpr int BLK = 16 * 64;                       // floats of one accumulator block
       constexpr int STRIDE = (KS == 2 ? RN : 2 * RN - RN / 2) * BLK;    // most blocks a wave can have to park
-      static_assert(4 * STRIDE * 4 <= 4 * 2 * TILE_B, "exchange area must fit in the A-tile region");
+      static_assert(4 * STRIDE * 4 <= 4 * WAVE_B, "exchange area must fit in the A-tile region");
       __syncthreads();                                   // every wave is done with its A tiles
       float* ex_all = reinterpret_cast<float*>(sA_all);  // [wave][parked blocks, in (rm, rn) order][16][64]
       auto owned_by = [&](int k, int rm, int rn) {       // ownership rule for the wave with K part k
@@ -1026,7 +1052,10 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_k(ConvArgs a) {
 template <int RN, int MODE, int KS, bool PRO, int NPL, bool ROWG>
 int launch_conv(const ConvArgs& a0, int n_groups, hipStream_t s) {
   constexpr int BN = 32 * RN;
-  constexpr int lds = 4 * 2 * (ROWG ? RG_TILE_B : A_TILE_B) + 2 * 4 * BN * 2 * 4 + 4 * 64 * 4 + 4 * BN * 2 * 4;
+  constexpr bool SLIM = slim_tile<RN, MODE, NPL, ROWG>();
+  constexpr int wave_b = SLIM ? 2 * 2 * RG_SLIM_ROWS * A_ROW_B + 16 * A_ROW_B : 2 * (ROWG ? RG_TILE_B : A_TILE_B);
+  constexpr int lds = 4 * wave_b + 2 * 4 * BN * 2 * 4 + 4 * 64 * 4 + 4 * BN * 2 * 4;
+  static_assert(!SLIM || 2 * lds <= 160 * 1024, "two workgroups per CU");
   static bool attr_set = false;          // > 64 KiB of dynamic LDS has to be requested once per kernel
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_k<RN, MODE, KS, PRO, NPL, ROWG>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
@@ -1050,16 +1079,22 @@ int launch_conv(const ConvArgs& a0, int n_groups, hipStream_t s) {
 // one: the summation order of a sample then does not depend on how many other samples share its launch, so a
 // data-parallel shard reproduces the full batch's per-sample results bit for bit in the six-product form (MPOSE_F16X3=0); in the
 // default three-product form a tensor's scale follows the largest magnitude in the LOCAL batch, so shards agree to fp32 rounding.
-template <int RN, int NPL, bool ROWG>
+template <int RN, int NPL, bool ROWG, int MODE>
 inline int pick_ks(const ConvArgs& a, int cmax, int n_groups) {
   const int n_iter = (a.g.Cin / KC) * a.g.cls[0].n_taps;
   const long m_nominal = 32l * a.g.GH * a.g.GW;
   int best = 1;
   double best_cost = 0.0;
+  // (two workgroups per CU: 512 slots per round; and the split that bounds the accumulation chain of a training launch -- an
+  //  unsplit 128-channel 3x3 is ONE chain of 216 -- is kept whatever the model says: max error 8.8e-7 vs 5.4e-7 of the fp64 result
+  //  where torch's fp32 convolution shows 2.8e-7)
+  constexpr bool SLIM = slim_tile<RN, MODE, NPL, ROWG>();
+  static const bool unsplit_ok = [] { const char* e = getenv("MPOSE_SLIM"); return e && atoi(e) == 2; }();
+  const bool chain_bound = SLIM && a.op[0].epi_scale0 == nullptr && !unsplit_ok;
   for (int ks = 1; ks <= (RN > 1 ? 4 : 2); ks *= 2) {
     if (ks > 1 && n_iter < 2 * ks) break;
     const long wgs = ((m_nominal + 256 / ks - 1) / (256 / ks)) * a.g.n_classes * ((cmax + 32 * RN - 1) / (32 * RN)) * n_groups;
-    const long rounds = (wgs + 255) / 256;
+    const long rounds = SLIM ? (wgs + 511) / 512 : (wgs + 255) / 256;
     const double exchange = ks == 1 ? 0.0 : (ks == 2 ? 1.5 : 2.5);
     // (three instead of six products per k-group.  With row-group staging a tap costs ~0.3 us per 32 output channels -- the
     //  192-channel layers: 2.7 us per row group of three taps at RN = 3 -- and the 128-channel launch measured FASTER with 384
@@ -1072,7 +1107,7 @@ inline int pick_ks(const ConvArgs& a, int cmax, int n_groups) {
     const double per_iter = fast ? 0.05 + 0.29 * RN : (NPL <= 2 ? 0.55 + 0.27 * RN : 0.65 + 0.49 * RN);
     const double fixed = fast ? 18.0 : 9.5;
     const double cost = (double)rounds * (fixed + exchange + (double)((n_iter + ks - 1) / ks) * per_iter);
-    if (ks == 1 || cost < 0.97 * best_cost) { best = ks; best_cost = cost; }     // ties go to the smaller split
+    if (ks == 1 || cost < 0.97 * best_cost || (chain_bound && best == 1)) { best = ks; best_cost = cost; }     // ties go to the smaller split
   }
   return best;
 }
@@ -1097,7 +1132,7 @@ inline bool rowg_eligible(const mpose_conv_geom& g) {
 
 template <int RN, int MODE, bool PRO, int NPL, bool ROWG>
 int launch_conv_kp(const ConvArgs& a, int cmax, int n_groups, hipStream_t s) {
-  const int ks = pick_ks<RN, NPL, ROWG>(a, cmax, n_groups);
+  const int ks = pick_ks<RN, NPL, ROWG, MODE>(a, cmax, n_groups);
   if constexpr (RN > 1) {                  // (32-wide tiles never profit from a 4-way split)
     if (ks == 4) return launch_conv<RN, MODE, 4, PRO, NPL, ROWG>(a, n_groups, s);
   }
@@ -1707,9 +1742,17 @@ extern "C" int mpose_conv_fwd(const mpose_conv_geom* geom_, const mpose_conv_ope
   if (cmax <= 32) return launch_conv_ks<1>(a, mode, cmax, n_groups, s);
   if (npad % 64) return MPOSE_EINVAL;
   // widest wave tile that divides the padded N: 128 channels (RN=4), 96 (RN=3) or 64 (RN=2)
-  // (MPOSE_RN2=1, timing probe: 64-channel wave tiles where 128-channel ones would run -- half the MFMAs per staged tile)
-  static const bool rn2 = [] { const char* e = getenv("MPOSE_RN2"); return e && atoi(e) != 0; }();
-  if (cmax % 128 == 0 && !rn2) return launch_conv_ks<4>(a, mode, cmax, n_groups, s);
+  // Single-pass row-group launches in the three-product form with the FUSED OUTPUT STAGE (inference: the second 3x3 of a block)
+  // run with 64-channel wave tiles, two workgroups per CU (slim_tile() above), where the widest tile would be 128 channels.
+  // Measured on the 128 -> 128 launches at 32 x 32, B = 32: unsplit (one chain of 216 accumulations per output) 112 -> 97 us
+  // forward, 114 -> 91 us data-gradient; with the two-way K split that training keeps for its accumulation chains (pick_ks) the
+  // gain is gone (114-120 -> 122, 113 -> 111 us), and at 192 channels the 96-channel tiles are faster (58 vs 65 us).  So:
+  // inference launches only.  MPOSE_SLIM=0: never; 2: every eligible launch (timing runs; training then runs unsplit chains).
+  static const int slim = [] { const char* e = getenv("MPOSE_SLIM"); return e ? atoi(e) : 1; }();
+  if (slim && (slim == 2 || a.op[0].epi_scale0 != nullptr) && mode == 0 && (flags & MPOSE_CONV_F16X3) && !(flags & MPOSE_CONV_F16X1) &&
+      (cmax % 128) == 0 && rowg_env() && rowg_eligible(a.g))
+    return launch_conv_ks<2>(a, mode, cmax, n_groups, s);
+  if (cmax % 128 == 0) return launch_conv_ks<4>(a, mode, cmax, n_groups, s);
   if (cmax % 96 == 0 && npad % 96 == 0) return launch_conv_ks<3>(a, mode, cmax, n_groups, s);
   return launch_conv_ks<2>(a, mode, cmax, n_groups, s);
 }
