@@ -180,7 +180,7 @@ __device__ __forceinline__ f32x16 mfma_f16(const u32x4 a, const u32x4 b, const f
 // one per plane and buffer brings the workgroup to 79 KB of LDS: the second workgroup's waves issue their MFMAs into the gaps
 // the first one's leave (prologue, exchange, epilogue, every s_waitcnt) -- see slim_tile().
 template <int RN, int MODE, int NPL, bool ROWG>
-constexpr bool slim_tile() { return ROWG && MODE == 0 && RN == 2 && NPL == 2; }
+constexpr bool slim_tile() { return ROWG && MODE == 0 && RN == 2 && NPL <= 2; }
 constexpr int RG_SLIM_ROWS = 68;
 
 template <int RN, int MODE, int KS, bool PRO, int NPL, bool ROWG>
@@ -1090,7 +1090,7 @@ inline int pick_ks(const ConvArgs& a, int cmax, int n_groups) {
   //  where torch's fp32 convolution shows 2.8e-7)
   constexpr bool SLIM = slim_tile<RN, MODE, NPL, ROWG>();
   static const bool unsplit_ok = [] { const char* e = getenv("MPOSE_SLIM"); return e && atoi(e) == 2; }();
-  const bool chain_bound = SLIM && a.op[0].epi_scale0 == nullptr && !unsplit_ok;
+  const bool chain_bound = SLIM && NPL == 2 && a.op[0].epi_scale0 == nullptr && !unsplit_ok;      // (one product: a chain of 72)
   for (int ks = 1; ks <= (RN > 1 ? 4 : 2); ks *= 2) {
     if (ks > 1 && n_iter < 2 * ks) break;
     const long wgs = ((m_nominal + 256 / ks - 1) / (256 / ks)) * a.g.n_classes * ((cmax + 32 * RN - 1) / (32 * RN)) * n_groups;
@@ -1749,7 +1749,8 @@ extern "C" int mpose_conv_fwd(const mpose_conv_geom* geom_, const mpose_conv_ope
   // gain is gone (114-120 -> 122, 113 -> 111 us), and at 192 channels the 96-channel tiles are faster (58 vs 65 us).  So:
   // inference launches only.  MPOSE_SLIM=0: never; 2: every eligible launch (timing runs; training then runs unsplit chains).
   static const int slim = [] { const char* e = getenv("MPOSE_SLIM"); return e ? atoi(e) : 1; }();
-  if (slim && (slim == 2 || a.op[0].epi_scale0 != nullptr) && mode == 0 && (flags & MPOSE_CONV_F16X3) && !(flags & MPOSE_CONV_F16X1) &&
+  // (the single-product mode MPOSE_CONV_F16X1 accumulates a third as often: unsplit everywhere, training included)
+  if (slim && (slim == 2 || a.op[0].epi_scale0 != nullptr || (flags & MPOSE_CONV_F16X1)) && mode == 0 && (flags & MPOSE_CONV_F16X3) &&
       (cmax % 128) == 0 && rowg_env() && rowg_eligible(a.g))
     return launch_conv_ks<2>(a, mode, cmax, n_groups, s);
   if (cmax % 128 == 0) return launch_conv_ks<4>(a, mode, cmax, n_groups, s);
