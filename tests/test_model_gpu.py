@@ -747,3 +747,36 @@ def test_bf16_convolution_mode():
     cos = min(float((a * b).sum() / (a.norm() * b.norm() + 1e-30)) for a, b in big)
     assert cos > 0.95, cos
     assert abs(l32b - l32) <= 1e-5 * abs(l32)                 # and switching back restores the fp32 path
+
+
+@pytest.mark.parametrize('stem', ['patch8', 'inceptionv4'])
+def test_step_switches_leave_the_results_bit_identical(stem):
+    """Two scheduling switches of the engine that change WHO does a piece of work, not its arithmetic: the BatchNorm
+    finalisation run by the producing convolution launch's last workgroup (mpose_conv_operands.fin*; MPOSE_FUSE_FINALIZE) and the
+    split-K partials summed right behind each weight-gradient launch (MPOSE_INLINE_UNPACK).  Loss, every gradient, and the
+    running statistics must equal the default schedule's bit for bit."""
+    import copy
+    from margipose_amd import dsntnn
+    from margipose_amd.models import CanonicalSkeletonDesc, MargiPoseModel
+    T, B, seed = 1, 2, 470
+    x, target, mask = W.seeded_inputs(seed + 1000, B)
+    if stem == 'patch8':
+        m0 = build(T, seed, x).train()
+    else:
+        torch.manual_seed(seed)
+        m0 = MargiPoseModel(CanonicalSkeletonDesc, T, True, stem, 'jsd').cuda().train()
+    m1 = copy.deepcopy(m0)
+    eng = m1.inner.engine()
+    eng.fuse_finalize = True
+    eng.inline_unpack = True
+    res = []
+    for m in (m0, m1):
+        out = m(x.cuda())
+        loss = dsntnn.average_loss(m.forward_3d_losses(out, target.cuda()), mask.cuda())
+        loss.backward()
+        res.append((out.detach().clone(), float(loss.detach())))
+    assert res[0][1] == res[1][1] and torch.equal(res[0][0], res[1][0])
+    for (k, a), (_, b) in zip(m0.named_parameters(), m1.named_parameters()):
+        assert torch.equal(a.grad, b.grad), k
+    for (k, a), (_, b) in zip(m0.state_dict().items(), m1.state_dict().items()):
+        assert torch.equal(a, b), k
