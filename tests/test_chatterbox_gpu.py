@@ -169,3 +169,31 @@ def test_chatterbox_training_harness_eager_and_graphed():
     assert losses_e == losses_g, (losses_e, losses_g)
     for (k, a), (_, b) in zip(m_e.state_dict().items(), m_g.state_dict().items()):
         assert torch.equal(a, b), k
+
+
+def test_chatterbox_uint8_frames_are_normalised_on_device():
+    """uint8 RGB frames in -> same result as `ImageSpecs.convert` (to_tensor + (x - mean) / std, reference data_specs.py:6-13,
+    38-39) followed by the float path: the normalisation is fused into the first layer's patch gather."""
+    x, target, mask = W.seeded_inputs(9501, 1)
+    m = build(calibrated_state(950, x)).eval()
+    frames = torch.randint(0, 256, (2, 3, 256, 256), dtype=torch.uint8, generator=torch.Generator().manual_seed(5))
+    mean = torch.tensor(m.data_specs.input_specs.mean).view(1, 3, 1, 1)
+    std = torch.tensor(m.data_specs.input_specs.stddev).view(1, 3, 1, 1)
+    with torch.no_grad():
+        a = m(frames.cuda())
+        b = m(((frames.float() / 255.0 - mean) / std).cuda())
+    # ((x/255 - mean)/std on the host vs the kernel's fused form differ by an ulp per input pixel; ~45 convolutions of random weights
+    #  carry that to ~1e-4 of the coordinates -- the same conditioning the oracle comparisons above show)
+    assert rel(a.cpu(), b.cpu()) < 5e-4
+
+
+def test_chatterbox_data_parallel_two_ranks_share_one_gpu():
+    """tools/dp_check_chatterbox.py under torch.distributed.run: 2 ranks on cuda:0 over gloo; averaged gradients == mean of the
+    shards' gradients; one gradient bucket; broadcast of parameters and buffers."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MPOSE_DIST_BACKEND='gloo', MPOSE_SINGLE_DEVICE='1')
+    out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+                          '127.0.0.1', '--master-port', str(29900 + os.getpid() % 90), os.path.join(root, 'tools', 'dp_check_chatterbox.py')],
+                         env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900).stdout.decode(errors='replace')
+    assert 'DP_CHECK_OK' in out, out[-3000:]
