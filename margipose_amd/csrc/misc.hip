@@ -127,16 +127,20 @@ __global__ __launch_bounds__(256) void combiner_fwd_k(CombArgs a) {
 
 constexpr int G_STRIDE = CC + 4;
 constexpr int QH_MAX = 32;    // per-thread dW accumulators (Q <= 64)
+#ifndef COMB_EXP
+#define COMB_EXP 0             // timing experiments: 1 no d_hm loop, 2 no dW loop, 4 no tile loads
+#endif
 
 __global__ __launch_bounds__(256) void combiner_bwd_k(CombArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* sW = sm;                                // [Q][CC]
-  float* sH = sm + a.Q * CC;                     // [Q][CT]
-  float* sG = sH + a.Q * CT;                     // [CT][G_STRIDE]
+  float* sH = sm + a.Q * CC;                     // [2 * QH_MAX][CT]: rows >= Q stay zero (the dW loop below reads them unconditionally)
+  float* sG = sH + 2 * QH_MAX * CT;              // [CT][G_STRIDE]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   for (int i = tid; i < a.Q * CC; i += 256) { const int q = i / CC, c = i - q * CC; sW[i] = a.w[c * a.Q + q]; }
   const int tiles_per_img = a.HW / CT;
   const int n_tiles = a.B * tiles_per_img;
+  for (int i = a.Q * CT + tid; i < 2 * QH_MAX * CT; i += 256) sH[i] = 0.f;
   const int qh = (a.Q + 1) / 2;
   const int dwc = tid & 127, dwq0 = (tid >> 7) * qh;
   float dwacc[QH_MAX];
@@ -146,36 +150,58 @@ __global__ __launch_bounds__(256) void combiner_bwd_k(CombArgs a) {
   for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int b = tile / tiles_per_img, p0 = (tile - b * tiles_per_img) * CT;
     __syncthreads();
+    if (!(COMB_EXP & 4))
     for (int i = tid; i < a.Q * CT; i += 256) {
       const int q = i / CT, px = i - q * CT;
       const int pl = q / a.J, j = q - pl * a.J;
       const long ho = ((long)b * a.J + j) * a.HW + p0 + px;
     sH[i] = a.hm_bf16 ? __uint_as_float((unsigned)reinterpret_cast<const unsigned short*>(a.hm[pl])[ho] << 16) : a.hm[pl][ho];
     }
+    if (!(COMB_EXP & 4))
     for (int i = tid; i < CT * (CC / 4); i += 256) {
       const int px = i / (CC / 4), c4 = i - px * (CC / 4);
       *reinterpret_cast<float4*>(sG + px * G_STRIDE + c4 * 4) =
           *reinterpret_cast<const float4*>(a.g + ((long)b * a.HW + p0 + px) * CC + c4 * 4);
     }
     __syncthreads();
-    // d_hm[q][px] = sum_c W[c][q] * g[px][c]; wave w handles q = w, w+4, ...; lane = pixel
-    for (int q = wave; q < a.Q; q += 4) {
-      float s = 0.f;
-#pragma unroll 8
+    // d_hm[q][px] = sum_c W[c][q] * g[px][c]; wave w handles q = w, w+4, ...; lane = pixel.  All of the wave's (<= 16) q at once:
+    // one read of the lane's g per channel quad instead of one per (q, quad), and 16 independent accumulation chains instead
+    // of one (the q-outer form took 195 us for 0.86 GFLOP: each output was a chain of 128 dependent fused multiply-adds).
+    if (!(COMB_EXP & 1)) {
+      float sq[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) sq[e] = 0.f;
+#pragma unroll 2
       for (int c4 = 0; c4 < CC / 4; ++c4) {
         const float4 gv = *reinterpret_cast<const float4*>(sG + lane * G_STRIDE + c4 * 4);
-        const float4 wv = *reinterpret_cast<const float4*>(sW + q * CC + c4 * 4);
-        s = fmaf(gv.x, wv.x, s); s = fmaf(gv.y, wv.y, s); s = fmaf(gv.z, wv.z, s); s = fmaf(gv.w, wv.w, s);
-      }
-      const int pl = q / a.J, j = q - pl * a.J;
-      a.d_hm[pl][((long)b * a.J + j) * a.HW + p0 + lane] = s;
-    }
-    // dW[c][q] += sum_px g[px][c] * hm[q][px]
-    for (int px = 0; px < CT; ++px) {
-      const float gv = sG[px * G_STRIDE + dwc];
 #pragma unroll
-      for (int e = 0; e < QH_MAX; ++e)
-        if (e < qh && dwq0 + e < a.Q) dwacc[e] = fmaf(gv, sH[(dwq0 + e) * CT + px], dwacc[e]);
+        for (int e = 0; e < 16; ++e) {
+          const int q = wave + 4 * e;
+          if (q < a.Q) {                        // (wave-uniform)
+            const float4 wv = *reinterpret_cast<const float4*>(sW + q * CC + c4 * 4);
+            sq[e] = fmaf(gv.x, wv.x, sq[e]); sq[e] = fmaf(gv.y, wv.y, sq[e]); sq[e] = fmaf(gv.z, wv.z, sq[e]); sq[e] = fmaf(gv.w, wv.w, sq[e]);
+          }
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int q = wave + 4 * e;
+        if (q < a.Q) {
+          const int pl = q / a.J, j = q - pl * a.J;
+          a.d_hm[pl][((long)b * a.J + j) * a.HW + p0 + lane] = sq[e];
+        }
+      }
+    }
+    // dW[c][q] += sum_px g[px][c] * hm[q][px]: four pixels per step, every one of the thread's QH_MAX rows of hm (those past Q hold
+    // zeros: no conditions in the loop -- with them it took 115 us of the kernel's 177, ~80 cycles per multiply-add)
+    for (int px = 0; px < ((COMB_EXP & 2) ? 0 : CT); px += 4) {
+      const float g0 = sG[px * G_STRIDE + dwc], g1 = sG[(px + 1) * G_STRIDE + dwc];
+      const float g2 = sG[(px + 2) * G_STRIDE + dwc], g3 = sG[(px + 3) * G_STRIDE + dwc];
+#pragma unroll
+      for (int e = 0; e < QH_MAX; ++e) {
+        const float4 h = *reinterpret_cast<const float4*>(sH + (dwq0 + e) * CT + px);
+        dwacc[e] = fmaf(g3, h.w, fmaf(g2, h.z, fmaf(g1, h.y, fmaf(g0, h.x, dwacc[e]))));
+      }
     }
   }
 #pragma unroll
@@ -617,7 +643,7 @@ extern "C" int mpose_combiner_bwd(const float* const* hm, const float* w, const 
   CombArgs a{};
   for (int p = 0; p < 3; ++p) { a.hm[p] = hm[p]; a.d_hm[p] = d_hm[p]; }
   a.w = w; a.g = g; a.dw_partial = dw_partial; a.B = B; a.J = J; a.HW = HW; a.Q = 3 * J;
-  const int lds = (a.Q * CC + a.Q * CT + CT * G_STRIDE) * 4;
+  const int lds = (a.Q * CC + 2 * QH_MAX * CT + CT * G_STRIDE) * 4;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(combiner_bwd_k), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
