@@ -11,7 +11,10 @@ w = torch.randn(C, 3 * J, device='cuda')
 d = [torch.empty_like(h) for h in hm]
 n_part = int(os.environ.get("NPART", "256"))
 dwp = torch.empty(n_part * w.numel(), device='cuda')
+dw = torch.empty_like(w)
+import ctypes
 def run():
+    check(L.mpose_reduce_partials(ptr(dwp), ptr(dw), n_part, ctypes.c_int64(w.numel()), 0, stream_ptr()), 'red')
     check(L.mpose_combiner_bwd(ptr_array(hm), ptr(w), ptr(g), ptr_array(d), ptr(dwp), n_part, B, J, HW, C, stream_ptr()), 'comb')
 for _ in range(5): run()
 torch.cuda.synchronize()
@@ -19,4 +22,4 @@ e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=Tr
 e0.record()
 for _ in range(50): run()
 e1.record(); torch.cuda.synchronize()
-print('combiner_bwd %.1f us' % (1e3 * e0.elapsed_time(e1) / 50))
+print('combiner_bwd + reduce_partials %.1f us' % (1e3 * e0.elapsed_time(e1) / 50))
