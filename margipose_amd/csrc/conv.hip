@@ -1519,12 +1519,16 @@ __global__ __launch_bounds__(256) void pack_weights_k(const mpose_pack_job* __re
   __bf16* dst = reinterpret_cast<__bf16*>(j.dst);
   const long plane = (long)j.Npad * 16;
   const float w_mul = (j.layout == 2 && j.amax != nullptr) ? pow2f(f16_scale_exp(*j.amax)) : 1.f;
-  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
-    const int k_lo = (int)(e & 15);              // half * 8 + j
-    long r = e >> 4;
-    const int n = (int)(r % j.Npad); r /= j.Npad;
-    const int k16 = (int)(r % (j.Kpad / 16));
-    const int t = (int)(r / (j.Kpad / 16));
+  // (32-bit index arithmetic: a job is at most taps x Kpad x Npad < 2^31 elements (max_elems_per_job is an int), and the three
+  //  64-bit divisions per element this loop used to do were most of its instructions)
+  const unsigned k16n = (unsigned)j.Kpad / 16u, npad = (unsigned)j.Npad;
+  for (unsigned e = blockIdx.x * 256u + threadIdx.x; e < (unsigned)total; e += gridDim.x * 256u) {
+    const int k_lo = (int)(e & 15u);             // half * 8 + j
+    unsigned r = e >> 4;
+    const unsigned r1_ = r / npad;
+    const int n = (int)(r - r1_ * npad);
+    const int t = (int)(r1_ / k16n);
+    const int k16 = (int)(r1_ - (unsigned)t * k16n);
     const int k = k16 * 16 + k_lo;
     float v = 0.f;
     if (n < j.N && k < j.K) v = j.src[n * j.sn + k * j.sk + t * j.st];
