@@ -1751,7 +1751,7 @@ extern "C" int mpose_conv_fwd(const mpose_conv_geom* geom_, const mpose_conv_ope
   // Measured on the 128 -> 128 launches at 32 x 32, B = 32: unsplit (one chain of 216 accumulations per output) 112 -> 97 us
   // forward, 114 -> 91 us data-gradient; with the two-way K split that training keeps for its accumulation chains (pick_ks) the
   // gain is gone (114-120 -> 122, 113 -> 111 us), and at 192 channels the 96-channel tiles are faster (58 vs 65 us).  So:
-  // inference launches only.  MPOSE_SLIM=0: never; 2: every eligible launch (timing runs; training then runs unsplit chains).
+  // inference launches only.  MPOSE_SLIM=0: never; 2: every eligible launch, without the rule that keeps training's K split (timing runs).
   static const int slim = [] { const char* e = getenv("MPOSE_SLIM"); return e ? atoi(e) : 1; }();
   // (the single-product mode MPOSE_CONV_F16X1 accumulates a third as often: unsplit everywhere, training included)
   if (slim && (slim == 2 || a.op[0].epi_scale0 != nullptr || (flags & MPOSE_CONV_F16X1)) && mode == 0 && (flags & MPOSE_CONV_F16X3) &&
