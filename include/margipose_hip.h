@@ -214,6 +214,19 @@ typedef struct {
                                    * only -- operands ROUNDED to fp16 (11 significant bits) after the per-tensor power-of-two scale,
                                    * one MFMA product per multiply-add, fp32 accumulation.  The reduced-precision mode of BASELINE
                                    * configs[4] ("fp16 convs with MFMA"), NOT fp32-equivalent; BatchNorm, losses, soft-argmax stay fp32. */
+#define MPOSE_CONV_H2_IN 128      /* with MPOSE_CONV_F16X3 (same arithmetic, scales and amax operands): `in` / `in1` are PRODUCER-SPLIT
+                                   * activations -- the two fp16 planes (h, l) of x * 2^k, k = the scale exponent of the tensor's
+                                   * amax slot, in the blocked layout H8[Cin/8][plane 2][B*IH*IW][8] (4 bytes per element;
+                                   * mpose_split_h2 and the *_h2 outputs of the BatchNorm kernels write it) -- and `w0` / `w1` are
+                                   * packed with layout 3; in_scale must be NULL, in_ld 0.  Runs conv_h.hip's engine: both operands
+                                   * reach LDS by DMA, two workgroups per CU, no operand arithmetic in the K loop, two accumulators
+                                   * per output block (h x h products / cross products) instead of a split-K.  The slot of such a
+                                   * tensor holds a BOUND on its largest magnitude that its producer and every consumer read (never
+                                   * a measured maximum: the producer needs the scale before it writes).  A bound B >= amax costs
+                                   * no precision while B / amax < 2^12 or so: an element keeps 22 significant bits down to 2^-18
+                                   * of B and an absolute error of 2^-40 B below that.
+                                   * Epilogues: stats0 / stats1, mm0, mask_src, red_*, out0_amax (max |out0| as stored, also
+                                   * without the fused output stage); not: epi_*, add_*, out0_planes, fin*, MPOSE_CONV_ACCUMULATE. */
 #define MPOSE_CONV_SUM_INPUTS 2   /* taps with acc == 1 read `in1` through `w1` and add into out0 (one pass, one
                                    * output): the data-gradient of a ResidualBlock's input, dX = conv_in^T(dC1) +
                                    * shortcut^T(dSC), models/margipose_model.py:39 */
@@ -264,7 +277,8 @@ typedef struct {
   float* dst;                          /* packed 16-bit planes, at most 1.5 floats per element:
                                         *   layout 0: [T][Kpad/16][3 (hi,mid,lo)][Npad][2][8] bf16  (conv.hip: fragments from L2)
                                         *   layout 1: [T][Kpad/16][3][2 (k half)][Npad][8] bf16     (conv_p.hip: B tiles by DMA)
-                                        *   layout 2: [T][Kpad/16][2 (h,l)][Npad][2][8] fp16 of w * 2^k(*amax)   (MPOSE_CONV_F16X3) */
+                                        *   layout 2: [T][Kpad/16][2 (h,l)][Npad][2][8] fp16 of w * 2^k(*amax)   (MPOSE_CONV_F16X3)
+                                        *   layout 3: [T][Kpad/16][2 (h,l)][2 (k half)][Npad][8] fp16, same values  (MPOSE_CONV_H2_IN) */
   int N, K, T, Npad, Kpad;
   int64_t sn, sk, st;                  /* element strides of n, k, tap in src */
   int layout;
@@ -321,6 +335,19 @@ typedef struct {
 } mpose_split_operands;
 int64_t mpose_planes_bytes(int64_t npix, int C);
 int mpose_split_planes(const mpose_split_operands* ops, int n_groups, int64_t npix, int C, int relu, void* stream);
+
+/* Producer-split activations for MPOSE_CONV_H2_IN (csrc/split.hip): planes = the two fp16 pieces of
+ * [relu](scale * src + shift) * 2^k, k = f16 scale exponent of max over the sub-slots of `amax` (a BOUND the caller guarantees),
+ * layout H8[C/8][2][npix][8]; mpose_h2_bytes gives the buffer size (= the fp32 tensor's). */
+typedef struct {
+  const float* src;
+  const float* scale;
+  const float* shift;
+  void* planes;
+  const float* amax;
+} mpose_split_h2_operands;
+int64_t mpose_h2_bytes(int64_t npix, int C);
+int mpose_split_h2(const mpose_split_h2_operands* ops, int n_groups, int64_t npix, int C, int relu, void* stream);
 
 /* BatchNorm pieces (models/margipose_model.py:31,34,37; train = batch statistics, biased variance,
  * eps 1e-5; running update momentum 0.1 with unbiased variance). */

@@ -17,7 +17,7 @@ c_int = ctypes.c_int
 c_float = ctypes.c_float
 c_int64 = ctypes.c_int64
 
-ABI_VERSION = 12         # must equal mpose_abi_version() of the library (csrc/tail.hip)
+ABI_VERSION = 13         # must equal mpose_abi_version() of the library (csrc/tail.hip)
 MAX_GROUP = 3
 MAX_TAPS = 12
 MAX_CLASSES = 8
@@ -41,6 +41,8 @@ def lib():
         _LIB.mpose_planes_bytes.restype = c_int64
         _LIB.mpose_planes_bytes.argtypes = [c_int64, c_int]
         _LIB.mpose_bn_bwd_reduce_ws_bytes.restype = c_int64
+        _LIB.mpose_h2_bytes.restype = c_int64
+        _LIB.mpose_h2_bytes.argtypes = [c_int64, c_int]
     return _LIB
 
 
@@ -126,6 +128,10 @@ class BnAddOperands(ctypes.Structure):
 
 class SplitOperands(ctypes.Structure):
     _fields_ = [('src', c_void_p), ('scale', c_void_p), ('shift', c_void_p), ('planes', c_void_p)]
+
+
+class SplitH2Operands(ctypes.Structure):
+    _fields_ = [('src', c_void_p), ('scale', c_void_p), ('shift', c_void_p), ('planes', c_void_p), ('amax', c_void_p)]
 
 
 class BnBwdReduceOperands(ctypes.Structure):

@@ -37,8 +37,14 @@ def build(force=False, verbose=False):
         return LIB_PATH
     objs = []
     procs = []
+    # a source is recompiled when it, or any header, is newer than its object (conv.hip alone takes four minutes)
+    hdrs = glob.glob(os.path.join(CSRC, '*.h')) + glob.glob(os.path.join(PKG_DIR, '..', 'include', '*.h'))
+    t_hdr = max(os.path.getmtime(h) for h in hdrs)
     for src in sources():
         obj = os.path.splitext(src)[0] + '.o'
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), t_hdr):
+            objs.append(obj)
+            continue
         cmd = [_hipcc()] + HIPCC_FLAGS + ['-Rpass-analysis=kernel-resource-usage', '-c', src, '-o', obj]
         if verbose:
             print(' '.join(cmd))
@@ -53,7 +59,7 @@ def build(force=False, verbose=False):
         log.append('==== %s\n%s' % (os.path.basename(src), text))
         if verbose:
             print('\n'.join(l for l in text.splitlines() if 'remark:' not in l))
-    with open(LOG_PATH, 'w') as f:
+    with open(LOG_PATH, 'w' if len(procs) == len(objs) else 'a') as f:
         f.write('\n'.join(log))
     cmd = [_hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB_PATH] + objs
     subprocess.run(cmd, check=True)

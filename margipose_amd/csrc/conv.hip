@@ -1518,7 +1518,7 @@ __global__ __launch_bounds__(256) void pack_weights_k(const mpose_pack_job* __re
   const long total = (long)j.T * j.Kpad * j.Npad;
   __bf16* dst = reinterpret_cast<__bf16*>(j.dst);
   const long plane = (long)j.Npad * 16;
-  const float w_mul = (j.layout == 2 && j.amax != nullptr) ? pow2f(f16_scale_exp(*j.amax)) : 1.f;
+  const float w_mul = ((j.layout == 2 || j.layout == 3) && j.amax != nullptr) ? pow2f(f16_scale_exp(*j.amax)) : 1.f;
   // (32-bit index arithmetic: a job is at most taps x Kpad x Npad < 2^31 elements (max_elems_per_job is an int), and the three
   //  64-bit divisions per element this loop used to do were most of its instructions)
   const unsigned k16n = (unsigned)j.Kpad / 16u, npad = (unsigned)j.Npad;
@@ -1532,11 +1532,12 @@ __global__ __launch_bounds__(256) void pack_weights_k(const mpose_pack_job* __re
     const int k = k16 * 16 + k_lo;
     float v = 0.f;
     if (n < j.N && k < j.K) v = j.src[n * j.sn + k * j.sk + t * j.st];
-    if (j.layout == 2) {           // two fp16 planes of w * 2^k (MPOSE_CONV_F16X3)
+    if (j.layout == 2 || j.layout == 3) {           // two fp16 planes of w * 2^k (MPOSE_CONV_F16X3; layout 3: conv_h.hip's B tiles)
       const float vs = v * w_mul;
       const _Float16 h = (_Float16)vs;
       const _Float16 l = (_Float16)(vs - (float)h);
-      _Float16* d = reinterpret_cast<_Float16*>(j.dst) + ((long)(t * (j.Kpad / 16) + k16) * 2) * plane + (long)n * 16 + k_lo;
+      _Float16* d = reinterpret_cast<_Float16*>(j.dst) + ((long)(t * (j.Kpad / 16) + k16) * 2) * plane +
+                    (j.layout == 3 ? ((long)(k_lo >> 3) * j.Npad + n) * 8 + (k_lo & 7) : (long)n * 16 + k_lo);
       d[0] = h; d[plane] = l;
       continue;
     }
@@ -1588,6 +1589,8 @@ using namespace mpose;
 
 int mpose_conv_planes_launch(const mpose_conv_geom* geom, const mpose_conv_operands* ops, int n_groups, int flags, int mode,
                              int cmax, void* stream);      // conv_p.hip
+int mpose_conv_h2_launch(const mpose_conv_geom* geom, const mpose_conv_operands* ops, int n_groups, int flags, int mode,
+                         int cmax, void* stream);          // conv_h.hip
 int mpose_wgrad_rows_units(const mpose_conv_geom* geom);                                                                       // wgrad.hip
 int mpose_wgrad_rows_launch(const mpose_conv_geom* geom, const mpose_wgrad_operands* ops, int n_groups, int n_split, void* stream);
 
@@ -1661,12 +1664,15 @@ extern "C" int mpose_conv_fwd(const mpose_conv_geom* geom_, const mpose_conv_ope
     if (ops[i].epi_scale0 && (!ops[i].epi_shift0 || ops[i].stats0 || ops[i].mask_src || (flags & MPOSE_CONV_ACCUMULATE))) return MPOSE_EINVAL;
     if (ops[i].add_src && (!ops[i].epi_scale0 || !ops[i].add_scale || !ops[i].add_shift)) return MPOSE_EINVAL;
     if ((ops[i].epi_scale0 != nullptr) != (ops[0].epi_scale0 != nullptr) || (ops[i].add_src != nullptr) != (ops[0].add_src != nullptr)) return MPOSE_EINVAL;
-    if (ops[i].out0_amax && !ops[i].epi_scale0) return MPOSE_EINVAL;
+    if (ops[i].out0_amax && !ops[i].epi_scale0 && !(flags & MPOSE_CONV_H2_IN)) return MPOSE_EINVAL;
     if (ops[i].red_sums && ((flags & MPOSE_CONV_PLANES_IN) || !ops[i].red_a || !ops[i].red_b || !ops[i].red_scale || !ops[i].red_shift ||
                             ops[i].stats0 || ops[i].stats1 || ops[i].epi_scale0 || (acc1 && !sum_inputs)))
       return MPOSE_EINVAL;
     if ((ops[i].red_sums != nullptr) != (ops[0].red_sums != nullptr)) return MPOSE_EINVAL;
     if (ops[i].mm0 && ((flags & MPOSE_CONV_PLANES_IN) || !ops[i].stats0)) return MPOSE_EINVAL;
+    if ((flags & MPOSE_CONV_H2_IN) && (ops[i].epi_scale0 || ops[i].add_src || ops[i].out0_planes || ops[i].fin_count || ops[i].in_scale ||
+                                       (flags & (MPOSE_CONV_ACCUMULATE | MPOSE_CONV_PLANES_IN | MPOSE_CONV_F16X1)) || !(flags & MPOSE_CONV_F16X3)))
+      return MPOSE_EINVAL;
     if (ops[i].fin_count && ((flags & MPOSE_CONV_PLANES_IN) || !ops[i].fin0 || !ops[i].stats0 || (ops[i].fin1 && (!acc1 || !ops[i].stats1)) ||
                              sum_inputs)) return MPOSE_EINVAL;
     if (!ops[i].fin_count && (ops[i].fin0 || ops[i].fin1)) return MPOSE_EINVAL;
@@ -1717,6 +1723,15 @@ extern "C" int mpose_conv_fwd(const mpose_conv_geom* geom_, const mpose_conv_ope
       if (sum_inputs && (!ops[i].in1_amax || !ops[i].w1_amax)) return MPOSE_EINVAL;
       if (acc1 && !ops[i].w1_amax) return MPOSE_EINVAL;
     }
+  }
+  if (flags & MPOSE_CONV_H2_IN) {          // producer-split fp16 planes: conv_h.hip
+    if ((geom->Cout0 % 32) || (acc1 && (geom->Cout1 % 32)) || (geom->Npad0 % 64) || (geom->Cin % 16)) return MPOSE_EINVAL;
+    const int cm = (acc1 && geom->Cout1 > geom->Cout0) ? geom->Cout1 : geom->Cout0;
+    if (cm > geom->Npad0) return MPOSE_EINVAL;
+    const int ldm = geom->out_ld0 > geom->out_ld1 ? geom->out_ld0 : geom->out_ld1;
+    if ((long)geom->B * geom->OH * geom->OW * (ldm > cm ? ldm : cm) * 4 >= 0xFFFFF000l) return MPOSE_EINVAL;
+    rc = mpose_conv_h2_launch(geom, ops, n_groups, flags, sum_inputs ? 2 : (acc1 ? 1 : 0), cm, stream);
+    return rc == MPOSE_ENOSYS ? MPOSE_EINVAL : rc;
   }
   a.div_gw = make_fastdiv((unsigned)geom->GW);
   a.div_ghw = make_fastdiv((unsigned)(geom->GH * geom->GW));

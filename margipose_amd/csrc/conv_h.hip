@@ -1,0 +1,603 @@
+// Implicit-GEMM convolution on PRODUCER-SPLIT fp16 operands for gfx950 (round 4: the "H2" engine).
+//
+// Arithmetic: the three-product fp16 form of conv.hip (MPOSE_CONV_F16X3 in include/margipose_hip.h) -- an fp32 convolution
+// as  a*b ~= a_l*b_h + a_h*b_l + a_h*b_h  over operands x * 2^k = h + l (two fp16 values, 22 significant bits), fp32
+// accumulation on v_mfma_f32_32x32x16_f16 -- but NOTHING of the split happens here any more:
+//   * activations arrive as two fp16 planes (h, l) of x * 2^k in the blocked layout
+//         H8[C/8][plane 2][pixel][8]                   (16 bytes per pixel per (channel octet, plane): 4 bytes per element,
+//     the size of the fp32 tensor they replace), written ONCE by the elementwise pass that produces the tensor (split.hip:
+//     BatchNorm+ReLU, the residual sum, the BatchNorm-backward application) with the scale k that the tensor's amax SLOT
+//     prescribes -- a bound on the tensor's largest magnitude that exists BEFORE the producer runs (bn.hip: the coefficient
+//     kernels derive it; a loose bound costs no precision, see MPOSE_CONV_H2_IN);
+//   * weights: the same two planes, packed [widx][K/16][plane][k half][Npad][8] by pack_weights_k (layout 3).
+// conv_igemm_k (conv.hip) spent a third of its non-MFMA instructions scaling and splitting fp32 operands inside the K loop,
+// on the one wave per SIMD that also had to issue the MFMAs (MFMA busy 0.25-0.33).  Here both operands go global -> LDS by DMA
+// (buffer_load_dwordx4 ... lds: 64 consecutive pixels or output channels x 16 B = 1 KiB per wave instruction, zero padding by
+// the buffer unit's range check), the workgroup SHARES its tiles through LDS, TWO workgroups are resident per CU (two waves
+// per SIMD, <= 256 registers), and the K loop is fragment reads + MFMAs only.
+//
+// Accumulation: TWO accumulators per output block -- `acc` takes the h x h products (one rounding of the running sum per
+// 16 channels: 72 for a 128-channel 3x3), `acx` the two cross products (2^-11 of the sum: its roundings do not matter).  That
+// bounds the fp32 accumulation chain better than conv_igemm_k's two-way split-K (108) without any exchange between waves, so
+// training launches run unsplit.
+//
+// Structure (conv_p.hip's, re-cut for 3 products): 256 threads = 4 waves as WM x WN, wave tile 32*RM pixels x 32*RN channels.
+// A ring slot holds KST k-groups (16 input channels each) of one tap: per k-group A [plane][k half][BM pixels][16 B] and
+// B [plane][k half][BNL columns][16 B] (every ds_read_b128: 32 consecutive lanes on 32 consecutive 16-byte words, conflict
+// free).  ONE s_barrier per slot; the DMA of slot s+NBUF is issued when slot s has been drained into registers; fragments
+// of k-group q+1 are read while k-group q multiplies (single register set, refilled as blocks retire).
+// Geometry (tap lists, classes), fused shortcut (MODE 1: a second pass into a second output), two-input sum (MODE 2: dX =
+// conv_in^T(dC1) + shortcut^T(dSC)), BatchNorm statistics / channel extremes / ReLU mask / consumer BatchNorm-backward sums /
+// output amax epilogues: the contracts of include/margipose_hip.h (mpose_conv_operands).
+//
+// Replaces Conv2d / ConvTranspose2d of reference src/margipose/models/margipose_model.py:33,67-82 and their data-gradients
+// inside the columns.
+#include <stdlib.h>
+#include "common.h"
+
+namespace mpose {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_void_p;
+
+struct FastDiv {
+  unsigned mul, shift;
+};
+inline FastDiv make_fastdiv(unsigned d) {
+  FastDiv f;
+  unsigned l = 0;
+  while ((1u << l) < d) ++l;
+  f.shift = l;
+  f.mul = (unsigned)(((uint64_t)((1ull << l) - d) << 32) / d) + 1u;
+  return f;
+}
+__device__ __forceinline__ unsigned fdiv(unsigned n, FastDiv f) { return (__umulhi(n, f.mul) + n) >> f.shift; }
+
+constexpr unsigned kOob = 0xFFFFFFF0u;      // voffset beyond num_records: the buffer unit returns (and the DMA stores) zeros
+
+struct ConvHArgs {
+  mpose_conv_geom g;
+  mpose_conv_operands op[MPOSE_MAX_GROUP];
+  FastDiv div_gw, div_ghw;
+  int M;                          // slots per class = B*GH*GW
+  int n_mtiles;
+  int flags;
+  unsigned in_slab;               // bytes of one (channel octet, plane) slab of the input: B*IH*IW*16
+};
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned char* lds_wave_base, unsigned voff, unsigned soff) {
+  // 64 lanes x 16 B: lane l's bytes land at lds_wave_base + 16*l (the LDS address is wave-uniform, carried in M0)
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_p)lds_wave_base, 16, (int)voff, (int)soff, 0, 0);
+}
+
+__device__ __forceinline__ f32x16 mfma_f16(const f16x8 a, const f16x8 b, const f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+#ifndef CH_EXP
+#define CH_EXP 0      // timing experiments (tools/h2_exp.sh; wrong results): 1 no A traffic after the first tap of a chunk, 2 no B traffic,
+                      // 4 plain tile order, 8 no DMA at all, 16 no MFMAs, 32 no fragment reads, 64 no epilogue stores, 128 no K loop
+#endif
+
+template <int WM, int WN, int RM, int RN, int KST, int NBUF, int MODE, bool DUAL>
+__global__ __launch_bounds__(256, 2) void conv_h2_k(ConvHArgs a) {
+  static_assert(WM * WN == 4, "four waves");
+  static_assert(RM == 1 || RM == 2, "row blocks per wave");
+  constexpr bool ACC1 = MODE == 1, SUM2 = MODE == 2;
+  constexpr int NPASS = MODE ? 2 : 1;
+  constexpr int BM = 32 * RM * WM, BN = 32 * RN * WN, BNL = (BN + 63) / 64 * 64;
+  constexpr int SGN = BM / 64, NGN = BNL / 64;                 // 64-pixel / 64-column groups = DMA instructions per (plane, half)
+  static_assert(SGN == 1 || SGN == 2 || SGN == 4, "slot groups must divide the wave count");
+  constexpr int A_B = 4 * BM * 16, B_B = 4 * BNL * 16, SUB_B = A_B + B_B, BUF_B = KST * SUB_B;   // per k-group: [plane][half][row][16 B]
+  constexpr int NA = KST * 4 * SGN, NB = KST * 4 * NGN, TOT = NA + NB;     // DMA instructions per slot (workgroup)
+  static_assert(TOT % 4 == 0, "every wave issues the same number of DMA instructions per slot");
+  constexpr int LW = TOT / 4;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned* sRow = reinterpret_cast<unsigned*>(smem + NBUF * BUF_B);                 // [BM] output row byte offsets
+  float* sRed = reinterpret_cast<float*>(smem + NBUF * BUF_B + BM * 4);              // [2 sets][4 waves][32*RN][2]  (or [4 waves][32*RN][4])
+  float* sMM = sRed + 2 * 4 * 32 * RN * 2;                                           // [4 waves][32*RN][2] channel extremes of out0
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int wm = wave % WM, wn = wave / WM;
+  const mpose_conv_geom& g = a.g;
+  // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed placement, speed only); an XCD gets a CONTIGUOUS run of pixel
+  // tiles, so neighbouring tiles share their halo rows (and a class's tiles their weights) in one L2.
+  unsigned bid = blockIdx.x;
+  if ((gridDim.x & 7u) == 0 && !(CH_EXP & 4)) bid = (bid & 7u) * (gridDim.x >> 3) + (bid >> 3);
+  const int cls = bid / a.n_mtiles;
+  const int m0 = (bid - cls * a.n_mtiles) * BM;
+  const int n0 = blockIdx.y * BN;
+  const mpose_conv_operands& op = a.op[blockIdx.z];
+  const int n_taps = g.cls[cls].n_taps;
+  // lane t keeps tap t ({dy, dx, widx, acc} in one dword); v_readlane hands it to the scalar unit
+  const int lane_tap = lane < MPOSE_MAX_TAPS ? *reinterpret_cast<const int*>(&g.cls[cls].taps[lane < MPOSE_MAX_TAPS ? lane : 0]) : 0;
+  auto tap_word = [&](int t) { return __builtin_amdgcn_readlane(lane_tap, t); };
+
+  // ---- this lane's input pixel for the A-tile DMA (slot group sg of the wave, pixel `lane` of the group) ----
+  const int sg = wave % SGN;
+  unsigned pix_off = 0, row_taps = 0;          // byte offset of the anchor pixel inside a slab; bit t: tap t in bounds
+  {
+    const unsigned m = (unsigned)(m0 + sg * 64 + lane);
+    const bool in_m = (int)m < a.M;
+    const unsigned mm = in_m ? m : 0u;
+    const unsigned b = fdiv(mm, a.div_ghw);
+    const unsigned rem = mm - b * (unsigned)(g.GH * g.GW);
+    const unsigned gy = fdiv(rem, a.div_gw);
+    const unsigned gx = rem - gy * (unsigned)g.GW;
+    const int iy0 = (int)gy * g.in_mul, ix0 = (int)gx * g.in_mul_x;
+    pix_off = ((b * (unsigned)g.IH + (unsigned)iy0) * (unsigned)g.IW + (unsigned)ix0) * 16u;
+    for (int t = 0; t < n_taps; ++t) {
+      const int tp = tap_word(t);
+      const int iy = iy0 + (int)(signed char)(tp & 0xff), ix = ix0 + (int)(signed char)((tp >> 8) & 0xff);
+      if (in_m && (unsigned)iy < (unsigned)g.IH && (unsigned)ix < (unsigned)g.IW) row_taps |= 1u << t;
+    }
+  }
+  // ---- output row table: byte offset of output pixel m0 + i, or an offset the buffer unit rejects ----
+  const int oyc = g.cls[cls].oy, oxc = g.cls[cls].ox;
+  auto fill_rows = [&](int out_ld) {
+    if (tid < BM) {
+      const unsigned m = (unsigned)(m0 + tid);
+      const unsigned mm = (int)m < a.M ? m : 0u;
+      const unsigned b = fdiv(mm, a.div_ghw);
+      const unsigned rem = mm - b * (unsigned)(g.GH * g.GW);
+      const unsigned gy = fdiv(rem, a.div_gw);
+      const unsigned gx = rem - gy * (unsigned)g.GW;
+      const unsigned pix = (b * (unsigned)g.OH + (gy * g.out_mul + oyc)) * (unsigned)g.OW + (gx * g.out_mul_x + oxc);
+      sRow[tid] = (int)m < a.M ? pix * (unsigned)out_ld * 4u : 0xFFFFF000u;
+    }
+  };
+
+  const int k16_total = g.Cin >> 4;
+  const int n_chunks = k16_total / KST;                            // (Cin % (16 * KST) == 0: checked by the launcher)
+  const int npad = g.Npad0;                                        // == Npad1 when a second weight set is used
+  const unsigned w_plane_b = (unsigned)npad * 16u;                 // bytes of one (plane, half) slab of packed weights
+  const __amdgpu_buffer_rsrc_t rs_in0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(op.in), 0, 0xFFFFFF00, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_in1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(SUM2 ? op.in1 : op.in), 0, 0xFFFFFF00, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(op.w0), 0, 0xFFFFFF00, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(MODE ? op.w1 : op.w0), 0, 0xFFFFFF00, 0x00020000);
+
+  // scale exponents of this launch's tensors: pass `set` multiplies input ka[set] with weights kw[set]
+  const int ka0 = f16_scale_exp(amax_gather(op.in_amax));
+  const int ka1 = SUM2 ? f16_scale_exp(amax_gather(op.in1_amax)) : ka0;
+  const int kw0 = f16_scale_exp(*op.w0_amax);
+  const int kw1 = MODE ? f16_scale_exp(*op.w1_amax) : kw0;
+  // MODE 2: the first pass's accumulators are re-expressed in the second pass's units (a power of two: exact) before the second
+  // input accumulates on top.  A second input 2^60 times smaller than the first (a shortcut BatchNorm with gamma == 0 gives an
+  // all-zero one) would make that factor overflow fp32; its planes are already written with the scale its slot prescribes, so it
+  // cannot be scaled less as conv.hip does -- it is DROPPED instead: its whole sum is below 2^-60 of the first input's scale.
+  const bool skip1 = SUM2 && (ka1 + kw1) - (ka0 + kw0) > 60;
+  f32x16 acc[RM][RN], acx[RM][DUAL ? RN : 1];
+  // taps with acc == 0 first, taps with acc == 1 (second weight set) last
+  int n_taps0 = 0;
+  for (int t = 0; t < n_taps; ++t) n_taps0 += (((tap_word(t) >> 24) & 0xff) == 0) ? 1 : 0;
+
+#pragma unroll 1
+  for (int set = 0; set < NPASS; ++set) {
+    const int t_lo = set ? n_taps0 : 0;
+    const int nt = set ? n_taps - n_taps0 : (MODE ? n_taps0 : n_taps);
+    const int n_steps = ((set && skip1) || (CH_EXP & 128)) ? 0 : n_chunks * nt;
+    if (!SUM2 || set == 0) {
+#pragma unroll
+      for (int rm = 0; rm < RM; ++rm)
+#pragma unroll
+        for (int rn = 0; rn < RN; ++rn)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            acc[rm][rn][r] = 0.0f;
+            if (DUAL) acx[rm][rn % (DUAL ? RN : 1)][r] = 0.0f;
+          }
+    }
+    if (set == 0 || ACC1) {
+      const int ld_ = (set && ACC1) ? g.out_ld1 : g.out_ld0;
+      fill_rows(ld_ > 0 ? ld_ : ((set && ACC1) ? g.Cout1 : g.Cout0));
+    }
+    const bool second = set != 0;              // which weight set (MODE 1, 2) / input (MODE 2) this pass reads
+
+    // ---- one slot's DMA: instruction gidx of the workgroup's list (A first, then B) goes to wave gidx % 4 ----
+    auto issue = [&](int buf, int c, int t) {
+      const int tp = tap_word(t_lo + t);
+      const int dy = (int)(signed char)(tp & 0xff), dx = (int)(signed char)((tp >> 8) & 0xff);
+      const int widx = (tp >> 16) & 0xff;
+      unsigned voff_a = ((row_taps >> (t_lo + t)) & 1u) ? pix_off + (unsigned)((dy * g.IW + dx) * 16) : kOob;
+      if ((CH_EXP & 1) && t != 0) voff_a = kOob;
+      unsigned char* bufp = smem + buf * BUF_B;
+#pragma unroll
+      for (int k = 0; k < ((CH_EXP & 8) ? 0 : LW); ++k) {
+        const int gidx = wave + 4 * k;                            // (wave-uniform: the branches below are scalar)
+        if (gidx < NA) {
+          const int kp = gidx / SGN;                               // kk * 4 + plane * 2 + half
+          const int kk = kp >> 2, ph = kp & 3;
+          const unsigned soff = (unsigned)((((c * KST + kk) * 2 + (ph & 1)) * 2) + (ph >> 1)) * a.in_slab;
+          unsigned char* dst = bufp + kk * SUB_B + (ph * BM + sg * 64) * 16;
+          if (SUM2 && second) dma16(rs_in1, dst, voff_a, soff);
+          else dma16(rs_in0, dst, voff_a, soff);
+        } else {
+          const int j = gidx - NA;
+          const int kp = j / NGN, ng = j - kp * NGN;
+          const int kk = kp >> 2, ph = kp & 3;
+          const unsigned voff_b = (CH_EXP & 2) ? kOob : (unsigned)((n0 + ng * 64 + lane) * 16);
+          const unsigned soff = ((unsigned)(widx * k16_total + c * KST + kk) * 4u + (unsigned)ph) * w_plane_b;
+          unsigned char* dst = bufp + kk * SUB_B + A_B + (ph * BNL + ng * 64) * 16;
+          if (second) dma16(rs_w1, dst, voff_b, soff);
+          else dma16(rs_w0, dst, voff_b, soff);
+        }
+      }
+    };
+
+    // issue cursor: (chunk, tap) of the next slot to fetch, tap fastest (the taps of a chunk re-read the same pixels)
+    int ic = 0, itp = 0, issued = 0;
+    auto issue_next = [&]() {
+      issue(issued % NBUF, ic, itp);
+      ++issued;
+      if (++itp == nt) { itp = 0; ++ic; }
+    };
+    auto wait_slots_outstanding = [&](int k) {         // at most k slots' worth of this wave's DMA still in flight
+      if (NBUF > 2 && k == NBUF - 2) wait_vmcnt<(NBUF - 2) * LW>();
+      else if (NBUF > 2 && k == NBUF - 1) wait_vmcnt<(NBUF - 1) * LW>();
+      else wait_vmcnt<0>();
+    };
+    f16x8 af[RM][2], bfr[RN][2], afn[2];
+    auto read_a = [&](int slot, int kk, int rm, f16x8 (&dst)[2]) {
+      if constexpr (CH_EXP & 32) { asm volatile("" : "+v"(dst[0]), "+v"(dst[1])); return; }
+      const unsigned char* pa = smem + slot * BUF_B + kk * SUB_B + (lh * BM + wm * 32 * RM + rm * 32 + li) * 16;
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) dst[pl] = *reinterpret_cast<const f16x8*>(pa + pl * 2 * BM * 16);
+    };
+    auto read_b = [&](int slot, int kk, int rn, f16x8 (&dst)[2]) {
+      if constexpr (CH_EXP & 32) { asm volatile("" : "+v"(dst[0]), "+v"(dst[1])); return; }
+      const unsigned char* pb = smem + slot * BUF_B + kk * SUB_B + A_B + (lh * BNL + wn * 32 * RN + rn * 32 + li) * 16;
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) dst[pl] = *reinterpret_cast<const f16x8*>(pb + pl * 2 * BNL * 16);
+    };
+    auto block = [&](int rm, int rn) {
+      if constexpr (CH_EXP & 16) {
+        asm volatile("" :: "v"(af[rm][0]), "v"(af[rm][1]), "v"(bfr[rn][0]), "v"(bfr[rn][1]));
+      } else if constexpr (DUAL) {
+        f32x16 c = acx[rm][rn];
+        c = mfma_f16(af[rm][1], bfr[rn][0], c);
+        c = mfma_f16(af[rm][0], bfr[rn][1], c);
+        acx[rm][rn] = c;
+        acc[rm][rn] = mfma_f16(af[rm][0], bfr[rn][0], acc[rm][rn]);
+      } else {
+        f32x16 c = acc[rm][rn];
+        c = mfma_f16(af[rm][1], bfr[rn][0], c);
+        c = mfma_f16(af[rm][0], bfr[rn][1], c);
+        c = mfma_f16(af[rm][0], bfr[rn][0], c);
+        acc[rm][rn] = c;
+      }
+    };
+    // the slot's one barrier: everyone has drained slot s into registers, slot s+1 has landed for everyone; refill slot s
+    auto sync = [&](int s_, bool more) {
+      if (more) wait_slots_outstanding(issued - s_ - 2);
+      __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0) -- the builtin, so that hipcc's own wait-count bookkeeping sees it
+      __builtin_amdgcn_s_barrier();
+      if (issued < n_steps) issue_next();
+    };
+    auto group0 = [&]() {
+      if constexpr (RM == 2) {
+#pragma unroll
+        for (int rn = 0; rn < RN; ++rn) block(0, rn);
+      } else if constexpr (RN > 1) {
+        block(0, 0);
+      }
+    };
+    for (int p = 0; p < NBUF && p < n_steps; ++p) issue_next();
+    if (n_steps > 0) {
+      wait_slots_outstanding(issued - 1);
+      __builtin_amdgcn_s_barrier();
+#pragma unroll
+      for (int rm = 0; rm < RM; ++rm) read_a(0, 0, rm, af[rm]);
+#pragma unroll
+      for (int rn = 0; rn < RN; ++rn) read_b(0, 0, rn, bfr[rn]);
+      group0();
+    }
+    // Rotated loop over k-groups q = (slot s, kk): [sync(s) before the last k-group's second half], second half of q, first half
+    // of q+1 -- every prefetched fragment is consumed inside the iteration that fetched it (exact lgkmcnt counts from hipcc).
+#pragma unroll 1
+    for (int s = 0; s < n_steps; ++s) {
+      const bool more = s + 1 < n_steps;
+      const int slot = s % NBUF, nslot = (s + 1) % NBUF;
+#pragma unroll
+      for (int kk = 0; kk < KST; ++kk) {
+        const bool last = kk == KST - 1;
+        if (last) sync(s, more);
+        // (the prefetches are unconditional -- after the last slot they read a stale slot and the values are dropped -- so that
+        //  the iteration is one basic block)
+        const int rs = last ? nslot : slot, rk = last ? 0 : kk + 1;
+        if constexpr (RM == 2) {
+          read_a(rs, rk, 0, af[0]);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int rn = 0; rn < RN; ++rn) {
+            block(1, rn);
+            __builtin_amdgcn_sched_barrier(0);
+            read_b(rs, rk, rn, bfr[rn]);
+            if (rn == RN - 1) read_a(rs, rk, 1, af[1]);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        } else {
+          static_assert(RM == 2 || RN > 1, "single-block wave tiles are not instantiated");
+          read_b(rs, rk, 0, bfr[0]);
+          read_a(rs, rk, 0, afn);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int rn = 1; rn < RN; ++rn) {
+            block(0, rn);
+            __builtin_amdgcn_sched_barrier(0);
+            read_b(rs, rk, rn, bfr[rn]);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+#pragma unroll
+          for (int pl = 0; pl < 2; ++pl) af[0][pl] = afn[pl];
+        }
+        if (!last || more) group0();
+      }
+    }
+    __builtin_amdgcn_s_barrier();              // the ring may be refilled by the next pass; sRow is complete
+
+    if (SUM2 && set == 0) {
+      // second input accumulates on top: re-express this pass's sums in the second pass's units (exact: powers of two)
+      const int shift = skip1 ? 0 : (ka1 + kw1) - (ka0 + kw0);
+#pragma unroll
+      for (int rm = 0; rm < RM; ++rm)
+#pragma unroll
+        for (int rn = 0; rn < RN; ++rn)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            acc[rm][rn][r] = __builtin_ldexpf(acc[rm][rn][r], shift);
+            if (DUAL) acx[rm][rn % (DUAL ? RN : 1)][r] = __builtin_ldexpf(acx[rm][rn % (DUAL ? RN : 1)][r], shift);
+          }
+      continue;
+    }
+
+    // ---- epilogue (branch-free: rows beyond M carry an offset the buffer unit rejects) ----
+    const int k_back = (SUM2 && skip1) ? -(ka0 + kw0) : -((set ? ka1 : ka0) + (set ? kw1 : kw0));
+    const int oset = SUM2 ? 0 : set;
+    float* outp = oset ? op.out1 : op.out0;
+    const int cout = oset ? g.Cout1 : g.Cout0;
+    double* stats = oset ? op.stats1 : op.stats0;
+    const bool masked = (oset == 0) && op.mask_src != nullptr;
+    const bool red = (oset == 0) && op.red_sums != nullptr;
+    const bool want_mm = (oset == 0) && op.mm0 != nullptr;
+    const bool want_amax = (oset == 0) && op.out0_amax != nullptr;
+    const int old_ = oset ? g.out_ld1 : g.out_ld0;
+    const int out_ld = old_ > 0 ? old_ : cout;
+    const unsigned out_bytes = (unsigned)((((long)g.B * g.OH * g.OW - 1) * out_ld + cout) * 4);
+    const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(outp, 0, out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_m = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(masked ? op.mask_src : outp), 0, out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(red ? op.red_a : outp), 0, out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(red ? op.red_b : outp), 0, out_bytes, 0x00020000);
+    float csum[RN], csq[RN], rs0[RN], rs1[RN], rs2[RN], rs3[RN], vmx[RN], vng[RN];
+    const float kNegInf = __uint_as_float(0xff800000u);
+    float out_amax = 0.f;
+#pragma unroll
+    for (int rn = 0; rn < RN; ++rn) { csum[rn] = csq[rn] = rs0[rn] = rs1[rn] = rs2[rn] = rs3[rn] = 0.f; vmx[rn] = vng[rn] = kNegInf; }
+    const int ncol0 = n0 + wn * 32 * RN;
+    const unsigned col_off = (unsigned)((ncol0 + li) * 4);
+#pragma unroll
+    for (int rm = 0; rm < ((CH_EXP & 64) ? 0 : RM); ++rm) {
+      unsigned voff[16];
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const u32x4 e = *reinterpret_cast<const u32x4*>(sRow + wm * 32 * RM + rm * 32 + 8 * rg + 4 * lh);
+        voff[4 * rg] = e.x + col_off; voff[4 * rg + 1] = e.y + col_off; voff[4 * rg + 2] = e.z + col_off; voff[4 * rg + 3] = e.w + col_off;
+      }
+#pragma unroll
+      for (int rn = 0; rn < RN; ++rn) {
+        const int nb = ncol0 + rn * 32;              // wave-uniform: a 32-column group is in or out as a whole (cout % 32 == 0)
+        if (nb < cout) {
+          const int n = nb + li;
+          float v[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            v[r] = __builtin_ldexpf(DUAL ? acc[rm][rn][r] + acx[rm][rn % (DUAL ? RN : 1)][r] : acc[rm][rn][r], k_back);
+          if (masked) {
+            const float msc = op.mask_scale[n], msh = op.mask_shift[n];
+            float src[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              src[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_m, (int)(voff[r] + (unsigned)(rn * 128)), 0, 0));
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              if (!(fmaf(src[r], msc, msh) > 0.f)) v[r] = 0.f;
+              csq[rn] = fmaf(v[r], src[r], csq[rn]);
+            }
+          }
+          if (red) {
+            const float ms = op.red_scale[n], mt = op.red_shift[n];
+            float xa[16], xb[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              xa[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_ra, (int)(voff[r] + (unsigned)(rn * 128)), 0, 0));
+              xb[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_rb, (int)(voff[r] + (unsigned)(rn * 128)), 0, 0));
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {       // (rows beyond M hold v = 0 and read 0: they add nothing)
+              const float ga = fmaf(xa[r], ms, mt) > 0.f ? v[r] : 0.f;
+              rs0[rn] += ga;
+              rs1[rn] = fmaf(ga, xa[r], rs1[rn]);
+              rs2[rn] += v[r];
+              rs3[rn] = fmaf(v[r], xb[r], rs3[rn]);
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[r]), rs_o, (int)(voff[r] + (unsigned)(rn * 128)), 0, 0);
+            csum[rn] += v[r];                        // rows beyond M accumulated zeros (their inputs were read as 0)
+            if (!masked) csq[rn] = fmaf(v[r], v[r], csq[rn]);
+          }
+          if (want_mm) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const bool ok = voff[r] < 0xFFFFF000u;
+              vmx[rn] = fmaxf(vmx[rn], ok ? v[r] : kNegInf);
+              vng[rn] = fmaxf(vng[rn], ok ? -v[r] : kNegInf);
+            }
+          }
+          if (want_amax) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) out_amax = fmaxf(out_amax, fabsf(v[r]));     // (rows beyond M hold zeros)
+          }
+        }
+      }
+    }
+    if (want_mm) {
+#pragma unroll
+      for (int rn = 0; rn < RN; ++rn) {
+        const float a_ = fmaxf(vmx[rn], __shfl_xor(vmx[rn], 32, 64)), b_ = fmaxf(vng[rn], __shfl_xor(vng[rn], 32, 64));
+        if (lh == 0) { sMM[(wave * 32 * RN + rn * 32 + li) * 2] = a_; sMM[(wave * 32 * RN + rn * 32 + li) * 2 + 1] = b_; }
+      }
+    }
+    if (want_amax) {       // one look-then-atomic per wave into the workgroup's sub-slot (common.h)
+      float m = wave_max(out_amax);
+      if (lane == 0) {
+        if (!(m == m)) m = __uint_as_float(0x7f800000u);
+        unsigned* dst = reinterpret_cast<unsigned*>(op.out0_amax + (blockIdx.x % MPOSE_AMAX_SUBSLOTS) * MPOSE_AMAX_STRIDE);
+        if (__float_as_uint(m) > __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(dst, __float_as_uint(m));
+      }
+    }
+    if (red) {       // (sRed is free: red_* and stats* exclude each other) [4 waves][32*RN][4]
+#pragma unroll
+      for (int rn = 0; rn < RN; ++rn) {
+        const float t0 = rs0[rn] + __shfl_xor(rs0[rn], 32, 64), t1 = rs1[rn] + __shfl_xor(rs1[rn], 32, 64);
+        const float t2 = rs2[rn] + __shfl_xor(rs2[rn], 32, 64), t3 = rs3[rn] + __shfl_xor(rs3[rn], 32, 64);
+        if (lh == 0) *reinterpret_cast<float4*>(sRed + (wave * 32 * RN + rn * 32 + li) * 4) = make_float4(t0, t1, t2, t3);
+      }
+    }
+    if (stats != nullptr) {
+#pragma unroll
+      for (int rn = 0; rn < RN; ++rn) {
+        const float s_ = csum[rn] + __shfl_xor(csum[rn], 32, 64);
+        const float q_ = csq[rn] + __shfl_xor(csq[rn], 32, 64);
+        if (lh == 0) {
+          float* d = sRed + ((oset * 4 + wave) * 32 * RN + rn * 32 + li) * 2;
+          d[0] = s_; d[1] = q_;
+        }
+      }
+    }
+    if (ACC1 && set == 0) __builtin_amdgcn_s_barrier();      // sRow is rewritten for the second output
+  }
+  __syncthreads();
+  // cross-wave sums: column `tid` of the workgroup's BN output columns is held by the WM waves (wn_, 0..WM-1)
+  const int wn_ = tid / (32 * RN), col = tid - wn_ * 32 * RN;
+#pragma unroll
+  for (int set = 0; set < (ACC1 ? 2 : 1); ++set) {
+    double* stats = set ? op.stats1 : op.stats0;
+    const int cout = set ? g.Cout1 : g.Cout0;
+    if (stats != nullptr && tid < BN) {
+      float s = 0.f, q = 0.f;
+#pragma unroll
+      for (int w = 0; w < WM; ++w) {
+        const float* d = sRed + ((set * 4 + (wn_ * WM + w)) * 32 * RN + col) * 2;
+        s += d[0]; q += d[1];
+      }
+      const int n = n0 + tid;
+      if (n < cout) {
+        atomicAdd(stats + (size_t)n * 2, (double)s);
+        atomicAdd(stats + (size_t)n * 2 + 1, (double)q);
+      }
+    }
+  }
+  if (op.mm0 != nullptr && tid < BN && n0 + tid < g.Cout0) {
+    float a_ = __uint_as_float(0xff800000u), b_ = a_;
+#pragma unroll
+    for (int w = 0; w < WM; ++w) {
+      a_ = fmaxf(a_, sMM[((wn_ * WM + w) * 32 * RN + col) * 2]);
+      b_ = fmaxf(b_, sMM[((wn_ * WM + w) * 32 * RN + col) * 2 + 1]);
+    }
+    atomicMax(op.mm0 + (size_t)(n0 + tid) * 2, float_key(a_));
+    atomicMax(op.mm0 + (size_t)(n0 + tid) * 2 + 1, float_key(b_));
+  }
+  if (op.red_sums != nullptr && tid < BN && n0 + tid < g.Cout0) {
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int w = 0; w < WM; ++w) {
+      const float4 d = *reinterpret_cast<const float4*>(sRed + ((wn_ * WM + w) * 32 * RN + col) * 4);
+      t.x += d.x; t.y += d.y; t.z += d.z; t.w += d.w;
+    }
+    double* d = op.red_sums + (size_t)(n0 + tid) * 4;
+    atomicAdd(d, (double)t.x); atomicAdd(d + 1, (double)t.y); atomicAdd(d + 2, (double)t.z); atomicAdd(d + 3, (double)t.w);
+  }
+}
+
+template <int WM, int WN, int RM, int RN, int KST, int NBUF, int MODE, bool DUAL>
+int launch_h2(const ConvHArgs& a0, int n_groups, hipStream_t s) {
+  constexpr int BM = 32 * RM * WM, BN = 32 * RN * WN, BNL = (BN + 63) / 64 * 64;
+  constexpr int lds = NBUF * KST * (4 * BM * 16 + 4 * BNL * 16) + BM * 4 + 2 * 4 * 32 * RN * 2 * 4 + 4 * 32 * RN * 2 * 4;
+  static_assert(2 * lds <= 160 * 1024, "two workgroups per CU");
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_h2_k<WM, WN, RM, RN, KST, NBUF, MODE, DUAL>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+      return MPOSE_EINVAL;
+    attr_set = true;
+  }
+  if (a0.g.Cin % (16 * KST)) return MPOSE_EINVAL;
+  ConvHArgs a = a0;
+  a.n_mtiles = (a.M + BM - 1) / BM;
+  const int cmax = a.g.Cout1 > a.g.Cout0 && MODE == 1 ? a.g.Cout1 : a.g.Cout0;
+  dim3 grid(a.n_mtiles * a.g.n_classes, (cmax + BN - 1) / BN, n_groups);
+  conv_h2_k<WM, WN, RM, RN, KST, NBUF, MODE, DUAL><<<grid, 256, lds, s>>>(a);
+  return launch_status();
+}
+
+template <int WM, int WN, int RM, int RN, int KST, int NBUF, bool DUAL>
+int launch_h2_mode(const ConvHArgs& a, int mode, int n_groups, hipStream_t s) {
+  if (mode == 1) return launch_h2<WM, WN, RM, RN, KST, NBUF, 1, DUAL>(a, n_groups, s);
+  if (mode == 2) return launch_h2<WM, WN, RM, RN, KST, NBUF, 2, DUAL>(a, n_groups, s);
+  return launch_h2<WM, WN, RM, RN, KST, NBUF, 0, DUAL>(a, n_groups, s);
+}
+
+// Tile choice (MPOSE_H2_TILE overrides for timing runs: see the table in the function).
+int launch_h2_shape(const ConvHArgs& a, int mode, int cmax, int n_groups, hipStream_t s) {
+  static const int forced = [] { const char* e = getenv("MPOSE_H2_TILE"); return e ? atoi(e) : 0; }();
+  if (cmax % 128 == 0) {
+    switch (forced) {
+      case 1: return launch_h2_mode<2, 2, 2, 2, 1, 4, true>(a, mode, n_groups, s);      // 128 x 128, 16-channel slots, 4 deep
+      case 2: return launch_h2_mode<2, 2, 2, 2, 1, 3, true>(a, mode, n_groups, s);
+      case 3: return launch_h2_mode<2, 2, 2, 2, 2, 2, false>(a, mode, n_groups, s);     // single accumulator (A/B of the chain bound)
+      default: return launch_h2_mode<2, 2, 2, 2, 2, 2, true>(a, mode, n_groups, s);     // 128 x 128, 32-channel slots, 2 deep
+    }
+  }
+  if (cmax % 192 == 0) {
+    switch (forced) {
+      case 1: return launch_h2_mode<2, 2, 1, 3, 1, 4, true>(a, mode, n_groups, s);
+      case 4: return launch_h2_mode<2, 2, 2, 3, 1, 2, false>(a, mode, n_groups, s);     // 128 x 192, single accumulator
+      default: return launch_h2_mode<2, 2, 1, 3, 2, 2, true>(a, mode, n_groups, s);     // 64 x 192
+    }
+  }
+  if (cmax % 64 == 0) return launch_h2_mode<4, 1, 1, 2, 2, 2, true>(a, mode, n_groups, s);
+  return MPOSE_ENOSYS;
+}
+
+}  // namespace
+}  // namespace mpose
+
+using namespace mpose;
+
+// Entry used by mpose_conv_fwd when MPOSE_CONV_H2_IN is set (conv.hip validated geometry and operands).
+int mpose_conv_h2_launch(const mpose_conv_geom* geom, const mpose_conv_operands* ops, int n_groups, int flags, int mode,
+                         int cmax, void* stream) {
+  ConvHArgs a{};
+  a.g = *geom;
+  for (int i = 0; i < n_groups; ++i) a.op[i] = ops[i];
+  a.M = geom->B * geom->GH * geom->GW;
+  a.div_gw = make_fastdiv((unsigned)geom->GW);
+  a.div_ghw = make_fastdiv((unsigned)(geom->GH * geom->GW));
+  a.flags = flags;
+  const long npix = (long)geom->B * geom->IH * geom->IW;
+  const long in_bytes = npix * 16 * 2 * (geom->Cin / 8);
+  if (in_bytes >= 0xFFFFFF00l - (1l << 20) || geom->in_ld > 0) return MPOSE_EINVAL;       // 32-bit buffer offsets; dense inputs only
+  if ((long)geom->Npad0 * 16 * 4 * (geom->Cin / 16) * MPOSE_MAX_TAPS >= 0xFFFFFF00l) return MPOSE_EINVAL;
+  a.in_slab = (unsigned)(npix * 16);
+  return launch_h2_shape(a, mode, cmax, n_groups, (hipStream_t)stream);
+}

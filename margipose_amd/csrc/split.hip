@@ -55,6 +55,56 @@ __device__ __forceinline__ void load_vec8(const float* __restrict__ vec, int c0,
   v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
 }
 
+// ---- producer-split fp16 planes (conv_h.hip): x * 2^k = h + l, layout H8[C/8][2][npix][8] ----
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split2h(const float x0, const float x1, unsigned& h, unsigned& l) {
+  const f16x2 hh = __builtin_convertvector(f32x2{x0, x1}, f16x2);
+  h = __builtin_bit_cast(unsigned, hh);
+  const float r0 = x0 - (float)hh[0], r1 = x1 - (float)hh[1];
+  l = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{r0, r1}, f16x2));
+}
+// 8 channels of one pixel (already multiplied by the tensor's power-of-two scale) -> the two planes of channel octet c8
+__device__ __forceinline__ void store_h2(void* planes, long npix, int c8, long p, const float (&v)[8]) {
+  uint4 h, l;
+  split2h(v[0], v[1], h.x, l.x);
+  split2h(v[2], v[3], h.y, l.y);
+  split2h(v[4], v[5], h.z, l.z);
+  split2h(v[6], v[7], h.w, l.w);
+  uint4* d = reinterpret_cast<uint4*>(planes) + (long)c8 * 2 * npix + p;
+  d[0] = h; d[npix] = l;
+}
+
+struct SplitH2Args {
+  mpose_split_h2_operands op[MPOSE_MAX_GROUP];
+  long npix;
+  int C, relu;
+};
+
+// planes = h2([relu](scale*x + shift) * 2^k)   (scale NULL: identity; k from the tensor's amax slot)
+__global__ __launch_bounds__(256) void split_h2_k(SplitH2Args a) {
+  const mpose_split_h2_operands& op = a.op[blockIdx.z];
+  const int c8 = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const long p = (long)blockIdx.x * 64 + (threadIdx.x & 63);
+  const float mul = pow2f(f16_scale_exp(amax_gather(op.amax)));
+  if (c8 * 8 >= a.C || p >= a.npix) return;
+  float v[8];
+  load8(op.src, p, a.C, c8 * 8, v);
+  if (op.scale != nullptr) {
+    float sc[8], sh[8];
+    load_vec8(op.scale, c8 * 8, sc);
+    load_vec8(op.shift, c8 * 8, sh);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = fmaf(v[e], sc[e], sh[e]);
+  }
+  if (a.relu) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] *= mul;
+  store_h2(op.planes, a.npix, c8, p, v);
+}
+
 struct SplitArgs {
   mpose_split_operands op[MPOSE_MAX_GROUP];
   long npix;
@@ -175,6 +225,21 @@ extern "C" int mpose_split_planes(const mpose_split_operands* ops, int n_groups,
   }
   a.npix = npix; a.C = C; a.relu = relu;
   split_planes_k<<<plane_grid(npix, C, n_groups), 256, 0, (hipStream_t)stream>>>(a);
+  return launch_status();
+}
+
+extern "C" int64_t mpose_h2_bytes(int64_t npix, int C) { return npix * (int64_t)((C + 7) / 8) * 2 * 16; }
+
+extern "C" int mpose_split_h2(const mpose_split_h2_operands* ops, int n_groups, int64_t npix, int C, int relu, void* stream) {
+  if (n_groups < 1 || n_groups > MPOSE_MAX_GROUP || (C & 7) || npix < 0 || npix >= (1l << 31)) return MPOSE_EINVAL;
+  if (npix == 0) return 0;
+  SplitH2Args a{};
+  for (int i = 0; i < n_groups; ++i) {
+    a.op[i] = ops[i];
+    if (!ops[i].src || !ops[i].planes || !ops[i].amax || (ops[i].scale && !ops[i].shift)) return MPOSE_EINVAL;
+  }
+  a.npix = npix; a.C = C; a.relu = relu;
+  split_h2_k<<<plane_grid(npix, C, n_groups), 256, 0, (hipStream_t)stream>>>(a);
   return launch_status();
 }
 
