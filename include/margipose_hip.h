@@ -227,6 +227,19 @@ typedef struct {
                                    * of B and an absolute error of 2^-40 B below that.
                                    * Epilogues: stats0 / stats1, mm0, mask_src, red_*, out0_amax (max |out0| as stored, also
                                    * without the fused output stage); not: epi_*, add_*, out0_planes, fin*, MPOSE_CONV_ACCUMULATE. */
+#define MPOSE_CONV_STATS_PART 256  /* stats0 / stats1 / red_sums / mm0 are per-WORKGROUP partial buffers of fp32, WRITTEN with plain stores
+                                   * instead of accumulated with fp64 atomics (768 workgroups x 256 device-scope atomics cost a
+                                   * 128-channel launch 20 us of its ~110; round 4):
+                                   *     stats0 / stats1 -> float [4 + rows*Cout*2]:  header, then [rows][Cout][2] (sum, sum of squares |
+                                   *                                                  sum d, sum d*mask_src)
+                                   *     red_sums        -> float [4 + rows*Cout0*4]: header, then [rows][Cout0][4]
+                                   *     mm0             -> float [4 + rows*Cout0*2]: header, then [rows][Cout0][2] (max v, max -v:
+                                   *                                                  plain floats, -inf = no pixel)
+                                   * The launch writes `rows` (an int) into the first header word; rows = mpose_conv_stat_rows() of
+                                   * the same call = its workgroups along the pixel axis (<= ceil(B*GH*GW / 64) * n_classes: size
+                                   * the buffers with that, 16-byte aligned).  Every row of every channel the launch covers is
+                                   * written (nothing to zero).  mpose_bn_finalize / mpose_bn_bwd_coef add the rows in a fixed order
+                                   * (jobs' `part` fields): deterministic.  Not with fin* or MPOSE_CONV_PLANES_IN. */
 #define MPOSE_CONV_SUM_INPUTS 2   /* taps with acc == 1 read `in1` through `w1` and add into out0 (one pass, one
                                    * output): the data-gradient of a ResidualBlock's input, dX = conv_in^T(dC1) +
                                    * shortcut^T(dSC), models/margipose_model.py:39 */
@@ -236,6 +249,9 @@ typedef struct {
  * is stored, and stats0 receives (sum d, sum d*mask_src) instead of (sum, sum of squares). */
 int mpose_conv_fwd(const mpose_conv_geom* geom, const mpose_conv_operands* ops, int n_groups,
                    int flags, void* stream);
+/* Rows of the MPOSE_CONV_STATS_PART buffers that exactly this call of mpose_conv_fwd would write (nothing is launched;
+ * depends on the tile the library picks for the geometry, operands and flags), or a negative error code. */
+int mpose_conv_stat_rows(const mpose_conv_geom* geom, const mpose_conv_operands* ops, int n_groups, int flags);
 
 /* Weight-gradient of the same family: for every tap slice `widx`,
  *   dWp[split][widx][Cin/4][Npad][4] = sum over the split's slots of in(tap-shifted)^T * gout.
@@ -369,9 +385,16 @@ typedef struct {
   const unsigned* minmax;              /* optional (C, 2) extremes of the normalised tensor (mpose_conv_operands.mm0) ...           */
   float* amax_out;                     /* ... -> max over channels of max(0, scale*max + shift, scale*min + shift), accumulated     */
                                        /*     (atomic max) into sub-slot 0 of this activation amax slot (see mpose_absmax)          */
+  /* MPOSE_CONV_STATS_PART: when part != NULL the statistics are the sums over the rows of that buffer (header + [rows][part_ld][2],
+   * at most n_part rows) in place of `stats`, and when mm_part != NULL the extremes are the maxima over the rows of that buffer
+   * in place of `minmax` (amax_out is then WRITTEN to sub-slot 0, not accumulated). */
+  const float* part;
+  const float* mm_part;
+  int n_part, part_ld;
 } mpose_bn_job;
 
-/* For every job: derive scale/shift (+ mean/invstd); train != 0 also updates the running stats. */
+/* For every job: derive scale/shift (+ mean/invstd); train bit 0: batch statistics (also updates the running stats);
+ * train bit 1: the jobs carry MPOSE_CONV_STATS_PART rows (`part`; the launch then runs 1024 threads per job). */
 int mpose_bn_finalize(const mpose_bn_job* jobs_dev, int n_jobs, int train, float eps,
                       float momentum, void* stream);
 
@@ -444,9 +467,15 @@ typedef struct {
   int sg_col;                          /* column of `sums` holding sum g for this BN */
   float* dconv_bias;                   /* optional: gradient of the producing conv's bias (zero in train mode, where the
                                         * batch mean removes the bias; gamma*invstd*sum g with frozen statistics) */
+  /* MPOSE_CONV_STATS_PART: when part != NULL (and bit 1 of mode is clear) the sums are the sums over the rows of that buffer
+   * (header + [rows][part_ld][sums_stride], at most n_part rows), same columns as `sums`. */
+  const float* part;
+  int n_part, part_ld;
 } mpose_bn_bwd_coef_job;
 
-int mpose_bn_bwd_coef(const mpose_bn_bwd_coef_job* jobs_dev, int n_jobs, int eval_mode, void* stream);
+/* mode: bit 0 = eval_mode (running statistics were constants), bit 1 = read `sums` even where a job has `part`,
+ * bit 2 = 1024 threads per job (launches whose jobs carry partial rows). */
+int mpose_bn_bwd_coef(const mpose_bn_bwd_coef_job* jobs_dev, int n_jobs, int mode, void* stream);
 
 /* 3x3 pooling over NHWC with the producer's BN+ReLU applied on the fly (scale/shift may be NULL = identity).
  * kind 0: max pool, stride 2, pad 1 (the reference rewrites MaxPool2d padding to k//2, models/margipose_model.py:111-117);

@@ -59,8 +59,15 @@ def build(force=False, verbose=False):
         log.append('==== %s\n%s' % (os.path.basename(src), text))
         if verbose:
             print('\n'.join(l for l in text.splitlines() if 'remark:' not in l))
-    with open(LOG_PATH, 'w' if len(procs) == len(objs) else 'a') as f:
-        f.write('\n'.join(log))
+    # the log keeps ONE section per source: sections of the sources that were not recompiled are carried over
+    sections = {}
+    if len(procs) != len(objs) and os.path.exists(LOG_PATH):
+        for sec in open(LOG_PATH).read().split('==== ')[1:]:
+            sections[sec.split('\n', 1)[0]] = '==== ' + sec.rstrip('\n')
+    for entry in log:
+        sections[entry.split('\n', 1)[0][5:]] = entry.rstrip('\n')
+    with open(LOG_PATH, 'w') as f:
+        f.write('\n'.join(sections[k] for k in sorted(sections)) + '\n')
     cmd = [_hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB_PATH] + objs
     subprocess.run(cmd, check=True)
     return LIB_PATH

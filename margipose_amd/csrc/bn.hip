@@ -18,8 +18,12 @@
 namespace mpose {
 namespace {
 
-__global__ __launch_bounds__(256) void bn_finalize_k(const mpose_bn_job* __restrict__ jobs, int train, float eps, float momentum) {
-  bn_finalize_job<false>(jobs[blockIdx.x], train, eps, momentum);       // (common.h)
+// 256 threads per job, or 1024 when the statistics arrive as per-workgroup partial rows (MPOSE_CONV_STATS_PART: a 128-channel
+// job then sums 256 rows with eight row slices of 128 channel lanes, 32 rows per thread, eight loads in flight)
+__global__ __launch_bounds__(1024) void bn_finalize_k(const mpose_bn_job* __restrict__ jobs, int train, float eps, float momentum) {
+  __shared__ double sh[1024 * 2];
+  // (common.h; bit 1: the statistics are the jobs' partial rows -- gridDim.y workgroups share a job's channels)
+  bn_finalize_job<false>(jobs[blockIdx.x], train & 1, eps, momentum, (train & 2) ? sh : nullptr, (int)blockIdx.y, (int)gridDim.y);
 }
 
 struct BnAddArgs {
@@ -193,12 +197,34 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_finish_k(BnReduceArgs a, in
 
 // eval_mode: the forward normalised with the RUNNING statistics (constants), so dx = gamma*invstd*g (c1 = c2 = 0);
 // dgamma / dbeta keep their formulas with mean / invstd = the running ones (bn_finalize_k stores them in eval mode too).
-__global__ __launch_bounds__(256) void bn_bwd_coef_k(const mpose_bn_bwd_coef_job* __restrict__ jobs, int eval_mode) {
+__global__ __launch_bounds__(1024) void bn_bwd_coef_k(const mpose_bn_bwd_coef_job* __restrict__ jobs, int mode) {
+  __shared__ double sh[1024 * 4];
   const mpose_bn_bwd_coef_job j = jobs[blockIdx.x];
+  const int eval_mode = mode & 1;
+  const bool from_part = j.part != nullptr && !(mode & 2);       // MPOSE_CONV_STATS_PART rows instead of `sums`
   const double n = (double)j.count;
-  for (int c = threadIdx.x; c < j.C; c += 256) {
-    const double sg = j.sums[(size_t)c * j.sums_stride + j.sg_col];
-    const double sgx = j.sums[(size_t)c * j.sums_stride + j.which];
+  const int nth = (int)blockDim.x;
+  // (gridDim.y workgroups share a job's channels, 32-channel granules)
+  const int gran = ((j.C + 31) / 32 + (int)gridDim.y - 1) / (int)gridDim.y * 32;
+  const int c_lo = (int)blockIdx.y * gran, c_hi = (c_lo + gran < j.C) ? c_lo + gran : j.C;
+  for (int cblk = c_lo; cblk < c_hi; cblk += nth) {
+    const int c = cblk + (int)threadIdx.x;
+    double ps[4] = {0.0, 0.0, 0.0, 0.0};
+    if (from_part) {       // (uniform per workgroup: the helper contains barriers)
+      const int nc = c_hi - cblk < nth ? c_hi - cblk : nth;
+      if (j.sums_stride == 4) {
+        reduce_part_rows<4>(j.part, j.n_part, j.part_ld, cblk, nc, sh, ps);
+      } else {
+        double p2[2] = {0.0, 0.0};
+        reduce_part_rows<2>(j.part, j.n_part, j.part_ld, cblk, nc, sh, p2);
+        ps[0] = p2[0]; ps[1] = p2[1];
+      }
+    }
+    if (c >= c_hi) continue;
+    // (selects, not ps[runtime index]: a dynamically indexed register array goes to scratch)
+    auto pick = [&](int k) { return k == 0 ? ps[0] : (k == 1 ? ps[1] : (k == 2 ? ps[2] : ps[3])); };
+    const double sg = from_part ? pick(j.sg_col) : j.sums[(size_t)c * j.sums_stride + j.sg_col];
+    const double sgx = from_part ? pick(j.which) : j.sums[(size_t)c * j.sums_stride + j.which];
     const double mean = (double)j.mean[c], invstd = (double)j.invstd[c], gamma = (double)j.gamma[c];
     const double sgxhat = invstd * (sgx - mean * sg);
     const double c0 = gamma * invstd;
@@ -318,9 +344,11 @@ extern "C" int mpose_sizeof(int which) {
   }
 }
 
+// train: bit 0 = batch statistics; bit 1 = the jobs carry MPOSE_CONV_STATS_PART rows (1024 threads per job)
 extern "C" int mpose_bn_finalize(const mpose_bn_job* jobs_dev, int n_jobs, int train, float eps, float momentum, void* stream) {
   if (n_jobs <= 0) return 0;
-  bn_finalize_k<<<n_jobs, 256, 0, (hipStream_t)stream>>>(jobs_dev, train, eps, momentum);
+  if (train & 2) bn_finalize_k<<<dim3(n_jobs, 4), 1024, 0, (hipStream_t)stream>>>(jobs_dev, train & 3, eps, momentum);
+  else bn_finalize_k<<<n_jobs, 256, 0, (hipStream_t)stream>>>(jobs_dev, train & 3, eps, momentum);
   return launch_status();
 }
 
@@ -401,9 +429,11 @@ extern "C" int mpose_bn_bwd_reduce_ws(const mpose_bn_bwd_reduce_operands* ops, i
   return launch_status();
 }
 
-extern "C" int mpose_bn_bwd_coef(const mpose_bn_bwd_coef_job* jobs_dev, int n_jobs, int eval_mode, void* stream) {
+// mode: bit 0 = eval_mode, bit 1 = ignore the jobs' partial rows (read `sums`), bit 2 = 1024 threads per job (jobs with partial rows)
+extern "C" int mpose_bn_bwd_coef(const mpose_bn_bwd_coef_job* jobs_dev, int n_jobs, int mode, void* stream) {
   if (n_jobs <= 0) return 0;
-  bn_bwd_coef_k<<<n_jobs, 256, 0, (hipStream_t)stream>>>(jobs_dev, eval_mode);
+  if (mode & 4) bn_bwd_coef_k<<<dim3(n_jobs, 4), 1024, 0, (hipStream_t)stream>>>(jobs_dev, mode & 3);
+  else bn_bwd_coef_k<<<n_jobs, 256, 0, (hipStream_t)stream>>>(jobs_dev, mode & 3);
   return launch_status();
 }
 

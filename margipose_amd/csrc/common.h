@@ -75,19 +75,20 @@ __device__ __forceinline__ float amax_gather(const float* slot) {          // wa
 }
 
 // Largest magnitude seen by a 256-thread workgroup -> atomic max on the uint view of its sub-slot (non-negative floats order
-// like their bit patterns).  Every thread of the workgroup must call it (it contains a barrier).
+// like their bit patterns).  Every thread of the workgroup (<= 1024 threads) must call it (it contains a barrier).
 __device__ __forceinline__ void block_amax_commit(float m, float* slot) {
   float* dst = slot + (blockIdx.x % MPOSE_AMAX_SUBSLOTS) * MPOSE_AMAX_STRIDE;
   block_amax_commit_one(m, dst);
 }
 // (single address: the weight tensors' slots, 16 workgroups each)
 __device__ __forceinline__ void block_amax_commit_one(float m, float* dst) {
-  __shared__ float amax_sm[4];
+  __shared__ float amax_sm[16];
   m = wave_max(m);
   if ((threadIdx.x & 63) == 0) amax_sm[threadIdx.x >> 6] = m;
   __syncthreads();
   if (threadIdx.x == 0) {
-    m = fmaxf(fmaxf(amax_sm[0], amax_sm[1]), fmaxf(amax_sm[2], amax_sm[3]));
+    m = amax_sm[0];
+    for (int w = 1; w < (int)((blockDim.x + 63) >> 6); ++w) m = fmaxf(m, amax_sm[w]);
     if (!(m == m)) m = __uint_as_float(0x7f800000u);          // NaN anywhere -> +inf (ordered above everything)
     // look first: a workgroup that would not raise the value skips the atomic (a stale look costs one extra atomic)
     const unsigned seen = __hip_atomic_load(reinterpret_cast<unsigned*>(dst), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -107,14 +108,75 @@ __device__ __forceinline__ float key_float(unsigned k) {
   return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
 }
 
+// mpose_conv_stat_rows: while non-NULL the convolution launchers add their grid's x extent to *mpose_dry_rows and launch nothing.
+extern thread_local int* mpose_dry_rows;
+// MPOSE_CONV_STATS_PART buffers are self-describing: float words 0..3 are a header whose first word holds (as an int) the number
+// of rows the last launch wrote; the rows start at word 4.  A launch that is one of several writing one buffer (the residue
+// launches of an x-dilated kernel) takes its first row and the total from here; {0, 0} = rows 0 .. gridDim.x - 1.
+struct PartPhase { int row0, total; };
+extern thread_local PartPhase mpose_part_phase;
+constexpr int kPartHdr = 4;
+
+// Sum over the rows of an MPOSE_CONV_STATS_PART buffer, float [n_part][ld][NV]: channels c0 .. c0+nc-1 (nc <= blockDim.x), fixed
+// order, fp64.  All threads of the workgroup call it; thread t < nc returns with channel c0+t's NV sums in out[].  sh: >= blockDim.x * NV doubles.
+template <int NV, bool MAXIMUM = false>
+__device__ __forceinline__ void reduce_part_rows(const float* __restrict__ part, int max_rows, int ld, int c0, int nc, double* sh, double (&out)[NV]) {
+  const int nt = blockDim.x;
+  int n_part = *reinterpret_cast<const int*>(part);      // rows written by the producing launch (header)
+  n_part = n_part < 0 ? 0 : (n_part > max_rows ? max_rows : n_part);
+  part += kPartHdr;
+  const int cw = ((nc + 63) / 64) * 64;            // channel lanes per slice
+  const int S = nt / cw > 0 ? nt / cw : 1;         // row slices
+  const int t = threadIdx.x, cl = t % cw, sl = t / cw;
+  double a[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) a[v] = MAXIMUM ? -__builtin_huge_val() : 0.0;
+  if (sl < S && cl < nc) {
+    const float* p = part + (size_t)(c0 + cl) * NV;
+    int r = sl;
+    for (; r + 7 * S < n_part; r += 8 * S) {         // eight rows in flight per thread
+      float v[8][NV];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int k = 0; k < NV; ++k) v[u][k] = p[(size_t)(r + u * S) * ld * NV + k];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int k = 0; k < NV; ++k) a[k] = MAXIMUM ? fmax(a[k], (double)v[u][k]) : a[k] + (double)v[u][k];
+    }
+    for (; r < n_part; r += S)
+#pragma unroll
+      for (int k = 0; k < NV; ++k) { const double x = (double)p[(size_t)r * ld * NV + k]; a[k] = MAXIMUM ? fmax(a[k], x) : a[k] + x; }
+  }
+  __syncthreads();                                   // (sh may still be read from an earlier call)
+  if (sl < S && cl < nc) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) sh[(size_t)(sl * cw + cl) * NV + k] = a[k];
+  }
+  __syncthreads();
+  if (t < nc) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) out[k] = MAXIMUM ? -__builtin_huge_val() : 0.0;
+    for (int s_ = 0; s_ < S; ++s_)
+#pragma unroll
+      for (int k = 0; k < NV; ++k) { const double x = sh[(size_t)(s_ * cw + t) * NV + k]; out[k] = MAXIMUM ? fmax(out[k], x) : out[k] + x; }
+  }
+}
+
 // One mpose_bn_finalize job: BatchNorm statistics -> (scale, shift, mean, invstd), the running-statistics update, and the exact
 // largest relu(scale*x + shift) from the channel extremes.  Run by bn_finalize_k (bn.hip) and -- FRESH -- by the last workgroup
 // of the convolution launch whose epilogues accumulated the statistics (conv.hip): those sums and extremes were written by other
 // workgroups' atomics moments ago, so they are read at device scope.  All 256 threads of the workgroup call it.
 template <bool FRESH>
-__device__ __forceinline__ void bn_finalize_job(const mpose_bn_job& j, int train, float eps, float momentum) {
+__device__ __forceinline__ void bn_finalize_job(const mpose_bn_job& j, int train, float eps, float momentum, double* sh = nullptr,
+                                                int part_i = 0, int n_parts = 1) {
+  // (n_parts > 1: this workgroup takes the part_i-th share of the job's channels, 32-channel granules)
+  const int gran = ((j.C + 31) / 32 + n_parts - 1) / n_parts * 32;
+  const int c_lo = part_i * gran, c_hi = (c_lo + gran < j.C) ? c_lo + gran : j.C;
   if (j.eps > 0.f) eps = j.eps;
-  const bool want_amax = train && j.minmax != nullptr && j.amax_out != nullptr;
+  const bool from_part = !FRESH && train && sh != nullptr && j.part != nullptr;        // MPOSE_CONV_STATS_PART (sh: blockDim.x * 2 doubles)
+  const bool want_amax = train && (j.minmax != nullptr || (from_part && j.mm_part != nullptr)) && j.amax_out != nullptr;
   float amax = 0.f;
   auto ld_f64 = [](const double* p) -> double {
     if (!FRESH) return *p;
@@ -124,15 +186,24 @@ __device__ __forceinline__ void bn_finalize_job(const mpose_bn_job& j, int train
     if (!FRESH) return *p;
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
-  for (int c = threadIdx.x; c < j.C; c += 256) {
+  const int nth = (int)blockDim.x;
+  for (int cblk = c_lo; cblk < c_hi; cblk += nth) {
+    const int c = cblk + (int)threadIdx.x;
+    double psum[2] = {0.0, 0.0}, pmm[2] = {0.0, 0.0};
+    if (from_part) {       // (uniform per workgroup: the helper contains barriers)
+      const int nc = c_hi - cblk < nth ? c_hi - cblk : nth;
+      reduce_part_rows<2>(j.part, j.n_part, j.part_ld, cblk, nc, sh, psum);
+      if (want_amax && j.mm_part != nullptr) reduce_part_rows<2, true>(j.mm_part, j.n_part, j.part_ld, cblk, nc, sh, pmm);
+    }
+    if (c >= c_hi) continue;
     // The conv kernels are bias-free; a producing conv's bias b only shifts the BN input: batch/running mean
     // of (y + b) = mean(y) + b, and  scale*(y + b) + beta - (mean + b)*scale  ==  scale*y + beta - mean*scale.
     const double cb = (j.conv_bias != nullptr) ? (double)j.conv_bias[c] : 0.0;
     double mean, var;
     if (train) {
       const double n = (double)j.count;
-      mean = ld_f64(j.stats + 2 * c) / n;
-      var = ld_f64(j.stats + 2 * c + 1) / n - mean * mean;
+      mean = (from_part ? psum[0] : ld_f64(j.stats + 2 * c)) / n;
+      var = (from_part ? psum[1] : ld_f64(j.stats + 2 * c + 1)) / n - mean * mean;
       if (var < 0.0) var = 0.0;
       if (j.running_mean != nullptr) {
         const double unbiased = (j.count > 1) ? var * n / (n - 1.0) : var;
@@ -150,11 +221,29 @@ __device__ __forceinline__ void bn_finalize_job(const mpose_bn_job& j, int train
     j.shift[c] = shf;
     if (j.mean != nullptr) { j.mean[c] = (float)mean; j.invstd[c] = (float)invstd; }
     if (want_amax) {       // relu(scale * x + shift) is monotone in x: its largest value sits at one of the channel's two extremes
-      const float vmax = key_float(ld_u32(j.minmax + 2 * c)), vmin = -key_float(ld_u32(j.minmax + 2 * c + 1));
-      amax = fmaxf(amax, fmaxf(fmaf(vmax, scf, shf), fmaf(vmin, scf, shf)));       // (fmaxf drops the NaN of an untouched key)
+      const bool pm = from_part && j.mm_part != nullptr;
+      const float vmax = pm ? (float)pmm[0] : key_float(ld_u32(j.minmax + 2 * c));
+      const float vmin = pm ? -(float)pmm[1] : -key_float(ld_u32(j.minmax + 2 * c + 1));
+      amax = fmaxf(amax, fmaxf(fmaf(vmax, scf, shf), fmaf(vmin, scf, shf)));       // (fmaxf drops the NaN of an untouched key / -inf * 0)
     }
   }
-  if (want_amax) block_amax_commit_one(amax, j.amax_out);       // (uniform: every thread of the workgroup gets here)
+  if (want_amax) {       // (uniform: every thread of the workgroup gets here)
+    if (from_part && j.mm_part != nullptr && n_parts == 1) {       // the slot is this job's alone: written, not accumulated
+      float* amax_sm = reinterpret_cast<float*>(sh);
+      __syncthreads();
+      amax = wave_max(amax);
+      if ((threadIdx.x & 63) == 0) amax_sm[threadIdx.x >> 6] = amax;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        float m = 0.f;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) m = fmaxf(m, amax_sm[w]);
+        if (!(m == m)) m = __uint_as_float(0x7f800000u);
+        j.amax_out[0] = m;
+      }
+    } else {
+      block_amax_commit_one(amax, j.amax_out);
+    }
+  }
 }
 
 struct Ptr3 {

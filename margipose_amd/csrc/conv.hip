@@ -30,7 +30,7 @@
 #endif
 #ifndef CV_EXP
 #define CV_EXP 0      // timing experiments (tools/igemm_exp.sh; wrong results): 32 no scale gathers, 1 no epilogue, 2 no K loop, 4 no split-K exchange,
-                      // 8 every B fragment from one place (L1-resident weights), 16 every A row from one place
+                      // 8 every B fragment from one place (L1-resident weights), 16 every A row from one place, 64 no statistics atomics
 #endif
 
 namespace mpose {
@@ -78,6 +78,7 @@ struct ConvArgs {
   int M;                          // slots per class = B*GH*GW
   int n_mtiles;
   int flags;
+  int part_row0, part_rows;       // MPOSE_CONV_STATS_PART: first row this launch writes, rows in the buffers' headers
   int in_bias;                    // bytes: max negative tap shift, folded into the input buffer base
 };
 
@@ -995,6 +996,11 @@ __global__ __launch_bounds__(256, (slim_tile<RN, MODE, NPL, ROWG>() ? 2 : 1)) vo
     }
   }
   __syncthreads();
+  // MPOSE_CONV_STATS_PART: this workgroup's sums go to row blockIdx.x of fp32 partial buffers with plain stores (the finalize /
+  // coefficient kernels add the rows up); otherwise fp64 atomics into the (C, 2) / (C, 4) accumulators.
+  const bool part = (a.flags & MPOSE_CONV_STATS_PART) != 0;
+  const int prow = a.part_row0 + (int)blockIdx.x;
+  const bool hdr_writer = prow == 0 && blockIdx.y == 0;
 #pragma unroll
   for (int set = 0; set < (ACC1 ? 2 : 1); ++set) {
     double* stats = set ? op.stats1 : op.stats0;
@@ -1007,9 +1013,15 @@ __global__ __launch_bounds__(256, (slim_tile<RN, MODE, NPL, ROWG>() ? 2 : 1)) vo
         s += d[0]; q += d[1];
       }
       const int n = n0 + tid;
-      if (n < cout) {
-        atomicAdd(stats + (size_t)n * 2, (double)s);
-        atomicAdd(stats + (size_t)n * 2 + 1, (double)q);
+      if (n < cout && !(CV_EXP & 64)) {
+        if (part) {
+          float* pb = reinterpret_cast<float*>(stats);
+          if (hdr_writer && tid == 0) *reinterpret_cast<int*>(pb) = a.part_rows;
+          reinterpret_cast<float2*>(pb + kPartHdr)[(size_t)prow * cout + n] = make_float2(s, q);
+        } else {
+          atomicAdd(stats + (size_t)n * 2, (double)s);
+          atomicAdd(stats + (size_t)n * 2 + 1, (double)q);
+        }
       }
     }
   }
@@ -1017,8 +1029,14 @@ __global__ __launch_bounds__(256, (slim_tile<RN, MODE, NPL, ROWG>() ? 2 : 1)) vo
     float a_ = sMM[tid * 2], b_ = sMM[tid * 2 + 1];
 #pragma unroll
     for (int w = 1; w < 4; ++w) { a_ = fmaxf(a_, sMM[(w * BN + tid) * 2]); b_ = fmaxf(b_, sMM[(w * BN + tid) * 2 + 1]); }
-    atomicMax(op.mm0 + (size_t)(n0 + tid) * 2, float_key(a_));
-    atomicMax(op.mm0 + (size_t)(n0 + tid) * 2 + 1, float_key(b_));
+    if (part) {
+      float* pb = reinterpret_cast<float*>(op.mm0);
+      if (hdr_writer && tid == 0) *reinterpret_cast<int*>(pb) = a.part_rows;
+      reinterpret_cast<float2*>(pb + kPartHdr)[(size_t)prow * g.Cout0 + n0 + tid] = make_float2(a_, b_);
+    } else {
+      atomicMax(op.mm0 + (size_t)(n0 + tid) * 2, float_key(a_));
+      atomicMax(op.mm0 + (size_t)(n0 + tid) * 2 + 1, float_key(b_));
+    }
   }
   if (op.red_sums != nullptr && tid < BN && n0 + tid < g.Cout0) {
     float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1027,8 +1045,14 @@ __global__ __launch_bounds__(256, (slim_tile<RN, MODE, NPL, ROWG>() ? 2 : 1)) vo
       const float4 d = *reinterpret_cast<const float4*>(sRed + (w * BN + tid) * 4);
       t.x += d.x; t.y += d.y; t.z += d.z; t.w += d.w;
     }
-    double* d = op.red_sums + (size_t)(n0 + tid) * 4;
-    atomicAdd(d, (double)t.x); atomicAdd(d + 1, (double)t.y); atomicAdd(d + 2, (double)t.z); atomicAdd(d + 3, (double)t.w);
+    if (part) {
+      float* pb = reinterpret_cast<float*>(op.red_sums);
+      if (hdr_writer && tid == 0) *reinterpret_cast<int*>(pb) = a.part_rows;
+      reinterpret_cast<float4*>(pb + kPartHdr)[(size_t)prow * g.Cout0 + n0 + tid] = t;
+    } else if (!(CV_EXP & 64)) {
+      double* d = op.red_sums + (size_t)(n0 + tid) * 4;
+      atomicAdd(d, (double)t.x); atomicAdd(d + 1, (double)t.y); atomicAdd(d + 2, (double)t.z); atomicAdd(d + 3, (double)t.w);
+    }
   }
   // The last workgroup of this group's launch to get here turns the statistics into the BatchNorm vectors (mpose_bn_finalize's
   // job, common.h).  Every workgroup waits until its device-scope atomics have been ACKNOWLEDGED (vmcnt: they are performed at
@@ -1056,6 +1080,7 @@ int launch_conv(const ConvArgs& a0, int n_groups, hipStream_t s) {
   constexpr int wave_b = SLIM ? 2 * 2 * RG_SLIM_ROWS * A_ROW_B + 16 * A_ROW_B : 2 * (ROWG ? RG_TILE_B : A_TILE_B);
   constexpr int lds = 4 * wave_b + 2 * 4 * BN * 2 * 4 + 4 * 64 * 4 + 4 * BN * 2 * 4;
   static_assert(!SLIM || 2 * lds <= 160 * 1024, "two workgroups per CU");
+  if (mpose_dry_rows) { *mpose_dry_rows += ((a0.M + 256 / KS - 1) / (256 / KS)) * a0.g.n_classes; return 0; }     // (mpose_conv_stat_rows)
   static bool attr_set = false;          // > 64 KiB of dynamic LDS has to be requested once per kernel
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_k<RN, MODE, KS, PRO, NPL, ROWG>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
@@ -1066,6 +1091,8 @@ int launch_conv(const ConvArgs& a0, int n_groups, hipStream_t s) {
   a.n_mtiles = (a.M + 256 / KS - 1) / (256 / KS);
   const int cmax = a.g.Cout1 > a.g.Cout0 ? a.g.Cout1 : a.g.Cout0;
   dim3 grid(a.n_mtiles * a.g.n_classes, (cmax + BN - 1) / BN, n_groups);
+  a.part_row0 = mpose_part_phase.row0;
+  a.part_rows = mpose_part_phase.total > 0 ? mpose_part_phase.total : (int)grid.x;
   conv_igemm_k<RN, MODE, KS, PRO, NPL, ROWG><<<grid, 256, lds, s>>>(a);
   return launch_status();
 }
@@ -1587,6 +1614,9 @@ __global__ __launch_bounds__(256) void unpack_wgrads_k(const mpose_unpack_job* _
 
 using namespace mpose;
 
+thread_local int* mpose::mpose_dry_rows = nullptr;
+thread_local mpose::PartPhase mpose::mpose_part_phase = {0, 0};
+
 int mpose_conv_planes_launch(const mpose_conv_geom* geom, const mpose_conv_operands* ops, int n_groups, int flags, int mode,
                              int cmax, void* stream);      // conv_p.hip
 int mpose_conv_h2_launch(const mpose_conv_geom* geom, const mpose_conv_operands* ops, int n_groups, int flags, int mode,
@@ -1676,6 +1706,7 @@ extern "C" int mpose_conv_fwd(const mpose_conv_geom* geom_, const mpose_conv_ope
     if (ops[i].fin_count && ((flags & MPOSE_CONV_PLANES_IN) || !ops[i].fin0 || !ops[i].stats0 || (ops[i].fin1 && (!acc1 || !ops[i].stats1)) ||
                              sum_inputs)) return MPOSE_EINVAL;
     if (!ops[i].fin_count && (ops[i].fin0 || ops[i].fin1)) return MPOSE_EINVAL;
+    if ((flags & MPOSE_CONV_STATS_PART) && (ops[i].fin_count || (flags & MPOSE_CONV_PLANES_IN))) return MPOSE_EINVAL;
     if (acc1 && (!ops[i].w1 || !ops[i].out1)) return MPOSE_EINVAL;
     if ((ops[i].in_scale != nullptr) != (ops[0].in_scale != nullptr)) return MPOSE_EINVAL;
     if (ops[i].in_scale && (acc1 || !ops[i].in_shift)) return MPOSE_EINVAL;
@@ -1691,6 +1722,11 @@ extern "C" int mpose_conv_fwd(const mpose_conv_geom* geom_, const mpose_conv_ope
                !ops[i].red_sums && !ops[i].fin_count;
     if (simple) {
       const int in_ld = geom->in_ld > 0 ? geom->in_ld : geom->Cin, o_ld = geom->out_ld0 > 0 ? geom->out_ld0 : geom->Cout0;
+      int rows_phase = 0;
+      if ((flags & MPOSE_CONV_STATS_PART) && !mpose_dry_rows) {     // each residue's launch writes its own block of partial rows
+        rows_phase = mpose_conv_stat_rows(&pg, ops, n_groups, flags);
+        if (rows_phase < 0) return rows_phase;
+      }
       for (int r = 0; r < d; ++r) {
         mpose_conv_operands po[MPOSE_MAX_GROUP];
         for (int i = 0; i < n_groups; ++i) {
@@ -1698,7 +1734,9 @@ extern "C" int mpose_conv_fwd(const mpose_conv_geom* geom_, const mpose_conv_ope
           po[i].in = ops[i].in + (long)r * in_ld;
           po[i].out0 = ops[i].out0 + (long)r * o_ld;
         }
+        if (rows_phase) mpose_part_phase = PartPhase{r * rows_phase, d * rows_phase};
         rc = mpose_conv_fwd(&pg, po, n_groups, flags, stream);
+        mpose_part_phase = PartPhase{0, 0};
         if (rc) return rc;
       }
       return 0;
@@ -1775,6 +1813,15 @@ extern "C" int mpose_conv_fwd(const mpose_conv_geom* geom_, const mpose_conv_ope
   if (cmax % 128 == 0) return launch_conv_ks<4>(a, mode, cmax, n_groups, s);
   if (cmax % 96 == 0 && npad % 96 == 0) return launch_conv_ks<3>(a, mode, cmax, n_groups, s);
   return launch_conv_ks<2>(a, mode, cmax, n_groups, s);
+}
+
+extern "C" int mpose_conv_stat_rows(const mpose_conv_geom* geom, const mpose_conv_operands* ops, int n_groups, int flags) {
+  int rows = 0;
+  int* const outer = mpose_dry_rows;
+  mpose_dry_rows = &rows;
+  const int rc = mpose_conv_fwd(geom, ops, n_groups, flags, nullptr);
+  mpose_dry_rows = outer;
+  return rc ? (rc < 0 ? rc : -rc) : rows;
 }
 
 static int x_phases(const mpose_conv_geom& g, mpose_conv_geom* phase) {       // ... whose weight gradient the row form takes

@@ -65,6 +65,7 @@ struct ConvHArgs {
   int M;                          // slots per class = B*GH*GW
   int n_mtiles;
   int flags;
+  int part_row0, part_rows;       // MPOSE_CONV_STATS_PART: first row this launch writes, rows in the buffers' headers
   unsigned in_slab;               // bytes of one (channel octet, plane) slab of the input: B*IH*IW*16
 };
 
@@ -489,6 +490,9 @@ __global__ __launch_bounds__(256, 2) void conv_h2_k(ConvHArgs a) {
   __syncthreads();
   // cross-wave sums: column `tid` of the workgroup's BN output columns is held by the WM waves (wn_, 0..WM-1)
   const int wn_ = tid / (32 * RN), col = tid - wn_ * 32 * RN;
+  const bool part = (a.flags & MPOSE_CONV_STATS_PART) != 0;      // plain stores into row blockIdx.x of fp32 partial buffers
+  const int prow = a.part_row0 + (int)blockIdx.x;
+  const bool hdr_writer = prow == 0 && blockIdx.y == 0;
 #pragma unroll
   for (int set = 0; set < (ACC1 ? 2 : 1); ++set) {
     double* stats = set ? op.stats1 : op.stats0;
@@ -502,8 +506,14 @@ __global__ __launch_bounds__(256, 2) void conv_h2_k(ConvHArgs a) {
       }
       const int n = n0 + tid;
       if (n < cout) {
-        atomicAdd(stats + (size_t)n * 2, (double)s);
-        atomicAdd(stats + (size_t)n * 2 + 1, (double)q);
+        if (part) {
+          float* pb = reinterpret_cast<float*>(stats);
+          if (hdr_writer && tid == 0) *reinterpret_cast<int*>(pb) = a.part_rows;
+          reinterpret_cast<float2*>(pb + kPartHdr)[(size_t)prow * cout + n] = make_float2(s, q);
+        } else {
+          atomicAdd(stats + (size_t)n * 2, (double)s);
+          atomicAdd(stats + (size_t)n * 2 + 1, (double)q);
+        }
       }
     }
   }
@@ -514,8 +524,14 @@ __global__ __launch_bounds__(256, 2) void conv_h2_k(ConvHArgs a) {
       a_ = fmaxf(a_, sMM[((wn_ * WM + w) * 32 * RN + col) * 2]);
       b_ = fmaxf(b_, sMM[((wn_ * WM + w) * 32 * RN + col) * 2 + 1]);
     }
-    atomicMax(op.mm0 + (size_t)(n0 + tid) * 2, float_key(a_));
-    atomicMax(op.mm0 + (size_t)(n0 + tid) * 2 + 1, float_key(b_));
+    if (part) {
+      float* pb = reinterpret_cast<float*>(op.mm0);
+      if (hdr_writer && tid == 0) *reinterpret_cast<int*>(pb) = a.part_rows;
+      reinterpret_cast<float2*>(pb + kPartHdr)[(size_t)prow * g.Cout0 + n0 + tid] = make_float2(a_, b_);
+    } else {
+      atomicMax(op.mm0 + (size_t)(n0 + tid) * 2, float_key(a_));
+      atomicMax(op.mm0 + (size_t)(n0 + tid) * 2 + 1, float_key(b_));
+    }
   }
   if (op.red_sums != nullptr && tid < BN && n0 + tid < g.Cout0) {
     float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -524,8 +540,14 @@ __global__ __launch_bounds__(256, 2) void conv_h2_k(ConvHArgs a) {
       const float4 d = *reinterpret_cast<const float4*>(sRed + ((wn_ * WM + w) * 32 * RN + col) * 4);
       t.x += d.x; t.y += d.y; t.z += d.z; t.w += d.w;
     }
-    double* d = op.red_sums + (size_t)(n0 + tid) * 4;
-    atomicAdd(d, (double)t.x); atomicAdd(d + 1, (double)t.y); atomicAdd(d + 2, (double)t.z); atomicAdd(d + 3, (double)t.w);
+    if (part) {
+      float* pb = reinterpret_cast<float*>(op.red_sums);
+      if (hdr_writer && tid == 0) *reinterpret_cast<int*>(pb) = a.part_rows;
+      reinterpret_cast<float4*>(pb + kPartHdr)[(size_t)prow * g.Cout0 + n0 + tid] = t;
+    } else {
+      double* d = op.red_sums + (size_t)(n0 + tid) * 4;
+      atomicAdd(d, (double)t.x); atomicAdd(d + 1, (double)t.y); atomicAdd(d + 2, (double)t.z); atomicAdd(d + 3, (double)t.w);
+    }
   }
 }
 
@@ -534,6 +556,8 @@ int launch_h2(const ConvHArgs& a0, int n_groups, hipStream_t s) {
   constexpr int BM = 32 * RM * WM, BN = 32 * RN * WN, BNL = (BN + 63) / 64 * 64;
   constexpr int lds = NBUF * KST * (4 * BM * 16 + 4 * BNL * 16) + BM * 4 + 2 * 4 * 32 * RN * 2 * 4 + 4 * 32 * RN * 2 * 4;
   static_assert(2 * lds <= 160 * 1024, "two workgroups per CU");
+  if (a0.g.Cin % (16 * KST)) return MPOSE_EINVAL;
+  if (mpose_dry_rows) { *mpose_dry_rows += ((a0.M + BM - 1) / BM) * a0.g.n_classes; return 0; }     // (mpose_conv_stat_rows)
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_h2_k<WM, WN, RM, RN, KST, NBUF, MODE, DUAL>),
@@ -546,6 +570,8 @@ int launch_h2(const ConvHArgs& a0, int n_groups, hipStream_t s) {
   a.n_mtiles = (a.M + BM - 1) / BM;
   const int cmax = a.g.Cout1 > a.g.Cout0 && MODE == 1 ? a.g.Cout1 : a.g.Cout0;
   dim3 grid(a.n_mtiles * a.g.n_classes, (cmax + BN - 1) / BN, n_groups);
+  a.part_row0 = mpose_part_phase.row0;
+  a.part_rows = mpose_part_phase.total > 0 ? mpose_part_phase.total : (int)grid.x;
   conv_h2_k<WM, WN, RM, RN, KST, NBUF, MODE, DUAL><<<grid, 256, lds, s>>>(a);
   return launch_status();
 }

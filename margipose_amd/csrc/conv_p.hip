@@ -500,6 +500,7 @@ int launch_planes(const ConvPArgs& a0, int n_groups, hipStream_t s) {
   constexpr int BM = 32 * RM * WM, BN = 32 * RN * WN, BNL = (BN + 63) / 64 * 64;
   constexpr int lds = NBUF * (NPL * 2 * BM * 16 + NPL * 2 * BNL * 16) + 2 * BM * 4 + 2 * 4 * 32 * RN * 2 * 4;
   static_assert(2 * lds <= 160 * 1024, "two workgroups per CU");
+  if (mpose_dry_rows) { *mpose_dry_rows += ((a0.M + BM - 1) / BM) * a0.g.n_classes; return 0; }     // (mpose_conv_stat_rows)
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_planes_k<WM, WN, RM, RN, NBUF, MODE, NPL>),

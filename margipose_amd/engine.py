@@ -43,10 +43,11 @@ UNPACK_DT = np.dtype([('src', 'u8'), ('dst', 'u8'), ('N', 'i4'), ('K', 'i4'), ('
                       ('n_split', 'i4'), ('sn', 'i8'), ('sk', 'i8'), ('st', 'i8'), ('accumulate', 'i4')], align=True)
 BN_DT = np.dtype([('stats', 'u8'), ('gamma', 'u8'), ('beta', 'u8'), ('running_mean', 'u8'), ('running_var', 'u8'),
                   ('scale', 'u8'), ('shift', 'u8'), ('mean', 'u8'), ('invstd', 'u8'), ('C', 'i4'), ('count', 'i4'),
-                  ('conv_bias', 'u8'), ('eps', 'f4'), ('pad_', 'i4'), ('minmax', 'u8'), ('amax_out', 'u8')], align=True)
+                  ('conv_bias', 'u8'), ('eps', 'f4'), ('pad_', 'i4'), ('minmax', 'u8'), ('amax_out', 'u8'),
+                  ('part', 'u8'), ('mm_part', 'u8'), ('n_part', 'i4'), ('part_ld', 'i4')], align=True)
 COEF_DT = np.dtype([('sums', 'u8'), ('gamma', 'u8'), ('mean', 'u8'), ('invstd', 'u8'), ('coef', 'u8'), ('dgamma', 'u8'),
                     ('dbeta', 'u8'), ('sums_stride', 'i4'), ('which', 'i4'), ('C', 'i4'), ('c_stride', 'i4'), ('count', 'i4'),
-                    ('sg_col', 'i4'), ('dconv_bias', 'u8')], align=True)
+                    ('sg_col', 'i4'), ('dconv_bias', 'u8'), ('part', 'u8'), ('n_part', 'i4'), ('part_ld', 'i4')], align=True)
 
 AMAX_SLOT = 16 * 64          # floats per activation amax slot (MPOSE_AMAX_SUBSLOTS * MPOSE_AMAX_STRIDE)
 _SIZES_CHECKED = False
@@ -343,6 +344,11 @@ class Engine:
         self._side_keep = []         # tensors the side stream still reads (released at the next bucket boundary)
         # (measured: no faster -- the step is bound by the sum of the heavy kernels' work, not by the main stream's chain of launches -- off)
         self.fuse_finalize = os.environ.get('MPOSE_FUSE_FINALIZE', '0') != '0'
+        # BatchNorm statistics (forward sums, channel extremes, backward sums) leave the convolution launches as per-workgroup
+        # partial rows written with plain stores (MPOSE_CONV_STATS_PART) and are added up by the finalize / coefficient kernels:
+        # the fp64 device-scope atomics they replace cost a 128-channel launch 20 us of ~110 -- 2.8 ms of a 24.6 ms training step
+        # (round 4, same box: 24.6 -> 21.8 ms).  MPOSE_STATS_PART=0 keeps the atomics (A/B runs); the fused finalize needs them.
+        self.stats_part = os.environ.get('MPOSE_STATS_PART', '1') != '0'
         self.inline_unpack = os.environ.get('MPOSE_INLINE_UNPACK', '0') != '0'     # (see unpack_after: measured no faster, off)
         self.overlap_wgrad = True    # +2.3 % step rate, bit-identical results; launches bracketed by a KernelTimer stay serial
         self.dp = None               # optional (process_group, world_size): gradient all-reduce after backward
@@ -557,6 +563,18 @@ class Engine:
             part_off += nsp * conv.size_g
             mx = max(mx, conv.cout * conv.cin * conv.T)
 
+        # MPOSE_CONV_STATS_PART buffers (header + rows): per BatchNorm the forward sums and, for bn1, the channel extremes; per
+        # block the backward sums of bn1 (2 per channel, from the second 3x3's data-gradient) and of bn2 + shortcut (4 per channel,
+        # from the next block's data-gradient).  Sized for the smallest pixel tile any engine uses (64).
+        sp_off = 0
+        sp = {}
+
+        def part_buf(key, g, Cs, k):
+            nonlocal sp_off
+            rows = -(-(g.B * g.GH * g.GW) // 64) * g.n_classes
+            sp[key] = (sp_off, rows)
+            sp_off += _rup(4 + rows * Cs * k, 4)
+
         k = 1
         for t in range(self.T):
             for i in range(10):
@@ -564,6 +582,14 @@ class Engine:
                 grp = self.stage_blocks[t][i]
                 base = (t * 10 + i) * 9
                 for c, b in enumerate(grp):
+                    gname = {'regular': 'f_in_regular', 'down': 'f_in_down', 'up': 'f_in_up'}[b.kind]
+                    g_in, g_c2 = self.geom(gname, B, hw_in(i), b), self.geom('f_conv2', B, hw_out(i), b)
+                    part_buf((id(b.bn1), 'f'), g_in, b.cout_s, 2)
+                    part_buf((id(b.bn1), 'mm'), g_in, b.cout_s, 2)
+                    part_buf((id(b.bns), 'f'), g_in, b.cout_s, 2)
+                    part_buf((id(b.bn2), 'f'), g_c2, b.cout_s, 2)
+                    part_buf((id(b.bn1), 'b'), g_c2, b.cout_s, 2)            # (d_conv2: the grid of f_conv2)
+                    part_buf((id(b.bn2), 'b'), g_c2, b.cout_s, 4)            # (the next block's d_in writes this block's output grid)
                     bn_job(fj[1 + base + c], b.bn1, cnt)
                     # largest relu(bn1(c1)) -- the operand of the block's second convolution -- from c1's channel extremes
                     fj[1 + base + c]['minmax'], fj[1 + base + c]['amax_out'] = self._mm_ptr(b.bn1), self._amax_f(t, i, 1, c)
@@ -585,6 +611,19 @@ class Engine:
         else:
             for i, op in enumerate([o for o in self.stem.ops if hasattr(o, 'conv')]):
                 unpack_job(uj[self.T * 90 + i], op.conv, self.stem_n_split(B, 8 * F, op))
+        tb['stat_part'] = torch.zeros(max(sp_off, 4), dtype=torch.float32, device=dev)
+        spb = tb['stat_part'].data_ptr()
+        tb['sp_ptr'] = dict((k_, spb + 4 * v[0]) for k_, v in sp.items())
+        if self.stats_part:
+            for t in range(self.T):
+                for i in range(10):
+                    base = (t * 10 + i) * 9
+                    for c, b in enumerate(self.stage_blocks[t][i]):
+                        for jn, bn in ((1 + base + c, b.bn1), (1 + base + 3 + c, b.bns), (1 + base + 6 + c, b.bn2)):
+                            fj[jn]['part'], fj[jn]['n_part'], fj[jn]['part_ld'] = tb['sp_ptr'][(id(bn), 'f')], sp[(id(bn), 'f')][1], b.cout_s
+                        fj[1 + base + c]['mm_part'] = tb['sp_ptr'][(id(b.bn1), 'mm')]
+                        for jn, pk in ((base + c, (id(b.bn2), 'b')), (base + 3 + c, (id(b.bn2), 'b')), (base + 6 + c, (id(b.bn1), 'b'))):
+                            cj[jn]['part'], cj[jn]['n_part'], cj[jn]['part_ld'] = tb['sp_ptr'][pk], sp[pk][1], b.cout_s
         tb['n_unpack'] = self.T * 90 + n_stem_convs
         tb['partials'] = torch.empty(part_off, dtype=torch.float32, device=dev)
         pbase = tb['partials'].data_ptr()
@@ -799,10 +838,14 @@ class Engine:
         op.fin_count = counters.data_ptr() + 4 * job0
         op.fin_eps, op.fin_momentum = BN_EPS, BN_MOMENTUM
 
-    def finalize_table(self, table, first, n, train):
+    def part_stats(self):
+        """Statistics leave the convolution launches as partial rows (MPOSE_CONV_STATS_PART); the fused finalize needs the atomics."""
+        return self.stats_part and not self.fuse_finalize
+
+    def finalize_table(self, table, first, n, train, part=False):
         base = table.data_ptr() + first * BN_DT.itemsize
-        check(lib().mpose_bn_finalize(c_void_p(base), n, int(train), ctypes.c_float(BN_EPS), ctypes.c_float(BN_MOMENTUM),
-                                      stream_ptr()), 'mpose_bn_finalize')
+        check(lib().mpose_bn_finalize(c_void_p(base), n, int(train) | (2 if (part and train) else 0), ctypes.c_float(BN_EPS),
+                                      ctypes.c_float(BN_MOMENTUM), stream_ptr()), 'mpose_bn_finalize')
 
     def part_ptr(self, B, S, conv):
         return self._tables_for(B, S // 8)['part_ptr'][id(conv)]
@@ -823,10 +866,10 @@ class Engine:
             nsp = g._n_split = d * self._n_split(slots // d, tiles, groups)
         return nsp
 
-    def finalize(self, tb, first, n, train):
+    def finalize(self, tb, first, n, train, part=False):
         base = tb['fin'].data_ptr() + first * BN_DT.itemsize
-        check(lib().mpose_bn_finalize(c_void_p(base), n, int(train), ctypes.c_float(BN_EPS), ctypes.c_float(BN_MOMENTUM),
-                                      stream_ptr()), 'mpose_bn_finalize')
+        check(lib().mpose_bn_finalize(c_void_p(base), n, int(train) | (2 if (part and train) else 0), ctypes.c_float(BN_EPS),
+                                      ctypes.c_float(BN_MOMENTUM), stream_ptr()), 'mpose_bn_finalize')
 
     def pack_weights(self, cmode):
         jobs = self._pack_jobs[cmode]
@@ -887,6 +930,9 @@ class Engine:
         f16 = cmode == 2
         # train mode on conv_igemm_k: the convolution launches finalise their own BatchNorms (no mpose_bn_finalize launches)
         fin_fused = train and not planes and self.fuse_finalize
+        # statistics as per-workgroup partial rows (MPOSE_CONV_STATS_PART) instead of fp64 atomics: conv_igemm_k / conv_h2_k only
+        spart = ctx['spart'] = bool(train and self.part_stats() and not planes)
+        sp = tb['sp_ptr']
         self.pack_weights(cmode)
         if f16:
             self.amax_f.zero_()
@@ -993,16 +1039,20 @@ class Engine:
                         if fused_h:          # c1 holds relu(bn1(conv)) here
                             op.epi_scale0, op.epi_shift0 = self._bnf_ptr(b.bn1, 0), self._bnf_ptr(b.bn1, 1)
                             op.out0_amax = self._amax_f(t, i, 1, c)
-                    if train:
+                    if train and spart:
+                        op.stats0, op.stats1 = sp[(id(b.bn1), 'f')], sp[(id(b.bns), 'f')]
+                        if f16:
+                            op.mm0 = sp[(id(b.bn1), 'mm')]
+                    elif train:
                         op.stats0, op.stats1 = self._stats_ptr(b.bn1), self._stats_ptr(b.bns)
                         if f16:
                             op.mm0 = self._mm_ptr(b.bn1)
                         if fin_fused:        # (the launch's last workgroup per column runs the two finalize jobs)
                             self.fuse_fin(op, tb['fin'], tb['fin_count'], self.fin_index(t, i, 0) + c, self.fin_index(t, i, 1) + c)
                     ops.append(op)
-                self.conv(g1, ops, pflags | (16 if (fused or fused_h) else 0))
+                self.conv(g1, ops, pflags | (16 if (fused or fused_h) else 0) | (256 if spart else 0))
                 if train and not fin_fused:
-                    self.finalize(tb, self.fin_index(t, i, 0), 6, True)
+                    self.finalize(tb, self.fin_index(t, i, 0), 6, True, spart)
                 # largest relu(bn1(c1)): what the next K loop (and its weight gradient) will split.  In training bn_finalize just
                 # derived it from c1's channel extremes (the convolution's epilogue took them); otherwise it is measured
                 if f16 and not fused_h and not train:
@@ -1048,14 +1098,16 @@ class Engine:
                         op.out0_amax = self._amax_f(t, i + 1, 0, c)           # (the axis permutation after block 4 keeps the maximum)
                     else:
                         op.out0 = c2[c].data_ptr()
-                    if train:
+                    if train and spart:
+                        op.stats0 = sp[(id(b.bn2), 'f')]
+                    elif train:
                         op.stats0 = self._stats_ptr(b.bn2)
                         if fin_fused:
                             self.fuse_fin(op, tb['fin'], tb['fin_count'], self.fin_index(t, i, 2) + c)
                     ops.append(op)
-                self.conv(self.geom('f_conv2', B, Hout, b0), ops, pflags | (16 if (fuse2 or fuse2_h) else 0))
+                self.conv(self.geom('f_conv2', B, Hout, b0), ops, pflags | (16 if (fuse2 or fuse2_h) else 0) | (256 if spart else 0))
                 if train and not fin_fused:
-                    self.finalize(tb, self.fin_index(t, i, 2), 3, True)
+                    self.finalize(tb, self.fin_index(t, i, 2), 3, True, spart)
                 if fuse2:
                     cur_p = nxt_p
                 elif fuse2_h:
@@ -1205,8 +1257,14 @@ class Engine:
         if f16:
             self.amax_b.zero_()
 
-        def run_coef(first, n):
-            check(L.mpose_bn_bwd_coef(c_void_p(coef_base + first * COEF_DT.itemsize), n, eval_bn, st()), 'mpose_bn_bwd_coef')
+        # (the backward's sums as partial rows too; an eval-mode forward has ctx['spart'] False but its backward may still use them)
+        spart = bool(self.part_stats() and not planes)
+        sp = tb['sp_ptr']
+
+        def run_coef(first, n, from_sums=False):
+            # mode: bit 0 eval, bit 1 the jobs' `sums` were written by a reduction pass (not partial rows), bit 2: 1024 threads
+            mode = eval_bn | (0 if (spart and not from_sums) else 2) | (4 if (spart and not from_sums) else 0)
+            check(L.mpose_bn_bwd_coef(c_void_p(coef_base + first * COEF_DT.itemsize), n, mode, st()), 'mpose_bn_bwd_coef')
 
         works = []          # in-flight gradient all-reduces (data parallel), one per finished bucket
         D = None            # gradient w.r.t. the stage input, cumulative over later stages (:195 is `inp = inp + ...`)
@@ -1250,7 +1308,7 @@ class Engine:
                         ro.sums = self._stats_ptr(b.bn2, True)
                         rops.append(ro)
                     self.bn_bwd_reduce(rops, Hout * Hout, B, Cs)
-                run_coef(jb, 6)
+                run_coef(jb, 6, from_sums=not sums_done)
                 d_c2 = [torch.empty(B, Hout, Hout, Cs, **f32) for _ in range(3)]
                 d_sc = [torch.empty(B, Hout, Hout, Cs, **f32) for _ in range(3)]
                 aops = []
@@ -1281,9 +1339,9 @@ class Engine:
                         op.in_amax, op.w0_amax = self._amax_b(t, i, 0, c), b.conv2.amax_ptr
                     op.mask_src = sv['c1'][c].data_ptr()
                     op.mask_scale, op.mask_shift = self._bnf_ptr(b.bn1, 0), self._bnf_ptr(b.bn1, 1)
-                    op.stats0 = self._stats_ptr(b.bn1, True)
+                    op.stats0 = sp[(id(b.bn1), 'b')] if spart else self._stats_ptr(b.bn1, True)
                     ops.append(op)
-                self.conv(self.geom('d_conv2', B, Hout, b0), ops, pflags)
+                self.conv(self.geom('d_conv2', B, Hout, b0), ops, pflags | (256 if spart else 0))
                 # (3) wgrad of the second 3x3 (its input relu(bn1(c1)) is recomputed while staging)
                 wops = []
                 for c, b in enumerate(grp):
@@ -1346,9 +1404,9 @@ class Engine:
                         pb, psv = self.stage_blocks[t][i - 1][c], saved[i - 1]
                         op.red_a, op.red_b = psv['c2'][c].data_ptr(), psv['sc'][c].data_ptr()
                         op.red_scale, op.red_shift = self._bnf_ptr(pb.bn2, 0), self._bnf_ptr(pb.bn2, 1)
-                        op.red_sums = self._stats_ptr(pb.bn2, True)
+                        op.red_sums = sp[(id(pb.bn2), 'b')] if spart else self._stats_ptr(pb.bn2, True)
                     ops.append(op)
-                self.conv(self.geom(kd, B, Hout, b0), ops, 2 | pflags)
+                self.conv(self.geom(kd, B, Hout, b0), ops, 2 | pflags | (256 if (spart and fuse_sums) else 0))
                 sums_done = fuse_sums
                 g = d_x
                 if i == 5 and any(sp != 0 for sp in self.spaces):     # the permutation is an involution

@@ -321,6 +321,21 @@ class _GraphStem:
                 coef.append(k)
             tb['fin_range'][n.name] = (f0, len(fin) - f0)
             tb['coef_range'][n.name] = (c0_, len(coef) - c0_)
+        # MPOSE_CONV_STATS_PART: one buffer of per-workgroup partial rows (header + [rows][cout][2]) per convolution that feeds a BatchNorm
+        sp_off, sp = 0, {}
+        for op in self.ops:
+            pk = (op.dst.name, getattr(op, 'c0', 0))
+            if isinstance(op, _ConvOp) and pk in tb['fin_job']:
+                g = self.geom(op, B, S, 'f')
+                rows = -(-(g.B * g.GH * g.GW) // 64) * g.n_classes + 8        # (smallest pixel tile; slack for x-dilated residue launches)
+                sp[pk] = (sp_off, rows, op.cout_s)
+                sp_off += (4 + rows * op.cout_s * 2 + 3) // 4 * 4
+        tb['stat_part'] = torch.zeros(max(sp_off, 4), dtype=torch.float32, device=eng.device)
+        tb['sp_ptr'] = dict((k_, tb['stat_part'].data_ptr() + 4 * v[0]) for k_, v in sp.items())
+        if eng.stats_part:
+            for pk, (_, rows, ld) in sp.items():
+                j = fin[tb['fin_job'][pk]]
+                j['part'], j['n_part'], j['part_ld'] = tb['sp_ptr'][pk], rows, ld
         tb['fin'] = _jobs_to_device(np.array(fin, dtype=BN_DT), eng.device)
         tb['coef'] = _jobs_to_device(np.array(coef, dtype=COEF_DT), eng.device)
         tb['n_fin'] = len(fin)
@@ -413,7 +428,10 @@ class _GraphStem:
                 o.in_, o.w0 = raw[src.name].data_ptr(), eng._wptr(op.conv)
                 o.in_scale, o.in_shift = sc, sh
                 o.out0 = raw[n.name].data_ptr() + 4 * op.c0
-                if train:
+                spart = train and eng.part_stats() and (n.name, op.c0) in tb['sp_ptr']
+                if spart:           # statistics as per-workgroup partial rows (no fp64 atomics); the finalize kernel adds them up
+                    o.stats0 = tb['sp_ptr'][(n.name, op.c0)]
+                elif train:
                     o.stats0 = self.sptr(n, False, op.c0)
                     job = tb['fin_job'].get((n.name, op.c0))
                     if eng.fuse_finalize and job is not None:     # the launch finalises this BatchNorm itself
@@ -424,7 +442,7 @@ class _GraphStem:
                                    relu=sc is not None)
                         measured.add(src.name)
                     o.in_amax, o.w0_amax = src.amax_f, op.conv.amax_ptr
-                eng.conv(self.geom(op, B, S, 'f'), [o], cflags)
+                eng.conv(self.geom(op, B, S, 'f'), [o], cflags | (256 if spart else 0))
             elif isinstance(op, _AddOp):
                 ao = BnAddOperands()
                 ao.a, ao.a_scale, ao.a_shift = raw[op.a.name].data_ptr(), self.fptr(op.a, 0), self.fptr(op.a, 1)
@@ -440,7 +458,7 @@ class _GraphStem:
             if train and all(id(p) in done for p in n.producers):
                 f0, nf = tb['fin_range'][n.name]
                 if nf and not eng.fuse_finalize:       # (otherwise the producing launches have finalised their channel ranges)
-                    eng.finalize_table(tb['fin'], f0, nf, True)
+                    eng.finalize_table(tb['fin'], f0, nf, True, eng.part_stats())
         if self.out_nodes is not None:
             out = [raw[n.name] for n in self.out_nodes]
         else:

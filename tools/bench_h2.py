@@ -17,6 +17,7 @@ from margipose_amd._lib import AbsmaxOperands, ConvOperands, SplitH2Operands, st
 L = _lib.lib()
 B = int(os.environ.get('B', '32'))
 CHECK = int(os.environ.get('CHECK', '0'))
+NOSTATS = int(os.environ.get('NOSTATS', '0'))      # 1: no BatchNorm statistics, 2: also no channel extremes / masks / consumer sums
 SLOT = 16 * 64
 F16X3, H2 = 32, 128
 
@@ -99,7 +100,7 @@ def run(H, C):
         fl = F16X3 | (H2 if h2 else 0)
         out0 = [torch.zeros(B, H, H, C, device='cuda') for _ in range(G)]
         out1 = [torch.zeros(B, H, H, C, device='cuda') for _ in range(G)]
-        stats = [torch.zeros(C, 8, dtype=torch.float64, device='cuda') for _ in range(G)]
+        stats = [torch.zeros(C, 8 + 2 * 64, dtype=torch.float64, device='cuda') for _ in range(G)]
         flavours = {}
         g = eng._geom(B, H, C, H, C, 0, H, 1, 1, [(0, 0, t9)], npad)
         ops = []
@@ -110,7 +111,10 @@ def run(H, C):
             else:
                 o.in_, o.in_scale, o.in_shift = xs[c].data_ptr(), sc.data_ptr(), sh.data_ptr()
             o.in_amax, o.w0_amax = axp[c].data_ptr(), a3.data_ptr()
-            o.stats0 = stats[c].data_ptr(); o.mm0 = stats[c].data_ptr() + 8 * 6 * C
+            if not NOSTATS:
+                o.stats0 = stats[c].data_ptr(); o.mm0 = stats[c].data_ptr() + 8 * 6 * C
+            elif NOSTATS == 3:
+                o.stats0 = stats[c].data_ptr()
             ops.append(o)
         flavours['f_conv2'] = (g, ops, fl)
         g = eng._geom(B, H, C, H, C, C, H, 1, 1, [(0, 0, t9 + [(0, 0, 0, 1)])], npad, npad)
@@ -127,7 +131,10 @@ def run(H, C):
         for c in range(G):
             o = ConvOperands(); o.in_, o.w0, o.out0 = (xs_h if h2 else xs)[c].data_ptr(), p3.data_ptr(), out0[c].data_ptr()
             o.in_amax, o.w0_amax = ax[c].data_ptr(), a3.data_ptr()
-            o.mask_src, o.mask_scale, o.mask_shift, o.stats0 = aux_a[c].data_ptr(), sc.data_ptr(), sh.data_ptr(), stats[c].data_ptr()
+            if NOSTATS < 2:
+                o.mask_src, o.mask_scale, o.mask_shift = aux_a[c].data_ptr(), sc.data_ptr(), sh.data_ptr()
+            if not NOSTATS:
+                o.stats0 = stats[c].data_ptr()
             ops.append(o)
         flavours['d_conv2'] = (g, ops, fl)
         g = eng._geom(B, H, C, H, C, C, H, 1, 1, [(0, 0, t9d + [(0, 0, 0, 1)])], npad, npad)
