@@ -33,6 +33,7 @@
 // Replaces Conv2d / ConvTranspose2d of reference src/margipose/models/margipose_model.py:33,67-82 and their data-gradients
 // inside the columns.
 #include <stdlib.h>
+#include <type_traits>
 #include "common.h"
 
 namespace mpose {
@@ -83,6 +84,9 @@ __device__ __forceinline__ f32x16 mfma_f16(const f16x8 a, const f16x8 b, const f
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
 
+#ifndef SCHED_HINTS
+#define SCHED_HINTS 1   // sched_group_barrier patterns in conv_h2r_k's K loop (0: hipcc's own order; A/B builds)
+#endif
 #ifndef CH_EXP
 #define CH_EXP 0      // timing experiments (tools/h2_exp.sh; wrong results): 1 no A traffic after the first tap of a chunk, 2 no B traffic,
                       // 4 plain tile order, 8 no DMA at all, 16 no MFMAs, 32 no fragment reads, 64 no epilogue stores, 128 no K loop
@@ -551,6 +555,605 @@ __global__ __launch_bounds__(256, 2) void conv_h2_k(ConvHArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// conv_h2r_k: the stride-1 form (one class, output grid = input grid: every 3x3 / 1x1 of a regular ResidualBlock and their
+// data-gradients).  What bounded conv_h2_k above is the LDS-DMA path itself: ~26 cycles per KiB and CU whatever the source
+// (measured: the same with every DMA out of range, i.e. without any L2 traffic), and a 128 x 128 tile that re-stages its A tile
+// for each of the nine taps moves 32 KiB per 96 MFMAs.  Here
+//   * A is staged ONCE per 16-channel chunk as a halo tile: the BM + (largest - smallest tap shift) consecutive pixels
+//     m0 + lo .. of both planes; a tap is an address shift of the fragment read, and a lane whose (pixel, tap) falls outside
+//     the image reads one of sixteen zero rows (the one of its own bank class: the read stays conflict-free) -- A traffic / 6;
+//   * the tile is tall and narrow, 256 pixels x 64 channels (4 waves stacked along the pixels, 64 x 64 each): all four waves
+//     share one B tile, half the B traffic per MFMA of a 128 x 128 tile; the 192-channel layers get 3 column tiles, 288 workgroups;
+//   * a step is one chunk x up to three taps (36 MFMAs per wave and barrier); B tiles of the next-but-one step and a share of the
+//     next chunk's A tile are issued at each barrier (one batch in flight: plain vmcnt(0)).
+// 9.2 MFMAs per KiB of DMA instead of 3.  Two workgroups per CU; two accumulators per block as above.
+// ---------------------------------------------------------------------------------------------------------------------
+struct ConvHRArgs {
+  mpose_conv_geom g;
+  mpose_conv_operands op[MPOSE_MAX_GROUP];
+  FastDiv div_gw, div_ghw;
+  int M;
+  int n_mtiles;
+  int flags;
+  int part_row0, part_rows;
+  unsigned in_slab;               // bytes of one (channel octet, plane) slab of the input: B*IH*IW*16
+  int lo;                         // smallest tap shift dy*IW + dx over ALL taps of the launch (pixels)
+  int NG;                         // 64-row groups of one staged A plane-half: ceil((256 + largest - smallest shift) / 64)
+  int a_rows;                     // rows of one (plane, half) sub-array of an A buffer: NG * 64 + 16 zero rows
+};
+
+constexpr int HR_BM = 256;
+constexpr int HR_TG = 3;          // taps per step
+constexpr int HR_MAXT = 9;        // taps per pass
+constexpr int HR_MAXNG = 6;       // 64-row groups of an A plane-half: 256 + (largest - smallest tap shift) <= 384 pixels
+
+template <int RN, int MODE>
+__global__ __launch_bounds__(256, 2) void conv_h2r_k(ConvHRArgs a) {
+  constexpr bool ACC1 = MODE == 1, SUM2 = MODE == 2;
+  constexpr int NPASS = MODE ? 2 : 1;
+  constexpr int BM = HR_BM, BN = 32 * RN, BNL = (BN + 63) / 64 * 64, NGN = BNL / 64;
+  constexpr int TG = HR_TG;
+  constexpr int B_TAP = 4 * BNL * 16;          // one tap's B tile: [plane][k half][BNL columns][16 B]
+  constexpr int B_SLOT = TG * B_TAP;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int SA = (HR_MAXNG * 64 + 16) * 16;        // bytes of one (plane, half) sub-array: compile-time, so that planes are immediate offsets
+  const int ABUF = 4 * SA;
+  unsigned char* sB = smem + 2 * ABUF;                                         // [2 slots][B_SLOT]
+  unsigned* sRow = reinterpret_cast<unsigned*>(sB + 2 * B_SLOT);               // [BM] output row byte offsets
+  float* sRed = reinterpret_cast<float*>(sB);                                  // epilogue scratch, aliases the (then idle) B ring:
+  float* sMM = sRed + 4 * BN * 4;                                              //   [4 waves][BN][4] and [4 waves][BN][2]
+  static_assert(4 * BN * 4 * 4 + 4 * BN * 2 * 4 <= 2 * B_SLOT, "epilogue scratch fits in the B ring");
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const mpose_conv_geom& g = a.g;
+  unsigned bid = blockIdx.x;
+  if ((gridDim.x & 7u) == 0 && !(CH_EXP & 4)) bid = (bid & 7u) * (gridDim.x >> 3) + (bid >> 3);
+  const int m0 = bid * BM;
+  const int n0 = blockIdx.y * BN;
+  const mpose_conv_operands& op = a.op[blockIdx.z];
+  const int n_taps = g.cls[0].n_taps;
+  const int IW = g.IW;
+  // lane t keeps tap t ({dy, dx, widx, acc}) and its row shift inside the staged tile, (dy*IW + dx) - lo
+  const int lane_tap = lane < MPOSE_MAX_TAPS ? *reinterpret_cast<const int*>(&g.cls[0].taps[lane < MPOSE_MAX_TAPS ? lane : 0]) : 0;
+  const int lane_shift = (int)(signed char)(lane_tap & 0xff) * IW + (int)(signed char)((lane_tap >> 8) & 0xff) - a.lo;
+  auto tap_word = [&](int t) { return __builtin_amdgcn_readlane(lane_tap, t); };
+  auto tap_shift = [&](int t) { return __builtin_amdgcn_readlane(lane_shift, t); };
+
+  // ---- per-lane state of the fragment reads: tile row of output pixel (wave, rm, li) and which taps stay inside the image ----
+  unsigned fr_ok[2] = {0u, 0u};
+#pragma unroll
+  for (int rm = 0; rm < 2; ++rm) {
+    const unsigned m = (unsigned)(m0 + wave * 64 + rm * 32 + li);
+    if ((int)m < a.M) {
+      const unsigned b = fdiv(m, a.div_ghw);
+      const unsigned rem = m - b * (unsigned)(g.GH * g.GW);
+      const int gy = (int)fdiv(rem, a.div_gw);
+      const int gx = (int)rem - gy * g.GW;
+      for (int t = 0; t < n_taps; ++t) {
+        const int tp = tap_word(t);
+        const int iy = gy + (int)(signed char)(tp & 0xff), ix = gx + (int)(signed char)((tp >> 8) & 0xff);
+        if ((unsigned)iy < (unsigned)g.IH && (unsigned)ix < (unsigned)g.IW) fr_ok[rm] |= 1u << t;
+      }
+    }
+  }
+  constexpr int zrow = HR_MAXNG * 64;          // first zero row of a sub-array
+  // ---- output row table ----
+  auto fill_rows = [&](int out_ld) {
+    const unsigned m = (unsigned)(m0 + tid);
+    sRow[tid] = (int)m < a.M ? m * (unsigned)out_ld * 4u : 0xFFFFF000u;      // (output grid = slot grid: pixel index = m)
+  };
+  // the zero rows of both A buffers (never written by the DMA: it covers rows 0 .. NG*64-1)
+  for (int i = tid; i < 2 * 4 * 16; i += 256) {
+    const int sub = i >> 4, r = i & 15;
+    *reinterpret_cast<u32x4*>(smem + sub * SA + (zrow + r) * 16) = u32x4{0u, 0u, 0u, 0u};
+  }
+
+  const int k16_total = g.Cin >> 4;
+  const int npad = g.Npad0;
+  const unsigned w_plane_b = (unsigned)npad * 16u;
+  const long npix = (long)g.B * g.IH * g.IW;
+  const __amdgpu_buffer_rsrc_t rs_in0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(op.in), 0, 0xFFFFFF00, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_in1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(SUM2 ? op.in1 : op.in), 0, 0xFFFFFF00, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(op.w0), 0, 0xFFFFFF00, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(MODE ? op.w1 : op.w0), 0, 0xFFFFFF00, 0x00020000);
+
+  const int ka0 = f16_scale_exp(amax_gather(op.in_amax));
+  const int ka1 = SUM2 ? f16_scale_exp(amax_gather(op.in1_amax)) : ka0;
+  const int kw0 = f16_scale_exp(*op.w0_amax);
+  const int kw1 = MODE ? f16_scale_exp(*op.w1_amax) : kw0;
+  const bool skip1 = SUM2 && (ka1 + kw1) - (ka0 + kw0) > 60;      // (see conv_h2_k)
+
+  f32x16 acc[2][RN], acx[2][RN];
+  int n_taps0 = 0;
+  for (int t = 0; t < n_taps; ++t) n_taps0 += (((tap_word(t) >> 24) & 0xff) == 0) ? 1 : 0;
+  const bool part = (a.flags & MPOSE_CONV_STATS_PART) != 0;
+  const int prow = a.part_row0 + (int)blockIdx.x;
+  const bool hdr_writer = prow == 0 && blockIdx.y == 0;
+
+#pragma unroll 1
+  for (int set = 0; set < NPASS; ++set) {
+    const int t_lo = set ? n_taps0 : 0;
+    const int nt = set ? n_taps - n_taps0 : (MODE ? n_taps0 : n_taps);
+    const int ng = (nt + TG - 1) / TG;                               // steps per chunk
+    const int n_steps = ((set && skip1) || (CH_EXP & 128)) ? 0 : k16_total * ng;
+    const bool second = set != 0;
+    if (!SUM2 || set == 0) {
+#pragma unroll
+      for (int rm = 0; rm < 2; ++rm)
+#pragma unroll
+        for (int rn = 0; rn < RN; ++rn)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { acc[rm][rn][r] = 0.0f; acx[rm][rn][r] = 0.0f; }
+    }
+    if (set == 0 || ACC1) {
+      const int ld_ = (set && ACC1) ? g.out_ld1 : g.out_ld0;
+      fill_rows(ld_ > 0 ? ld_ : ((set && ACC1) ? g.Cout1 : g.Cout0));
+    }
+
+    // ---- loop-invariant addresses of this pass ----
+    const int la = (a.NG + ng - 1) / ng;                            // A instructions per wave and batch
+    const unsigned bvoff0 = (CH_EXP & 2) ? kOob : (unsigned)((n0 + lane) * 16);
+    const int rowb0 = wave * 64 + li, rowb1 = rowb0 + 32;           // tile rows of this lane's two output pixels (before the tap shift)
+    // An LDS-DMA instruction costs its wave ~25 cycles when its operands are ready and ~180 when they are computed in line (scalar
+    // divisions, 64-bit compares: measured, 10 us of a 35 us workgroup), so everything that does not change from batch to batch
+    // lives in lane tables, handed to the scalar unit by v_readlane:
+    //   lane t (a tap of this pass):   byte offset of the tap's packed weights (chunk 0, plane 0, half 0)
+    //   lane k (this wave's k-th instruction of a halo tile, id = wave + 4k -> sub-array id / NG, row group id % NG):
+    //                                  LDS offset inside an A buffer, slab offset of (plane, half) inside a channel octet pair, first row
+    const unsigned tab_b = (unsigned)(((lane_tap >> 16) & 0xff) * k16_total * 4) * w_plane_b;
+    unsigned tab_adst, tab_asoff;
+    int tab_arow;
+    {
+      const int id = wave + 4 * (lane < HR_MAXNG ? lane : 0);
+      const int sub = id / a.NG, grp = id - sub * a.NG;
+      tab_adst = (unsigned)(sub * SA + grp * 1024);
+      tab_asoff = (unsigned)((sub & 1) * 2 + (sub >> 1)) * a.in_slab;
+      tab_arow = grp * 64;
+    }
+    const unsigned q0 = (unsigned)(m0 + a.lo + lane);               // pixel staged by this lane in row group 0 (wraps below zero: out of range)
+    const unsigned b_chunk = 4u * w_plane_b, a_chunk = 4u * a.in_slab;
+    const unsigned lds_b0 = (unsigned)(2 * ABUF) + (unsigned)(wave * BNL * 16);
+
+    // One DMA batch = the B tiles of step (cb, gb) into ring slot `bslot` + share `ja` of chunk ca's halo tile into A buffer ca & 1
+    // (b_live / a_live, wave-uniform: the step / chunk exists; otherwise the sources are out of range and zeros land where nobody reads).
+    auto issue_batch = [&](int cb, int gb, int bslot, bool b_live, int ca, int ja, bool a_live) {
+      if constexpr (CH_EXP & 8) return;
+      static_assert(NGN == 1, "one B instruction per wave and tap");
+#pragma unroll
+      for (int ti = 0; ti < TG; ++ti) {
+        const int t = gb * TG + ti;
+        if (t < nt) {                                              // (wave-uniform; always true for the 3x3 passes)
+          const unsigned soff = __builtin_amdgcn_readlane(tab_b, t_lo + t) + (unsigned)cb * b_chunk + (unsigned)wave * w_plane_b;
+          unsigned char* dst = smem + lds_b0 + bslot * B_SLOT + ti * B_TAP;
+          if (second) dma16(rs_w1, dst, b_live ? bvoff0 : kOob, b_live ? soff : 0u);
+          else dma16(rs_w0, dst, b_live ? bvoff0 : kOob, b_live ? soff : 0u);
+        }
+      }
+      const int k_hi = (ja + 1) * la < a.NG ? (ja + 1) * la : a.NG;
+      for (int k = ja * la; k < k_hi; ++k) {
+        const unsigned q = q0 + (unsigned)__builtin_amdgcn_readlane(tab_arow, k);
+        const unsigned vo = (a_live && q < (unsigned)npix && !(CH_EXP & 1)) ? q * 16u : kOob;
+        const unsigned soff = a_live ? __builtin_amdgcn_readlane(tab_asoff, k) + (unsigned)ca * a_chunk : 0u;
+        unsigned char* dst = smem + (ca & 1) * ABUF + __builtin_amdgcn_readlane(tab_adst, k);
+        if (SUM2 && second) dma16(rs_in1, dst, vo, soff);
+        else dma16(rs_in0, dst, vo, soff);
+      }
+    };
+
+    f16x8 fa[2][2][2], fb[2][RN][2];             // [register set][row block | column block][plane]
+    // fragments of tap t of the pass (B tile ti of ring slot bslot; A buffer abuf) into register set ST.  A lane whose tap leaves
+    // the image reads the zero row of its own bank class.
+    auto read_frags = [&](auto ST, int t, int ti, int bslot, int abuf) {
+      constexpr int st = decltype(ST)::value;
+      if constexpr (CH_EXP & 32) {
+        asm volatile("" : "+v"(fa[st][0][0]), "+v"(fa[st][0][1]), "+v"(fa[st][1][0]), "+v"(fa[st][1][1]));
+#pragma unroll
+        for (int rn = 0; rn < RN; ++rn) asm volatile("" : "+v"(fb[st][rn][0]), "+v"(fb[st][rn][1]));
+        return;
+      }
+      const int sh = tap_shift(t_lo + t);
+      const unsigned char* pa = smem + abuf * ABUF + lh * SA;
+#pragma unroll
+      for (int rm = 0; rm < 2; ++rm) {
+        const int row = (rm ? rowb1 : rowb0) + sh;
+        const bool ok = (fr_ok[rm] >> (t_lo + t)) & 1u;
+        const int r = ok ? row : zrow + (row & 15);
+        fa[st][rm][0] = *reinterpret_cast<const f16x8*>(pa + r * 16);
+        fa[st][rm][1] = *reinterpret_cast<const f16x8*>(pa + r * 16 + 2 * SA);
+      }
+      const unsigned char* pb = sB + bslot * B_SLOT + ti * B_TAP + (lh * BNL + li) * 16;
+#pragma unroll
+      for (int rn = 0; rn < RN; ++rn) {
+        fb[st][rn][0] = *reinterpret_cast<const f16x8*>(pb + rn * 32 * 16);
+        fb[st][rn][1] = *reinterpret_cast<const f16x8*>(pb + rn * 32 * 16 + 2 * BNL * 16);
+      }
+    };
+    auto mfma_tap = [&](auto ST) {                // products outermost: no two consecutive MFMAs on one accumulator
+      constexpr int st = decltype(ST)::value;
+      if constexpr (CH_EXP & 16) {
+        asm volatile("" :: "v"(fa[st][0][0]), "v"(fa[st][0][1]), "v"(fa[st][1][0]), "v"(fa[st][1][1]), "v"(fb[st][0][0]), "v"(fb[st][0][1]));
+        return;
+      }
+#pragma unroll
+      for (int rm = 0; rm < 2; ++rm)
+#pragma unroll
+        for (int rn = 0; rn < RN; ++rn) acx[rm][rn] = mfma_f16(fa[st][rm][1], fb[st][rn][0], acx[rm][rn]);
+#pragma unroll
+      for (int rm = 0; rm < 2; ++rm)
+#pragma unroll
+        for (int rn = 0; rn < RN; ++rn) acx[rm][rn] = mfma_f16(fa[st][rm][0], fb[st][rn][1], acx[rm][rn]);
+#pragma unroll
+      for (int rm = 0; rm < 2; ++rm)
+#pragma unroll
+        for (int rn = 0; rn < RN; ++rn) acc[rm][rn] = mfma_f16(fa[st][rm][0], fb[st][rn][0], acc[rm][rn]);
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    // the batch that rides on step (c, g): B of step s+2, share (g + 1) % ng of the halo tile of the chunk after step s+1's
+    auto batch_of = [&](int c, int g_, int s_) {
+      int c2 = c, g2 = g_ + 2;
+      if (g2 >= ng) { g2 -= ng; ++c2; }
+      if (g2 >= ng) { g2 -= ng; ++c2; }
+      const int nc = g_ + 1 < ng ? c : c + 1;
+      const int ja = g_ + 1 < ng ? g_ + 1 : 0;
+      issue_batch(c2, g2, s_ & 1, c2 < k16_total, nc + 1, ja, nc + 1 < k16_total);
+    };
+
+    if (n_steps > 0) {
+      // prologue: the whole first halo tile, the first two steps' B tiles, and what the batch "before step 0" would have carried
+      __builtin_amdgcn_s_barrier();              // (the previous pass's epilogue scratch / the zero rows are settled)
+      for (int j = 0; j < ng; ++j) issue_batch(0, ng, 0, false, 0, j, true);       // A(0), whole (tap group ng: no B instruction)
+      issue_batch(0, 0, 0, true, 1, 0, 1 < k16_total);                             // B(0), share 0 of A(1)
+      issue_batch(ng > 1 ? 0 : 1, ng > 1 ? 1 : 0, 1, n_steps > 1, 0, ng, false); // B(1) (share index ng: no A instruction)
+      wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      if (nt == TG * ng) {
+        // ---- full steps of three taps (every 3x3).  The first tap's fragments of a step already sit in a register set:
+        //   tap 0, 1:  MFMAs  ||  fragment reads of the next tap
+        //   then everything of the step is in registers -> wait for the batch issued one step ago, s_barrier
+        //   tap 2:     MFMAs  ||  the next DMA batch (B two steps ahead into the slot just drained, an A share into the buffer
+        //                         the previous chunk has left)  ||  fragment reads of the NEXT step's first tap
+        // so that every wait has a tap's MFMAs in flight.  Three taps flip the register-set parity: two steps per iteration.
+        read_frags(I0{}, 0, 0, 0, 0);
+        int c = 0, g_ = 0;
+        auto advance = [&]() { if (++g_ == ng) { g_ = 0; ++c; } };
+        // (CH_EXP & 256: s_memtime stamps of the even steps of workgroup 0 / wave 0 into the out1 buffer: tools/h2_stamps.py)
+#if (CH_EXP & 256)
+#define STAMP(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && wave == 0 && lane == 0 && s_ < 48) { \
+          __builtin_amdgcn_sched_barrier(0); reinterpret_cast<unsigned long long*>(op.out1)[(s_ / 2) * 8 + (i)] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+        // issue order inside a tap's block: every MFMA gap takes one fragment read (and its address arithmetic) or one DMA
+        // instruction of the batch; without the hints hipcc bunches the reads in front of the MFMAs and the DMA behind them
+        auto spread_reads = [&]() {
+          if constexpr (SCHED_HINTS) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+              __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+              __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 4 * RN - 4 > 0 ? 6 * RN - 8 : 0, 0);
+          }
+        };
+        auto spread_batch = [&]() {
+          if constexpr (SCHED_HINTS) {
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+              __builtin_amdgcn_sched_group_barrier(0x004, 4, 0);
+              __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+              __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 6 * RN - 5; ++i) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+              __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+              __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            }
+          }
+        };
+#pragma unroll 1
+        for (int s_ = 0; s_ < n_steps; s_ += 2) {
+          {   // step s_: sets 0, 1, 0; leaves the next step's first fragments in set 1
+            const int t0 = g_ * TG;
+            STAMP(0);
+            read_frags(I1{}, t0 + 1, 1, s_ & 1, c & 1);
+            mfma_tap(I0{});
+            spread_reads();
+            STAMP(1);
+            read_frags(I0{}, t0 + 2, 2, s_ & 1, c & 1);
+            mfma_tap(I1{});
+            spread_reads();
+            STAMP(2);
+            wait_vmcnt<0>();
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            STAMP(3);
+            __builtin_amdgcn_s_barrier();
+            STAMP(4);
+            batch_of(c, g_, s_);
+            advance();
+            read_frags(I1{}, g_ * TG, 0, (s_ + 1) & 1, c & 1);      // (after the last step: stale data, never used)
+            mfma_tap(I0{});
+            spread_batch();
+            STAMP(5);
+          }
+          if (s_ + 1 < n_steps) {   // step s_+1: sets 1, 0, 1; leaves the next step's first fragments in set 0
+            const int t0 = g_ * TG, s1 = s_ + 1;
+            read_frags(I0{}, t0 + 1, 1, s1 & 1, c & 1);
+            mfma_tap(I1{});
+            spread_reads();
+            read_frags(I1{}, t0 + 2, 2, s1 & 1, c & 1);
+            mfma_tap(I0{});
+            spread_reads();
+            wait_vmcnt<0>();
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_s_barrier();
+            batch_of(c, g_, s1);
+            advance();
+            read_frags(I0{}, g_ * TG, 0, (s1 + 1) & 1, c & 1);
+            mfma_tap(I1{});
+            spread_batch();
+          }
+        }
+      } else {
+        // ---- any other tap count (the 1x1 shortcut passes: one tap per step): plain order, one register set ----
+        int c = 0, g_ = 0;
+#pragma unroll 1
+        for (int s_ = 0; s_ < n_steps; ++s_) {
+          const int ntap = (g_ + 1) * TG <= nt ? TG : nt - g_ * TG;
+          for (int ti = 0; ti < ntap; ++ti) {
+            read_frags(I0{}, g_ * TG + ti, ti, s_ & 1, c & 1);
+            mfma_tap(I0{});
+          }
+          wait_vmcnt<0>();
+          __builtin_amdgcn_s_waitcnt(0xC07F);
+          __builtin_amdgcn_s_barrier();
+          batch_of(c, g_, s_);
+          if (++g_ == ng) { g_ = 0; ++c; }
+        }
+      }
+      wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();              // (nobody reads the ring any more: the epilogue may use it)
+    }
+
+    if (SUM2 && set == 0) {
+      const int shift = skip1 ? 0 : (ka1 + kw1) - (ka0 + kw0);
+#pragma unroll
+      for (int rm = 0; rm < 2; ++rm)
+#pragma unroll
+        for (int rn = 0; rn < RN; ++rn)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            acc[rm][rn][r] = __builtin_ldexpf(acc[rm][rn][r], shift);
+            acx[rm][rn][r] = __builtin_ldexpf(acx[rm][rn][r], shift);
+          }
+      continue;
+    }
+
+    // ---- epilogue (branch-free: rows beyond M carry an offset the buffer unit rejects) ----
+    const int k_back = (SUM2 && skip1) ? -(ka0 + kw0) : -((set ? ka1 : ka0) + (set ? kw1 : kw0));
+    const int oset = SUM2 ? 0 : set;
+    float* outp = oset ? op.out1 : op.out0;
+    const int cout = oset ? g.Cout1 : g.Cout0;
+    // (which epilogue options a MODE may carry is fixed at compile time -- the launcher rejects the others: every option costs
+    //  registers beside 128 accumulators; MODE 2 with all of them spilled)
+    double* stats = SUM2 ? nullptr : (oset ? op.stats1 : op.stats0);
+    const bool masked = MODE == 0 && op.mask_src != nullptr;
+    const bool red = !ACC1 && (oset == 0) && op.red_sums != nullptr;
+    const bool want_mm = !SUM2 && (oset == 0) && op.mm0 != nullptr;
+    const bool want_amax = (oset == 0) && op.out0_amax != nullptr;
+    const int old_ = oset ? g.out_ld1 : g.out_ld0;
+    const int out_ld = old_ > 0 ? old_ : cout;
+    const unsigned out_bytes = (unsigned)((((long)g.B * g.OH * g.OW - 1) * out_ld + cout) * 4);
+    const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(outp, 0, out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_m = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(masked ? op.mask_src : outp), 0, out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(red ? op.red_a : outp), 0, out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(red ? op.red_b : outp), 0, out_bytes, 0x00020000);
+    float csum[RN], csq[RN], rs0[RN], rs1[RN], rs2[RN], rs3[RN], vmx[RN], vng[RN];
+    const float kNegInf = __uint_as_float(0xff800000u);
+    float out_amax = 0.f;
+#pragma unroll
+    for (int rn = 0; rn < RN; ++rn) { csum[rn] = csq[rn] = rs0[rn] = rs1[rn] = rs2[rn] = rs3[rn] = 0.f; vmx[rn] = vng[rn] = kNegInf; }
+    const unsigned col_off = (unsigned)((n0 + li) * 4);
+#pragma unroll
+    for (int rm = 0; rm < ((CH_EXP & 64) ? 0 : 2); ++rm) {
+      unsigned voff[16];
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const u32x4 e = *reinterpret_cast<const u32x4*>(sRow + wave * 64 + rm * 32 + 8 * rg + 4 * lh);
+        voff[4 * rg] = e.x + col_off; voff[4 * rg + 1] = e.y + col_off; voff[4 * rg + 2] = e.z + col_off; voff[4 * rg + 3] = e.w + col_off;
+      }
+#pragma unroll
+      for (int rn = 0; rn < RN; ++rn) {
+        const int nb = n0 + rn * 32;                 // wave-uniform: a 32-column group is in or out as a whole (cout % 32 == 0)
+        if (nb < cout) {
+          const int n = nb + li;
+          float v[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] = __builtin_ldexpf(acc[rm][rn][r] + acx[rm][rn][r], k_back);
+          if (masked) {
+            const float msc = op.mask_scale[n], msh = op.mask_shift[n];
+            float src[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              src[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_m, (int)(voff[r] + (unsigned)(rn * 128)), 0, 0));
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              if (!(fmaf(src[r], msc, msh) > 0.f)) v[r] = 0.f;
+              csq[rn] = fmaf(v[r], src[r], csq[rn]);
+            }
+          }
+          if (red) {
+            const float ms = op.red_scale[n], mt = op.red_shift[n];
+#pragma unroll
+            for (int h8 = 0; h8 < 2; ++h8) {       // (eight rows at a time: sixteen of both tensors beside the accumulators spilled)
+              float xa[8], xb[8];
+#pragma unroll
+              for (int r = 0; r < 8; ++r) {
+                xa[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_ra, (int)(voff[h8 * 8 + r] + (unsigned)(rn * 128)), 0, 0));
+                xb[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_rb, (int)(voff[h8 * 8 + r] + (unsigned)(rn * 128)), 0, 0));
+              }
+#pragma unroll
+              for (int r = 0; r < 8; ++r) {       // (rows beyond M hold v = 0 and read 0: they add nothing)
+                const float vv = v[h8 * 8 + r];
+                const float ga = fmaf(xa[r], ms, mt) > 0.f ? vv : 0.f;
+                rs0[rn] += ga;
+                rs1[rn] = fmaf(ga, xa[r], rs1[rn]);
+                rs2[rn] += vv;
+                rs3[rn] = fmaf(vv, xb[r], rs3[rn]);
+              }
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[r]), rs_o, (int)(voff[r] + (unsigned)(rn * 128)), 0, 0);
+            csum[rn] += v[r];                        // rows beyond M accumulated zeros (their inputs were read as 0)
+            if (!masked) csq[rn] = fmaf(v[r], v[r], csq[rn]);
+          }
+          if (want_mm) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const bool ok = voff[r] < 0xFFFFF000u;
+              vmx[rn] = fmaxf(vmx[rn], ok ? v[r] : kNegInf);
+              vng[rn] = fmaxf(vng[rn], ok ? -v[r] : kNegInf);
+            }
+          }
+          if (want_amax) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) out_amax = fmaxf(out_amax, fabsf(v[r]));     // (rows beyond M hold zeros)
+          }
+        }
+      }
+    }
+    if (want_amax) {       // one look-then-atomic per wave into the workgroup's sub-slot (common.h)
+      float m = wave_max(out_amax);
+      if (lane == 0) {
+        if (!(m == m)) m = __uint_as_float(0x7f800000u);
+        unsigned* dst = reinterpret_cast<unsigned*>(op.out0_amax + (blockIdx.x % MPOSE_AMAX_SUBSLOTS) * MPOSE_AMAX_STRIDE);
+        if (__float_as_uint(m) > __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(dst, __float_as_uint(m));
+      }
+    }
+    // ---- per-channel sums of the four waves through the (idle) B ring, then one row of the partial buffers / atomics ----
+    if (want_mm) {
+#pragma unroll
+      for (int rn = 0; rn < RN; ++rn) {
+        const float a_ = fmaxf(vmx[rn], __shfl_xor(vmx[rn], 32, 64)), b_ = fmaxf(vng[rn], __shfl_xor(vng[rn], 32, 64));
+        if (lh == 0) { sMM[(wave * BN + rn * 32 + li) * 2] = a_; sMM[(wave * BN + rn * 32 + li) * 2 + 1] = b_; }
+      }
+    }
+    if (red) {
+#pragma unroll
+      for (int rn = 0; rn < RN; ++rn) {
+        const float t0 = rs0[rn] + __shfl_xor(rs0[rn], 32, 64), t1 = rs1[rn] + __shfl_xor(rs1[rn], 32, 64);
+        const float t2 = rs2[rn] + __shfl_xor(rs2[rn], 32, 64), t3 = rs3[rn] + __shfl_xor(rs3[rn], 32, 64);
+        if (lh == 0) *reinterpret_cast<float4*>(sRed + (wave * BN + rn * 32 + li) * 4) = make_float4(t0, t1, t2, t3);
+      }
+    } else if (stats != nullptr) {
+#pragma unroll
+      for (int rn = 0; rn < RN; ++rn) {
+        const float s_ = csum[rn] + __shfl_xor(csum[rn], 32, 64);
+        const float q_ = csq[rn] + __shfl_xor(csq[rn], 32, 64);
+        if (lh == 0) { float* d = sRed + (wave * BN + rn * 32 + li) * 4; d[0] = s_; d[1] = q_; }
+      }
+    }
+    __syncthreads();
+    if (tid < BN && n0 + tid < cout) {
+      const int n = n0 + tid;
+      if (red) {
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          const float4 d = *reinterpret_cast<const float4*>(sRed + (w * BN + tid) * 4);
+          t.x += d.x; t.y += d.y; t.z += d.z; t.w += d.w;
+        }
+        if (part) {
+          float* pb = reinterpret_cast<float*>(op.red_sums);
+          if (hdr_writer && tid == 0) *reinterpret_cast<int*>(pb) = a.part_rows;
+          reinterpret_cast<float4*>(pb + kPartHdr)[(size_t)prow * cout + n] = t;
+        } else {
+          double* d = op.red_sums + (size_t)n * 4;
+          atomicAdd(d, (double)t.x); atomicAdd(d + 1, (double)t.y); atomicAdd(d + 2, (double)t.z); atomicAdd(d + 3, (double)t.w);
+        }
+      } else if (stats != nullptr) {
+        float s_ = 0.f, q_ = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { const float* d = sRed + (w * BN + tid) * 4; s_ += d[0]; q_ += d[1]; }
+        if (part) {
+          float* pb = reinterpret_cast<float*>(stats);
+          if (hdr_writer && tid == 0) *reinterpret_cast<int*>(pb) = a.part_rows;
+          reinterpret_cast<float2*>(pb + kPartHdr)[(size_t)prow * cout + n] = make_float2(s_, q_);
+        } else {
+          atomicAdd(stats + (size_t)n * 2, (double)s_);
+          atomicAdd(stats + (size_t)n * 2 + 1, (double)q_);
+        }
+      }
+      if (want_mm) {
+        float a_ = kNegInf, b_ = kNegInf;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { a_ = fmaxf(a_, sMM[(w * BN + tid) * 2]); b_ = fmaxf(b_, sMM[(w * BN + tid) * 2 + 1]); }
+        if (part) {
+          float* pb = reinterpret_cast<float*>(op.mm0);
+          if (hdr_writer && tid == 0) *reinterpret_cast<int*>(pb) = a.part_rows;
+          reinterpret_cast<float2*>(pb + kPartHdr)[(size_t)prow * cout + n] = make_float2(a_, b_);
+        } else {
+          atomicMax(op.mm0 + (size_t)n * 2, float_key(a_));
+          atomicMax(op.mm0 + (size_t)n * 2 + 1, float_key(b_));
+        }
+      }
+    }
+  }
+}
+
+// eligibility of the stride-1 form and its tile parameters
+inline bool h2r_eligible(const mpose_conv_geom& g, int* lo_out, int* hi_out) {
+  if (g.n_classes != 1 || g.in_mul != 1 || g.in_mul_x != 1 || g.out_mul != 1 || g.out_mul_x != 1) return false;
+  if (g.IH != g.GH || g.IW != g.GW || g.OH != g.GH || g.OW != g.GW || g.cls[0].oy || g.cls[0].ox) return false;
+  if (g.cls[0].n_taps < 1) return false;
+  int n0 = 0;
+  for (int t = 0; t < g.cls[0].n_taps; ++t) n0 += g.cls[0].taps[t].acc == 0;
+  if (n0 > HR_MAXT || g.cls[0].n_taps - n0 > HR_MAXT) return false;
+  int lo = 1 << 30, hi = -(1 << 30);
+  for (int t = 0; t < g.cls[0].n_taps; ++t) {
+    const int sft = g.cls[0].taps[t].dy * g.IW + g.cls[0].taps[t].dx;
+    lo = sft < lo ? sft : lo; hi = sft > hi ? sft : hi;
+  }
+  *lo_out = lo; *hi_out = hi;
+  return true;
+}
+
+template <int RN, int MODE>
+int launch_h2r(ConvHRArgs a, int cmax, int n_groups, hipStream_t s) {
+  constexpr int BN = 32 * RN, BNL = (BN + 63) / 64 * 64;
+  constexpr int lds = 2 * 4 * (HR_MAXNG * 64 + 16) * 16 + 2 * HR_TG * 4 * BNL * 16 + HR_BM * 4;
+  static_assert(2 * lds <= 160 * 1024, "two workgroups per CU");
+  if (a.NG > HR_MAXNG) return MPOSE_ENOSYS;
+  a.n_mtiles = (a.M + HR_BM - 1) / HR_BM;
+  if (mpose_dry_rows) { *mpose_dry_rows += a.n_mtiles; return 0; }     // (mpose_conv_stat_rows)
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_h2r_k<RN, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+      return MPOSE_EINVAL;
+    attr_set = true;
+  }
+  dim3 grid(a.n_mtiles, (cmax + BN - 1) / BN, n_groups);
+  a.part_row0 = mpose_part_phase.row0;
+  a.part_rows = mpose_part_phase.total > 0 ? mpose_part_phase.total : (int)grid.x;
+  conv_h2r_k<RN, MODE><<<grid, 256, lds, s>>>(a);
+  return launch_status();
+}
+
+template <int RN>
+int launch_h2r_mode(const ConvHRArgs& a, int mode, int cmax, int n_groups, hipStream_t s) {
+  if (mode == 1) return launch_h2r<RN, 1>(a, cmax, n_groups, s);
+  if (mode == 2) return launch_h2r<RN, 2>(a, cmax, n_groups, s);
+  return launch_h2r<RN, 0>(a, cmax, n_groups, s);
+}
+
 template <int WM, int WN, int RM, int RN, int KST, int NBUF, int MODE, bool DUAL>
 int launch_h2(const ConvHArgs& a0, int n_groups, hipStream_t s) {
   constexpr int BM = 32 * RM * WM, BN = 32 * RN * WN, BNL = (BN + 63) / 64 * 64;
@@ -625,5 +1228,24 @@ int mpose_conv_h2_launch(const mpose_conv_geom* geom, const mpose_conv_operands*
   if (in_bytes >= 0xFFFFFF00l - (1l << 20) || geom->in_ld > 0) return MPOSE_EINVAL;       // 32-bit buffer offsets; dense inputs only
   if ((long)geom->Npad0 * 16 * 4 * (geom->Cin / 16) * MPOSE_MAX_TAPS >= 0xFFFFFF00l) return MPOSE_EINVAL;
   a.in_slab = (unsigned)(npix * 16);
+  static const int form = [] { const char* e = getenv("MPOSE_H2_FORM"); return e ? atoi(e) : 1; }();      // 0: the general kernel only (A/B runs)
+  int lo = 0, hi = 0;
+  bool opts_ok = true;       // epilogue options per mode (conv_h2r_k): 0: all; 1: statistics + extremes; 2: consumer sums + output amax
+  for (int i = 0; i < n_groups; ++i) {
+    if (mode == 1 && (ops[i].mask_src || ops[i].red_sums)) opts_ok = false;
+    if (mode == 2 && (ops[i].mask_src || ops[i].stats0 || ops[i].mm0)) opts_ok = false;
+  }
+  if (form && opts_ok && h2r_eligible(*geom, &lo, &hi)) {
+    ConvHRArgs r{};
+    r.g = a.g;
+    for (int i = 0; i < n_groups; ++i) r.op[i] = ops[i];
+    r.M = a.M; r.div_gw = a.div_gw; r.div_ghw = a.div_ghw; r.flags = flags; r.in_slab = a.in_slab;
+    r.lo = lo;
+    r.NG = (HR_BM + hi - lo + 63) / 64;
+    r.a_rows = r.NG * 64 + 16;
+    const int rc = cmax <= 32 ? launch_h2r_mode<1>(r, mode, cmax, n_groups, (hipStream_t)stream)
+                              : launch_h2r_mode<2>(r, mode, cmax, n_groups, (hipStream_t)stream);
+    if (rc != MPOSE_ENOSYS) return rc;
+  }
   return launch_h2_shape(a, mode, cmax, n_groups, (hipStream_t)stream);
 }
