@@ -314,11 +314,15 @@ def main():
                    'conv_engine': {0: 'conv_igemm_k / conv_wgrad_k (conv.hip), six bf16 products per fp32 multiply-add',
                                    1: 'plane engine (conv_p.hip)',
                                    2: 'conv_igemm_k / conv_wgrad_k (conv.hip), three fp16 products per fp32 multiply-add of per-tensor-scaled, '
-                                      'two-way split operands (MPOSE_CONV_F16X3: fp32-equivalent, tests/test_conv_f16x3_gpu.py)'}[
+                                      'two-way split operands (MPOSE_CONV_F16X3: fp32-equivalent, tests/test_conv_f16x3_gpu.py)',
+                                   3: 'three fp16 products per fp32 multiply-add (MPOSE_CONV_F16X3) on two engines: conv_h2r_k (conv_h.hip: operands '
+                                      'split once by their producer into two fp16 planes, DMA-fed shared LDS tiles, two workgroups per CU) for the '
+                                      'forward and second-3x3 data-gradient of the regular 128-channel blocks, conv_igemm_k / conv_wgrad_k '
+                                      '(conv.hip) for everything else'}[
                                        model.inner.engine().conv_mode_for(True, True)],
                    'final_loss': loss_value},
     }
-    products = 3.0 if model.inner.engine().conv_mode_for(True, True) == 2 else 6.0
+    products = 3.0 if model.inner.engine().conv_mode_for(True, True) in (2, 3) else 6.0
     if args.conv_dtype == 'f16':
         products = 1.0                 # one MFMA product per multiply-add: priced against the full dense 16-bit MFMA peak
     peak_equiv = PEAK_BF16_MFMA_TFLOPS / products

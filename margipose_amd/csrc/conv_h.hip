@@ -727,7 +727,10 @@ __global__ __launch_bounds__(256, 2) void conv_h2r_k(ConvHRArgs a) {
         if (t < nt) {                                              // (wave-uniform; always true for the 3x3 passes)
           const unsigned soff = __builtin_amdgcn_readlane(tab_b, t_lo + t) + (unsigned)cb * b_chunk + (unsigned)wave * w_plane_b;
           unsigned char* dst = smem + lds_b0 + bslot * B_SLOT + ti * B_TAP;
-          if (second) dma16(rs_w1, dst, b_live ? bvoff0 : kOob, b_live ? soff : 0u);
+          if constexpr (CH_EXP & 512) {       // timing experiment: the B tile by a plain load (no LDS-DMA, results wrong)
+            const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rs_w0, (int)bvoff0, (int)soff, 0);
+            asm volatile("" :: "v"(r));
+          } else if (second) dma16(rs_w1, dst, b_live ? bvoff0 : kOob, b_live ? soff : 0u);
           else dma16(rs_w0, dst, b_live ? bvoff0 : kOob, b_live ? soff : 0u);
         }
       }
@@ -1150,7 +1153,9 @@ int launch_h2r(ConvHRArgs a, int cmax, int n_groups, hipStream_t s) {
 template <int RN>
 int launch_h2r_mode(const ConvHRArgs& a, int mode, int cmax, int n_groups, hipStream_t s) {
   if (mode == 1) return launch_h2r<RN, 1>(a, cmax, n_groups, s);
-  if (mode == 2) return launch_h2r<RN, 2>(a, cmax, n_groups, s);
+  // (MODE 2, the two-input sum: its second pass restages the whole halo tile for one tap per step, and the 64-channel form
+  //  spilled 36 bytes per lane beside the consumer-sums epilogue -- conv_h2_k takes it)
+  if (mode == 2) return MPOSE_ENOSYS;
   return launch_h2r<RN, 0>(a, cmax, n_groups, s);
 }
 

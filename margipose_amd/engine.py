@@ -24,7 +24,7 @@ import torch
 import torch.distributed
 
 from . import _lib
-from ._lib import (BnAddOperands, BnBwdApplyOperands, BnBwdReduceOperands, AbsmaxOperands, ConvGeom, ConvOperands, SplitOperands, WgradOperands, c_int,
+from ._lib import (BnAddOperands, BnBwdApplyOperands, BnBwdReduceOperands, AbsmaxOperands, ConvGeom, ConvOperands, SplitH2Operands, SplitOperands, WgradOperands, c_int,
                    c_int64, c_void_p, check, lib, ptr, ptr_array, stream_ptr)
 
 BN_EPS = 1e-5
@@ -185,6 +185,9 @@ class _BN:
         self.f_off = self.s_off = -1             # offsets into the float / double arenas
 
 
+_H2_CHANNELS = tuple(int(v) for v in os.environ.get('MPOSE_H2_CHANNELS', '128').split(',') if v)
+
+
 class _Block:
     """One ResidualBlock (reference models/margipose_model.py:25-40) of one column."""
 
@@ -199,6 +202,8 @@ class _Block:
         self.bn1 = _BN(rb.module[1], cout, self.cout_s)
         self.bn2 = _BN(rb.module[4], cout, self.cout_s)
         self.bns = _BN(rb.shortcut[1], cout, self.cout_s)
+        # the H2 engine (csrc/conv_h.hip: producer-split fp16 planes) takes the 128-channel regular blocks: see Engine.h2
+        self.h2 = kind == 'regular' and cin == cout and cin in _H2_CHANNELS
 
 
 class KernelTimer:
@@ -349,6 +354,11 @@ class Engine:
         # the fp64 device-scope atomics they replace cost a 128-channel launch 20 us of ~110 -- 2.8 ms of a 24.6 ms training step
         # (round 4, same box: 24.6 -> 21.8 ms).  MPOSE_STATS_PART=0 keeps the atomics (A/B runs); the fused finalize needs them.
         self.stats_part = os.environ.get('MPOSE_STATS_PART', '1') != '0'
+        # Training / differentiable forwards run the forward and the second 3x3's data-gradient of the regular 128-channel blocks
+        # on conv_h2r_k (csrc/conv_h.hip): operands split ONCE into two fp16 planes by an elementwise pass (mpose_split_h2), both
+        # DMA'd into workgroup-shared LDS tiles, two workgroups per CU, no operand arithmetic in the K loop -- 85 instead of
+        # 117 us per 128 -> 128 launch (round 4).  MPOSE_H2=0: conv_igemm_k everywhere (A/B runs).
+        self.h2 = os.environ.get('MPOSE_H2', '1') != '0'
         self.inline_unpack = os.environ.get('MPOSE_INLINE_UNPACK', '0') != '0'     # (see unpack_after: measured no faster, off)
         self.overlap_wgrad = True    # +2.3 % step rate, bit-identical results; launches bracketed by a KernelTimer stay serial
         self.dp = None               # optional (process_group, world_size): gradient all-reduce after backward
@@ -483,8 +493,18 @@ class Engine:
             if c.layout == 1 or getattr(c, 'generic', False):      # columns and the feature extractor's graph (not the patch8 stem)
                 jobs_h[2 * i]['layout'] = jobs_h[2 * i + 1]['layout'] = 2
                 jobs_h[2 * i]['amax'] = jobs_h[2 * i + 1]['amax'] = c.amax_ptr
-        # [0] conv_igemm_k, six bf16 products; [1] plane engine; [2] conv_igemm_k, three fp16 products
-        self._pack_jobs = tuple(_jobs_to_device(j, device) for j in (jobs, jobs_p, jobs_h))
+        # [3]: [2] with layout 3 (conv_h.hip's B tiles) for what the H2 engine runs: forward of conv_in / shortcut / conv2 and the
+        # data-gradient of conv2 of the H2 blocks
+        jobs_h2 = jobs_h.copy()
+        h2_convs = {}
+        for b in self._all_blocks:
+            if b.h2:
+                h2_convs[id(b.conv_in)] = (0,); h2_convs[id(b.conv_sc)] = (0,); h2_convs[id(b.conv2)] = (0, 1)
+        for i, c in enumerate(self._convs):
+            for d in h2_convs.get(id(c), ()):
+                jobs_h2[2 * i + d]['layout'] = 3
+        # [0] conv_igemm_k, six bf16 products; [1] plane engine; [2] conv_igemm_k, three fp16 products; [3] the same + the H2 engine
+        self._pack_jobs = tuple(_jobs_to_device(j, device) for j in (jobs, jobs_p, jobs_h, jobs_h2))
         self._packed_for = None      # which of the three the packed arena currently holds
         self._pack_max = mx
         self._tables = {}
@@ -721,6 +741,26 @@ class Engine:
         check(lib().mpose_split_planes((SplitOperands * 3)(*ops), len(ops), c_int64(npix), C, int(relu), stream_ptr()), 'mpose_split_planes')
         return outs
 
+    def split_h2(self, srcs, slots, npix, C, scales=None, shifts=None, relu=False):
+        """fp32 NHWC tensors -> two fp16 planes of [relu](scale*x + shift) * 2^k (mpose_split_h2; k from each tensor's amax slot);
+        tensors that share storage are split once."""
+        outs, ops, done = [], [], {}
+        for i, src in enumerate(srcs):
+            key = (src.data_ptr(), slots[i])
+            if key in done:
+                outs.append(done[key])
+                continue
+            pl = torch.empty(npix * C, dtype=torch.float32, device=self.device)
+            so = SplitH2Operands()
+            so.src, so.planes, so.amax = src.data_ptr(), pl.data_ptr(), slots[i]
+            if scales is not None:
+                so.scale, so.shift = scales[i], shifts[i]
+            ops.append(so)
+            done[key] = pl
+            outs.append(pl)
+        check(lib().mpose_split_h2((SplitH2Operands * 3)(*ops), len(ops), c_int64(npix), C, int(relu), stream_ptr()), 'mpose_split_h2')
+        return outs
+
     def bn_bwd_reduce(self, rops, pixels_per_image, B, C):
         """BatchNorm-backward sums of one grouped launch (mpose_bn_bwd_reduce_ws: per-workgroup partials, no atomics)."""
         L = lib()
@@ -741,13 +781,19 @@ class Engine:
         return self.conv_bf16 or (not self.f16x3 and not (train or save))
 
     def conv_mode_for(self, train, save):
-        """0: conv_igemm_k with six bf16 products, 1: plane engine, 2: conv_igemm_k with three fp16 products."""
+        """0: conv_igemm_k with six bf16 products, 1: plane engine, 2: conv_igemm_k with three fp16 products, 3: 2 with the H2
+        engine on the regular 128-channel blocks (training and differentiable forwards: the unfused block schedule)."""
         if self.planes_for(train, save):
             return 1
+        if self.f16x3 and self.h2 and (train or save) and not self.conv_f16x1 and self.stages_have_h2():
+            return 3
         return 2 if self.f16x3 else 0
 
+    def stages_have_h2(self):
+        return any(b.h2 for b in self._all_blocks)
+
     def conv_flags(self, cmode):
-        return (4 | (8 if self.conv_bf16 else 0)) if cmode == 1 else ((32 | (64 if self.conv_f16x1 else 0)) if cmode == 2 else 0)
+        return (4 | (8 if self.conv_bf16 else 0)) if cmode == 1 else ((32 | (64 if self.conv_f16x1 else 0)) if cmode in (2, 3) else 0)
 
     def absmax(self, tensors, slots, C, scales=None, shifts=None, relu=False):
         """Largest magnitude of each NHWC tensor (after an optional per-channel affine map + ReLU) into its device slot; tensors
@@ -873,7 +919,7 @@ class Engine:
 
     def pack_weights(self, cmode):
         jobs = self._pack_jobs[cmode]
-        if cmode == 2:
+        if cmode in (2, 3):
             check(lib().mpose_weights_absmax(ptr(jobs), 2 * len(self._convs), stream_ptr()), 'mpose_weights_absmax')
         check(lib().mpose_pack_weights(ptr(jobs), 2 * len(self._convs), self._pack_max, stream_ptr()), 'mpose_pack_weights')
         self._packed_for = cmode
@@ -927,7 +973,8 @@ class Engine:
         #  anything a replayed graph or a raw kernel such as DeviceSGD writes)
         cmode = ctx['cmode'] = self.conv_mode_for(train, save)
         planes = cmode == 1
-        f16 = cmode == 2
+        f16 = cmode in (2, 3)
+        h2 = cmode == 3
         # train mode on conv_igemm_k: the convolution launches finalise their own BatchNorms (no mpose_bn_finalize launches)
         fin_fused = train and not planes and self.fuse_finalize
         # statistics as per-workgroup partial rows (MPOSE_CONV_STATS_PART) instead of fp64 atomics: conv_igemm_k / conv_h2_k only
@@ -1023,10 +1070,13 @@ class Engine:
                     cur_slot = [self._amax_f(t, i, 0, _first_same(cur, c)) for c in range(3)]
                     if i == 0:               # later blocks: the previous block's residual add measured its output as it wrote it
                         self.absmax(cur, cur_slot, b0.cin_s)
+                blk_h2 = h2 and b0.h2        # this block's forward convolutions read producer-split fp16 planes (conv_h.hip)
+                if blk_h2:
+                    cur_h = self.split_h2(cur, cur_slot, B * Hin * Hin, b0.cin_s)
                 ops = []
                 for c, b in enumerate(grp):
                     op = ConvOperands()
-                    op.in_ = (cur_p[c] if planes else cur[c]).data_ptr()
+                    op.in_ = (cur_p[c] if planes else (cur_h[c] if blk_h2 else cur[c])).data_ptr()
                     op.w0, op.w1 = self._wptr(b.conv_in), self._wptr(b.conv_sc)
                     if f16:
                         op.in_amax, op.w0_amax, op.w1_amax = cur_slot[c], b.conv_in.amax_ptr, b.conv_sc.amax_ptr
@@ -1050,7 +1100,7 @@ class Engine:
                         if fin_fused:        # (the launch's last workgroup per column runs the two finalize jobs)
                             self.fuse_fin(op, tb['fin'], tb['fin_count'], self.fin_index(t, i, 0) + c, self.fin_index(t, i, 1) + c)
                     ops.append(op)
-                self.conv(g1, ops, pflags | (16 if (fused or fused_h) else 0) | (256 if spart else 0))
+                self.conv(g1, ops, pflags | (16 if (fused or fused_h) else 0) | (256 if spart else 0) | (128 if blk_h2 else 0))
                 if train and not fin_fused:
                     self.finalize(tb, self.fin_index(t, i, 0), 6, True, spart)
                 # largest relu(bn1(c1)): what the next K loop (and its weight gradient) will split.  In training bn_finalize just
@@ -1058,6 +1108,9 @@ class Engine:
                 if f16 and not fused_h and not train:
                     self.absmax(c1, [self._amax_f(t, i, 1, c) for c in range(3)], b0.cout_s, [self._bnf_ptr(b.bn1, 0) for b in grp],
                                 [self._bnf_ptr(b.bn1, 1) for b in grp], relu=True)
+                if blk_h2:                   # relu(bn1(c1)) * 2^k as two fp16 planes, once (its amax slot: exact, from c1's channel extremes)
+                    a1_h = self.split_h2(c1, [self._amax_f(t, i, 1, c) for c in range(3)], npix_o, b0.cout_s,
+                                         [self._bnf_ptr(b.bn1, 0) for b in grp], [self._bnf_ptr(b.bn1, 1) for b in grp], relu=True)
                 if planes and not fused:     # relu(bn1(c1)) is written once, pre-split, instead of being recomputed by every tap
                     a1_p = self.split_planes(c1, npix_o, b0.cout_s, [self._bnf_ptr(b.bn1, 0) for b in grp],
                                              [self._bnf_ptr(b.bn1, 1) for b in grp], relu=True)
@@ -1080,8 +1133,8 @@ class Engine:
                     if planes:
                         op.in_ = a1_p[c].data_ptr()
                     else:
-                        op.in_ = c1[c].data_ptr()
-                        if not fused_h:
+                        op.in_ = (a1_h[c] if blk_h2 else c1[c]).data_ptr()
+                        if not fused_h and not blk_h2:
                             op.in_scale, op.in_shift = self._bnf_ptr(b.bn1, 0), self._bnf_ptr(b.bn1, 1)
                         if f16:
                             op.in_amax, op.w0_amax = self._amax_f(t, i, 1, c), b.conv2.amax_ptr
@@ -1105,7 +1158,8 @@ class Engine:
                         if fin_fused:
                             self.fuse_fin(op, tb['fin'], tb['fin_count'], self.fin_index(t, i, 2) + c)
                     ops.append(op)
-                self.conv(self.geom('f_conv2', B, Hout, b0), ops, pflags | (16 if (fuse2 or fuse2_h) else 0) | (256 if spart else 0))
+                self.conv(self.geom('f_conv2', B, Hout, b0), ops,
+                          pflags | (16 if (fuse2 or fuse2_h) else 0) | (256 if spart else 0) | (128 if blk_h2 else 0))
                 if train and not fin_fused:
                     self.finalize(tb, self.fin_index(t, i, 2), 3, True, spart)
                 if fuse2:
@@ -1180,7 +1234,7 @@ class Engine:
         if cmode == 1:
             raise _lib.MposeError('graph models run on conv_igemm_k (MPOSE_PLANES=1 is set)')
         self.pack_weights(cmode)
-        outs, ctx['stem_ctx'] = self.stem.forward(x, train, save, cmode == 2, features=features)
+        outs, ctx['stem_ctx'] = self.stem.forward(x, train, save, cmode in (2, 3), features=features)
         if train and features is None:
             self._nbt += 1
         return outs, ctx
@@ -1249,7 +1303,7 @@ class Engine:
         goff = dict((id(p), o) for p, o in zip(self.param_list(), self._grad_offsets))
         coef_base = tb['coef'].data_ptr()
         cmode = ctx['cmode']
-        planes, f16 = cmode == 1, cmode == 2
+        planes, f16, h2 = cmode == 1, cmode in (2, 3), cmode == 3
         pflags = ctx['pflags']         # (the forward's convolution engine and precision)
         x1 = f16 and bool(pflags & 64)
         if self._packed_for != cmode:      # a forward on another engine ran in between: the parameters are unchanged (checked
@@ -1330,10 +1384,13 @@ class Engine:
                     check(L.mpose_bn_bwd_apply((BnBwdApplyOperands * 3)(*aops), 3, Hout * Hout, B, Cs, 0, 0, st()), 'mpose_bn_bwd_apply')
                 # (2) dgrad of the second 3x3; ReLU mask and the BN1-backward sums happen in its epilogue
                 d_a1 = [torch.empty(B, Hout, Hout, Cs, **f32) for _ in range(3)]
+                blk_h2 = h2 and b0.h2
+                if blk_h2:               # the second 3x3's data-gradient on conv_h.hip: its operand as two fp16 planes
+                    d_c2_h = self.split_h2(d_c2, [self._amax_b(t, i, 0, c) for c in range(3)], cnt, Cs)
                 ops = []
                 for c, b in enumerate(grp):
                     op = ConvOperands()
-                    op.in_ = (d_c2_p[c] if planes else d_c2[c]).data_ptr()
+                    op.in_ = (d_c2_p[c] if planes else (d_c2_h[c] if blk_h2 else d_c2[c])).data_ptr()
                     op.w0, op.out0 = self._wptr(b.conv2, True), d_a1[c].data_ptr()
                     if f16:
                         op.in_amax, op.w0_amax = self._amax_b(t, i, 0, c), b.conv2.amax_ptr
@@ -1341,7 +1398,7 @@ class Engine:
                     op.mask_scale, op.mask_shift = self._bnf_ptr(b.bn1, 0), self._bnf_ptr(b.bn1, 1)
                     op.stats0 = sp[(id(b.bn1), 'b')] if spart else self._stats_ptr(b.bn1, True)
                     ops.append(op)
-                self.conv(self.geom('d_conv2', B, Hout, b0), ops, pflags | (256 if spart else 0))
+                self.conv(self.geom('d_conv2', B, Hout, b0), ops, pflags | (256 if spart else 0) | (128 if blk_h2 else 0))
                 # (3) wgrad of the second 3x3 (its input relu(bn1(c1)) is recomputed while staging)
                 wops = []
                 for c, b in enumerate(grp):
