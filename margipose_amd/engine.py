@@ -785,7 +785,7 @@ class Engine:
         engine on the regular 128-channel blocks (training and differentiable forwards: the unfused block schedule)."""
         if self.planes_for(train, save):
             return 1
-        if self.f16x3 and self.h2 and (train or save) and not self.conv_f16x1 and self.stages_have_h2():
+        if self.f16x3 and self.h2 and (train or save) and not self.conv_f16x1 and not self.fuse_finalize and self.stages_have_h2():
             return 3
         return 2 if self.f16x3 else 0
 

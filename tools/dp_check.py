@@ -101,7 +101,9 @@ if rank == 0:
     e_ref = np.array([float((g32[k] - g64[k]).norm() / g64[k].norm()) for k in keys])
     print('DP gradients vs oracle mean-of-shards (fp64): median %.2e p99 %.2e | fp32 oracle: median %.2e p99 %.2e'
           % (np.median(e_gpu), np.quantile(e_gpu, 0.99), np.median(e_ref), np.quantile(e_ref, 0.99)))
-    assert np.median(e_gpu) <= max(1e-4, 1.5 * np.median(e_ref)) and np.quantile(e_gpu, 0.99) <= max(1e-4, 1.5 * np.quantile(e_ref, 0.99))
+    # free running (each implementation on its own ReLU piece): the rule of tests/test_grad_parity_gpu.py -- within FREE_RATIO = 3 x
+    # the reference's own fp32 deviation (which sites flip is luck; check (1) above is the exact statement about the averaging)
+    assert np.median(e_gpu) <= max(1e-4, 3.0 * np.median(e_ref)) and np.quantile(e_gpu, 0.99) <= max(1e-4, 3.0 * np.quantile(e_ref, 0.99))
 dist.barrier()
 if rank == 0:
     print('DP_CHECK_OK')
