@@ -391,10 +391,19 @@ typedef struct {
   const float* part;
   const float* mm_part;
   int n_part, part_ld;
+  /* MPOSE_CONV_H2_IN producers need a tensor's scale BEFORE they write it: when bound_out != NULL (train only) the job also writes
+   *     max over channels of (|gamma| + |gamma2|) * sqrt(count) + |beta| + |beta2|          (bound_gamma2 / bound_beta2 may be NULL)
+   * into sub-slot 0 of the amax slot bound_out (accumulated with an atomic max: zero the slot first) -- a bound on
+   * |[relu](bn(x))| + |bn2(y)|, the ResidualBlock's output sum, that needs no look at the data: a value normalised with its
+   * own batch statistics is at most sqrt(count - 1) standard deviations from the mean. */
+  const float* bound_gamma2;
+  const float* bound_beta2;
+  float* bound_out;
 } mpose_bn_job;
 
 /* For every job: derive scale/shift (+ mean/invstd); train bit 0: batch statistics (also updates the running stats);
- * train bit 1: the jobs carry MPOSE_CONV_STATS_PART rows (`part`; the launch then runs 1024 threads per job). */
+ * train bit 1: the jobs carry MPOSE_CONV_STATS_PART rows (`part`; the launch then runs 1024 threads per job);
+ * train bit 2: write the jobs' bounds (bound_out). */
 int mpose_bn_finalize(const mpose_bn_job* jobs_dev, int n_jobs, int train, float eps,
                       float momentum, void* stream);
 
@@ -413,6 +422,10 @@ int mpose_bn_add_fwd(const mpose_bn_add_operands* ops, int n_groups, int pixels_
                      int C, int layout, int c_keep, void* stream);
 int mpose_bn_add_planes(const mpose_bn_add_operands* ops, void* const* planes, int n_groups, int64_t npix, int C,
                         void* stream);
+/* mpose_bn_add_fwd (layout 0) that also writes the sum as the two fp16 planes of MPOSE_CONV_H2_IN, h2[i], scaled as the amax
+ * slot ops[i].out_amax prescribes -- which is READ here (a bound somebody else wrote, see mpose_bn_job.bound_out), never
+ * measured.  ops[i].out may be NULL (planes only). */
+int mpose_bn_add_h2(const mpose_bn_add_operands* ops, void* const* h2, int n_groups, int64_t npix, int C, void* stream);
 
 /* out = relu(x*scale + shift) over an NHWC tensor of n elements with C channels (the stem's BN+ReLU,
  * materialised because every column of every stage reads it), and the ReLU backward gm = g*[y>0]. */
@@ -453,6 +466,10 @@ int mpose_bn_bwd_apply(const mpose_bn_bwd_apply_operands* ops, int n_groups, int
                        int B, int C, int layout, int c_keep, void* stream);
 int mpose_bn_bwd_apply_planes(const mpose_bn_bwd_apply_operands* ops, void* const* da_planes, void* const* db_planes,
                               int n_groups, int64_t npix, int C, void* stream);
+/* mpose_bn_bwd_apply that also writes da as the two fp16 planes of MPOSE_CONV_H2_IN, da_h2[i], scaled as the amax slot
+ * ops[i].da_amax prescribes (READ: the bound of mpose_bn_bwd_coef_job.bound_out); db is written as fp32 and its largest
+ * magnitude accumulated into ops[i].db_amax as mpose_bn_bwd_apply does. */
+int mpose_bn_bwd_apply_h2(const mpose_bn_bwd_apply_operands* ops, void* const* da_h2, int n_groups, int64_t npix, int C, void* stream);
 
 typedef struct {
   const double* sums;                  /* (Cs, 3) from mpose_bn_bwd_reduce, or (Cs, 2) from a conv epilogue */
@@ -471,10 +488,15 @@ typedef struct {
    * (header + [rows][part_ld][sums_stride], at most n_part rows), same columns as `sums`. */
   const float* part;
   int n_part, part_ld;
+  /* MPOSE_CONV_H2_IN: when bound_out != NULL the job also accumulates (atomic max, sub-slot 0: zero the slot first)
+   *     max over channels of |c0| * (gmax + |mean g| + sqrt(count) * |mean(g * xhat)|),  gmax = the maximum of the amax slot g_amax,
+   * a bound on |c0*g + c1*(x - mean) + c2| -- the gradient mpose_bn_bwd_apply is about to write -- into the amax slot bound_out. */
+  const float* g_amax;
+  float* bound_out;
 } mpose_bn_bwd_coef_job;
 
 /* mode: bit 0 = eval_mode (running statistics were constants), bit 1 = read `sums` even where a job has `part`,
- * bit 2 = 1024 threads per job (launches whose jobs carry partial rows). */
+ * bit 2 = 1024 threads per job (launches whose jobs carry partial rows), bit 3 = write the jobs' bounds (bound_out). */
 int mpose_bn_bwd_coef(const mpose_bn_bwd_coef_job* jobs_dev, int n_jobs, int mode, void* stream);
 
 /* 3x3 pooling over NHWC with the producer's BN+ReLU applied on the fly (scale/shift may be NULL = identity).

@@ -23,7 +23,7 @@ namespace {
 __global__ __launch_bounds__(1024) void bn_finalize_k(const mpose_bn_job* __restrict__ jobs, int train, float eps, float momentum) {
   __shared__ double sh[1024 * 2];
   // (common.h; bit 1: the statistics are the jobs' partial rows -- gridDim.y workgroups share a job's channels)
-  bn_finalize_job<false>(jobs[blockIdx.x], train & 1, eps, momentum, (train & 2) ? sh : nullptr, (int)blockIdx.y, (int)gridDim.y);
+  bn_finalize_job<false>(jobs[blockIdx.x], train & 1, eps, momentum, (train & 2) ? sh : nullptr, (int)blockIdx.y, (int)gridDim.y, (train & 4) != 0);
 }
 
 struct BnAddArgs {
@@ -204,6 +204,9 @@ __global__ __launch_bounds__(1024) void bn_bwd_coef_k(const mpose_bn_bwd_coef_jo
   const bool from_part = j.part != nullptr && !(mode & 2);       // MPOSE_CONV_STATS_PART rows instead of `sums`
   const double n = (double)j.count;
   const int nth = (int)blockDim.x;
+  const bool want_bound = (mode & 8) && j.bound_out != nullptr;
+  const float gmax = want_bound ? amax_gather(j.g_amax) : 0.f;      // (whole waves call it: uniform)
+  float bound = 0.f;
   // (gridDim.y workgroups share a job's channels, 32-channel granules)
   const int gran = ((j.C + 31) / 32 + (int)gridDim.y - 1) / (int)gridDim.y * 32;
   const int c_lo = (int)blockIdx.y * gran, c_hi = (c_lo + gran < j.C) ? c_lo + gran : j.C;
@@ -230,6 +233,8 @@ __global__ __launch_bounds__(1024) void bn_bwd_coef_k(const mpose_bn_bwd_coef_jo
     const double c0 = gamma * invstd;
     const double c1 = eval_mode ? 0.0 : -c0 * invstd * (sgxhat / n);
     const double c2 = eval_mode ? 0.0 : -c0 * (sg / n);
+    if (want_bound)       // |c0 g + c1 (x - mean) + c2| <= |c0| (gmax + sqrt(n) |mean(g xhat)| + |mean g|):  |x - mean| invstd <= sqrt(n)
+      bound = fmaxf(bound, (float)(fabs(c0) * ((double)gmax + (eval_mode ? 0.0 : sqrt(n) * fabs(sgxhat / n) + fabs(sg / n)))));
     j.coef[c] = (float)c0;
     j.coef[j.c_stride + c] = (float)c1;
     j.coef[2 * j.c_stride + c] = (float)c2;
@@ -237,6 +242,7 @@ __global__ __launch_bounds__(1024) void bn_bwd_coef_k(const mpose_bn_bwd_coef_jo
     if (j.dgamma != nullptr) { j.dgamma[c] = (float)sgxhat; j.dbeta[c] = (float)sg; }
     if (j.dconv_bias != nullptr) j.dconv_bias[c] = eval_mode ? (float)(c0 * sg) : 0.f;
   }
+  if (want_bound) block_amax_commit_one(bound * 1.0001f, j.bound_out);       // (uniform; a bound that is not finite -> +inf, like a NaN maximum)
 }
 
 struct BnApplyArgs {
@@ -344,11 +350,11 @@ extern "C" int mpose_sizeof(int which) {
   }
 }
 
-// train: bit 0 = batch statistics; bit 1 = the jobs carry MPOSE_CONV_STATS_PART rows (1024 threads per job)
+// train: bit 0 = batch statistics; bit 1 = the jobs carry MPOSE_CONV_STATS_PART rows (1024 threads per job); bit 2 = write the jobs' bounds
 extern "C" int mpose_bn_finalize(const mpose_bn_job* jobs_dev, int n_jobs, int train, float eps, float momentum, void* stream) {
   if (n_jobs <= 0) return 0;
-  if (train & 2) bn_finalize_k<<<dim3(n_jobs, 4), 1024, 0, (hipStream_t)stream>>>(jobs_dev, train & 3, eps, momentum);
-  else bn_finalize_k<<<n_jobs, 256, 0, (hipStream_t)stream>>>(jobs_dev, train & 3, eps, momentum);
+  if (train & 2) bn_finalize_k<<<dim3(n_jobs, 4), 1024, 0, (hipStream_t)stream>>>(jobs_dev, train & 7, eps, momentum);
+  else bn_finalize_k<<<n_jobs, 256, 0, (hipStream_t)stream>>>(jobs_dev, train & 7, eps, momentum);
   return launch_status();
 }
 
@@ -429,11 +435,12 @@ extern "C" int mpose_bn_bwd_reduce_ws(const mpose_bn_bwd_reduce_operands* ops, i
   return launch_status();
 }
 
-// mode: bit 0 = eval_mode, bit 1 = ignore the jobs' partial rows (read `sums`), bit 2 = 1024 threads per job (jobs with partial rows)
+// mode: bit 0 = eval_mode, bit 1 = ignore the jobs' partial rows (read `sums`), bit 2 = 1024 threads per job (jobs with partial rows),
+// bit 3 = write the jobs' bounds (bound_out)
 extern "C" int mpose_bn_bwd_coef(const mpose_bn_bwd_coef_job* jobs_dev, int n_jobs, int mode, void* stream) {
   if (n_jobs <= 0) return 0;
-  if (mode & 4) bn_bwd_coef_k<<<dim3(n_jobs, 4), 1024, 0, (hipStream_t)stream>>>(jobs_dev, mode & 3);
-  else bn_bwd_coef_k<<<n_jobs, 256, 0, (hipStream_t)stream>>>(jobs_dev, mode & 3);
+  if (mode & 4) bn_bwd_coef_k<<<dim3(n_jobs, 4), 1024, 0, (hipStream_t)stream>>>(jobs_dev, mode & 11);
+  else bn_bwd_coef_k<<<n_jobs, 256, 0, (hipStream_t)stream>>>(jobs_dev, mode & 11);
   return launch_status();
 }
 

@@ -170,14 +170,16 @@ __device__ __forceinline__ void reduce_part_rows(const float* __restrict__ part,
 // workgroups' atomics moments ago, so they are read at device scope.  All 256 threads of the workgroup call it.
 template <bool FRESH>
 __device__ __forceinline__ void bn_finalize_job(const mpose_bn_job& j, int train, float eps, float momentum, double* sh = nullptr,
-                                                int part_i = 0, int n_parts = 1) {
+                                                int part_i = 0, int n_parts = 1, bool bounds = false) {
   // (n_parts > 1: this workgroup takes the part_i-th share of the job's channels, 32-channel granules)
   const int gran = ((j.C + 31) / 32 + n_parts - 1) / n_parts * 32;
   const int c_lo = part_i * gran, c_hi = (c_lo + gran < j.C) ? c_lo + gran : j.C;
   if (j.eps > 0.f) eps = j.eps;
   const bool from_part = !FRESH && train && sh != nullptr && j.part != nullptr;        // MPOSE_CONV_STATS_PART (sh: blockDim.x * 2 doubles)
   const bool want_amax = train && (j.minmax != nullptr || (from_part && j.mm_part != nullptr)) && j.amax_out != nullptr;
-  float amax = 0.f;
+  const bool want_bound = train && bounds && j.bound_out != nullptr;
+  float amax = 0.f, bound = 0.f;
+  const float root_n = sqrtf((float)j.count) * 1.0001f;
   auto ld_f64 = [](const double* p) -> double {
     if (!FRESH) return *p;
     return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
@@ -220,6 +222,11 @@ __device__ __forceinline__ void bn_finalize_job(const mpose_bn_job& j, int train
     j.scale[c] = scf;
     j.shift[c] = shf;
     if (j.mean != nullptr) { j.mean[c] = (float)mean; j.invstd[c] = (float)invstd; }
+    if (want_bound) {      // |gamma * xhat + beta| <= |gamma| sqrt(n) + |beta|  (+ the partner BatchNorm's: the residual sum)
+      float b_ = fabsf(j.gamma[c]) * root_n + fabsf(j.beta[c]);
+      if (j.bound_gamma2 != nullptr) b_ += fabsf(j.bound_gamma2[c]) * root_n + fabsf(j.bound_beta2[c]);
+      bound = fmaxf(bound, b_);
+    }
     if (want_amax) {       // relu(scale * x + shift) is monotone in x: its largest value sits at one of the channel's two extremes
       const bool pm = from_part && j.mm_part != nullptr;
       const float vmax = pm ? (float)pmm[0] : key_float(ld_u32(j.minmax + 2 * c));
@@ -227,6 +234,7 @@ __device__ __forceinline__ void bn_finalize_job(const mpose_bn_job& j, int train
       amax = fmaxf(amax, fmaxf(fmaf(vmax, scf, shf), fmaf(vmin, scf, shf)));       // (fmaxf drops the NaN of an untouched key / -inf * 0)
     }
   }
+  if (want_bound) block_amax_commit_one(bound * 1.0001f, j.bound_out);       // (uniform; contains barriers)
   if (want_amax) {       // (uniform: every thread of the workgroup gets here)
     if (from_part && j.mm_part != nullptr && n_parts == 1) {       // the slot is this job's alone: written, not accumulated
       float* amax_sm = reinterpret_cast<float*>(sh);

@@ -833,6 +833,7 @@ __global__ __launch_bounds__(256, (slim_tile<RN, MODE, NPL, ROWG>() ? 2 : 1)) vo
     const bool epi_add = epi && op.add_src != nullptr;
     const bool epi_relu = (a.flags & MPOSE_CONV_EPI_RELU0) != 0;
     float epi_amax = 0.f;
+    const bool plain_amax = !epi && (oset == 0) && op.out0_amax != nullptr;      // max |out0| as stored, without the fused output stage
     // BatchNorm-backward sums of the tensor's consumer, taken from the values as they are stored (see mpose_conv_operands.red_*)
     const bool red = (oset == 0) && op.red_sums != nullptr;
     float rs0[RN], rs1[RN], rs2[RN], rs3[RN];
@@ -949,6 +950,10 @@ __global__ __launch_bounds__(256, (slim_tile<RN, MODE, NPL, ROWG>() ? 2 : 1)) vo
             csum[rn] += v[r];
             if (!masked) csq[rn] = fmaf(v[r], v[r], csq[rn]);
           }
+          if (plain_amax) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) epi_amax = fmaxf(epi_amax, fabsf(v[r]));      // (rows beyond M hold zeros unless accumulated into: the caller's bound stays a bound)
+          }
           if (want_mm) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -967,7 +972,7 @@ __global__ __launch_bounds__(256, (slim_tile<RN, MODE, NPL, ROWG>() ? 2 : 1)) vo
         if (lh == 0) { sMM[(wave * BN + rn * 32 + li) * 2] = a_; sMM[(wave * BN + rn * 32 + li) * 2 + 1] = b_; }
       }
     }
-    if (epi && op.out0_amax != nullptr) {      // one look-then-atomic per wave into the workgroup's sub-slot (common.h)
+    if ((epi || plain_amax) && op.out0_amax != nullptr) {      // one look-then-atomic per wave into the workgroup's sub-slot (common.h)
       float m = wave_max(epi_amax);
       if (lane == 0) {
         if (!(m == m)) m = __uint_as_float(0x7f800000u);
@@ -1694,7 +1699,7 @@ extern "C" int mpose_conv_fwd(const mpose_conv_geom* geom_, const mpose_conv_ope
     if (ops[i].epi_scale0 && (!ops[i].epi_shift0 || ops[i].stats0 || ops[i].mask_src || (flags & MPOSE_CONV_ACCUMULATE))) return MPOSE_EINVAL;
     if (ops[i].add_src && (!ops[i].epi_scale0 || !ops[i].add_scale || !ops[i].add_shift)) return MPOSE_EINVAL;
     if ((ops[i].epi_scale0 != nullptr) != (ops[0].epi_scale0 != nullptr) || (ops[i].add_src != nullptr) != (ops[0].add_src != nullptr)) return MPOSE_EINVAL;
-    if (ops[i].out0_amax && !ops[i].epi_scale0 && !(flags & MPOSE_CONV_H2_IN)) return MPOSE_EINVAL;
+    if (ops[i].out0_amax && !ops[i].epi_scale0 && ((flags & MPOSE_CONV_PLANES_IN) || !(flags & MPOSE_CONV_F16X3) || (flags & MPOSE_CONV_ACCUMULATE))) return MPOSE_EINVAL;
     if (ops[i].red_sums && ((flags & MPOSE_CONV_PLANES_IN) || !ops[i].red_a || !ops[i].red_b || !ops[i].red_scale || !ops[i].red_shift ||
                             ops[i].stats0 || ops[i].stats1 || ops[i].epi_scale0 || (acc1 && !sum_inputs)))
       return MPOSE_EINVAL;

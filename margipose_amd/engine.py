@@ -44,10 +44,12 @@ UNPACK_DT = np.dtype([('src', 'u8'), ('dst', 'u8'), ('N', 'i4'), ('K', 'i4'), ('
 BN_DT = np.dtype([('stats', 'u8'), ('gamma', 'u8'), ('beta', 'u8'), ('running_mean', 'u8'), ('running_var', 'u8'),
                   ('scale', 'u8'), ('shift', 'u8'), ('mean', 'u8'), ('invstd', 'u8'), ('C', 'i4'), ('count', 'i4'),
                   ('conv_bias', 'u8'), ('eps', 'f4'), ('pad_', 'i4'), ('minmax', 'u8'), ('amax_out', 'u8'),
-                  ('part', 'u8'), ('mm_part', 'u8'), ('n_part', 'i4'), ('part_ld', 'i4')], align=True)
+                  ('part', 'u8'), ('mm_part', 'u8'), ('n_part', 'i4'), ('part_ld', 'i4'),
+                  ('bound_gamma2', 'u8'), ('bound_beta2', 'u8'), ('bound_out', 'u8')], align=True)
 COEF_DT = np.dtype([('sums', 'u8'), ('gamma', 'u8'), ('mean', 'u8'), ('invstd', 'u8'), ('coef', 'u8'), ('dgamma', 'u8'),
                     ('dbeta', 'u8'), ('sums_stride', 'i4'), ('which', 'i4'), ('C', 'i4'), ('c_stride', 'i4'), ('count', 'i4'),
-                    ('sg_col', 'i4'), ('dconv_bias', 'u8'), ('part', 'u8'), ('n_part', 'i4'), ('part_ld', 'i4')], align=True)
+                    ('sg_col', 'i4'), ('dconv_bias', 'u8'), ('part', 'u8'), ('n_part', 'i4'), ('part_ld', 'i4'),
+                    ('g_amax', 'u8'), ('bound_out', 'u8')], align=True)
 
 AMAX_SLOT = 16 * 64          # floats per activation amax slot (MPOSE_AMAX_SUBSLOTS * MPOSE_AMAX_STRIDE)
 _SIZES_CHECKED = False
@@ -359,6 +361,15 @@ class Engine:
         # DMA'd into workgroup-shared LDS tiles, two workgroups per CU, no operand arithmetic in the K loop -- 85 instead of
         # 117 us per 128 -> 128 launch (round 4).  MPOSE_H2=0: conv_igemm_k everywhere (A/B runs).
         self.h2 = os.environ.get('MPOSE_H2', '1') != '0'
+        # ... and in TRAINING the elementwise passes that produce an H2 block's operands write the fp16 planes themselves (the
+        # residual sum of the block before: mpose_bn_add_h2; the BatchNorm-backward application: mpose_bn_bwd_apply_h2), scaled by a
+        # BOUND on the tensor's magnitude that the finalize / coefficient kernels derive before the pass runs (mpose_bn_job.bound_out,
+        # mpose_bn_bwd_coef_job.bound_out) -- no measuring, no separate split pass.  (Batch statistics bound a normalised value;
+        # running statistics do not: eval-mode forwards measure and split.)  MPOSE_H2_FUSE=0: measure + mpose_split_h2 everywhere;
+        # 1 (default): the residual sum only -- the fused BatchNorm-backward application moves 300 MB (three inputs, two fp32 outputs
+        # that the weight gradients still read, the planes), past the Infinity Cache, and measured 55 us against 27 + 16 us for
+        # mpose_bn_bwd_apply + mpose_split_h2; 2: both.
+        self.h2_fuse = int(os.environ.get('MPOSE_H2_FUSE', '1'))
         self.inline_unpack = os.environ.get('MPOSE_INLINE_UNPACK', '0') != '0'     # (see unpack_after: measured no faster, off)
         self.overlap_wgrad = True    # +2.3 % step rate, bit-identical results; launches bracketed by a KernelTimer stay serial
         self.dp = None               # optional (process_group, world_size): gradient all-reduce after backward
@@ -485,7 +496,7 @@ class Engine:
         self.wamax = torch.zeros(len(self._convs), dtype=torch.float32, device=device)
         # (an activation slot is 16 sub-slots 64 floats apart = 1024 floats: include/margipose_hip.h, mpose_absmax)
         self.amax_f = torch.zeros(self.T * 10 * 6 * AMAX_SLOT, dtype=torch.float32, device=device)
-        self.amax_b = torch.zeros(self.T * 10 * 9 * AMAX_SLOT, dtype=torch.float32, device=device)
+        self.amax_b = torch.zeros(self.T * 10 * 12 * AMAX_SLOT, dtype=torch.float32, device=device)      # (+ 3 per block: the gradient w.r.t. its output)
         for i, c in enumerate(self._convs):
             c.amax_ptr = self.wamax.data_ptr() + 4 * i
             if c.layout == 1:                      # a column convolution
@@ -634,6 +645,16 @@ class Engine:
         tb['stat_part'] = torch.zeros(max(sp_off, 4), dtype=torch.float32, device=dev)
         spb = tb['stat_part'].data_ptr()
         tb['sp_ptr'] = dict((k_, spb + 4 * v[0]) for k_, v in sp.items())
+        for t in range(self.T):              # bounds for the H2 engine's fused producers (used when the launch asks for them)
+            for i in range(10):
+                base = (t * 10 + i) * 9
+                for c, b in enumerate(self.stage_blocks[t][i]):
+                    if self.h2_next(t, i):       # |relu(bn2(c2)) + bn_s(sc)| <= (|g2| + |gs|) sqrt(n) + |b2| + |bs|: the next block's input
+                        j = fj[1 + base + 6 + c]
+                        j['bound_gamma2'], j['bound_beta2'] = b.bns.m.weight.data_ptr(), b.bns.m.bias.data_ptr()
+                        j['bound_out'] = self._amax_f(t, i + 1, 0, c)
+                    if b.h2:                     # the BatchNorm-backward application of bn2: d_c2, the data-gradient's operand
+                        cj[base + c]['g_amax'], cj[base + c]['bound_out'] = self._amax_b(t, i, 3, c), self._amax_b(t, i, 0, c)
         if self.stats_part:
             for t in range(self.T):
                 for i in range(10):
@@ -817,8 +838,12 @@ class Engine:
         return self.amax_f.data_ptr() + 4 * AMAX_SLOT * (((t * 10 + i) * 2 + which) * 3 + c)
 
     def _amax_b(self, t, i, which, c):
-        """which: 0 d_c2, 1 d_c1, 2 d_sc."""
-        return self.amax_b.data_ptr() + 4 * AMAX_SLOT * (((t * 10 + i) * 3 + which) * 3 + c)
+        """which: 0 d_c2, 1 d_c1, 2 d_sc, 3 the gradient w.r.t. the block's output."""
+        return self.amax_b.data_ptr() + 4 * AMAX_SLOT * (((t * 10 + i) * 4 + which) * 3 + c)
+
+    def h2_next(self, t, i):
+        """Block i's residual sum feeds an H2 block directly (no axis permutation in between): it can write that block's planes."""
+        return i + 1 < 10 and self.stage_blocks[t][i + 1][0].h2 and not (i == 4 and any(sp != 0 for sp in self.spaces))
 
     def wgrad(self, g, ops, n_split):
         arr = (WgradOperands * 3)(*ops)
@@ -912,10 +937,10 @@ class Engine:
             nsp = g._n_split = d * self._n_split(slots // d, tiles, groups)
         return nsp
 
-    def finalize(self, tb, first, n, train, part=False):
+    def finalize(self, tb, first, n, train, part=False, bounds=False):
         base = tb['fin'].data_ptr() + first * BN_DT.itemsize
-        check(lib().mpose_bn_finalize(c_void_p(base), n, int(train) | (2 if (part and train) else 0), ctypes.c_float(BN_EPS),
-                                      ctypes.c_float(BN_MOMENTUM), stream_ptr()), 'mpose_bn_finalize')
+        check(lib().mpose_bn_finalize(c_void_p(base), n, int(train) | (2 if (part and train) else 0) | (4 if (bounds and train) else 0),
+                                      ctypes.c_float(BN_EPS), ctypes.c_float(BN_MOMENTUM), stream_ptr()), 'mpose_bn_finalize')
 
     def pack_weights(self, cmode):
         jobs = self._pack_jobs[cmode]
@@ -975,6 +1000,7 @@ class Engine:
         planes = cmode == 1
         f16 = cmode in (2, 3)
         h2 = cmode == 3
+        h2f = ctx['h2f'] = bool(h2 and train and self.h2_fuse)       # the producers of the H2 blocks' operands write the planes themselves
         # train mode on conv_igemm_k: the convolution launches finalise their own BatchNorms (no mpose_bn_finalize launches)
         fin_fused = train and not planes and self.fuse_finalize
         # statistics as per-workgroup partial rows (MPOSE_CONV_STATS_PART) instead of fp64 atomics: conv_igemm_k / conv_h2_k only
@@ -1034,6 +1060,7 @@ class Engine:
                 inp_p = self.split_planes([inp], B * F * F, 128)[0]
                 cur_p = [inp_p, inp_p, inp_p]
             stage_saved = []
+            nxt_h = None
             for i in range(10):
                 grp = self.stage_blocks[t][i]
                 b0 = grp[0]
@@ -1072,7 +1099,10 @@ class Engine:
                         self.absmax(cur, cur_slot, b0.cin_s)
                 blk_h2 = h2 and b0.h2        # this block's forward convolutions read producer-split fp16 planes (conv_h.hip)
                 if blk_h2:
-                    cur_h = self.split_h2(cur, cur_slot, B * Hin * Hin, b0.cin_s)
+                    if nxt_h is not None:    # (the block before wrote them with its residual sum)
+                        cur_h, nxt_h = nxt_h, None
+                    else:
+                        cur_h = self.split_h2(cur, cur_slot, B * Hin * Hin, b0.cin_s)
                 ops = []
                 for c, b in enumerate(grp):
                     op = ConvOperands()
@@ -1160,8 +1190,9 @@ class Engine:
                     ops.append(op)
                 self.conv(self.geom('f_conv2', B, Hout, b0), ops,
                           pflags | (16 if (fuse2 or fuse2_h) else 0) | (256 if spart else 0) | (128 if blk_h2 else 0))
+                add_h2 = h2f and self.h2_next(t, i)      # this block's sum is the next (H2) block's input: planes written here
                 if train and not fin_fused:
-                    self.finalize(tb, self.fin_index(t, i, 2), 3, True, spart)
+                    self.finalize(tb, self.fin_index(t, i, 2), 3, True, spart, bounds=add_h2)
                 if fuse2:
                     cur_p = nxt_p
                 elif fuse2_h:
@@ -1176,7 +1207,11 @@ class Engine:
                         if f16 and not last:
                             ao.out_amax = self._amax_f(t, i + 1, 0, c)       # (the axis permutation after block 4 keeps the maximum)
                         aops.append(ao)
-                    if planes and not last:
+                    if add_h2:               # (out_amax is READ there: the bound bn_finalize just wrote)
+                        nxt_h = [torch.empty(npix_o * b0.cout_s, **f32) for _ in range(3)]
+                        check(L.mpose_bn_add_h2((BnAddOperands * 3)(*aops), ptr_array(nxt_h), 3, c_int64(npix_o), b0.cout_s, st()),
+                              'mpose_bn_add_h2')
+                    elif planes and not last:
                         cur_p = [self.planes_empty(npix_o, b0.cout_s) for _ in range(3)]
                         check(L.mpose_bn_add_planes((BnAddOperands * 3)(*aops), ptr_array(cur_p), 3, c_int64(npix_o), b0.cout_s, st()),
                               'mpose_bn_add_planes')
@@ -1315,9 +1350,12 @@ class Engine:
         spart = bool(self.part_stats() and not planes)
         sp = tb['sp_ptr']
 
-        def run_coef(first, n, from_sums=False):
-            # mode: bit 0 eval, bit 1 the jobs' `sums` were written by a reduction pass (not partial rows), bit 2: 1024 threads
-            mode = eval_bn | (0 if (spart and not from_sums) else 2) | (4 if (spart and not from_sums) else 0)
+        h2f = bool(h2 and ctx.get('h2f', False))
+
+        def run_coef(first, n, from_sums=False, bounds=False):
+            # mode: bit 0 eval, bit 1 the jobs' `sums` were written by a reduction pass (not partial rows), bit 2: 1024 threads,
+            # bit 3: the jobs' bounds (mpose_bn_bwd_coef_job.bound_out)
+            mode = eval_bn | (0 if (spart and not from_sums) else 2) | (4 if (spart and not from_sums) else 0) | (8 if bounds else 0)
             check(L.mpose_bn_bwd_coef(c_void_p(coef_base + first * COEF_DT.itemsize), n, mode, st()), 'mpose_bn_bwd_coef')
 
         works = []          # in-flight gradient all-reduces (data parallel), one per finished bucket
@@ -1362,7 +1400,9 @@ class Engine:
                         ro.sums = self._stats_ptr(b.bn2, True)
                         rops.append(ro)
                     self.bn_bwd_reduce(rops, Hout * Hout, B, Cs)
-                run_coef(jb, 6, from_sums=not sums_done)
+                blk_h2 = h2 and b0.h2
+                app_h2 = h2f and blk_h2 and self.h2_fuse >= 2     # bn2's backward application writes d_c2 as planes too, scaled by the coefficient kernel's bound
+                run_coef(jb, 6, from_sums=not sums_done, bounds=app_h2)
                 d_c2 = [torch.empty(B, Hout, Hout, Cs, **f32) for _ in range(3)]
                 d_sc = [torch.empty(B, Hout, Hout, Cs, **f32) for _ in range(3)]
                 aops = []
@@ -1375,7 +1415,11 @@ class Engine:
                     if f16:
                         ao.da_amax, ao.db_amax = self._amax_b(t, i, 0, c), self._amax_b(t, i, 2, c)
                     aops.append(ao)
-                if planes:           # the gradients feed a convolution next: written pre-split as well
+                if app_h2:           # (da_amax is READ there)
+                    d_c2_h = [torch.empty(cnt * Cs, **f32) for _ in range(3)]
+                    check(L.mpose_bn_bwd_apply_h2((BnBwdApplyOperands * 3)(*aops), ptr_array(d_c2_h), 3, c_int64(cnt), Cs, st()),
+                          'mpose_bn_bwd_apply_h2')
+                elif planes:         # the gradients feed a convolution next: written pre-split as well
                     d_c2_p = [self.planes_empty(cnt, Cs) for _ in range(3)]
                     d_sc_p = [self.planes_empty(cnt, Cs) for _ in range(3)]
                     check(L.mpose_bn_bwd_apply_planes((BnBwdApplyOperands * 3)(*aops), ptr_array(d_c2_p), ptr_array(d_sc_p), 3, c_int64(cnt),
@@ -1384,8 +1428,7 @@ class Engine:
                     check(L.mpose_bn_bwd_apply((BnBwdApplyOperands * 3)(*aops), 3, Hout * Hout, B, Cs, 0, 0, st()), 'mpose_bn_bwd_apply')
                 # (2) dgrad of the second 3x3; ReLU mask and the BN1-backward sums happen in its epilogue
                 d_a1 = [torch.empty(B, Hout, Hout, Cs, **f32) for _ in range(3)]
-                blk_h2 = h2 and b0.h2
-                if blk_h2:               # the second 3x3's data-gradient on conv_h.hip: its operand as two fp16 planes
+                if blk_h2 and not app_h2:    # the second 3x3's data-gradient on conv_h.hip: its operand as two fp16 planes
                     d_c2_h = self.split_h2(d_c2, [self._amax_b(t, i, 0, c) for c in range(3)], cnt, Cs)
                 ops = []
                 for c, b in enumerate(grp):
@@ -1462,6 +1505,8 @@ class Engine:
                         op.red_a, op.red_b = psv['c2'][c].data_ptr(), psv['sc'][c].data_ptr()
                         op.red_scale, op.red_shift = self._bnf_ptr(pb.bn2, 0), self._bnf_ptr(pb.bn2, 1)
                         op.red_sums = sp[(id(pb.bn2), 'b')] if spart else self._stats_ptr(pb.bn2, True)
+                    if h2f and self.h2_fuse >= 2 and i >= 1 and self.stage_blocks[t][i - 1][0].h2:     # d_x is an H2 block's g: its largest magnitude for that block's bound
+                        op.out0_amax = self._amax_b(t, i - 1, 3, c)
                     ops.append(op)
                 self.conv(self.geom(kd, B, Hout, b0), ops, 2 | pflags | (256 if (spart and fuse_sums) else 0))
                 sums_done = fuse_sums
