@@ -427,6 +427,17 @@ int mpose_bn_add_planes(const mpose_bn_add_operands* ops, void* const* planes, i
  * measured.  ops[i].out may be NULL (planes only). */
 int mpose_bn_add_h2(const mpose_bn_add_operands* ops, void* const* h2, int n_groups, int64_t npix, int C, void* stream);
 
+/* The last ResidualBlock's residual sum (mpose_bn_add_fwd layout 1: models/margipose_model.py:34-40) fused with flat_softmax + dsnt:
+ * heatmaps[g] (B, J, H, W) = flat_softmax(relu(a_scale*a + a_shift) + (b_scale*b + b_shift)) over the first J of the C NHWC channels
+ * of ops[g].a / ops[g].b, plane_coords (n_groups, B*J, 2) = dsnt(heatmaps) (may be NULL); the logits never reach memory, and the
+ * heatmaps are bit-identical to the two-launch path's.  io_dtype: 0 fp32 heatmaps, 2 bf16 heatmaps.  H*W <= 4096, W % 4 == 0, C % 4 == 0. */
+int mpose_bn_add_softmax_fwd(const mpose_bn_add_operands* ops, void* const* heatmaps, float* plane_coords, int n_groups,
+                             int B, int H, int W, int C, int J, int io_dtype, void* stream);
+/* xyz (rows, 3) from plane_coords (3, rows, 2): MargiPoseModel.heatmaps_to_coords' merge, z = (zy.x + xz.y) / 2
+ * (models/margipose_model.py:254-261). */
+int mpose_coords_merge(const float* plane_coords, float* xyz, int rows, void* stream);
+
+
 /* out = relu(x*scale + shift) over an NHWC tensor of n elements with C channels (the stem's BN+ReLU,
  * materialised because every column of every stage reads it), and the ReLU backward gm = g*[y>0]. */
 int mpose_bn_relu_fwd(const float* x, const float* scale, const float* shift, float* out, int64_t n,

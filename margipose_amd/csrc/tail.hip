@@ -167,6 +167,132 @@ __global__ __launch_bounds__(64 * MPOSE_MAX_GROUP) void softmax_dsnt_fwd_k(Softm
 }
 
 // ---------------------------------------------------------------------------------------------
+// The last ResidualBlock's residual sum fused with flat_softmax + dsnt (round 4): the column's logits never reach memory.
+//   logits[b][j][p] = relu(a_scale*a + a_shift)[b,p,j] + (b_scale*b + b_shift)[b,p,j]     (models/margipose_model.py:34-40, NHWC in)
+//   heatmaps = flat_softmax(logits) (dsntnn.py:124-130), plane coordinates = dsnt(heatmaps) (dsntnn.py:84-96)
+// One workgroup per (image, column, float4 of joint channels): the four joints' H*W logits live in LDS (16 KB at 32 x 32); phase 1
+// reads that float4 of every pixel of the two NHWC tensors (every load of a thread in flight at once) and turns it into 4 rows,
+// phase 2 is softmax_dsnt_fwd_k's row arithmetic, instruction for instruction (bit-identical heatmaps), a wave per joint.
+// Replaces bn_add_nchw_k + softmax_dsnt_fwd_k: 13.4 MB of logits written and re-read per stage at B = 32, one launch instead of
+// two.  (A first form with ONE workgroup per image -- all 17 rows in 68 KB of LDS -- measured 18.4 us against the two launches'
+// 14.8: 96 workgroups leave 160 CUs idle.)
+// ---------------------------------------------------------------------------------------------
+struct BnAddSoftmaxArgs {
+  mpose_bn_add_operands op[MPOSE_MAX_GROUP];
+  void* heat[MPOSE_MAX_GROUP];
+  float* plane_coords;      // (n_groups, B*J, 2)
+  int B, P, C, J, H, W;
+};
+
+constexpr int kBasThreads = 256, kBasPad = 4, kBasU = 4;     // row pitch P + 4 floats: float4-aligned rows, the turn's stores spread over banks
+
+template <int NV, bool BF_OUT>
+__global__ __launch_bounds__(kBasThreads) void bn_add_softmax_k(BnAddSoftmaxArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float tile[];          // [4][P + kBasPad]: the workgroup's four joints
+  const mpose_bn_add_operands& op = a.op[blockIdx.y];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c0 = blockIdx.z * 4, pitch = a.P + kBasPad;                  // the float4 column of channels c0..c0+3
+  const size_t img = (size_t)b * a.P * a.C + c0;
+  float sa[4], ta[4], sb[4], tb[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int cc = min(c0 + e, a.J - 1);
+    sa[e] = op.a_scale[cc]; ta[e] = op.a_shift[cc]; sb[e] = op.b_scale[cc]; tb[e] = op.b_shift[cc];
+  }
+  // all of a thread's loads first (kBasU float4 pairs in flight per thread: 4 cover a 32 x 32 image in one pass), then the turn
+  for (int base = 0; base < a.P; base += kBasThreads * kBasU) {
+    float4 x[kBasU], y[kBasU];
+#pragma unroll
+    for (int u = 0; u < kBasU; ++u) {
+      const int px = base + u * kBasThreads + tid;
+      if (px < a.P) {
+        x[u] = *reinterpret_cast<const float4*>(op.a + img + (size_t)px * a.C);
+        y[u] = *reinterpret_cast<const float4*>(op.b + img + (size_t)px * a.C);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kBasU; ++u) {
+      const int px = base + u * kBasThreads + tid;
+      if (px < a.P) {
+        const float xs[4] = {x[u].x, x[u].y, x[u].z, x[u].w}, ys[4] = {y[u].x, y[u].y, y[u].z, y[u].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)      // (bn_add_nchw_k's expression; rows past J are computed from joint J-1's coefficients and never read)
+          tile[e * pitch + px] = fmaxf(fmaf(xs[e], sa[e], ta[e]), 0.f) + fmaf(ys[e], sb[e], tb[e]);
+      }
+    }
+  }
+  __syncthreads();
+  const RowGeom g = make_geom(a.H, a.W);
+  {
+    const int j = c0 + wave;                 // a wave per joint
+    if (j >= a.J) return;
+    const float* row = tile + wave * pitch;
+    float4 v[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int idx = i * 64 + lane;
+      v[i] = (idx < g.n4) ? reinterpret_cast<const float4*>(row)[idx] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    }
+    float m = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) m = fmaxf(m, fmaxf(fmaxf(v[i].x, v[i].y), fmaxf(v[i].z, v[i].w)));
+    m = wave_max(m);
+    float s_ = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      v[i].x = expf(v[i].x - m); v[i].y = expf(v[i].y - m); v[i].z = expf(v[i].z - m); v[i].w = expf(v[i].w - m);
+      s_ += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    s_ = wave_sum(s_);
+    const float rs_ = 1.0f / s_;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { v[i].x *= rs_; v[i].y *= rs_; v[i].z *= rs_; v[i].w *= rs_; }
+    float sx = 0.0f, sy = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      int h, w0;
+      elem_hw(g, i, lane, h, w0);
+      const float y = cell_coord(h, g.two_over_h, g.first_h);
+      const float x0 = cell_coord(w0, g.two_over_w, g.first_w);
+      const float rsum = (v[i].x + v[i].y) + (v[i].z + v[i].w);
+      sy = fmaf(rsum, y, sy);
+      sx += v[i].x * x0 + v[i].y * (x0 + g.two_over_w) + v[i].z * (x0 + 2.0f * g.two_over_w) + v[i].w * (x0 + 3.0f * g.two_over_w);
+    }
+    sx = wave_sum(sx);
+    sy = wave_sum(sy);
+    const size_t r = (size_t)b * a.J + j;
+    if (BF_OUT) store_row_bf16<NV>(reinterpret_cast<unsigned short*>(a.heat[blockIdx.y]) + r * a.P, lane, g.n4, v);
+    else store_row<NV>(reinterpret_cast<float*>(a.heat[blockIdx.y]) + r * a.P, lane, g.n4, v);
+    if (lane == 0 && a.plane_coords != nullptr) {
+      float* pc = a.plane_coords + ((size_t)blockIdx.y * a.B * a.J + r) * 2;
+      pc[0] = sx; pc[1] = sy;
+    }
+  }
+}
+
+template <int NV, bool BF_OUT>
+static int launch_bn_add_softmax(const BnAddSoftmaxArgs& a, int n_groups, int lds, hipStream_t s) {
+  static bool raised = false;            // (per instantiation; the attribute is per function and sticky)
+  if (lds > 48 * 1024 && !raised) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&bn_add_softmax_k<NV, BF_OUT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            72 * 1024) != hipSuccess)
+      return MPOSE_EINVAL;
+    raised = true;
+  }
+  bn_add_softmax_k<NV, BF_OUT><<<dim3(a.B, n_groups, (a.J + 3) / 4), kBasThreads, lds, s>>>(a);
+  return 0;
+}
+
+// MargiPoseModel.heatmaps_to_coords' merge (models/margipose_model.py:254-261) from the three planes' coordinates
+__global__ __launch_bounds__(256) void coords_merge_k(const float* __restrict__ pc, float* __restrict__ xyz, int rows) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= rows) return;
+  xyz[r * 3] = pc[r * 2];
+  xyz[r * 3 + 1] = pc[r * 2 + 1];
+  xyz[r * 3 + 2] = 0.5f * (pc[((size_t)rows + r) * 2] + pc[((size_t)2 * rows + r) * 2 + 1]);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Gaussian target of one plane, regenerated per lane (dsntnn.py:154-195)
 // ---------------------------------------------------------------------------------------------
 struct Gauss {
@@ -534,6 +660,35 @@ extern "C" int mpose_softmax_dsnt_fwd(const void* const* logits, void* const* he
   } else {
     return MPOSE_EINVAL;
   }
+  return launch_status();
+}
+
+extern "C" int mpose_bn_add_softmax_fwd(const mpose_bn_add_operands* ops, void* const* heatmaps, float* plane_coords, int n_groups,
+                                        int B, int H, int W, int C, int J, int io_dtype, void* stream) {
+  if (n_groups < 1 || n_groups > MPOSE_MAX_GROUP || B < 0 || (W & 3) || (C & 3) || J < 1 || J > C || (io_dtype != 0 && io_dtype != 2))
+    return MPOSE_EINVAL;
+  if (B == 0) return 0;
+  const int P = H * W;
+  const int lds = 4 * (P + kBasPad) * 4;                           // <= 64 KB (pick_nv: P <= 4096)
+  BnAddSoftmaxArgs a{};
+  for (int i = 0; i < n_groups; ++i) {
+    a.op[i] = ops[i];
+    a.heat[i] = heatmaps[i];
+    if (!ops[i].a || !ops[i].b || !ops[i].a_scale || !ops[i].a_shift || !ops[i].b_scale || !ops[i].b_shift || !heatmaps[i]) return MPOSE_EINVAL;
+  }
+  a.plane_coords = plane_coords; a.B = B; a.P = P; a.C = C; a.J = J; a.H = H; a.W = W;
+  const int nv = pick_nv(P);
+  int rc = 0;
+  if (io_dtype == 0) { MPOSE_DISPATCH_NV(nv, (rc = launch_bn_add_softmax<NV, false>(a, n_groups, lds, (hipStream_t)stream))); }
+  else { MPOSE_DISPATCH_NV(nv, (rc = launch_bn_add_softmax<NV, true>(a, n_groups, lds, (hipStream_t)stream))); }
+  if (rc) return rc;
+  return launch_status();
+}
+
+extern "C" int mpose_coords_merge(const float* plane_coords, float* xyz, int rows, void* stream) {
+  if (rows < 0 || !plane_coords || !xyz) return MPOSE_EINVAL;
+  if (rows == 0) return 0;
+  coords_merge_k<<<(rows + 255) / 256, 256, 0, (hipStream_t)stream>>>(plane_coords, xyz, rows);
   return launch_status();
 }
 

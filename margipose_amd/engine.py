@@ -370,6 +370,9 @@ class Engine:
         # that the weight gradients still read, the planes), past the Infinity Cache, and measured 55 us against 27 + 16 us for
         # mpose_bn_bwd_apply + mpose_split_h2; 2: both.
         self.h2_fuse = int(os.environ.get('MPOSE_H2_FUSE', '1'))
+        # the last ResidualBlock's residual sum, flat_softmax and dsnt as ONE launch per stage (mpose_bn_add_softmax_fwd: an image's
+        # logits stay in LDS); heatmaps and coordinates are bit-identical to the two-launch path (MPOSE_TAIL_FUSE=0)
+        self.tail_fuse = os.environ.get('MPOSE_TAIL_FUSE', '1') != '0'
         self.inline_unpack = os.environ.get('MPOSE_INLINE_UNPACK', '0') != '0'     # (see unpack_after: measured no faster, off)
         self.overlap_wgrad = True    # +2.3 % step rate, bit-identical results; launches bracketed by a KernelTimer stay serial
         self.dp = None               # optional (process_group, world_size): gradient all-reduce after backward
@@ -976,6 +979,7 @@ class Engine:
             raise _lib.MposeError('expected a (B, 3, S, S) input with S %% 16 == 0, got %s' % (tuple(x.shape),))
         F = S // 8
         Sm = F // 2
+        tail_fused = self.tail_fuse and (F & 3) == 0 and F * F <= 4096
         if 192 % Sm != 0 or (Sm % 4) != 0 or (F * F) % 64 != 0 or F * F > 4096:
             raise _lib.MposeError('unsupported input size %d (mid size %d must divide 192 and be a multiple of 4)' % (S, Sm))
         if save and Sm % 8 != 0:       # the weight-gradient kernel walks slot rows in octets (mpose_conv_wgrad: GW % 8 == 0)
@@ -1149,7 +1153,7 @@ class Engine:
                 need_f32 = (not fuse2) or (i == 4 and any(sp != 0 for sp in self.spaces))     # the axis permutation reads fp32
                 c2 = None if (fuse2 or fuse2_h) else [torch.empty(B, Hout, Hout, b0.cout_s, **f32) for _ in range(3)]
                 if last:
-                    outs = [torch.empty(B, self.J, F, F, **f32) for _ in range(3)]
+                    outs = [None] * 3 if tail_fused else [torch.empty(B, self.J, F, F, **f32) for _ in range(3)]
                 elif need_f32:
                     outs = [torch.empty(B, Hout, Hout, b0.cout_s, **f32) for _ in range(3)]
                 else:
@@ -1203,7 +1207,7 @@ class Engine:
                         ao = BnAddOperands()
                         ao.a, ao.a_scale, ao.a_shift = c2[c].data_ptr(), self._bnf_ptr(b.bn2, 0), self._bnf_ptr(b.bn2, 1)
                         ao.b, ao.b_scale, ao.b_shift = sc[c].data_ptr(), self._bnf_ptr(b.bns, 0), self._bnf_ptr(b.bns, 1)
-                        ao.out = outs[c].data_ptr()
+                        ao.out = outs[c].data_ptr() if outs[c] is not None else None
                         if f16 and not last:
                             ao.out_amax = self._amax_f(t, i + 1, 0, c)       # (the axis permutation after block 4 keeps the maximum)
                         aops.append(ao)
@@ -1215,22 +1219,35 @@ class Engine:
                         cur_p = [self.planes_empty(npix_o, b0.cout_s) for _ in range(3)]
                         check(L.mpose_bn_add_planes((BnAddOperands * 3)(*aops), ptr_array(cur_p), 3, c_int64(npix_o), b0.cout_s, st()),
                               'mpose_bn_add_planes')
+                    elif last and tail_fused:       # residual sum + flat_softmax + dsnt in one launch: no logits in memory
+                        heat = [torch.empty(B, self.J, F, F, dtype=torch.bfloat16 if hm_bf16 else torch.float32, device=x.device)
+                                for _ in range(3)]
+                        pc = torch.empty(3, B * self.J, 2, **f32) if t == self.T - 1 else None
+                        t0 = self.timer.start() if self.timer is not None else None
+                        check(L.mpose_bn_add_softmax_fwd((BnAddOperands * 3)(*aops), ptr_array(heat), ptr(pc) if pc is not None else None,
+                                                         3, B, F, F, b0.cout_s, self.J, 2 if hm_bf16 else 0, st()), 'mpose_bn_add_softmax_fwd')
+                        if t0 is not None:    # algorithmic bytes: the joint channels of both inputs once, the heatmaps once
+                            self.timer.stop('tail:bn_add_softmax_fwd', t0, 3 * B * self.J * F * F * (10 if hm_bf16 else 12))
+                        if pc is not None:
+                            xyz = torch.empty(B, self.J, 3, **f32)
+                            check(L.mpose_coords_merge(ptr(pc), ptr(xyz), B * self.J, st()), 'mpose_coords_merge')
                     else:
                         check(L.mpose_bn_add_fwd((BnAddOperands * 3)(*aops), 3, Hout * Hout, B, b0.cout_s, 1 if last else 0, self.J, st()),
                               'mpose_bn_add_fwd')
                 if save:
                     stage_saved.append({'x': cur, 'c1': c1, 'sc': sc, 'c2': c2})
                 cur = outs
-            logits = cur
-            heat = [torch.empty_like(l, dtype=torch.bfloat16 if hm_bf16 else torch.float32) for l in logits]
-            want_xyz = t == self.T - 1
-            if want_xyz:
-                xyz = torch.empty(B, self.J, 3, **f32)
-            t0 = self.timer.start() if self.timer is not None else None
-            check(L.mpose_softmax_dsnt_fwd(ptr_array(logits), ptr_array(heat), None, ptr(xyz) if want_xyz else None, 3, B * self.J, F,
-                                           F, 2 if hm_bf16 else 0, st()), 'mpose_softmax_dsnt_fwd')
-            if t0 is not None:      # algorithmic bytes: read logits once, write heatmaps once (+ coords)
-                self.timer.stop('tail:softmax_dsnt_fwd', t0, 3 * B * self.J * F * F * (6 if hm_bf16 else 8) + (B * self.J * 12 if want_xyz else 0))
+            if not tail_fused:
+                logits = cur
+                heat = [torch.empty_like(l, dtype=torch.bfloat16 if hm_bf16 else torch.float32) for l in logits]
+                want_xyz = t == self.T - 1
+                if want_xyz:
+                    xyz = torch.empty(B, self.J, 3, **f32)
+                t0 = self.timer.start() if self.timer is not None else None
+                check(L.mpose_softmax_dsnt_fwd(ptr_array(logits), ptr_array(heat), None, ptr(xyz) if want_xyz else None, 3, B * self.J, F,
+                                               F, 2 if hm_bf16 else 0, st()), 'mpose_softmax_dsnt_fwd')
+                if t0 is not None:      # algorithmic bytes: read logits once, write heatmaps once (+ coords)
+                    self.timer.stop('tail:softmax_dsnt_fwd', t0, 3 * B * self.J * F * F * (6 if hm_bf16 else 8) + (B * self.J * 12 if want_xyz else 0))
             for p in range(3):
                 hms[p].append(heat[p])
             ctx['blocks'].append(stage_saved)

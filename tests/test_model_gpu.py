@@ -778,6 +778,7 @@ def test_step_switches_leave_the_results_bit_identical(stem):
     eng.h2 = False
     eng.fuse_finalize = True
     eng.inline_unpack = True
+    eng.tail_fuse = False          # (fourth: the residual sum + soft-argmax as two launches through a logits tensor instead of one)
     res = []
     for m in (m0, m1):
         out = m(x.cuda())

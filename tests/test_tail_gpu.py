@@ -151,3 +151,62 @@ def test_bf16_heatmap_io(D):
     np.testing.assert_allclose(xyz.cpu().numpy(), ref_xyz, rtol=1e-5, atol=2e-6)    # fp32 soft-argmax on bf16 logits
     for h, r in zip(hm, ref_hm):
         np.testing.assert_allclose(h.float().cpu().numpy(), r, rtol=8e-3, atol=1e-30)  # bf16 rounding of outputs
+
+
+@pytest.mark.parametrize('F,bf16', [(32, False), (32, True), (48, False), (16, False), (64, False)])
+def test_fused_residual_sum_softmax_is_bit_identical(F, bf16):
+    """mpose_bn_add_softmax_fwd (the last ResidualBlock's sum + flat_softmax + dsnt, logits kept in LDS) against the two launches
+    it replaces (mpose_bn_add_fwd layout 1, then mpose_softmax_dsnt_fwd): same heatmaps and coordinates, bit for bit."""
+    from margipose_amd import _lib
+    from margipose_amd._lib import BnAddOperands
+    L = _lib.lib()
+    rng = np.random.default_rng(11 + F)
+    B, C, J = 5, 32, 17
+    g = lambda *s: torch.tensor(rng.standard_normal(s), dtype=torch.float32, device='cuda')
+    a = [g(B, F, F, C) * 3 for _ in range(3)]
+    b = [g(B, F, F, C) * 2 for _ in range(3)]
+    co = [[g(C) for _ in range(4)] for _ in range(3)]
+    logits = [torch.empty(B, J, F, F, device='cuda') for _ in range(3)]
+    dt = torch.bfloat16 if bf16 else torch.float32
+    heat0 = [torch.empty(B, J, F, F, device='cuda', dtype=dt) for _ in range(3)]
+    heat1 = [torch.full((B, J, F, F), 7.0, device='cuda', dtype=dt) for _ in range(3)]
+    pc0 = torch.empty(3, B * J, 2, device='cuda'); pc1 = torch.full((3, B * J, 2), 7.0, device='cuda')
+    xyz0 = torch.empty(B, J, 3, device='cuda'); xyz1 = torch.empty(B, J, 3, device='cuda')
+    ops = []
+    for c in range(3):
+        ao = BnAddOperands()
+        ao.a, ao.a_scale, ao.a_shift = a[c].data_ptr(), co[c][0].data_ptr(), co[c][1].data_ptr()
+        ao.b, ao.b_scale, ao.b_shift = b[c].data_ptr(), co[c][2].data_ptr(), co[c][3].data_ptr()
+        ao.out = logits[c].data_ptr()
+        ops.append(ao)
+    st = _lib.stream_ptr()
+    _lib.check(L.mpose_bn_add_fwd((BnAddOperands * 3)(*ops), 3, F * F, B, C, 1, J, st), 'bn_add')
+    _lib.check(L.mpose_softmax_dsnt_fwd(_lib.ptr_array(logits), _lib.ptr_array(heat0), _lib.ptr(pc0), _lib.ptr(xyz0), 3, B * J, F, F,
+                                        2 if bf16 else 0, st), 'softmax')
+    _lib.check(L.mpose_bn_add_softmax_fwd((BnAddOperands * 3)(*ops), _lib.ptr_array(heat1), _lib.ptr(pc1), 3, B, F, F, C, J,
+                                          2 if bf16 else 0, st), 'fused')
+    _lib.check(L.mpose_coords_merge(_lib.ptr(pc1), _lib.ptr(xyz1), B * J, st), 'merge')
+    torch.cuda.synchronize()
+    for h0, h1 in zip(heat0, heat1):
+        assert torch.equal(h0, h1)
+    assert torch.equal(pc0, pc1) and torch.equal(xyz0, xyz1)
+    # and against the oracle (fp64): the fused path is still the reference's tail
+    lg = [torch.relu(a[c][..., :J] * co[c][0][:J] + co[c][1][:J]) + (b[c][..., :J] * co[c][2][:J] + co[c][3][:J]) for c in range(3)]
+    ref = [T.flat_softmax(l.permute(0, 3, 1, 2).double().cpu().numpy()) for l in lg]
+    if not bf16:
+        np.testing.assert_allclose(xyz1.cpu().numpy(), T.heatmaps_to_coords(*ref), rtol=1e-4, atol=5e-6)
+
+
+def test_fused_residual_sum_softmax_rejects():
+    from margipose_amd import _lib
+    from margipose_amd._lib import BnAddOperands
+    L = _lib.lib()
+    t = torch.zeros(1, 64, 64, 32, device='cuda'); v = torch.zeros(32, device='cuda'); h = torch.zeros(1, 17, 64, 64, device='cuda')
+    ao = BnAddOperands()
+    ao.a = ao.b = t.data_ptr(); ao.a_scale = ao.a_shift = ao.b_scale = ao.b_shift = v.data_ptr()
+    ops = (BnAddOperands * 3)(ao)
+    hp = _lib.ptr_array([h])
+    assert L.mpose_bn_add_softmax_fwd(ops, hp, None, 1, 1, 68, 68, 32, 17, 0, _lib.stream_ptr()) == -22   # H*W > 4096
+    assert L.mpose_bn_add_softmax_fwd(ops, hp, None, 1, 1, 30, 30, 32, 17, 0, _lib.stream_ptr()) == -22   # W % 4
+    assert L.mpose_bn_add_softmax_fwd(ops, hp, None, 1, 1, 32, 32, 32, 33, 0, _lib.stream_ptr()) == -22   # J > C
+    assert L.mpose_bn_add_softmax_fwd(ops, hp, None, 1, 0, 32, 32, 32, 17, 0, _lib.stream_ptr()) == 0                   # empty batch
