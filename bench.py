@@ -73,6 +73,7 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--no-inference', action='store_true', help='skip the configs[1] inference micro-benchmark (profiling runs)')
+    ap.add_argument('--no-configs4', action='store_true', help='skip the short BASELINE configs[4] leg (5 stages, 384x384, fp16 convolutions)')
     ap.add_argument('--cpu-batch', type=int, default=8)
     ap.add_argument('--no-overlap-wgrad', action='store_true', help='keep the weight-gradient GEMMs on the main stream (the default '
                     'runs them on a side stream, +2.3 %% step rate; the steps whose kernels are bracketed by HIP events for the '
@@ -145,6 +146,107 @@ def tail_microbench(device, B, bf16_out=False, launches=200):
     return {'bound': 'hbm', 'achieved': nbytes / sec / 1e9, 'peak': PEAK_HBM_GBPS, 'unit': 'GB/s', 'frac': nbytes / sec / 1e9 / PEAK_HBM_GBPS,
             'traffic': None, 'us_per_launch': sec * 1e6, 'bytes_per_launch': nbytes, 'launches': launches,
             'kernel': 'softmax_dsnt_fwd_k (3 planes, B=%d, %s heatmaps)' % (B, 'bf16' if bf16_out else 'fp32')}
+
+
+def fused_tail_microbench(device, B, bf16_out=False, launches=200):
+    """What a training / inference step launches for the soft-argmax since round 4: the last ResidualBlock's residual sum, flat_softmax
+    and dsnt as one kernel (mpose_bn_add_softmax_fwd, tail.hip bn_add_softmax_k).  Algorithmic bytes: the 17 joint channels of the
+    two NHWC inputs read once, the heatmaps written once, the plane coordinates."""
+    from margipose_amd import _lib
+    from margipose_amd._lib import BnAddOperands
+    F, C, J = 32, 32, 17
+    a = [torch.randn(B, F, F, C, device=device) for _ in range(3)]
+    b = [torch.randn(B, F, F, C, device=device) for _ in range(3)]
+    v = [torch.randn(C, device=device) for _ in range(4)]
+    hm = [torch.empty(B, J, F, F, device=device, dtype=torch.bfloat16 if bf16_out else torch.float32) for _ in range(3)]
+    pc = torch.empty(3, B * J, 2, device=device)
+    ops = []
+    for c in range(3):
+        ao = BnAddOperands()
+        ao.a, ao.a_scale, ao.a_shift = a[c].data_ptr(), v[0].data_ptr(), v[1].data_ptr()
+        ao.b, ao.b_scale, ao.b_shift = b[c].data_ptr(), v[2].data_ptr(), v[3].data_ptr()
+        ops.append(ao)
+    ops = (BnAddOperands * 3)(*ops)
+    L = _lib.lib()
+
+    def run():
+        _lib.check(L.mpose_bn_add_softmax_fwd(ops, _lib.ptr_array(hm), _lib.ptr(pc), 3, B, F, F, C, J, 2 if bf16_out else 0,
+                                              _lib.stream_ptr()), 'bn_add_softmax')
+    for _ in range(5):
+        run()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    s.record()
+    for _ in range(launches):
+        run()
+    e.record()
+    torch.cuda.synchronize()
+    sec = s.elapsed_time(e) * 1e-3 / launches
+    nbytes = 3 * B * J * F * F * (10 if bf16_out else 12) + 3 * B * J * 8
+    return {'bound': 'hbm', 'achieved': nbytes / sec / 1e9, 'peak': PEAK_HBM_GBPS, 'unit': 'GB/s', 'frac': nbytes / sec / 1e9 / PEAK_HBM_GBPS,
+            'traffic': None, 'us_per_launch': sec * 1e6, 'bytes_per_launch': nbytes, 'launches': launches,
+            'kernel': 'bn_add_softmax_k (residual sum + flat_softmax + dsnt, 3 columns, B=%d, %s heatmaps)' % (B, 'bf16' if bf16_out else 'fp32')}
+
+
+def configs4_leg(device, steps=8, warmup=3, batch=32):
+    """BASELINE configs[4] on one GPU, short: 5-stage MargiPose at 384 x 384 (48 x 48 heatmaps), convolution operands rounded to
+    fp16 (one MFMA product per multiply-add, fp32 accumulate), same loss and optimiser as the headline step.  One extra step runs
+    with per-kernel events for its own roofline block (peak = the full dense 16-bit MFMA peak)."""
+    from margipose_amd import dsntnn
+    from margipose_amd.engine import KernelTimer
+    from margipose_amd.train_helpers import DeviceSGD
+    from margipose_amd.models import CanonicalSkeletonDesc, MargiPoseModel
+    torch.manual_seed(12345)
+    model = MargiPoseModel(CanonicalSkeletonDesc, 5, True, 'inceptionv4', 'jsd').to(device).train()
+    model.conv_dtype = torch.float16
+    opt = DeviceSGD(model.parameters(), lr=0.01, momentum=0.9)
+    g = torch.Generator(device='cpu').manual_seed(12345)
+    x = torch.randn(batch, 3, 384, 384, generator=g).to(device)
+    target = (torch.rand(batch, 17, 3, generator=g) * 2 - 1).to(device)
+    mask = torch.ones(batch, 17, device=device)
+
+    def step():
+        out = model(x)
+        loss = dsntnn.average_loss(model.forward_3d_losses(out, target), mask)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        return loss
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    res = {'workload': 'BASELINE configs[4] on 1 GPU: training step, batch %d, 5-stage MargiPose, 384x384 input, 48x48 heatmaps, '
+                       'convolutions on fp16-rounded operands (fp32 accumulate; BatchNorm / loss / soft-argmax fp32)' % batch,
+           'images_per_sec': batch / dt, 'ms_per_step': 1e3 * dt, 'steps': steps, 'warmup': warmup, 'dtype': 'f16',
+           'final_loss': float(loss.detach())}
+    timer = KernelTimer()
+    timer.calibrate()
+    eng = model.inner.engine()
+    eng.timer = timer
+    step()
+    eng.timer = None
+    torch.cuda.synchronize()
+    summ = timer.summary()
+    convs = {k: v for k, v in summ.items() if k.startswith('conv:') or k.startswith('wgrad:')}
+    if convs:
+        top = max(convs.items(), key=lambda kv: kv[1]['total_ms'])
+        tf = top[1]['work_per_launch'] / (top[1]['avg_us'] * 1e-6) / 1e12
+        all_flops = sum(v['work'] for v in convs.values())
+        all_ms = sum(v['total_ms'] for v in convs.values())
+        res['roofline'] = {'bound': 'mfma', 'achieved': tf, 'peak': PEAK_BF16_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': tf / PEAK_BF16_MFMA_TFLOPS,
+                           'traffic': None, 'kernel': top[0], 'avg_launch_us': top[1]['avg_us'], 'launches': top[1]['n'],
+                           'all_conv_kernels_tflops': all_flops / (all_ms * 1e-3) / 1e12,
+                           'all_conv_kernels_frac': all_flops / (all_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS,
+                           'note': 'one MFMA product per multiply-add: priced against the full dense 16-bit MFMA peak; HIP events '
+                                   'around every convolution launch of one serial step'}
+    del model, opt, x
+    torch.cuda.empty_cache()
+    return res
 
 
 def inference_microbench(model, device, size):
@@ -337,7 +439,10 @@ def main():
             all_ms = sum(v['total_ms'] for v in convs.values())
             tr_bytes, tr_detail = traffic_fields(top[0])
             res['roofline'] = {'bound': 'mfma', 'achieved': tf, 'peak': peak_equiv, 'unit': 'TFLOP/s',
-                               'frac': tf / peak_equiv, 'traffic': tr_bytes, 'traffic_detail': tr_detail, 'kernel': top[0],
+                               'frac': tf / peak_equiv, 'traffic': tr_bytes,
+                               'traffic_source': 'profiles/*_pmc_traffic.json: a SEPARATE rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE pass of this '
+                                                 'command (tools/profile.sh), not measured in this run' if tr_bytes is not None else None,
+                               'traffic_detail': tr_detail, 'kernel': top[0],
                                'mfma_busy_frac_pmc': (tr_detail or {}).get('mfma_busy_frac'),
                                'avg_launch_us': top[1]['avg_us'], 'launches': top[1]['n'],
                                'event_bracket_overhead_us_not_subtracted': 1e3 * timer.bracket_cal_ms,
@@ -363,7 +468,11 @@ def main():
                                                                         '(the HBM-roofline point of the metric)')
         res['tail_config_sizes'] = {
             'configs[2] training, B=%d fp32' % B: dict(tail_microbench(device, B), note='latency-bound: working set in Infinity Cache'),
-            'configs[1] inference, B=64 bf16 heatmaps': dict(tail_microbench(device, 64, bf16_out=True), note='latency-bound: working set in Infinity Cache')}
+            'configs[1] inference, B=64 bf16 heatmaps': dict(tail_microbench(device, 64, bf16_out=True), note='latency-bound: working set in Infinity Cache'),
+            'configs[2] training, B=%d fp32, as launched by the step (fused with the residual sum)' % B: dict(
+                fused_tail_microbench(device, B), note='replaces bn_add_nchw_k + softmax_dsnt_fwd_k; latency-bound'),
+            'configs[1] inference, B=64 bf16 heatmaps, as launched by the step (fused with the residual sum)': dict(
+                fused_tail_microbench(device, 64, bf16_out=True), note='latency-bound')}
     if allreduce is not None:
         res['allreduce_buckets'] = {'buckets': allreduce, 'xgmi_peak_GBps_per_gpu': 7 * 153.0, 'total_bytes': sum(b['bytes'] for b in allreduce),
                                     'total_ms_if_serial': sum(b['ms'] for b in allreduce)}
@@ -387,6 +496,9 @@ def main():
                                                 'tests/test_grad_parity_gpu.py)'}
     if world == 1 and not args.no_inference:
         res['inference'] = inference_microbench(model, device, args.size)
+    if world == 1 and not args.no_inference and not args.no_configs4 and args.conv_dtype == 'f32' and args.stages == 3:
+        del graphed
+        res['configs4_f16'] = configs4_leg(device)
     if world == 1 and not args.no_cpu_baseline:
         res['cpu_baseline'] = cpu_baseline(args.stages, args.size, args.cpu_batch, args.stem)
     print(json.dumps(res))

@@ -80,6 +80,7 @@ struct ConvArgs {
   int flags;
   int part_row0, part_rows;       // MPOSE_CONV_STATS_PART: first row this launch writes, rows in the buffers' headers
   int in_bias;                    // bytes: max negative tap shift, folded into the input buffer base
+  int xcd_order;                  // conv_igemm_k: tiles taken in XCD-contiguous order (see the kernel's head)
 };
 
 // Row of the 32x32 accumulator held in register r of lane-half h.
@@ -207,10 +208,21 @@ __global__ __launch_bounds__(256, (slim_tile<RN, MODE, NPL, ROWG>() ? 2 : 1)) vo
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lh = lane >> 5;
   const mpose_conv_geom& g = a.g;
-  const int cls = blockIdx.x / a.n_mtiles;
+  // XCD-aware tile order: workgroup L of a column's (x fastest) dispatch order runs on XCD L % 8 (observed placement, speed only),
+  // and every XCD has a private 4 MiB L2.  XCD c takes the CONTIGUOUS run c of the pixel tiles, their channel tiles innermost:
+  // neighbouring pixel tiles (which share 3x3 halo rows) and the channel tiles of one pixel tile (which read the same input) are
+  // dispatched 8 workgroups apart on ONE L2 instead of one on each -- measured 2.1x the algorithmic bytes at the L2s' memory side
+  // on the two-input data gradient before (profiles/r4_pmc_traffic.json).
+  unsigned bx = blockIdx.x, by = blockIdx.y;
+  if (a.xcd_order) {
+    const unsigned L = blockIdx.x + gridDim.x * blockIdx.y, w = L >> 3;
+    by = w % gridDim.y;
+    bx = (L & 7u) * (gridDim.x >> 3) + w / gridDim.y;
+  }
+  const int cls = bx / a.n_mtiles;
   const int kh = wave % KS;                                                       // K part of this wave
-  const int m0 = (blockIdx.x - cls * a.n_mtiles) * BM + (wave / KS) * 64;          // first row of THIS wave
-  const int n0 = blockIdx.y * BN;
+  const int m0 = (bx - cls * a.n_mtiles) * BM + (wave / KS) * 64;                  // first row of THIS wave
+  const int n0 = by * BN;
   const mpose_conv_operands& op = a.op[blockIdx.z];
   const int n_taps = g.cls[cls].n_taps;
   // taps are read from the kernel arguments (scalar loads): {dy, dx, widx, acc} packed in one dword
@@ -976,7 +988,7 @@ __global__ __launch_bounds__(256, (slim_tile<RN, MODE, NPL, ROWG>() ? 2 : 1)) vo
       float m = wave_max(epi_amax);
       if (lane == 0) {
         if (!(m == m)) m = __uint_as_float(0x7f800000u);
-        unsigned* dst = reinterpret_cast<unsigned*>(op.out0_amax + (blockIdx.x % MPOSE_AMAX_SUBSLOTS) * MPOSE_AMAX_STRIDE);
+        unsigned* dst = reinterpret_cast<unsigned*>(op.out0_amax + (bx % MPOSE_AMAX_SUBSLOTS) * MPOSE_AMAX_STRIDE);
         if (__float_as_uint(m) > __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(dst, __float_as_uint(m));
       }
     }
@@ -1004,8 +1016,8 @@ __global__ __launch_bounds__(256, (slim_tile<RN, MODE, NPL, ROWG>() ? 2 : 1)) vo
   // MPOSE_CONV_STATS_PART: this workgroup's sums go to row blockIdx.x of fp32 partial buffers with plain stores (the finalize /
   // coefficient kernels add the rows up); otherwise fp64 atomics into the (C, 2) / (C, 4) accumulators.
   const bool part = (a.flags & MPOSE_CONV_STATS_PART) != 0;
-  const int prow = a.part_row0 + (int)blockIdx.x;
-  const bool hdr_writer = prow == 0 && blockIdx.y == 0;
+  const int prow = a.part_row0 + (int)bx;
+  const bool hdr_writer = prow == 0 && by == 0;
 #pragma unroll
   for (int set = 0; set < (ACC1 ? 2 : 1); ++set) {
     double* stats = set ? op.stats1 : op.stats0;
@@ -1098,6 +1110,11 @@ int launch_conv(const ConvArgs& a0, int n_groups, hipStream_t s) {
   dim3 grid(a.n_mtiles * a.g.n_classes, (cmax + BN - 1) / BN, n_groups);
   a.part_row0 = mpose_part_phase.row0;
   a.part_rows = mpose_part_phase.total > 0 ? mpose_part_phase.total : (int)grid.x;
+  static const bool xcd_off = [] { const char* e = getenv("MPOSE_IGEMM_XCD"); return e && atoi(e) == 0; }();
+  // (row-group launches only -- the columns' convolutions: 308 -> 226 MB per launch on the two-input data gradient, 131 -> 73 MB on
+  //  the 64-channel 3x3, durations within 1 %; the feature extractor's wide launches, several channel tiles per pixel tile with an
+  //  unsplit K, measured 17-25 % SLOWER in this order and keep the plain one: tools/pmc_xcd.sh)
+  a.xcd_order = (ROWG && !xcd_off && (grid.x & 7u) == 0 && grid.x >= 16) ? 1 : 0;
   conv_igemm_k<RN, MODE, KS, PRO, NPL, ROWG><<<grid, 256, lds, s>>>(a);
   return launch_status();
 }

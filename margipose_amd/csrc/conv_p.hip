@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256, 2) void conv_planes_k(ConvPArgs a) {
       const int dy = (int)(signed char)(tp & 0xff), dx = (int)(signed char)((tp >> 8) & 0xff);
       const int widx = (tp >> 16) & 0xff;
       unsigned voff_a = ((row_taps >> (t_lo + t)) & 1u) ? pix_off + (unsigned)((dy * g.IW + dx) * 16) : kOob;
-      if ((a.flags & 0x100) && t != 0) voff_a = kOob;          // timing experiments only (MPOSE_EXP): no A traffic after a chunk's first tap
+      if ((a.flags & 0x100) && t != 0) voff_a = kOob;          // timing experiments only (CP_TRAFFIC_EXP builds): no A traffic after a chunk's first tap
       const bool skip_b = (a.flags & 0x200) != 0;               //                                       no B traffic
       const unsigned w_base = (unsigned)(widx * k16_total + c16) * 6u * w_plane_b;
       unsigned char* bufp = smem + buf * BUF_B;
@@ -556,7 +556,9 @@ int mpose_conv_planes_launch(const mpose_conv_geom* geom, const mpose_conv_opera
   a.div_gw = make_fastdiv((unsigned)geom->GW);
   a.div_ghw = make_fastdiv((unsigned)(geom->GH * geom->GW));
   a.flags = flags;
-  if (const char* e = getenv("MPOSE_EXP")) a.flags |= (atoi(e) & 7) << 8;       // timing experiments: 1 = skip A re-reads, 2 = skip B (wrong results); 4 = plain tile order
+#ifdef CP_TRAFFIC_EXP      // timing experiments, debug builds only (-DCP_TRAFFIC_EXP=<bits>): 1 = skip A re-reads, 2 = skip B (wrong results); 4 = plain tile order
+  a.flags |= (CP_TRAFFIC_EXP & 7) << 8;
+#endif
   const long npix = (long)geom->B * geom->IH * geom->IW;
   const long in_bytes = npix * 16 * 3 * (geom->Cin / 8);
   if (in_bytes >= 0xFFFFFF00l - (1l << 20) || geom->in_ld > 0) return MPOSE_EINVAL;       // 32-bit buffer offsets; dense inputs only

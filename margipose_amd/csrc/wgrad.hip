@@ -30,6 +30,10 @@
 #include <utility>
 #include "common.h"
 
+#ifndef WG_TRAFFIC_EXP
+#define WG_TRAFFIC_EXP 0       // WgRowsArgs::exp_flags of every launch (memory-side timing experiments: wrong results, debug builds only)
+#endif
+
 #ifndef WG_EXP
 #define WG_EXP 0      // timing experiments (tools/wgrad_exp.sh; wrong results): 1 no fragment reads, 2 no staging, 4 no barrier, 8 no MFMA
 #endif
@@ -80,7 +84,7 @@ struct WgRowsArgs {
   int n_ktiles, n_ntiles;
   int n_split, rows_per_split;
   int n_groups, chunk, total;
-  int exp_flags;                   // timing experiments (MPOSE_EXP): 1 = no operand traffic, 2 = no partial-sum stores, 4 = operands re-read from one place (wrong results)
+  int exp_flags;                   // timing experiments (compile-time -DWG_TRAFFIC_EXP=<bits>, 0 in every shipped build): 1 = no operand traffic, 2 = no partial-sum stores, 4 = operands re-read from one place (wrong results)
   FastDiv div_h;
 };
 
@@ -655,7 +659,7 @@ int mpose_wgrad_rows_launch(const mpose_conv_geom* geom, const mpose_wgrad_opera
   a.rows_per_split = (a.n_rows + n_split - 1) / n_split;
   a.n_groups = n_groups;
   a.div_h = make_fastdiv((unsigned)geom->GH);
-  if (const char* e = getenv("MPOSE_EXP")) a.exp_flags = atoi(e);
+  a.exp_flags = WG_TRAFFIC_EXP;
   hipStream_t s = (hipStream_t)stream;
   switch (rows_shape(geom->Cin, geom->Cout0)) {
     case 1: return wide192() ? launch_rows<2, 4, 3, 1>(a, s) : launch_rows<2, 2, 3, 1>(a, s);

@@ -346,6 +346,7 @@ class Engine:
         self._arena_key = None
         self._plist = None
         self._key_tensors = None
+        self._bn_bound = []
         self.timer = None            # optional KernelTimer (bench.py)
         self.side_stream = None      # weight-gradient GEMMs run here, off the data-gradient critical path
         self._side_keep = []         # tensors the side stream still reads (released at the next bucket boundary)
@@ -414,11 +415,27 @@ class Engine:
         mods = [n.m for n in self._bns] + (self.stem.bn_modules if self.stem is not None else [])
         return [t for m in mods for t in (m.running_mean, m.running_var)]
 
+    def _bn_bound_now(self):
+        """The tensor objects bound to the BatchNorm modules right now (module dicts directly, not Module.__getattr__)."""
+        out = []
+        for m in [n.m for n in self._bns] + (self.stem.bn_modules if self.stem is not None else []):
+            p, b = m._parameters, m._buffers
+            out += [p.get('weight'), p.get('bias'), b.get('running_mean'), b.get('running_var')]
+        return out
+
     def _ensure_arenas(self, device):
         # every address baked into the device-resident job tables takes part in the key: a parameter or buffer that was
         # re-bound outside Module._apply (load_state_dict(assign=True), p.data = ..., swap_tensors) rebuilds the tables
+        # (the tensor OBJECTS are cached; a BatchNorm parameter or buffer bound to a new object -- bn.running_mean = t,
+        # load_state_dict(assign=True) -- is caught by the identity walk below: dict lookups, ~40 us per call)
+        if self._key_tensors is not None:
+            bound = self._bn_bound_now()
+            if len(bound) != len(self._bn_bound) or any(a is not b for a, b in zip(bound, self._bn_bound)):
+                self._plist = None
+                self._key_tensors = None
         if self._key_tensors is None:
             self._key_tensors = self.param_list() + self._bn_buffers()
+            self._bn_bound = self._bn_bound_now()
         key = (str(device), hash(tuple([t.data_ptr() for t in self._key_tensors])))
         if self._arena_key == key:
             return

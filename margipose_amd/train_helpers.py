@@ -174,7 +174,7 @@ class DeviceSGD:
         self._np = np
         self._eager_table = torch.zeros(len(self.params) * _sgd_job_dtype().itemsize, dtype=torch.uint8, device=dev)
         self._uploaded = {}          # id(table) -> bytes it holds
-        self._table_key = {}         # id(table) -> gradient addresses it was built from (alignment / contiguity checked then)
+        self._table_key = {}         # id(table) -> gradient and parameter addresses it was built from (alignment / contiguity checked then)
         self._graph_table = torch.zeros_like(self._eager_table)                  # filled by finish_capture() (allocated HERE: an
         #   allocation inside the capture would come from the graph's pool and its zero-fill would be replayed before every step)
 
@@ -187,8 +187,11 @@ class DeviceSGD:
 
     def _fill_table(self, table):
         # (the gradients are usually where they were one or two steps ago: compare their addresses before rebuilding the table)
+        # -- and the parameters' own addresses with them: the table bakes those in too, and storage that moved (p.data = ...,
+        # model.to(), an engine arena rebuild) while the allocator handed the gradients back at the same addresses must not
+        # leave sgd_step_k writing through stale pointers
         try:
-            gptrs = tuple([p.grad.data_ptr() for p in self.params])
+            gptrs = tuple([p.grad.data_ptr() for p in self.params] + [p.data_ptr() for p in self.params])
         except AttributeError:
             raise RuntimeError('DeviceSGD.step(): a parameter has no gradient')
         if self._table_key.get(id(table)) == gptrs:
@@ -317,8 +320,9 @@ class BatchStager:
     """Host -> device staging of training batches (reference bin/train_3d.py:158-161: `batch['input'].to(device, float32)`,
     `batch['target']...`, `batch['joint_mask']...`, synchronous and from pageable memory), done the way the device wants it:
     pinned double buffers, one asynchronous copy per tensor on a dedicated copy stream, overlapped with the previous
-    iteration's kernels (the copy stream only waits for the consumer's position at the PREVIOUS stage() call -- by then the
-    last reader of this slot's device buffers, two iterations back, had been enqueued -- not for the work enqueued since);
+    iteration's kernels (the copy stream waits for the consumer's position at the stage() call depth-1 calls back -- by then the
+    last reader of this slot's device buffers had been enqueued -- not for the work enqueued since; stage(k) must be called
+    BEFORE iteration k is enqueued and after iteration k-1 was);
     the consumer stream waits on an event, never on the host.  Frames may stay uint8 across PCIe (a
     quarter of the bytes: 6.3 MB instead of 25 MB per 32 frames): MargiPoseModel normalises them on the device
     (`ImageSpecs.convert` fused into the feature extractor's first load).
@@ -335,7 +339,9 @@ class BatchStager:
         self.stream = torch.cuda.Stream(device=self.device)
         self._slots = [dict() for _ in range(depth)]          # key -> (pinned host tensor, device tensor)
         self._events = [None] * depth
-        self._consumer_mark = None                             # the consumer stream's position at the previous stage() call
+        self._marks = []                                       # the consumer stream's position at the last `depth` stage() calls
+        if depth < 1:
+            raise ValueError('BatchStager: depth must be >= 1')
         self._i = 0
 
     def _buffers(self, slot, key, t, dtype):
@@ -353,14 +359,20 @@ class BatchStager:
             self._events[i].synchronize()                      # the copy that last read this slot's pinned buffers is done
         out = dict(batch)
         consumer = torch.cuda.current_stream(self.device)
-        # The device buffers of this slot were last read by the iteration staged `depth` calls ago; everything up to the previous
-        # call is covered by the mark taken then.  (Waiting for the whole consumer stream here would put the copy BEHIND the
-        # iteration that was just enqueued: no overlap at all.)
-        if self._consumer_mark is not None:
-            self.stream.wait_event(self._consumer_mark)
+        # The device buffers of this slot were last read by the iteration fed by the stage() call `depth` calls ago, which (order
+        # contract: stage(k), then enqueue iteration k, then stage(k+1)) was fully enqueued when the NEXT call, depth-1 calls ago,
+        # took its mark of the consumer stream: that mark is the one to wait for.  depth 2: the previous call's mark (the
+        # iteration just enqueued is NOT waited for: the copy overlaps it); depth 1: the mark taken right now, i.e. the whole
+        # consumer stream (safe, no overlap).  (Waiting for the whole consumer stream at every depth would put the copy BEHIND
+        # the iteration that was just enqueued.)  A prefetching caller -- stage(k+1) BEFORE enqueuing iteration k -- breaks the
+        # contract: use depth >= 3 then, which leaves one more iteration of slack.
         mark = torch.cuda.Event()
         mark.record(consumer)
-        self._consumer_mark = mark
+        self._marks.append(mark)
+        if len(self._marks) > self.depth:
+            self._marks.pop(0)
+        if len(self._marks) == self.depth:            # (before that the slot has never been used)
+            self.stream.wait_event(self._marks[0])
         with torch.cuda.stream(self.stream):
             for key in self.keys:
                 if key not in batch:

@@ -9,6 +9,7 @@ largest element is 1e5 x the typical one, and a sum of two inputs nine orders of
 
 Reference layers: src/margipose/models/margipose_model.py:33,36,67-68,73-74 and their autograd gradients."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -543,3 +544,15 @@ def test_dilated_convolution_forward_and_data_gradient(B, hw, cin, cout, dil, pr
         return a.grad
     r64 = dgrad(torch.float64)
     _check(*_errs(dx - base, r64, dgrad(torch.float32)))
+
+
+def test_unsplit_k_launch_plan_in_a_fresh_process():
+    """MPOSE_SLIM=2 (read once per process by conv.hip's launch plan: the unsplit-K form of the 128-channel training launches, an
+    accumulation chain of 216 instead of 108) ships as a switch: the same fp32-equivalence cases must hold under it."""
+    import subprocess, sys
+    env = dict(os.environ, MPOSE_SLIM='2')
+    r = subprocess.run([sys.executable, '-m', 'pytest', '-q', '-x', '-m', 'gpu', os.path.abspath(__file__), '-k',
+                        'test_conv3x3_fp32_equivalent or test_conv_prologue_and_bn_statistics'],
+                       env=env, capture_output=True, text=True, timeout=600, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert ' passed' in r.stdout

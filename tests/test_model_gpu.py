@@ -790,3 +790,33 @@ def test_step_switches_leave_the_results_bit_identical(stem):
         assert torch.equal(a.grad, b.grad), k
     for (k, a), (_, b) in zip(m0.state_dict().items(), m1.state_dict().items()):
         assert torch.equal(a, b), k
+
+
+def test_rebound_batchnorm_tensors_are_picked_up():
+    """The engine bakes the BatchNorm tensors' addresses into device-resident job tables and caches the tensor objects
+    (Engine._ensure_arenas).  A buffer or parameter bound to a NEW tensor object after the first forward -- `bn.running_mean = t`,
+    load_state_dict(assign=True) -- must rebuild the tables: the eval forward then reads the new statistics (same result as a
+    fresh model holding them) and a training forward updates the new buffer, not the orphaned one."""
+    import copy
+    from margipose_amd.models import CanonicalSkeletonDesc, MargiPoseModel
+    torch.manual_seed(5)
+    m = MargiPoseModel(CanonicalSkeletonDesc, 1, True, 'patch8', 'jsd').cuda().eval()
+    x = torch.randn(2, 3, 256, 256, device='cuda')
+    with torch.no_grad():
+        out0 = m(x).clone()
+    bn = m.inner.xy_hm_cnns[0].down_layers[0].module[1]
+    assert isinstance(bn, torch.nn.BatchNorm2d)
+    old_mean = bn.running_mean
+    bn.running_mean = torch.full_like(old_mean, 0.25)             # a new tensor object at a new address
+    bn.weight = torch.nn.Parameter(bn.weight.detach() * 1.5)
+    ref = copy.deepcopy(m)                                         # a fresh engine over the same state
+    with torch.no_grad():
+        out1, out_ref = m(x).clone(), ref(x).clone()
+    assert torch.equal(out1, out_ref)
+    assert not torch.equal(out1, out0)
+    m.train()
+    before = bn.running_mean.clone()
+    m(x)
+    torch.cuda.synchronize()
+    assert not torch.equal(bn.running_mean, before)               # the bound buffer is the one updated
+    assert float(old_mean.abs().max()) == 0.0                      # the orphan (initial zeros) is left alone

@@ -22,14 +22,18 @@ for sub, name in (('trace', 'kernel_stats'), ('tail', 'tail_kernel_stats')):
 rows = [r for f in glob.glob(os.path.join(src, 'tail', '**', '*kernel_trace.csv'), recursive=True) for r in csv.DictReader(open(f))]
 by = collections.defaultdict(list)
 for r in rows:
+    dur = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
     if 'softmax_dsnt' in r['Kernel_Name']:
-        by[(short(r['Kernel_Name']).split('(')[0], int(r['Grid_Size_X']) // 192 // 17)].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
+        by[(short(r['Kernel_Name']).split('(')[0], int(r['Grid_Size_X']) // 192 // 17)].append(dur)
+    elif 'bn_add_softmax_k' in r['Kernel_Name']:      # grid (B, 3, 5) x 256 threads: Grid_Size_X = B * 256
+        by[(short(r['Kernel_Name']).split('(')[0], int(r['Grid_Size_X']) // 256)].append(dur)
 tail = {}
 for (k, B), v in sorted(by.items(), key=lambda kv: -kv[0][1]):
-    bf16 = 'false, true, true' in k
-    nbytes = 3 * B * 17 * 1024 * (6 if bf16 else 8) + B * 17 * 12
+    fused = 'bn_add_softmax_k' in k
+    bf16 = ('true>' in k) if fused else ('false, true, true' in k)
+    nbytes = 3 * B * 17 * 1024 * ((10 if bf16 else 12) if fused else (6 if bf16 else 8)) + (3 * B * 17 * 8 if fused else B * 17 * 12)
     med = statistics.median(v)
-    tail['B=%d %s heatmaps' % (B, 'bf16' if bf16 else 'fp32')] = {
+    tail['%sB=%d %s heatmaps' % ('fused with the residual sum: ' if fused else '', B, 'bf16' if bf16 else 'fp32')] = {
         'kernel': k, 'launches': len(v), 'median_us': med, 'mean_us': sum(v) / len(v), 'algorithmic_bytes': nbytes,
         'GBps': nbytes / med / 1e3, 'frac_of_8TBps': nbytes / med / 1e3 / 8000.0}
 json.dump({'_source': 'rocprofv3 --kernel-trace --stats -- python tools/prof_tail.py (the loops of bench.py::tail_microbench); kernel durations by '
@@ -43,9 +47,11 @@ for sub in ('pmc_sq', 'pmc_lds', 'pmc_fetch', 'pmc_write'):
             ctr[(short(r['Kernel_Name']).split('(')[0], int(r['Grid_Size']))][r['Counter_Name']].append(float(r['Counter_Value']))
 labels = {   # bench.py kernel tag -> (template, threads in the grid, algorithmic bytes) at B = 32, three column groups; the columns run
     # conv_igemm_k / conv_wgrad_k in their three-product fp16 form with row-group staging (template arguments ..., 2, true): fp32 activations in and out
-    'conv:f_conv2/32x32/128->128': ('conv_igemm_k<4, 0, 2, true, 2, true>', 256 * 3 * 256, 3 * 32768 * (128 * 4 + 128 * 4) + 3 * 9 * 128 * 128 * 4),
-    'conv:d_conv2/32x32/128->128': ('conv_igemm_k<4, 0, 2, false, 2, true>', 256 * 3 * 256, 3 * 32768 * (128 * 4 + 128 * 4 + 128 * 4) + 3 * 9 * 128 * 128 * 4),
-    'conv:f_in_regular/32x32/128->128': ('conv_igemm_k<4, 1, 2, false, 2, true>', 256 * 3 * 256, 3 * 32768 * (128 * 4 + 2 * 128 * 4) + 3 * 10 * 128 * 128 * 4),
+    # round 4: the regular 128-channel blocks' forward launches and second-3x3 data gradient run conv_h.hip's conv_h2r_k<RN, MODE> on
+    # producer-split fp16 planes (4 bytes per element, like fp32); MODE 0 serves both forward launches (9 and 10 taps: the PMC average mixes them)
+    'conv:f_conv2/32x32/128->128': ('conv_h2r_k<2, 0>', None, 3 * 32768 * (128 * 4 + 128 * 4) + 3 * 9 * 128 * 128 * 4),
+    'conv:d_conv2/32x32/128->128': ('conv_h2r_k<2, 1>', None, 3 * 32768 * (128 * 4 + 128 * 4 + 128 * 4) + 3 * 9 * 128 * 128 * 4),
+    'conv:f_in_regular/32x32/128->128': ('conv_h2r_k<2, 0>', None, 3 * 32768 * (128 * 4 + 2 * 128 * 4) + 3 * 10 * 128 * 128 * 4),
     'conv:d_in_regular/32x32/128->128': ('conv_igemm_k<4, 2, 2, false, 2, true>', 256 * 3 * 256, 3 * 32768 * (2 * 128 * 4 + 128 * 4) + 3 * 10 * 128 * 128 * 4),
     'conv:f_conv2/16x16/192->192': ('conv_igemm_k<3, 0, 1, true, 2, true>', None, 3 * 8192 * (192 * 4 + 192 * 4) + 3 * 9 * 192 * 192 * 4),
     'conv:d_conv2/16x16/192->192': ('conv_igemm_k<3, 0, 1, false, 2, true>', None, 3 * 8192 * (192 * 4 + 192 * 8) + 3 * 9 * 192 * 192 * 4),

@@ -9,5 +9,8 @@ import bench
 dev = torch.device('cuda', 0)
 out = {'B=2048 fp32 (856 MB/launch)': bench.tail_microbench(dev, 2048, launches=100),
        'B=32 fp32 (configs[2])': bench.tail_microbench(dev, 32, launches=100),
-       'B=64 bf16 heatmaps (configs[1])': bench.tail_microbench(dev, 64, bf16_out=True, launches=100)}
+       'B=64 bf16 heatmaps (configs[1])': bench.tail_microbench(dev, 64, bf16_out=True, launches=100),
+       'fused with the residual sum, B=2048 fp32': bench.fused_tail_microbench(dev, 2048, launches=100),
+       'fused with the residual sum, B=32 fp32 (configs[2])': bench.fused_tail_microbench(dev, 32, launches=100),
+       'fused with the residual sum, B=64 bf16 heatmaps (configs[1])': bench.fused_tail_microbench(dev, 64, bf16_out=True, launches=100)}
 print(json.dumps(out, indent=1))
