@@ -30,7 +30,9 @@ PLANES = ('xy', 'zy', 'xz')
 # different pieces, and the gradients of the two pieces differ by O(1e-3), not O(1e-7).  With RELU_MASKS set to
 # {site: 0/1 tensor} the oracle evaluates relu(x) as x * mask, i.e. it is forced onto the piece another
 # implementation chose, which separates "different piece" from "arithmetic error".  RELU_RECORD (a dict) receives
-# the oracle's own masks.  Sites are named '<block prefix>.relu1' / '.relu2' and 'inner.in_cnn.relu' (patch8 stem).
+# the oracle's own masks.  Sites are named '<block prefix>.relu1' / '.relu2', 'inner.in_cnn.relu' (patch8 stem), and for the
+# InceptionV4 stem '<BatchNorm module name>.relu' plus the two max-pools 'inner.in_cnn.3.maxpool' / 'inner.in_cnn.5.maxpool'
+# (window choices, see _maxpool3s2).
 RELU_MASKS = None
 RELU_RECORD = None
 
@@ -41,6 +43,17 @@ def _relu(x, site):
     if RELU_MASKS is not None and site in RELU_MASKS:
         return x * RELU_MASKS[site].to(x.dtype)
     return F.relu(x)
+
+
+def _maxpool3s2(x, site):
+    """max_pool2d(3, stride 2, padding 1) with the same piece control as _relu: RELU_MASKS[site], when present, holds the flat
+    H*W index (torch's return_indices convention) of the element every window selects; RELU_RECORD receives the oracle's own."""
+    if RELU_RECORD is not None:
+        RELU_RECORD[site] = F.max_pool2d(x.detach(), 3, stride=2, padding=1, return_indices=True)[1]
+    if RELU_MASKS is not None and site in RELU_MASKS:
+        idx = RELU_MASKS[site].to(x.device)
+        return x.flatten(2).gather(2, idx.flatten(2)).view(idx.shape)
+    return F.max_pool2d(x, 3, stride=2, padding=1)
 
 
 def _bn(sd, key, x, train):
@@ -115,7 +128,7 @@ def _basic_conv(sd, key, x, train, stride=1):
     y = F.conv2d(x, w, None, stride=stride, padding=(w.shape[2] // 2, w.shape[3] // 2))
     y = F.batch_norm(y, sd[key + '.bn.running_mean'], sd[key + '.bn.running_var'], sd[key + '.bn.weight'], sd[key + '.bn.bias'],
                      training=train, momentum=BN_MOMENTUM, eps=1e-3)
-    return F.relu(y)
+    return _relu(y, key + '.bn.relu')
 
 
 def inceptionv4_stem(sd, x, train):
@@ -125,13 +138,13 @@ def inceptionv4_stem(sd, x, train):
     x = _basic_conv(sd, p + '0', x, train, 2)
     x = _basic_conv(sd, p + '1', x, train)
     x = _basic_conv(sd, p + '2', x, train)
-    x = torch.cat([F.max_pool2d(x, 3, stride=2, padding=1), _basic_conv(sd, p + '3.conv', x, train, 2)], 1)            # Mixed_3a
+    x = torch.cat([_maxpool3s2(x, p + '3.maxpool'), _basic_conv(sd, p + '3.conv', x, train, 2)], 1)                     # Mixed_3a
     b0 = _basic_conv(sd, p + '4.branch0.1', _basic_conv(sd, p + '4.branch0.0', x, train), train)
     b1 = x
     for i in range(4):
         b1 = _basic_conv(sd, p + '4.branch1.%d' % i, b1, train)
     x = torch.cat([b0, b1], 1)                                                                                          # Mixed_4a
-    x = torch.cat([_basic_conv(sd, p + '5.conv', x, train, 2), F.max_pool2d(x, 3, stride=2, padding=1)], 1)             # Mixed_5a
+    x = torch.cat([_basic_conv(sd, p + '5.conv', x, train, 2), _maxpool3s2(x, p + '5.maxpool')], 1)                      # Mixed_5a
     b0 = _basic_conv(sd, p + '6.branch0', x, train)
     b1 = _basic_conv(sd, p + '6.branch1.1', _basic_conv(sd, p + '6.branch1.0', x, train), train)
     b2 = x
@@ -140,7 +153,7 @@ def inceptionv4_stem(sd, x, train):
     b3 = _basic_conv(sd, p + '6.branch3.1', F.avg_pool2d(x, 3, stride=1, padding=1, count_include_pad=False), train)
     x = torch.cat([b0, b1, b2, b3], 1)                                                                                  # Inception_A
     y = F.conv2d(x, sd[p + '7.weight'], sd[p + '7.bias'])
-    return F.relu(_bn(sd, p + '8', y, train))
+    return _relu(_bn(sd, p + '8', y, train), p + '8.relu')
 
 
 def resnet_stem(sd, x, train):

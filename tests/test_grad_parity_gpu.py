@@ -31,6 +31,7 @@ MASKED_TOL_CONFIG = 1e-4   # the same at the configuration size (B=32: sums over
                            # (the shortcut BatchNorm bias gradients of each stage's first block: the 2^-22 representation
                            # residual of a WEIGHT is the same for every pixel, so it does not average out of a sum over pixels
                            # the way activation roundings do), 1e-5 on the plane engine (six bf16 products, two accumulators).
+P99_RATIO = 4.0            # same-piece p99 against the fp32 oracle's p99 at the configuration's size
 FREE_RATIO = 3.0           # free running, the GPU may deviate from fp64 by this multiple of what the fp32 oracle does.  Which
                            # ReLU sites flip is luck, how many scales with the forward error: 6.6e-6 on a heatmap for the default
                            # form, 2.6e-6 for the plane engine (gated at 1.5 below), 1.4e-5 for round 1's six-product conv_igemm_k
@@ -55,6 +56,8 @@ def gpu_step(m, x, target, mask):
     out = m(xg)
     ectx = m.xy_heatmaps[0].grad_fn.ectx               # the engine's saved activations of THIS forward
     masks = gpu_relu_masks(m.inner.engine(), ectx)      # (before backward: the BatchNorm vectors are this forward's)
+    if m.inner.engine().stem is not None:
+        masks.update(gpu_stem_masks(m, m.inner.engine(), ectx))
     loss = dsntnn.average_loss(m.forward_3d_losses(out, target.cuda()), mask.cuda())
     loss.backward()
     grads = OrderedDict((k, p.grad.detach().cpu()) for k, p in m.named_parameters())
@@ -82,6 +85,38 @@ def gpu_relu_masks(eng, ectx):
                 masks[pre + '.relu2'] = site_mask(sv['c2'][c], b.bn2)
     if eng.stem is None:
         masks['inner.in_cnn.relu'] = site_mask(ectx['stem_raw'], eng.stem_bn)
+    return masks
+
+
+def gpu_stem_masks(m, eng, ectx):
+    """The InceptionV4 feature extractor's pieces (round 4): every BasicConv2d ReLU as the sign of fmaf(raw, scale, shift) of the
+    node's saved pre-activation, and the window choice of the two max-pools taken on the activations the pooling kernel sees
+    (the fp64 product-sum rounded once to fp32 = its fmaf; torch's return_indices convention)."""
+    import torch.nn.functional as F
+    from margipose_amd import stem as S
+    st = eng.stem
+    assert isinstance(st, S.InceptionV4Stem)
+    names = {id(mod): name for name, mod in m.named_modules()}
+    raw = ectx['stem_ctx']['raw']
+    masks = {}
+
+    def pre(n):         # (B, H, W, C) fp64: scale * raw + shift of the whole node (pooled channel ranges carry scale 1, shift 0)
+        sc = st.f_arena[n.f_off:n.f_off + n.C].double()
+        sh = st.f_arena[n.f_off + n.C:n.f_off + 2 * n.C].double()
+        return raw[n.name].double() * sc + sh
+
+    for n in st.nodes:
+        if n.is_image or not any(p[2] is not None for p in n.parts):
+            continue
+        v = pre(n)
+        for (a, b, bn, eps, bias) in n.parts:
+            if bn is not None:
+                masks[names[id(bn)] + '.relu'] = (v[..., a:b] > 0).permute(0, 3, 1, 2).contiguous().cpu()
+    pools = [op for op in st.ops if isinstance(op, S._PoolOp) and op.kind == 0]
+    assert len(pools) == 2
+    for op, site in zip(pools, ('inner.in_cnn.3.maxpool', 'inner.in_cnn.5.maxpool')):
+        act = pre(op.src).float().clamp_min(0).permute(0, 3, 1, 2).contiguous()
+        masks[site] = F.max_pool2d(act, 3, stride=2, padding=1, return_indices=True)[1].cpu()
     return masks
 
 
@@ -161,7 +196,7 @@ def mask_flips(a, b):
 
 
 @pytest.mark.parametrize('T,B,engine', [(1, 2, 'auto'), (2, 2, 'auto'), (1, 8, 'auto'), (1, 2, 'planes'), (1, 2, 'bf16x6'), (1, 2, 'igemm'),
-                                        (1, 2, 'h2split'), (1, 3, 'h2fuse2')])
+                                        (1, 2, 'h2split'), (1, 3, 'h2fuse2'), (1, 2, 'inceptionv4')])
 def test_grads_on_the_same_relu_piece(T, B, engine):
     """engine 'auto' = what training runs by default (three fp16 products: conv_h2r_k on producer-split planes for the regular
     128-channel blocks with the residual sum writing the next block's planes under an a-priori bound, conv_igemm_k elsewhere, the
@@ -176,9 +211,11 @@ def test_grads_on_the_same_relu_piece(T, B, engine):
     x, target, mask = W.seeded_inputs(seed + 1000, B)
     rng = np.random.default_rng(seed)
     mask = torch.tensor((rng.uniform(0, 1, (B, 17)) > 0.2).astype(np.float32))
-    m, sd = build(T, seed, x)
+    m, sd = build(T, seed, x, 'inceptionv4' if engine == 'inceptionv4' else 'patch8')
     tag = 'T%d_B%d' % (T, B)
-    if engine == 'planes':
+    if engine == 'inceptionv4':        # the default engine behind the reference's default feature extractor, its ReLU / max-pool pieces controlled too
+        tag += '_inceptionv4'
+    elif engine == 'planes':
         m.inner.engine().planes_mode = '1'
         tag += '_planes'
     elif engine == 'bf16x6':
@@ -206,7 +243,10 @@ def test_grads_on_the_same_relu_piece(T, B, engine):
                  'free_running_gpu_max': free['gpu_max']}
     st = compare('masked_' + tag, gpu, ref64, ref32, extra)
     assert abs(loss_gpu - loss64) <= 1e-5 * abs(loss64)
-    assert st['gpu_max'] <= MASKED_TOL, st
+    # (the InceptionV4 case at B=2 is a worse-conditioned problem for EVERY fp32 implementation: the fp32 oracle itself sits at
+    #  median 2.0e-5 / max 4.8e-5 of fp64 there, the GPU at 2.3e-5 / 4.4e-5 -- its absolute gate is the fp32 oracle's own level)
+    assert st['gpu_max'] <= max(MASKED_TOL, 1.5 * st['ref32_max']), st
+    assert st['gpu_max'] <= 1e-4, st
     assert st['gpu_median'] <= max(1.5 * st['ref32_median'], 2e-6), st
     assert st['zero_grad_abs_max'] < 1e-5, st
 
@@ -214,38 +254,20 @@ def test_grads_on_the_same_relu_piece(T, B, engine):
 @pytest.mark.parametrize('stem', ['patch8', 'inceptionv4'])
 def test_config_size_train_step_gradients(stem):
     """BASELINE.json configs[2]: batch 32, three stages, JS + Euclidean loss -- every gradient against the fp64 and the fp32
-    oracle.  patch8: on a COMMON ReLU piece (the oracle forced onto the masks the GPU used): pure arithmetic error at the
-    configuration's size.  inceptionv4 (the reference's default stem; no mask control for its ReLU / max-pool sites): free
-    running, each implementation on its own piece.  (Round 2 also ran patch8 free and on the plane engine here: two more CPU
-    fp64 / fp32 backward passes at B=32, dropped for the suite's time budget -- profiles/r2_gradient_parity.json has them.)"""
+    oracle on a COMMON piece (the oracle forced onto the ReLU masks and max-pool window choices the GPU used): pure arithmetic
+    error at the configuration's size, for the in-repo patch8 stem and (round 4) for the reference's default InceptionV4 feature
+    extractor, whose ReLU and max-pool sites are controlled too (gpu_stem_masks).  Free-running comparisons (every implementation
+    on its own piece) run at small sizes: test_grads_on_the_same_relu_piece[2-2-auto], tests/test_model_gpu.py's gradient-noise
+    gates, and profiles/r2_gradient_parity.json holds the B=32 ones of round 2."""
     T, B, seed = 3, 32, 900
     x, target, mask = W.seeded_inputs(seed + 1000, B)
     m, sd = build(T, seed, x, stem)
-    if stem == 'patch8':
-        gpu, masks, loss_gpu = gpu_step(m, x, target, mask)
-        m64, loss64, m32 = oracle_grads_pair(sd, T, x, target, mask, masks=masks)
-        sm = compare('config_%s_T3_B32_masked' % stem, gpu, m64, m32)
-        assert abs(loss_gpu - loss64) <= 1e-5 * abs(loss64)
-        assert sm['gpu_max'] <= MASKED_TOL_CONFIG, sm
-        assert sm['gpu_median'] <= 1.5 * sm['ref32_median'], sm
-        # the tail, not only the median: the worst percentile sits 3.4x above the fp32 oracle's (the weight-residual bias of the
-        # first blocks' shortcut BatchNorm bias gradients, see MASKED_TOL_CONFIG) -- gated so that it cannot grow unnoticed
-        assert sm['gpu_p99'] <= 4.0 * sm['ref32_p99'], sm
-        return
-    else:
-        from margipose_amd import dsntnn
-        xg = x.cuda().requires_grad_(True)
-        out = m(xg)
-        loss = dsntnn.average_loss(m.forward_3d_losses(out, target.cuda()), mask.cuda())
-        loss.backward()
-        gpu = OrderedDict((k, p.grad.detach().cpu()) for k, p in m.named_parameters())
-        gpu['__dx__'] = xg.grad.cpu()
-        masks, loss_gpu = None, float(loss.detach())
-    ref64, loss64, ref32 = oracle_grads_pair(sd, T, x, target, mask)
-    st = compare('config_%s_T3_B32' % stem, gpu, ref64, ref32)
+    gpu, masks, loss_gpu = gpu_step(m, x, target, mask)
+    m64, loss64, m32 = oracle_grads_pair(sd, T, x, target, mask, masks=masks)
+    sm = compare('config_%s_T3_B32_masked' % stem, gpu, m64, m32)
     assert abs(loss_gpu - loss64) <= 1e-5 * abs(loss64)
-    # free running: the GPU may sit on a different piece than fp64, exactly like the fp32 oracle does; tensor population
-    # against tensor population it must stay within FREE_RATIO x the reference's own fp32 path (1.5 x on the plane engine)
-    assert st['gpu_median'] <= max(1e-4, FREE_RATIO * st['ref32_median']), st
-    assert st['gpu_p99'] <= max(1e-4, FREE_RATIO * st['ref32_p99']), st
-
+    assert sm['gpu_max'] <= MASKED_TOL_CONFIG, sm
+    assert sm['gpu_median'] <= 1.5 * sm['ref32_median'], sm
+    # the tail, not only the median: the worst percentile sits above the fp32 oracle's (the weight-residual bias of the
+    # first blocks' shortcut BatchNorm bias gradients, see MASKED_TOL_CONFIG) -- gated so that it cannot grow unnoticed
+    assert sm['gpu_p99'] <= P99_RATIO * sm['ref32_p99'], sm
