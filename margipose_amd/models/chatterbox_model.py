@@ -108,6 +108,7 @@ class ChatterboxModel(nn.Module):
         self.xy_hm_cnns = self.zy_hm_cnns = self.xz_hm_cnns = self.hm_combiners = ()
         self.xy_heatmaps = self.zy_heatmaps = self.xz_heatmaps = None
         self._engine = None
+        self._last_out = None
 
     def engine(self):
         if self._engine is None:
@@ -128,20 +129,33 @@ class ChatterboxModel(nn.Module):
             return False
         raise Exception('unrecognised pixelwise loss: {}'.format(self.pixelwise_loss))
 
-    def _losses(self, target_var, three_d):
-        target = target_var.narrow(-1, 0, 3).contiguous() if target_var.size(-1) >= 3 else \
-            torch.cat([target_var.narrow(-1, 0, 2), torch.zeros_like(target_var.narrow(-1, 0, 1))], -1).contiguous()
-        # JS of the plane(s) + DSNT + z-merge + Euclidean in one launch: the same sum as :246-271
-        return dsntnn.stage_losses(self.xy_heatmaps[-1], self.zy_heatmaps[-1], self.xz_heatmaps[-1], target, 1.0,
-                                   self._pixelwise_flag(), three_d)
+    def _losses(self, out_var, target_var, three_d):
+        if out_var is self._last_out:
+            # the model's own output: JS of the plane(s) + DSNT + z-merge + Euclidean in one launch, the same sum as :246-271
+            target = target_var.narrow(-1, 0, 3).contiguous() if target_var.size(-1) >= 3 else \
+                torch.cat([target_var.narrow(-1, 0, 2), torch.zeros_like(target_var.narrow(-1, 0, 1))], -1).contiguous()
+            return dsntnn.stage_losses(self.xy_heatmaps[-1], self.zy_heatmaps[-1], self.xz_heatmaps[-1], target, 1.0,
+                                       self._pixelwise_flag(), three_d)
+        # any other `out_var` (detached, post-processed, another model's): the Euclidean term is taken on IT, as the reference
+        # does (:247-248, :256-257, :266); the pixelwise terms on this model's stored heatmaps
+        n = 3 if three_d else 2
+        tgt = target_var.narrow(-1, 0, n)
+        losses = dsntnn.euclidean_losses(out_var.narrow(-1, 0, n).contiguous(), tgt.contiguous())
+        if self._pixelwise_flag():
+            losses = losses + dsntnn.js_reg_losses(self.xy_heatmaps[-1], tgt.narrow(-1, 0, 2).contiguous(), 1.0)
+            if three_d:
+                zy = torch.cat([tgt.narrow(-1, 2, 1), tgt.narrow(-1, 1, 1)], -1).contiguous()
+                xz = torch.cat([tgt.narrow(-1, 0, 1), tgt.narrow(-1, 2, 1)], -1).contiguous()
+                losses = losses + dsntnn.js_reg_losses(self.zy_heatmaps[-1], zy, 1.0) + dsntnn.js_reg_losses(self.xz_heatmaps[-1], xz, 1.0)
+        return losses
 
     def forward_2d_losses(self, out_var, target_var):
-        """euclidean_losses(xy) + JS(xy) (:246-253)."""
-        return self._losses(target_var, False)
+        """euclidean_losses(out_var xy) + JS(xy) (:246-253)."""
+        return self._losses(out_var, target_var, False)
 
     def forward_3d_losses(self, out_var, target_var):
-        """euclidean_losses(xyz) + JS(xy) + JS(zy) + JS(xz) (:255-271)."""
-        return self._losses(target_var, True)
+        """euclidean_losses(out_var xyz) + JS(xy) + JS(zy) + JS(xz) (:255-271)."""
+        return self._losses(out_var, target_var, True)
 
     def forward(self, *inputs):
         x = inputs[0]
@@ -157,7 +171,9 @@ class ChatterboxModel(nn.Module):
         self.zy_heatmaps = [dsntnn.flat_softmax(logits[1])]
         self.xz_heatmaps = [dsntnn.flat_softmax(logits[2])]
         # x, y from the xy map; z = the mean of the two maps that carry it (:283-289)
-        return dsntnn.heatmaps_to_coords(self.xy_heatmaps[-1], self.zy_heatmaps[-1], self.xz_heatmaps[-1])
+        out = dsntnn.heatmaps_to_coords(self.xy_heatmaps[-1], self.zy_heatmaps[-1], self.xz_heatmaps[-1])
+        object.__setattr__(self, '_last_out', out)
+        return out
 
 
 def create_chatterbox_model(model_desc):

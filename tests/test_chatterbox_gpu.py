@@ -135,6 +135,18 @@ def test_chatterbox_2d_losses_and_no_pixelwise():
         m.pixelwise_loss = 'nope'
         with pytest.raises(Exception, match='unrecognised pixelwise loss: nope'):
             m.forward_3d_losses(out, target.cuda())
+        # `out_var` that is NOT the model's own output: the Euclidean term is taken on it (reference models/chatterbox_model.py:247-248,
+        # :256-257, :266), the pixelwise terms on the stored heatmaps
+        m.pixelwise_loss = 'jsd'
+        other = (out * 0.5 + 0.1).contiguous()
+        own3, own2 = m.forward_3d_losses(out, target.cuda()), m.forward_2d_losses(out, target.cuda())
+        got3, got2 = m.forward_3d_losses(other, target.cuda()), m.forward_2d_losses(other, target.cuda())
+        tg = target.cuda()
+        e_own3, e_oth3 = (out - tg).norm(dim=-1), (other - tg).norm(dim=-1)
+        e_own2, e_oth2 = (out[..., :2] - tg[..., :2]).norm(dim=-1), (other[..., :2] - tg[..., :2]).norm(dim=-1)
+        assert float((got3 - (own3 - e_own3 + e_oth3)).abs().max()) < 1e-5
+        assert float((got2 - (own2 - e_own2 + e_oth2)).abs().max()) < 1e-5
+        assert float((m.forward_3d_losses(out.clone(), tg) - own3).abs().max()) < 1e-5       # a copy of the output: same value, other path
 
 
 def test_chatterbox_training_harness_eager_and_graphed():

@@ -38,6 +38,8 @@ for _ in range(20):
     step()
 torch.cuda.synchronize()
 print('back-to-back %.2f ms/step' % ((time.perf_counter() - t0) / 20 * 1e3))
+if os.environ.get('HOST_PROFILE_SHORT'):       # (tools/host_profile8.sh: eight of these side by side)
+    sys.exit(0)
 torch.cuda.set_sync_debug_mode('warn')
 with warnings.catch_warnings(record=True) as w:
     warnings.simplefilter('always')
