@@ -1140,6 +1140,9 @@ inline int pick_ks(const ConvArgs& a, int cmax, int n_groups) {
   constexpr bool SLIM = slim_tile<RN, MODE, NPL, ROWG>();
   static const bool unsplit_ok = [] { const char* e = getenv("MPOSE_SLIM"); return e && atoi(e) == 2; }();
   const bool chain_bound = SLIM && NPL == 2 && a.op[0].epi_scale0 == nullptr && !unsplit_ok;      // (one product: a chain of 72)
+#ifdef CV_KS_FORCE          // (launch-plan experiments, debug builds: -DCV_KS_FORCE=<RN * 10 + ks>, e.g. 32 = the 96-wide tiles split two ways)
+  if (RN == CV_KS_FORCE / 10 && n_iter >= 2 * (CV_KS_FORCE % 10)) return CV_KS_FORCE % 10;
+#endif
   for (int ks = 1; ks <= (RN > 1 ? 4 : 2); ks *= 2) {
     if (ks > 1 && n_iter < 2 * ks) break;
     const long wgs = ((m_nominal + 256 / ks - 1) / (256 / ks)) * a.g.n_classes * ((cmax + 32 * RN - 1) / (32 * RN)) * n_groups;
