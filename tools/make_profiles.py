@@ -48,10 +48,11 @@ for sub in ('pmc_sq', 'pmc_lds', 'pmc_fetch', 'pmc_write'):
 labels = {   # bench.py kernel tag -> (template, threads in the grid, algorithmic bytes) at B = 32, three column groups; the columns run
     # conv_igemm_k / conv_wgrad_k in their three-product fp16 form with row-group staging (template arguments ..., 2, true): fp32 activations in and out
     # round 4: the regular 128-channel blocks' forward launches and second-3x3 data gradient run conv_h.hip's conv_h2r_k<RN, MODE> on
-    # producer-split fp16 planes (4 bytes per element, like fp32); MODE 0 serves both forward launches (9 and 10 taps: the PMC average mixes them)
+    # producer-split fp16 planes (4 bytes per element, like fp32); MODE 0 = one pass (f_conv2 AND d_conv2: the PMC average mixes the two,
+    # so does its algorithmic figure below), MODE 1 = the fused shortcut as a second pass into a second output (f_in_regular)
     'conv:f_conv2/32x32/128->128': ('conv_h2r_k<2, 0>', None, 3 * 32768 * (128 * 4 + 128 * 4) + 3 * 9 * 128 * 128 * 4),
-    'conv:d_conv2/32x32/128->128': ('conv_h2r_k<2, 1>', None, 3 * 32768 * (128 * 4 + 128 * 4 + 128 * 4) + 3 * 9 * 128 * 128 * 4),
-    'conv:f_in_regular/32x32/128->128': ('conv_h2r_k<2, 0>', None, 3 * 32768 * (128 * 4 + 2 * 128 * 4) + 3 * 10 * 128 * 128 * 4),
+    'conv:d_conv2/32x32/128->128': ('conv_h2r_k<2, 0>', None, 3 * 32768 * (128 * 4 + 128 * 4 + 128 * 4) + 3 * 9 * 128 * 128 * 4),
+    'conv:f_in_regular/32x32/128->128': ('conv_h2r_k<2, 1>', None, 3 * 32768 * (128 * 4 + 2 * 128 * 4) + 3 * 10 * 128 * 128 * 4),
     'conv:d_in_regular/32x32/128->128': ('conv_igemm_k<4, 2, 2, false, 2, true>', 256 * 3 * 256, 3 * 32768 * (2 * 128 * 4 + 128 * 4) + 3 * 10 * 128 * 128 * 4),
     'conv:f_conv2/16x16/192->192': ('conv_igemm_k<3, 0, 1, true, 2, true>', None, 3 * 8192 * (192 * 4 + 192 * 4) + 3 * 9 * 192 * 192 * 4),
     'conv:d_conv2/16x16/192->192': ('conv_igemm_k<3, 0, 1, false, 2, true>', None, 3 * 8192 * (192 * 4 + 192 * 8) + 3 * 9 * 192 * 192 * 4),
