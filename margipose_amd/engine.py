@@ -212,15 +212,24 @@ class KernelTimer:
     """HIP-event timing of individual launches on the stream they are enqueued on (torch's current stream).
     Used by bench.py to measure per-kernel average durations inside the timed region."""
 
-    def __init__(self):
+    def __init__(self, only=None):
         self.records = []          # (tag, start, end, work)
+        self.only = None if only is None else set(only)      # selective: bracket the launches with these tags, leave the schedule alone
 
-    def start(self):
+    @property
+    def selective(self):
+        return self.only is not None
+
+    def start(self, tag=None):
+        if self.only is not None and tag not in self.only:
+            return None
         ev = torch.cuda.Event(enable_timing=True)
         ev.record()
         return ev
 
     def stop(self, tag, start, work):
+        if start is None:
+            return
         ev = torch.cuda.Event(enable_timing=True)
         ev.record()
         self.records.append((tag, start, ev, work))
@@ -760,7 +769,7 @@ class Engine:
 
     def conv(self, g, ops, flags=0):
         arr = (ConvOperands * 3)(*ops)
-        t0 = self.timer.start() if self.timer is not None else None
+        t0 = self.timer.start('conv:' + g._name) if self.timer is not None else None
         check(lib().mpose_conv_fwd(ctypes.byref(g), arr, len(ops), flags, stream_ptr()), 'mpose_conv_fwd')
         if t0 is not None:
             self.timer.stop('conv:' + g._name, t0, g._flops * len(ops))
@@ -867,7 +876,7 @@ class Engine:
 
     def wgrad(self, g, ops, n_split):
         arr = (WgradOperands * 3)(*ops)
-        t0 = self.timer.start() if self.timer is not None else None
+        t0 = self.timer.start('wgrad:' + g._name) if self.timer is not None else None
         check(lib().mpose_conv_wgrad(ctypes.byref(g), arr, len(ops), n_split, stream_ptr()), 'mpose_conv_wgrad')
         if t0 is not None:
             self.timer.stop('wgrad:' + g._name, t0, g._flops * len(ops))
@@ -904,7 +913,7 @@ class Engine:
         # waited for the side stream and unpacked the partials) and off with gloo, whose host-staged collectives made a shared-GPU
         # step 2-6x slower with it (188-568 vs 95 ms); MPOSE_DP_OVERLAP=0/1 overrides.  (The RCCL combination has not run on
         # hardware: the pool has no multi-GPU node.  tests/test_model_gpu.py runs the schedule under gloo, functionally.)
-        if not self.overlap_wgrad or self.timer is not None or (self.dp is not None and not self.dp_overlap()):
+        if not self.overlap_wgrad or (self.timer is not None and not self.timer.selective) or (self.dp is not None and not self.dp_overlap()):
             self.wgrad(g, ops, n_split)
             self._unpack_now(unpack)
             return
@@ -1242,7 +1251,7 @@ class Engine:
                         heat = [torch.empty(B, self.J, F, F, dtype=torch.bfloat16 if hm_bf16 else torch.float32, device=x.device)
                                 for _ in range(3)]
                         pc = torch.empty(3, B * self.J, 2, **f32) if t == self.T - 1 else None
-                        t0 = self.timer.start() if self.timer is not None else None
+                        t0 = self.timer.start('tail:bn_add_softmax_fwd') if self.timer is not None else None
                         check(L.mpose_bn_add_softmax_fwd((BnAddOperands * 3)(*aops), ptr_array(heat), ptr(pc) if pc is not None else None,
                                                          3, B, F, F, b0.cout_s, self.J, 2 if hm_bf16 else 0, st()), 'mpose_bn_add_softmax_fwd')
                         if t0 is not None:    # algorithmic bytes: the joint channels of both inputs once, the heatmaps once
@@ -1262,7 +1271,7 @@ class Engine:
                 want_xyz = t == self.T - 1
                 if want_xyz:
                     xyz = torch.empty(B, self.J, 3, **f32)
-                t0 = self.timer.start() if self.timer is not None else None
+                t0 = self.timer.start('tail:softmax_dsnt_fwd') if self.timer is not None else None
                 check(L.mpose_softmax_dsnt_fwd(ptr_array(logits), ptr_array(heat), None, ptr(xyz) if want_xyz else None, 3, B * self.J, F,
                                                F, 2 if hm_bf16 else 0, st()), 'mpose_softmax_dsnt_fwd')
                 if t0 is not None:      # algorithmic bytes: read logits once, write heatmaps once (+ coords)
