@@ -383,6 +383,12 @@ class Engine:
         # the last ResidualBlock's residual sum, flat_softmax and dsnt as ONE launch per stage (mpose_bn_add_softmax_fwd: an image's
         # logits stay in LDS); heatmaps and coordinates are bit-identical to the two-launch path (MPOSE_TAIL_FUSE=0)
         self.tail_fuse = os.environ.get('MPOSE_TAIL_FUSE', '1') != '0'
+        # Training forward of the H2 blocks: the 1x1 shortcut convolution as its OWN launch on a second stream instead of a second
+        # pass of the 3x3's launch (114 us for the pair against 85-91 for the 3x3 alone: the pass restages every chunk's tile for
+        # one tap and runs a second epilogue).  Nothing needs the shortcut before the block's residual sum, the forward pass has
+        # no other side work, and the 3x3's 768 tiles leave half of the second round's slots idle.
+        self.sc_side = os.environ.get('MPOSE_SC_SIDE', '0') != '0'
+        self.fwd_side_stream = None
         self.inline_unpack = os.environ.get('MPOSE_INLINE_UNPACK', '0') != '0'     # (see unpack_after: measured no faster, off)
         self.overlap_wgrad = True    # +2.3 % step rate, bit-identical results; launches bracketed by a KernelTimer stay serial
         self.dp = None               # optional (process_group, world_size): gradient all-reduce after backward
@@ -728,6 +734,10 @@ class Engine:
             g = _geom(B, H, ci, H, co, co, H, 1, 1, [(0, 0, t9 + [(0, 0, 0, 1)])], np_f, np_f)
         elif name == 'f_conv2':
             g = _geom(B, H, co, H, co, 0, H, 1, 1, [(0, 0, t9)], np_f)
+        elif name == 'f_in3_regular':    # the 3x3 of f_in_regular alone / its 1x1 shortcut alone (Engine.sc_side)
+            g = _geom(B, H, ci, H, co, 0, H, 1, 1, [(0, 0, t9)], np_f)
+        elif name == 'f_in1_regular':
+            g = _geom(B, H, ci, H, co, 0, H, 1, 1, [(0, 0, [(0, 0, 0, 0)])], np_f)
         elif name == 'f_in_down':        # H = input size
             g = _geom(B, H, ci, H // 2, co, co, H // 2, 2, 1, [(0, 0, t9 + [(0, 0, 0, 1)])], np_f, np_f)
         elif name == 'f_in_up':          # H = input size
@@ -1162,9 +1172,34 @@ class Engine:
                         if fin_fused:        # (the launch's last workgroup per column runs the two finalize jobs)
                             self.fuse_fin(op, tb['fin'], tb['fin_count'], self.fin_index(t, i, 0) + c, self.fin_index(t, i, 1) + c)
                     ops.append(op)
-                self.conv(g1, ops, pflags | (16 if (fused or fused_h) else 0) | (256 if spart else 0) | (128 if blk_h2 else 0))
-                if train and not fin_fused:
-                    self.finalize(tb, self.fin_index(t, i, 0), 6, True, spart)
+                sc_side = (self.sc_side and blk_h2 and train and spart and not fin_fused and b0.kind == 'regular'
+                           and (self.timer is None or self.timer.selective))
+                if sc_side:
+                    main = torch.cuda.current_stream()
+                    if self.fwd_side_stream is None or self.fwd_side_stream.device != main.device:
+                        self.fwd_side_stream = torch.cuda.Stream(device=main.device)
+                    side = self.fwd_side_stream
+                    ready = torch.cuda.Event()
+                    ready.record(main)               # the input planes (and last step's readers of sc / the partial rows) are done here
+                    ops1 = []
+                    for c, (b, op) in enumerate(zip(grp, ops)):
+                        o1 = ConvOperands()
+                        o1.in_, o1.in_amax = op.in_, op.in_amax
+                        o1.w0, o1.w0_amax = op.w1, op.w1_amax
+                        o1.out0, o1.stats0 = op.out1, op.stats1
+                        ops1.append(o1)
+                        op.w1, op.w1_amax, op.out1, op.stats1 = None, None, None, None
+                    cflags = pflags | 256 | 128
+                    self.conv(self.geom('f_in3_regular', B, Hin, b0), ops, cflags)
+                    self.finalize(tb, self.fin_index(t, i, 0), 3, True, spart)
+                    with torch.cuda.stream(side):
+                        side.wait_event(ready)
+                        self.conv(self.geom('f_in1_regular', B, Hin, b0), ops1, cflags)
+                        self.finalize(tb, self.fin_index(t, i, 1), 3, True, spart)
+                else:
+                    self.conv(g1, ops, pflags | (16 if (fused or fused_h) else 0) | (256 if spart else 0) | (128 if blk_h2 else 0))
+                    if train and not fin_fused:
+                        self.finalize(tb, self.fin_index(t, i, 0), 6, True, spart)
                 # largest relu(bn1(c1)): what the next K loop (and its weight gradient) will split.  In training bn_finalize just
                 # derived it from c1's channel extremes (the convolution's epilogue took them); otherwise it is measured
                 if f16 and not fused_h and not train:
@@ -1222,6 +1257,8 @@ class Engine:
                     ops.append(op)
                 self.conv(self.geom('f_conv2', B, Hout, b0), ops,
                           pflags | (16 if (fuse2 or fuse2_h) else 0) | (256 if spart else 0) | (128 if blk_h2 else 0))
+                if sc_side:                  # the shortcut and its BatchNorm vectors are read from here on
+                    torch.cuda.current_stream().wait_stream(side)
                 add_h2 = h2f and self.h2_next(t, i)      # this block's sum is the next (H2) block's input: planes written here
                 if train and not fin_fused:
                     self.finalize(tb, self.fin_index(t, i, 2), 3, True, spart, bounds=add_h2)

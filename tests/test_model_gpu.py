@@ -853,3 +853,29 @@ def test_rebound_batchnorm_tensors_are_picked_up():
     torch.cuda.synchronize()
     assert not torch.equal(bn.running_mean, before)               # the bound buffer is the one updated
     assert float(old_mean.abs().max()) == 0.0                      # the orphan (initial zeros) is left alone
+
+
+def test_shortcut_on_a_second_stream_is_bit_identical():
+    """Engine.sc_side (MPOSE_SC_SIDE=1): the H2 blocks' 1x1 shortcut convolution and its BatchNorm finalisation as their own
+    launches on a second stream, joined before the residual sum, instead of a second pass of the 3x3's launch.  Same arithmetic
+    per output element and per partial-statistics row: loss, gradients and running statistics equal the default's bit for bit."""
+    import copy
+    from margipose_amd import dsntnn
+    T, B, seed = 1, 2, 471
+    x, target, mask = W.seeded_inputs(seed + 1000, B)
+    m0 = build(T, seed, x).train()
+    m1 = copy.deepcopy(m0)
+    m1.inner.engine().sc_side = True
+    assert m0.inner.engine().h2 and m0.inner.engine().part_stats()
+    res = []
+    for m in (m0, m1):
+        out = m(x.cuda())
+        loss = dsntnn.average_loss(m.forward_3d_losses(out, target.cuda()), mask.cuda())
+        loss.backward()
+        res.append((out.detach().clone(), float(loss.detach())))
+    assert m1.inner.engine().fwd_side_stream is not None            # the path really ran
+    assert res[0][1] == res[1][1] and torch.equal(res[0][0], res[1][0])
+    for (k, a), (_, b) in zip(m0.named_parameters(), m1.named_parameters()):
+        assert torch.equal(a.grad, b.grad), k
+    for (k, a), (_, b) in zip(m0.state_dict().items(), m1.state_dict().items()):
+        assert torch.equal(a, b), k
