@@ -314,6 +314,10 @@ def main():
     target = (torch.rand(B, 17, 3, generator=g) * 2 - 1).to(device)
     mask = torch.ones(B, 17, device=device)
 
+    hi_stream = torch.cuda.Stream(device=device, priority=int(os.environ['MPOSE_MAIN_PRIO'])) if os.environ.get('MPOSE_MAIN_PRIO') else None
+    if hi_stream is not None:          # (experiment: the whole step on a stream of another queue priority than the side stream's)
+        torch.cuda.set_stream(hi_stream)
+
     def eager_step():
         out = model(x)
         loss = dsntnn.average_loss(model.forward_3d_losses(out, target), mask)

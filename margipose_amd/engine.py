@@ -929,7 +929,8 @@ class Engine:
             return
         main = torch.cuda.current_stream()
         if self.side_stream is None or self.side_stream.device != main.device:
-            self.side_stream = torch.cuda.Stream(device=main.device)
+            # (a LOWER queue priority for the side stream was tried -- MPOSE_SIDE_PRIO -- see DESIGN 6.0)
+            self.side_stream = torch.cuda.Stream(device=main.device, priority=int(os.environ.get('MPOSE_SIDE_PRIO', '0')))
         side = self.side_stream
         side.wait_stream(main)
         with torch.cuda.stream(side):
