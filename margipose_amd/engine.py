@@ -389,6 +389,12 @@ class Engine:
         # no other side work, and the 3x3's 768 tiles leave half of the second round's slots idle.
         self.sc_side = os.environ.get('MPOSE_SC_SIDE', '0') != '0'
         self.fwd_side_stream = None
+        # Training forward of the feature extractor: a node whose channels all come out of a BatchNorm takes its amax slot from
+        # the finalize kernel's a-priori bound max_c(|gamma_c| sqrt(N) + |beta_c|) instead of a measuring pass (mpose_absmax): 12 of
+        # the 16 passes per step.  The bound is 2^5-2^7 above the true maximum at these sizes; a two-piece fp16 operand keeps its 22
+        # bits down to 2^-18 of the bound, and below that its ABSOLUTE error (bound * 2^-39) is far under fp32's at the tensor's
+        # typical magnitude.  MPOSE_STEM_BOUNDS=0: measure every node.
+        self.stem_bounds = os.environ.get('MPOSE_STEM_BOUNDS', '1') != '0'
         self.inline_unpack = os.environ.get('MPOSE_INLINE_UNPACK', '0') != '0'     # (see unpack_after: measured no faster, off)
         self.overlap_wgrad = True    # +2.3 % step rate, bit-identical results; launches bracketed by a KernelTimer stay serial
         self.dp = None               # optional (process_group, world_size): gradient all-reduce after backward
@@ -953,10 +959,10 @@ class Engine:
         """Statistics leave the convolution launches as partial rows (MPOSE_CONV_STATS_PART); the fused finalize needs the atomics."""
         return self.stats_part and not self.fuse_finalize
 
-    def finalize_table(self, table, first, n, train, part=False):
+    def finalize_table(self, table, first, n, train, part=False, bounds=False):
         base = table.data_ptr() + first * BN_DT.itemsize
-        check(lib().mpose_bn_finalize(c_void_p(base), n, int(train) | (2 if (part and train) else 0), ctypes.c_float(BN_EPS),
-                                      ctypes.c_float(BN_MOMENTUM), stream_ptr()), 'mpose_bn_finalize')
+        check(lib().mpose_bn_finalize(c_void_p(base), n, int(train) | (2 if (part and train) else 0) | (4 if (bounds and train) else 0),
+                                      ctypes.c_float(BN_EPS), ctypes.c_float(BN_MOMENTUM), stream_ptr()), 'mpose_bn_finalize')
 
     def part_ptr(self, B, S, conv):
         return self._tables_for(B, S // 8)['part_ptr'][id(conv)]

@@ -309,6 +309,8 @@ class _GraphStem:
                 j['C'] = b - a; j['count'] = B * H * W
                 j['conv_bias'] = bias.data_ptr() if bias is not None else 0
                 j['eps'] = eps
+                if all(pp[2] is not None for pp in n.parts):      # every channel of the node is a BatchNorm output: an a-priori bound exists
+                    j['bound_out'] = n.amax_f
                 tb['fin_job'][(n.name, a)] = len(fin)          # (the job of the convolution that writes channels a.. of this node)
                 fin.append(j)
                 k = np.zeros(1, dtype=COEF_DT)[0]
@@ -458,7 +460,10 @@ class _GraphStem:
             if train and all(id(p) in done for p in n.producers):
                 f0, nf = tb['fin_range'][n.name]
                 if nf and not eng.fuse_finalize:       # (otherwise the producing launches have finalised their channel ranges)
-                    eng.finalize_table(tb['fin'], f0, nf, True, eng.part_stats())
+                    bounded = f16 and eng.stem_bounds and all(pp[2] is not None for pp in n.parts)
+                    eng.finalize_table(tb['fin'], f0, nf, True, eng.part_stats(), bounds=bounded)
+                    if bounded:          # the node's amax slot now holds max_c(|gamma_c| sqrt(N) + |beta_c|): no measuring pass
+                        measured.add(n.name)
         if self.out_nodes is not None:
             out = [raw[n.name] for n in self.out_nodes]
         else:

@@ -116,3 +116,44 @@ def test_maxpool_backward_two_pass_matches_single_pass_and_torch(H, C):
     assert torch.equal(d1, d2)
     assert rel(d2.cpu(), act.grad) < 1e-6          # gradient w.r.t. the ACTIVATED input
     assert L.mpose_maxpool3_bwd_ws(ptr(xd), ptr(scd), ptr(shd), ptr(gd), ptr(d2), ptr(ws), ctypes.c_long(8), B, H, H, C, C, stream_ptr()) != 0
+
+
+def test_feature_extractor_scales_from_a_priori_bounds():
+    """Engine.stem_bounds (default on, training only): the nodes of the feature extractor whose channels all come out of a BatchNorm
+    take their fp16 scale from bn_finalize's bound max_c(|gamma_c| sqrt(N) + |beta_c|) instead of a measuring pass.  Any valid
+    bound gives the same result up to the operands' 22-bit representation: outputs and gradients agree with the measured-scale
+    run to 2e-6 relative, the slot holds a bound that is >= the measured maximum, and 12 mpose_absmax launches are gone."""
+    import copy
+    from margipose_amd import dsntnn
+    from margipose_amd.models import CanonicalSkeletonDesc, MargiPoseModel
+    torch.manual_seed(77)
+    m0 = MargiPoseModel(CanonicalSkeletonDesc, 1, True, 'inceptionv4', 'jsd').cuda().train()
+    m1 = copy.deepcopy(m0)
+    m0.inner.engine().stem_bounds = False
+    x = torch.randn(2, 3, 256, 256, device='cuda')
+    tgt = torch.rand(2, 17, 3, device='cuda') * 2 - 1
+    mask = torch.ones(2, 17, device='cuda')
+    outs, slots = [], []
+    for m in (m0, m1):
+        out = m(x)
+        slots.append(m.inner.engine().stem.amax_f.clone())
+        dsntnn.average_loss(m.forward_3d_losses(out, tgt), mask).backward()
+        outs.append(out.detach())
+    assert float((outs[0] - outs[1]).abs().max()) < 2e-5
+    typical = float(torch.stack([p.grad.norm() for p in m0.parameters()]).median())
+    for (k, a), (_, b) in zip(m0.named_parameters(), m1.named_parameters()):
+        if float(a.grad.norm()) < 1e-6 * typical:        # (analytically zero: the last shortcut BatchNorm's bias)
+            continue
+        assert float((a.grad - b.grad).norm() / a.grad.norm()) < 2e-2, k      # (free running: a few ReLU sites may flip)
+    from margipose_amd.engine import AMAX_SLOT
+    st = m1.inner.engine().stem
+    meas = slots[0].view(len(st.nodes), -1).max(dim=1).values
+    bnd = slots[1].view(len(st.nodes), -1).max(dim=1).values
+    n_bounded = 0
+    for i, n in enumerate(st.nodes):
+        if n.is_image or not all(p[2] is not None for p in n.parts):
+            continue
+        if float(meas[i]) > 0:               # (a node some convolution reads)
+            assert float(bnd[i]) >= float(meas[i]) and float(bnd[i]) <= 4096 * float(meas[i]), (n.name, float(bnd[i]), float(meas[i]))
+            n_bounded += 1
+    assert n_bounded >= 10
