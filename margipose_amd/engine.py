@@ -51,6 +51,7 @@ COEF_DT = np.dtype([('sums', 'u8'), ('gamma', 'u8'), ('mean', 'u8'), ('invstd', 
                     ('sg_col', 'i4'), ('dconv_bias', 'u8'), ('part', 'u8'), ('n_part', 'i4'), ('part_ld', 'i4'),
                     ('g_amax', 'u8'), ('bound_out', 'u8')], align=True)
 
+_WG_FIXED = float(os.environ.get('MPOSE_WG_FIXED', '3.0'))     # fixed per-workgroup cost of a weight-gradient launch, in 128-pixel row units (Engine._n_split)
 AMAX_SLOT = 16 * 64          # floats per activation amax slot (MPOSE_AMAX_SUBSLOTS * MPOSE_AMAX_STRIDE)
 _SIZES_CHECKED = False
 
@@ -1690,7 +1691,7 @@ class Engine:
             wgs = tiles * groups * n
             eff = wgs / (256.0 * ((wgs + 255) // 256))
             work = rows / (4.0 * n)
-            score = eff * work / (work + 3.0)
+            score = eff * work / (work + _WG_FIXED)
             if score > best_score + 1e-9:
                 best, best_score = n, score
         return best

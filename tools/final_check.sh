@@ -7,4 +7,4 @@ timeout 900 python bench.py > gpurun_out/bench_final.json 2> gpurun_out/bench_fi
 bash tools/profile.sh r4 > gpurun_out/profile_r4.log 2>&1; tail -5 gpurun_out/profile_r4.log
 bash tools/step_stats.sh r4 > gpurun_out/step_families_r4.txt 2>&1; head -3 gpurun_out/step_families_r4.txt
 # 2 ranks sharing the GPU through gloo (functional check of the DP bench path)
-MPOSE_SINGLE_DEVICE=1 MPOSE_DIST_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29515 bench.py --gpus 2 --steps 4 --warmup 2 --no-cpu-baseline --no-kernel-timing 2>&1 | tail -1 | cut -c1-400
+MPOSE_SINGLE_DEVICE=1 MPOSE_DIST_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29515 bench.py --gpus 2 --steps 4 --warmup 2 --no-cpu-baseline 2>&1 | tail -1 | cut -c1-400
