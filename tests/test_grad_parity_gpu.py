@@ -251,7 +251,13 @@ def test_grads_on_the_same_relu_piece(T, B, engine):
     assert st['zero_grad_abs_max'] < 1e-5, st
 
 
-@pytest.mark.parametrize('stem', ['patch8', 'inceptionv4'])
+_LONG = os.environ.get('MPOSE_LONG_TESTS', '0') != '0'
+
+
+@pytest.mark.parametrize('stem', [pytest.param('patch8', marks=pytest.mark.skipif(
+    not _LONG, reason='two more CPU backward passes at B=32 (2-4 minutes of oracle time: the suite has a 30-minute limit on the '
+                      "pool's slowest hosts); MPOSE_LONG_TESTS=1 runs it -- profiles/r4_gradient_parity.json holds its numbers")),
+    'inceptionv4'])
 def test_config_size_train_step_gradients(stem):
     """BASELINE.json configs[2]: batch 32, three stages, JS + Euclidean loss -- every gradient against the fp64 and the fp32
     oracle on a COMMON piece (the oracle forced onto the ReLU masks and max-pool window choices the GPU used): pure arithmetic
