@@ -2,6 +2,7 @@
 """Benchmark of the MargiPose hot path on MI355X (driver contract: see the task statement).
 
     python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus N --steps K --warmup W          (launches its own N ranks under torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -282,8 +283,25 @@ def inference_microbench(model, device, size):
                     'the heatmaps as bf16 (fp32 convolutions and soft-argmax): they are <1% of the bytes, so it is the same rate'}
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` on its own (no torchrun around it): re-execute this command under torch.distributed.run, one
+    rank per GPU, rendezvous on 127.0.0.1 at a free port -- the driver's own N > 1 form, which keeps working unchanged because
+    it sets WORLD_SIZE.  Rank 0's JSON line reaches this process's stdout through the launcher."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', OMP_NUM_THREADS=os.environ.get('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // args.gpus))))
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        raise SystemExit(self_launch(args))
     from margipose_amd import dsntnn, parallel
     from margipose_amd.engine import KernelTimer
     from margipose_amd.train_helpers import DeviceSGD, GraphedTrainStep

@@ -387,7 +387,8 @@ typedef struct {
                                        /*     (atomic max) into sub-slot 0 of this activation amax slot (see mpose_absmax)          */
   /* MPOSE_CONV_STATS_PART: when part != NULL the statistics are the sums over the rows of that buffer (header + [rows][part_ld][2],
    * at most n_part rows) in place of `stats`, and when mm_part != NULL the extremes are the maxima over the rows of that buffer
-   * in place of `minmax` (amax_out is then WRITTEN to sub-slot 0, not accumulated). */
+   * in place of `minmax` (amax_out is ACCUMULATED with an atomic max like everywhere else -- a job's channels may be split over
+   * several workgroups: zero the slot first). */
   const float* part;
   const float* mm_part;
   int n_part, part_ld;

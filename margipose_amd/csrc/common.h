@@ -84,6 +84,7 @@ __device__ __forceinline__ void block_amax_commit(float m, float* slot) {
 __device__ __forceinline__ void block_amax_commit_one(float m, float* dst) {
   __shared__ float amax_sm[16];
   m = wave_max(m);
+  __syncthreads();            // (two calls back to back: thread 0 may still be reading amax_sm of the first one)
   if ((threadIdx.x & 63) == 0) amax_sm[threadIdx.x >> 6] = m;
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -236,21 +237,7 @@ __device__ __forceinline__ void bn_finalize_job(const mpose_bn_job& j, int train
   }
   if (want_bound) block_amax_commit_one(bound * 1.0001f, j.bound_out);       // (uniform; contains barriers)
   if (want_amax) {       // (uniform: every thread of the workgroup gets here)
-    if (from_part && j.mm_part != nullptr && n_parts == 1) {       // the slot is this job's alone: written, not accumulated
-      float* amax_sm = reinterpret_cast<float*>(sh);
-      __syncthreads();
-      amax = wave_max(amax);
-      if ((threadIdx.x & 63) == 0) amax_sm[threadIdx.x >> 6] = amax;
-      __syncthreads();
-      if (threadIdx.x == 0) {
-        float m = 0.f;
-        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) m = fmaxf(m, amax_sm[w]);
-        if (!(m == m)) m = __uint_as_float(0x7f800000u);
-        j.amax_out[0] = m;
-      }
-    } else {
-      block_amax_commit_one(amax, j.amax_out);
-    }
+    block_amax_commit_one(amax, j.amax_out);      // (accumulated: the job's channel range may be split over several workgroups)
   }
 }
 

@@ -445,6 +445,34 @@ class Engine:
             out += [p.get('weight'), p.get('bias'), b.get('running_mean'), b.get('running_var')]
         return out
 
+    def grad_layout(self):
+        """Layout of the flat fp32 gradient buffer (pure host logic: tests/test_parallel_cpu.py checks it without a GPU).
+        Returns (offsets aligned with param_list(), buckets as [lo, hi) float ranges, total floats).
+        Buckets: the parameters of stage T-1 first (their gradients are complete first in the backward pass), ...,
+        stage 0, then the stem: each bucket is one contiguous slice = one all-reduce that overlaps the rest of the backward pass."""
+        order, buckets = [], []
+        for t in reversed(range(self.T)):
+            start = len(order)
+            for grp in self.stage_blocks[t]:
+                for b in grp:
+                    order += [b.conv_in.param, b.conv2.param, b.conv_sc.param]
+                    for n in (b.bn1, b.bn2, b.bns):
+                        order += [n.m.weight, n.m.bias]
+            if t > 0:
+                order.append(self.combiners[t - 1])
+            buckets.append((start, len(order)))
+        seen = set(id(p) for p in order)
+        start = len(order)
+        order += [p for p in self.param_list() if id(p) not in seen]          # stem (+ anything not stage-owned)
+        buckets.append((start, len(order)))
+        goff, off_of, bounds = 0, {}, []
+        for i, p in enumerate(order):
+            off_of[id(p)] = goff
+            goff += _rup(p.numel(), 4)
+            bounds.append(goff)
+        buckets = [((bounds[a - 1] if a > 0 else 0), (bounds[b - 1] if b > 0 else 0)) for a, b in buckets]
+        return [off_of[id(p)] for p in self.param_list()], buckets, goff
+
     def _ensure_arenas(self, device):
         # every address baked into the device-resident job tables takes part in the key: a parameter or buffer that was
         # re-bound outside Module._apply (load_state_dict(assign=True), p.data = ..., swap_tensors) rebuilds the tables
@@ -479,33 +507,8 @@ class Engine:
             n.s_off = soff; soff += 7 * n.Cs         # (+ Cs doubles = 2*Cs sortable keys: the channel extremes of the forward)
         self.bnf = torch.zeros(foff, dtype=torch.float32, device=device)
         self.stat_arena = torch.zeros(soff, dtype=torch.float64, device=device)
-        # grad layout: offsets of every parameter in the flat gradient buffer
-        # Buckets: the parameters of stage T-1 first (their gradients are complete first in the backward
-        # pass), ..., stage 0, then the stem: each bucket is one contiguous slice = one all-reduce that overlaps the
-        # rest of the backward pass.  `_grad_offsets` stays aligned with param_list().
-        order, self._buckets = [], []
-        for t in reversed(range(self.T)):
-            start = len(order)
-            for grp in self.stage_blocks[t]:
-                for b in grp:
-                    order += [b.conv_in.param, b.conv2.param, b.conv_sc.param]
-                    for n in (b.bn1, b.bn2, b.bns):
-                        order += [n.m.weight, n.m.bias]
-            if t > 0:
-                order.append(self.combiners[t - 1])
-            self._buckets.append((start, len(order)))
-        seen = set(id(p) for p in order)
-        start = len(order)
-        order += [p for p in self.param_list() if id(p) not in seen]          # stem (+ anything not stage-owned)
-        self._buckets.append((start, len(order)))
-        goff, off_of, bounds = 0, {}, []
-        for i, p in enumerate(order):
-            off_of[id(p)] = goff
-            goff += _rup(p.numel(), 4)
-            bounds.append(goff)
-        self._buckets = [((bounds[a - 1] if a > 0 else 0), (bounds[b - 1] if b > 0 else 0)) for a, b in self._buckets]
-        self._grad_offsets = [off_of[id(p)] for p in self.param_list()]
-        self._grad_total = goff
+        self._grad_offsets, self._buckets, self._grad_total = self.grad_layout()
+        goff = self._grad_total
         self.gflat = torch.zeros(goff, dtype=torch.float32, device=device)
         # num_batches_tracked of every BN becomes a view of one int64 vector: one increment per step
         bn_mods = [n.m for n in self._bns] + (self.stem.bn_modules if self.stem is not None else [])
@@ -643,8 +646,9 @@ class Engine:
         sp = {}
 
         def part_buf(key, g, Cs, k):
+            """(g: the geometry of the launch that WRITES the rows, or several when more than one kind of launch may: the largest counts)"""
             nonlocal sp_off
-            rows = -(-(g.B * g.GH * g.GW) // 64) * g.n_classes
+            rows = max(-(-(g_.B * g_.GH * g_.GW) // 64) * g_.n_classes for g_ in (g if isinstance(g, (list, tuple)) else [g]))
             sp[key] = (sp_off, rows)
             sp_off += _rup(4 + rows * Cs * k, 4)
 
@@ -662,7 +666,14 @@ class Engine:
                     part_buf((id(b.bns), 'f'), g_in, b.cout_s, 2)
                     part_buf((id(b.bn2), 'f'), g_c2, b.cout_s, 2)
                     part_buf((id(b.bn1), 'b'), g_c2, b.cout_s, 2)            # (d_conv2: the grid of f_conv2)
-                    part_buf((id(b.bn2), 'b'), g_c2, b.cout_s, 4)            # (the next block's d_in writes this block's output grid)
+                    # (block i+1's two-input data gradient writes these rows, so ITS launch geometry sizes the buffer -- a
+                    #  d_in_down launch has four output-parity classes of ceil(B*S*S / 64) rows each, more than f_conv2's single class
+                    #  whenever B*S*S is not a multiple of 64)
+                    g_wr = [g_c2]
+                    if i + 1 < 10:
+                        nb = self.stage_blocks[t][i + 1][c]
+                        g_wr.append(self.geom({'regular': 'd_in_regular', 'down': 'd_in_down', 'up': 'd_in_up'}[nb.kind], B, hw_out(i + 1), nb))
+                    part_buf((id(b.bn2), 'b'), g_wr, b.cout_s, 4)
                     bn_job(fj[1 + base + c], b.bn1, cnt)
                     # largest relu(bn1(c1)) -- the operand of the block's second convolution -- from c1's channel extremes
                     fj[1 + base + c]['minmax'], fj[1 + base + c]['amax_out'] = self._mm_ptr(b.bn1), self._amax_f(t, i, 1, c)

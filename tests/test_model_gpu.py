@@ -141,7 +141,7 @@ def test_inference_config_batch64_vs_oracle():
     assert err < TOL and worst <= 2.0 ** -7, (err, worst)
 
 
-def grad_noise_gate(name, gpu, ref64, ref32):
+def grad_noise_gate(name, gpu, ref64, ref32, same_piece=None):
     """Gradient parity gate.  Raw per-tensor gradients of this network are NOT reproducible to 1e-4 by ANY fp32
     implementation: ReLU-mask flips and small-batch BatchNorm make stock PyTorch fp32 (the reference's CPU path)
     deviate from fp64 by ~3e-4 median / ~3e-3 worst (relative L2) at these sizes.  So the gate is
@@ -154,11 +154,13 @@ def grad_noise_gate(name, gpu, ref64, ref32):
     1e-5 on the rest, the GPU path 4e-3 / 8e-4 / 1e-5.  The GPU's typical error may therefore reach, but not exceed,
     what the reference's own fp32 path shows on a tenth of the tensors; gpurun_out/gradnoise_*.json keeps every
     per-tensor pair.)
-    Round 4: the median term also admits p99(err_ref_fp32), the size of a single flip's effect as the reference's own fp32 run
-    shows it.  WHERE a flip falls is luck: one in the last blocks of a column perturbs every tensor upstream of it, i.e. most of
-    them, and the median then IS that effect (T=1, B=2 with the H2 engine's rounding: one flip in block 9 of the xz column,
-    median 1.4e-3 against the fp32 run's p90 1.2e-3 / p99 2.3e-3) -- while on a common piece the same step agrees with fp64 to
-    3.4e-6 median (tests/test_grad_parity_gpu.py, the gate that measures precision).
+    Round 5: the median term no longer admits p99(err_ref_fp32).  WHERE a flip falls is luck -- one in the last blocks
+    of a column perturbs every tensor upstream of it, i.e. most of them, and the median then IS that effect (T=1, B=2 with the H2
+    engine's rounding: one flip in block 9 of the xz column, median 1.4e-3 against the fp32 run's p90 1.2e-3) -- so a run that
+    misses the free-running median gate is accepted ONLY if `same_piece` (a callable returning the statistics of the comparison
+    with both oracles forced onto the GPU's ReLU piece, oracle/piece.py) shows pure arithmetic error inside the strict gates of
+    tests/test_grad_parity_gpu.py: every tensor <= max(3e-5, 1.5 x the fp32 oracle's worst), median <= 1.5 x the fp32 oracle's.
+    Callers without piece control (ResNet stems, ChatterboxModel) get no escape.
     Parameters whose true gradient is analytically zero (the last shortcut BN's bias: softmax is shift invariant)
     are checked for absolute smallness instead."""
     norms = np.array([float(ref64[k].norm()) for k in ref64])
@@ -182,7 +184,11 @@ def grad_noise_gate(name, gpu, ref64, ref32):
     with open(os.path.join('gpurun_out', 'gradnoise_%s.json' % name), 'w') as f:
         json.dump(stats, f, indent=1)
     print(name, {k: v for k, v in stats.items() if k not in ('worst_gpu', 'per_key')})
-    assert stats['gpu_median'] <= max(TOL, 3 * stats['ref32_median'], stats['ref32_p90'], stats['ref32_p99']), stats
+    if stats['gpu_median'] > max(TOL, 3 * stats['ref32_median'], stats['ref32_p90']):
+        assert same_piece is not None, stats
+        sp = same_piece()
+        print(name, 'free-running median outside the gate: a ReLU flip; same piece:', {k: v for k, v in sp.items() if k != 'worst_gpu'})
+        assert sp['gpu_max'] <= max(3e-5, 1.5 * sp['ref32_max']) and sp['gpu_median'] <= max(1.5 * sp['ref32_median'], 2e-6), (stats, sp)
     assert stats['gpu_p99'] <= max(TOL, 5 * stats['ref32_max']), stats
     assert stats['zero_grad_abs_max'] < 1e-4, stats
 
@@ -200,6 +206,8 @@ def test_train_step_vs_oracle(T, B, planes):
         m.inner.engine().planes_mode = '1'
     xg = x.cuda().requires_grad_(True)
     out = m(xg)
+    from oracle import piece
+    masks = piece.gpu_relu_masks(m.inner.engine(), m.xy_heatmaps[0].grad_fn.ectx)      # the piece this forward ran on (read before backward)
     l3 = m.forward_3d_losses(out, target.cuda())
     loss = dsntnn.average_loss(l3, mask.cuda())
     loss.backward()
@@ -224,7 +232,15 @@ def test_train_step_vs_oracle(T, B, planes):
     gpu['__dx__'] = xg.grad.cpu()
     r64 = OrderedDict(ref['grads']); r64['__dx__'] = ref['dx']
     r32 = OrderedDict(ref32['grads']); r32['__dx__'] = ref32['dx']
-    grad_noise_gate(name, gpu, r64, r32)
+
+    def same_piece():
+        from tests.test_grad_parity_gpu import compare
+        sd64 = OrderedDict((k, v.double() if v.is_floating_point() else v) for k, v in weights(T, seed, x, True).items())
+        g64, _ = piece.oracle_grads(sd64, T, x, target, mask, torch.float64, masks=masks)
+        g32, _ = piece.oracle_grads(sd64, T, x, target, mask, torch.float32, masks=masks)
+        return compare('fallback_' + name, gpu, g64, g32)
+
+    grad_noise_gate(name, gpu, r64, r32, same_piece)
 
 
 def test_model_T2_vs_reference_golden(golden_dir):
@@ -419,6 +435,33 @@ def test_data_parallel_rccl_single_rank():
     out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'dp_nccl_single.py')], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                          timeout=600).stdout.decode(errors='replace')
     assert 'DP_NCCL_SINGLE_OK' in out, out[-3000:]
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it: the script re-executes itself under
+    torch.distributed.run, two ranks share cuda:0 over gloo here (a box has one GPU), and rank 0 prints ONE valid JSON line that
+    carries n_gpus, the whole-job images/s and every gradient bucket's all-reduce time -- the line the driver's SCALE run reads.
+    `--gpus 1` stays a plain single process (WORLD_SIZE unset, no launcher)."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MPOSE_DIST_BACKEND='gloo', MPOSE_SINGLE_DEVICE='1')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    small = ['--steps', '3', '--warmup', '1', '--batch', '4', '--stages', '2', '--stem', 'patch8', '--no-cpu-baseline', '--no-inference']
+    lines = {}
+    for n in (2, 1):
+        r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', str(n)] + small + (['--no-kernel-timing'] if n == 1 else []),
+                           env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+        out = r.stdout.decode(errors='replace')
+        js = [l for l in out.splitlines() if l.startswith('{')]
+        assert r.returncode == 0 and len(js) == 1, (r.returncode, out[-2000:], r.stderr.decode(errors='replace')[-3000:])
+        lines[n] = json.loads(js[0])
+    two, one = lines[2], lines[1]
+    assert two['n_gpus'] == 2 and two['config']['global_batch'] == 8 and two['config']['parallelism'] == 'dp2' and two['scaling'] == 'weak'
+    assert abs(two['value'] - 2 * 4 * 3 / (two['ms_per_step'] * 3e-3)) < 1e-6 * two['value']        # whole-job images/s
+    bk = two['allreduce_buckets']['buckets']
+    assert len(bk) == 3 and all(b['ms'] > 0 and b['bus_GBps'] > 0 for b in bk)                      # stage 1, stage 0, stem
+    assert one['n_gpus'] == 1 and 'allreduce_buckets' not in one and one['config']['parallelism'] == 'dp1'
 
 
 def test_unused_stage_gets_zero_grads():
