@@ -113,3 +113,56 @@ def test_chatterbox_head_fixture_through_the_graph(golden_dir, tag):
         got = outs[idx][..., :17].permute(0, 3, 1, 2).cpu()
         want = g[key + tag]
         assert rel(got, want) < 1e-4, (tag, train, rel(got, want))
+
+
+@pytest.mark.parametrize('stem', ['inceptionv4', 'resnet18', 'resnet34', 'resnet50'])
+def test_stem_fixture_through_the_model(golden_dir, stem):
+    """tests/golden/stem_<name>.npz (tools/make_golden_stems.py: the reference's REAL make_image_feature_extractor,
+    models/margipose_model.py:103-139, over stand-in third-party constructors, inside the reference's MargiPoseModel) consumed
+    by the HIP path through the drop-in surface only: MargiPoseModel(skel, 1, True, stem, 'jsd'), strict load_state_dict of the
+    reference-schema weights, eval forward, train forward + loss + backward.  Forward quantities at the north star's 1e-4;
+    gradient norms against the reference's fp64 run, gated on the deviation of the reference's OWN fp32 run (stored beside it)."""
+    from margipose_amd import dsntnn
+    from margipose_amd.models import CanonicalSkeletonDesc, MargiPoseModel
+    from oracle import model_ref as R
+    g = np.load(os.path.join(golden_dir, 'stem_%s.npz' % stem), allow_pickle=False)
+    seed, T, B = int(g['seed']), 1, 2
+    x, target, _ = W.seeded_inputs(seed + 1000, B)
+    mask = torch.tensor(g['mask'], dtype=torch.float32).cuda()
+    sd = R.calibrate_running_stats(W.make_state_dict(T, seed, torch.float64, stem=stem), x.double(), T)      # (what the generator did)
+    m = MargiPoseModel(CanonicalSkeletonDesc, T, True, stem, 'jsd')
+    m.load_state_dict(OrderedDict((k, v.float() if v.is_floating_point() else v) for k, v in sd.items()), strict=True)
+    m = m.cuda().eval()
+    with torch.no_grad():
+        out = m(x.cuda())
+        errs = {'coords_eval': rel(out.cpu(), g['coords_eval_f64']),
+                'l3_eval': rel(m.forward_3d_losses(out, target.cuda()).cpu(), g['losses3d_eval_f64']),
+                'hm_xy_eval': rel(m.xy_heatmaps[-1].cpu().numpy()[:, :, ::4, ::4], g['hm_xy_eval_f64'])}
+    m.train()
+    xg = x.cuda().requires_grad_(True)
+    out = m(xg)
+    l3 = m.forward_3d_losses(out, target.cuda())
+    errs['coords_train'] = rel(out.detach().cpu(), g['coords_train_f64'])
+    errs['l3_train'] = rel(l3.detach().cpu(), g['losses3d_train_f64'])
+    errs['hm_xz_train'] = rel(m.xz_heatmaps[-1].detach().cpu().numpy()[:, :, ::4, ::4], g['hm_xz_train_f64'])
+    loss = dsntnn.average_loss(l3, mask)
+    loss.backward()
+    errs['loss'] = rel(loss.item(), g['loss_f64'])
+    running = np.concatenate([b.detach().cpu().numpy().flatten() for k, b in m.named_buffers() if 'running' in k])
+    errs['running_after'] = rel(running, g['running_after'])
+    print('stem fixture', stem, errs)
+    assert max(errs.values()) < 1e-4, errs
+    keys = [str(k) for k in g['param_keys']]
+    params = dict(m.named_parameters())
+    norms = np.array([float(params[k].grad.double().norm()) for k in keys])
+    typical = float(np.median(g['gnorm_f64']))
+    nz = g['gnorm_f64'] > 1e-9 * typical            # (analytically-zero gradients: the last shortcut BatchNorm's bias)
+    dev_gpu = np.abs(norms - g['gnorm_f64'])[nz] / g['gnorm_f64'][nz]
+    dev_ref = np.abs(g['gnorm_f32'] - g['gnorm_f64'])[nz] / g['gnorm_f64'][nz]
+    dxe = rel(xg.grad.cpu().numpy()[:, :, ::8, ::8], g['dx_f64'])
+    dxr = rel(g['dx_f32'], g['dx_f64'])
+    print('grad-norm deviation vs the reference fp64: ours median %.2e p90 %.2e max %.2e | reference fp32 median %.2e p90 %.2e max %.2e | dx %.2e (fp32 %.2e)'
+          % (np.median(dev_gpu), np.quantile(dev_gpu, 0.9), dev_gpu.max(), np.median(dev_ref), np.quantile(dev_ref, 0.9), dev_ref.max(), dxe, dxr))
+    assert np.median(dev_gpu) <= max(1e-4, 3 * np.median(dev_ref), np.quantile(dev_ref, 0.9)) and dev_gpu.max() <= max(1e-4, 5 * dev_ref.max())
+    assert norms[~nz].max() < 1e-4 * typical if (~nz).any() else True
+    assert dxe <= max(1e-4, 5 * dxr)

@@ -212,3 +212,77 @@ def test_chatterbox_cnn_vs_reference(golden_dir, tag):
     np.testing.assert_allclose(gn, g['train_gnorm_' + tag], rtol=1e-3)
     np.testing.assert_allclose(sd['down_convs.5.running_mean'].numpy(), g['running_mean_k8_' + tag], rtol=1e-4, atol=1e-6)
     np.testing.assert_allclose(sd['down_convs.5.running_var'].numpy(), g['running_var_k8_' + tag], rtol=1e-4, atol=1e-6)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Image feature extractors (reference models/margipose_model.py:103-139): the reference's REAL
+# make_image_feature_extractor run over stand-in third-party constructors (tools/make_golden_stems.py).  Pins the slice
+# features[0:7], the Conv2d(384,128,1)+BN+ReLU head, the padding rewrite, the ResNet slice and its 1x1-head rule, and the
+# state-dict schema; the third-party layer definitions themselves stay unpinned (their source is not in the image).
+# ---------------------------------------------------------------------------------------------------------------
+STEMS = ['inceptionv4', 'resnet18', 'resnet34', 'resnet50']
+
+
+@pytest.mark.parametrize('stem', STEMS)
+def test_stem_schema_vs_reference_assembled_model(golden_dir, stem):
+    import hashlib
+    with open(os.path.join(golden_dir, 'stem_keys.json')) as f:
+        ref = json.load(f)
+    items = [[k, list(s)] for k, s in W.schema(1, stem=stem).items()]
+    assert len(items) == ref[stem]['n_keys']
+    assert hashlib.sha256(json.dumps(items).encode()).hexdigest() == ref[stem]['sha256']
+    assert [it for it in items if it[0].startswith('inner.in_cnn.')] == ref[stem]['in_cnn_items']
+    # the product model carries the same keys and shapes (a reference checkpoint loads strictly) and the reference's error text
+    from margipose_amd.models import CanonicalSkeletonDesc, MargiPoseModel
+    m = MargiPoseModel(CanonicalSkeletonDesc, 1, True, stem, 'jsd')
+    assert [[k, list(v.shape)] for k, v in m.state_dict().items()] == items
+    assert sum(p.numel() for p in m.parameters()) == ref[stem]['n_params']
+    with pytest.raises(Exception) as e:
+        MargiPoseModel(CanonicalSkeletonDesc, 1, True, 'vgg16', 'jsd')
+    assert str(e.value) == ref['unknown_name_message']
+    # the padding rewrite (:111-117) touches Conv2d and MaxPool2d only: every one ends at kernel // 2, the AvgPool2d keeps its own
+    pads = dict((k, tuple(v)) for k, v in ref[stem]['paddings_after_rewrite'])
+    if stem == 'inceptionv4':
+        assert pads['0.conv'] == (1, 1) and pads['3.maxpool'] == (1, 1) and pads['4.branch1.1.conv'] == (0, 3)
+        assert pads['4.branch1.2.conv'] == (3, 0) and pads['4.branch0.0.conv'] == (0, 0) and pads['6.branch3.0'] == (1, 1) and pads['7'] == (0, 0)
+    else:
+        assert pads['0'] == (3, 3) and pads['3'] == (1, 1)
+
+
+@pytest.mark.parametrize('stem', STEMS)
+def test_stem_model_vs_reference(golden_dir, stem):
+    """oracle/model_ref.py (functional restatement) against the reference's MargiPoseModel with the reference-assembled stem:
+    the stem's output alone (eval and train mode), then the T=1 model's coordinates, losses, gradients and running statistics."""
+    g = _load(golden_dir, 'stem_%s.npz' % stem)
+    seed, T_, B = int(g['seed']), 1, 2
+    sd = W.make_state_dict(T_, seed, torch.float64, stem=stem)
+    x, target, _ = W.seeded_inputs(seed + 1000, B, dtype=torch.float64)
+    mask = torch.tensor(g['mask'])
+    R.calibrate_running_stats(sd, x, T_)
+    with torch.no_grad():
+        feat = R.stem_forward(sd, x, False)
+        np.testing.assert_allclose(feat.numpy()[:, ::4], g['feat_eval_f64'], rtol=2e-6, atol=2e-7)       # (stored as fp32)
+        xy, zy, xz = R.inner_forward(sd, x, T_, train=False)
+        np.testing.assert_allclose(R.heatmaps_to_coords(xy[-1], zy[-1], xz[-1]).numpy(), g['coords_eval_f64'], rtol=1e-8, atol=1e-10)
+        np.testing.assert_allclose(xy[-1].numpy()[:, :, ::4, ::4], g['hm_xy_eval_f64'], rtol=1e-7, atol=1e-14)
+        np.testing.assert_allclose(R.forward_3d_losses(xy, zy, xz, target).numpy(), g['losses3d_eval_f64'], rtol=1e-8)
+        sd_tr = OrderedDict((k, v.clone()) for k, v in sd.items())
+        np.testing.assert_allclose(R.stem_forward(sd_tr, x, True).numpy()[:, ::4], g['feat_train_f64'], rtol=2e-6, atol=2e-7)
+    params = OrderedDict((k, v.requires_grad_(True)) for k, v in sd.items() if v.is_floating_point() and 'running' not in k)
+    xr = x.clone().requires_grad_(True)
+    xy, zy, xz = R.inner_forward(sd, xr, T_, train=True)
+    np.testing.assert_allclose(R.heatmaps_to_coords(xy[-1], zy[-1], xz[-1]).detach().numpy(), g['coords_train_f64'], rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(xz[-1].detach().numpy()[:, :, ::4, ::4], g['hm_xz_train_f64'], rtol=1e-7, atol=1e-14)
+    l3 = R.forward_3d_losses(xy, zy, xz, target)
+    np.testing.assert_allclose(l3.detach().numpy(), g['losses3d_train_f64'], rtol=1e-8)
+    loss = R.average_loss(l3, mask)
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), g['loss_f64'], rtol=1e-9)
+    np.testing.assert_allclose(xr.grad.numpy()[:, :, ::8, ::8], g['dx_f64'], rtol=1e-6, atol=1e-13)
+    keys = [str(k) for k in g['param_keys']]
+    norms = np.array([float(params[k].grad.norm()) for k in keys])
+    np.testing.assert_allclose(norms, g['gnorm_f64'], rtol=1e-7, atol=1e-13)
+    heads = np.stack([np.pad(params[k].grad.flatten()[:8].numpy(), (0, max(0, 8 - params[k].numel()))) for k in keys])
+    np.testing.assert_allclose(heads, g['ghead_f64'], rtol=1e-6, atol=1e-12)
+    running = np.concatenate([v.numpy().flatten() for k, v in sd.items() if 'running' in k])
+    np.testing.assert_allclose(running, g['running_after'], rtol=1e-10)

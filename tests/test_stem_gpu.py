@@ -1,7 +1,9 @@
 """GPU parity of the InceptionV4 and ResNet feature extractors (margipose_amd/stem.py) against the oracle's restatements
 (oracle/model_ref.py::inceptionv4_stem / resnet_stem).  NOTE: both sides restate pretrainedmodels==0.6.0 (SURVEY.md
 Appendix B) and torchvision's ResNet blocks; the third-party originals are not available, so this pins the HIP path to
-the oracle, not to the originals."""
+the oracle, not to the originals.  Round 5: the oracle's restatements are themselves pinned to the module graph the reference's
+real make_image_feature_extractor assembles (tests/test_oracle_golden.py::test_stem_model_vs_reference), and the HIP path
+consumes those fixtures directly in tests/test_golden_direct_gpu.py::test_stem_fixture_through_the_model."""
 from collections import OrderedDict
 
 import numpy as np
@@ -44,7 +46,7 @@ def test_stem_eval_forward(stem):
     assert rel(m.xz_heatmaps[-1].cpu(), xz[-1]) < 1e-4
 
 
-@pytest.mark.parametrize('stem', ['inceptionv4', 'resnet18', 'resnet50'])
+@pytest.mark.parametrize('stem', ['inceptionv4', 'resnet18', 'resnet34', 'resnet50'])
 def test_stem_train_step(stem):
     from margipose_amd import dsntnn
     m, sd, x, target, mask = setup(1, 802, 2, stem)
