@@ -65,3 +65,65 @@ def test_five_step_training_curve_vs_reference(golden_dir):
     assert err[0] < 1e-5 * g['losses_f64'][0]
     assert all(times.count[k] == 5 and times.mean(k) > 0 for k in StepTimes.NAMES), (times.count, times.total)
     assert abs(times.train_loss - sum(losses)) < 1e-4 * sum(losses)       # (`tel['train_loss'].add(loss.sum().item())`)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('form', ['train_5key', 'exported_3key'])
+def test_reference_format_checkpoint_loads_and_runs_on_the_gpu(tmp_path, form):
+    """SURVEY 8 f2 on the device.  A checkpoint is written the way the REFERENCE writes it -- a plain
+    torch.save of {'state_dict', 'model_desc', 'train_datasets', 'optimizer', 'epoch'} (bin/train_3d.py:374-382) or the exported
+    {'state_dict', 'model_desc', 'train_datasets'} (bin/export_model.py:44-50), state_dict in the reference's key schema (pinned by
+    tests/golden/state_dict_keys.json / stem_keys.json), optimizer = torch.optim.SGD's own state dict -- from ORACLE weights,
+    not through this package's save_checkpoint.  margipose_amd.models.load_model (reference models/__init__.py:30-34) must build
+    the model its model_desc names (the default InceptionV4 feature extractor), load it strictly, and the HIP forward on those
+    weights must match the oracle's fp64 forward on the same state dict at 1e-4."""
+    from collections import OrderedDict
+    from oracle import model_ref as R
+    from oracle import weights as W
+    from margipose_amd.models import Default_MargiPose_Desc, load_model
+    T, seed, B = 2, 1501, 2
+    x, target, _ = W.seeded_inputs(seed + 1000, B)
+    sd64 = R.calibrate_running_stats(W.make_state_dict(T, seed, torch.float64, stem='inceptionv4'), x.double(), T)
+    desc = {'type': Default_MargiPose_Desc['type'], 'version': Default_MargiPose_Desc['version'],
+            'settings': dict(Default_MargiPose_Desc['settings'], n_stages=T)}
+    state = {'state_dict': OrderedDict((k, v.float() if v.is_floating_point() else v.clone()) for k, v in sd64.items()),
+             'model_desc': desc, 'train_datasets': ['mpi3d-train', 'mpii-train']}
+    if form == 'train_5key':
+        ps = [torch.nn.Parameter(v.clone()) for k, v in state['state_dict'].items() if v.is_floating_point() and 'running' not in k]
+        opt = torch.optim.SGD(ps, lr=0.37, momentum=0.9)
+        for p in ps[:3]:
+            p.grad = torch.ones_like(p)
+        opt.step()                         # (momentum buffers exist, like after a real epoch)
+        state['optimizer'] = opt.state_dict()
+        state['epoch'] = 7
+    path = os.path.join(tmp_path, 'margipose-%s.pth' % form)
+    torch.save(state, path)
+    m = load_model(path)
+    got = m.state_dict()
+    assert list(got.keys()) == list(state['state_dict'].keys())
+    m = m.cuda().eval()
+    with torch.no_grad():
+        out = m(x.cuda())
+        l3 = m.forward_3d_losses(out, target.cuda())
+        xy, zy, xz = R.inner_forward(sd64, x.double(), T, False)
+        ref = R.heatmaps_to_coords(xy[-1], zy[-1], xz[-1])
+        ref_l3 = R.forward_3d_losses(xy, zy, xz, target.double())
+
+    def rel(a, b):
+        a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
+        return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+    errs = {'coords': rel(out.cpu(), ref), 'l3': rel(l3.cpu(), ref_l3)}
+    for t in range(T):
+        for name, want in (('xy', xy), ('zy', zy), ('xz', xz)):
+            errs['hm_%s%d' % (name, t)] = rel(getattr(m, name + '_heatmaps')[t].cpu(), want[t])
+    print('checkpoint', form, errs)
+    assert max(errs.values()) < 1e-4, errs
+    assert len(m.xy_heatmaps) == T and tuple(m.xy_heatmaps[0].shape) == (B, 17, 32, 32)
+    # and back out in the exported form: what export_model.py writes from a loaded model loads again, bit for bit
+    from margipose_amd.train_helpers import save_checkpoint
+    back = save_checkpoint(os.path.join(tmp_path, 'exported.pth'), m, desc, train_datasets=state['train_datasets'])
+    assert set(back) == {'state_dict', 'model_desc', 'train_datasets'}
+    m2 = load_model(os.path.join(tmp_path, 'exported.pth'))
+    for (k1, v1), (k2, v2) in zip(m.state_dict().items(), m2.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1.cpu(), v2.cpu())
