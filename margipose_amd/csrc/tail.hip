@@ -8,6 +8,7 @@
 // wavefront per plane (xy / zy / xz).  A row of n = H*W <= 4096 fp32 values lives in registers as
 // NV float4 per lane (NV = 4 for 32x32, 9 for 48x48, 16 for 64x64), loaded with 16-byte coalesced
 // accesses (1 KiB per wave instruction).
+#include <stdlib.h>
 #include "common.h"
 
 namespace mpose {
@@ -28,21 +29,43 @@ __device__ __forceinline__ RowGeom make_geom(int H, int W) {
   return g;
 }
 
-template <int NV>
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+
+// NT: the access carries the non-temporal hint (`nt`: streamed once, do not keep the line) -- the soft-argmax reads every logit and
+// writes every heatmap element exactly once, and at sizes beyond the Infinity Cache the lines it would otherwise leave behind only
+// evict what is still to be read.
+template <int NV, bool NT = false>
 __device__ __forceinline__ void load_row(const float* __restrict__ src, int lane, int n4, float4 (&v)[NV], float fill) {
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int idx = i * 64 + lane;
-    v[i] = (idx < n4) ? reinterpret_cast<const float4*>(src)[idx] : make_float4(fill, fill, fill, fill);
+    if (idx < n4) {
+      if (NT) {
+        const f32x4_t r = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(src) + idx);
+        v[i] = make_float4(r.x, r.y, r.z, r.w);
+      } else {
+        v[i] = reinterpret_cast<const float4*>(src)[idx];
+      }
+    } else {
+      v[i] = make_float4(fill, fill, fill, fill);
+    }
   }
 }
 
-template <int NV>
+template <int NV, bool NT = false>
 __device__ __forceinline__ void store_row(float* __restrict__ dst, int lane, int n4, const float4 (&v)[NV]) {
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int idx = i * 64 + lane;
-    if (idx < n4) reinterpret_cast<float4*>(dst)[idx] = v[i];
+    if (idx < n4) {
+      if (NT) {
+        const f32x4_t r = {v[i].x, v[i].y, v[i].z, v[i].w};
+        __builtin_nontemporal_store(r, reinterpret_cast<f32x4_t*>(dst) + idx);
+      } else {
+        reinterpret_cast<float4*>(dst)[idx] = v[i];
+      }
+    }
   }
 }
 
@@ -53,13 +76,19 @@ __device__ __forceinline__ unsigned short f32_to_bf16(float f) {   // round to n
   return (unsigned short)(u >> 16);
 }
 
-template <int NV>
+template <int NV, bool NT = false>
 __device__ __forceinline__ void load_row_bf16(const unsigned short* __restrict__ src, int lane, int n4, float4 (&v)[NV], float fill) {
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int idx = i * 64 + lane;
     if (idx < n4) {
-      const uint2 r = reinterpret_cast<const uint2*>(src)[idx];
+      uint2 r;
+      if (NT) {
+        const u32x2_t t = __builtin_nontemporal_load(reinterpret_cast<const u32x2_t*>(src) + idx);
+        r.x = t.x; r.y = t.y;
+      } else {
+        r = reinterpret_cast<const uint2*>(src)[idx];
+      }
       v[i] = make_float4(bf16_to_f32(r.x & 0xffff), bf16_to_f32(r.x >> 16), bf16_to_f32(r.y & 0xffff), bf16_to_f32(r.y >> 16));
     } else {
       v[i] = make_float4(fill, fill, fill, fill);
@@ -67,16 +96,17 @@ __device__ __forceinline__ void load_row_bf16(const unsigned short* __restrict__
   }
 }
 
-template <int NV>
+template <int NV, bool NT = false>
 __device__ __forceinline__ void store_row_bf16(unsigned short* __restrict__ dst, int lane, int n4, const float4 (&v)[NV]) {
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int idx = i * 64 + lane;
     if (idx < n4) {
-      uint2 r;
+      u32x2_t r;
       r.x = (unsigned)f32_to_bf16(v[i].x) | ((unsigned)f32_to_bf16(v[i].y) << 16);
       r.y = (unsigned)f32_to_bf16(v[i].z) | ((unsigned)f32_to_bf16(v[i].w) << 16);
-      reinterpret_cast<uint2*>(dst)[idx] = r;
+      if (NT) __builtin_nontemporal_store(r, reinterpret_cast<u32x2_t*>(dst) + idx);
+      else reinterpret_cast<u32x2_t*>(dst)[idx] = r;
     }
   }
 }
@@ -86,6 +116,45 @@ __device__ __forceinline__ void elem_hw(const RowGeom& g, int i, int lane, int& 
   const int e0 = (i * 64 + lane) * 4;
   h = e0 / g.W;
   w0 = e0 - h * g.W;
+}
+
+// The row arithmetic of flat_softmax (dsntnn.py:124-130) and dsnt (dsntnn.py:84-96), shared by softmax_dsnt_fwd_k and
+// bn_add_softmax_k.  Every multiply-add is spelled out (fmaf / __fmul_rn / __fadd_rn) so that the compiler's contraction choices
+// cannot differ between the kernels that inline it: their heatmaps and coordinates are bit-identical by construction.
+template <int NV>
+__device__ __forceinline__ void row_softmax(float4 (&v)[NV]) {
+  float m = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) m = fmaxf(m, fmaxf(fmaxf(v[i].x, v[i].y), fmaxf(v[i].z, v[i].w)));
+  m = wave_max(m);
+  float s = 0.0f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    v[i].x = expf(__fsub_rn(v[i].x, m)); v[i].y = expf(__fsub_rn(v[i].y, m)); v[i].z = expf(__fsub_rn(v[i].z, m)); v[i].w = expf(__fsub_rn(v[i].w, m));
+    s = __fadd_rn(s, __fadd_rn(__fadd_rn(v[i].x, v[i].y), __fadd_rn(v[i].z, v[i].w)));
+  }
+  s = wave_sum(s);
+  const float rs = __fdiv_rn(1.0f, s);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) { v[i].x = __fmul_rn(v[i].x, rs); v[i].y = __fmul_rn(v[i].y, rs); v[i].z = __fmul_rn(v[i].z, rs); v[i].w = __fmul_rn(v[i].w, rs); }
+}
+
+template <int NV>
+__device__ __forceinline__ void row_expectation(const float4 (&v)[NV], const RowGeom& g, int lane, float& sx_out, float& sy_out) {
+  float sx = 0.0f, sy = 0.0f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    int h, w0;
+    elem_hw(g, i, lane, h, w0);
+    const float y = cell_coord(h, g.two_over_h, g.first_h);
+    const float x0 = cell_coord(w0, g.two_over_w, g.first_w);
+    const float x1 = __fadd_rn(x0, g.two_over_w), x2 = __fadd_rn(x0, __fmul_rn(2.0f, g.two_over_w)), x3 = __fadd_rn(x0, __fmul_rn(3.0f, g.two_over_w));
+    const float rs = __fadd_rn(__fadd_rn(v[i].x, v[i].y), __fadd_rn(v[i].z, v[i].w));
+    sy = fmaf(rs, y, sy);
+    sx = __fadd_rn(sx, fmaf(v[i].w, x3, fmaf(v[i].z, x2, fmaf(v[i].y, x1, __fmul_rn(v[i].x, x0)))));
+  }
+  sx_out = wave_sum(sx);
+  sy_out = wave_sum(sy);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -99,69 +168,53 @@ struct SoftmaxArgs {
   int n_planes, rows, H, W;
 };
 
-template <int NV, bool BF_IN, bool BF_OUT, bool EXP>
+// RPW rows per workgroup (the loads of ALL of them are issued before the first row's arithmetic starts: 4 KB per wave and row in
+// flight, half the workgroup dispatches per byte); NT bit 0: non-temporal heatmap stores, bit 1: non-temporal logit loads.  The row
+// arithmetic is the same instruction sequence for every (RPW, NT): heatmaps and coordinates are bit-identical across variants.
+template <int NV, bool BF_IN, bool BF_OUT, bool EXP, int RPW = 1, int NT = 0>
 __global__ __launch_bounds__(64 * MPOSE_MAX_GROUP) void softmax_dsnt_fwd_k(SoftmaxArgs a) {
-  __shared__ float s_mu[MPOSE_MAX_GROUP][2];
+  __shared__ float s_mu[RPW][MPOSE_MAX_GROUP][2];
   const int plane = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int row = blockIdx.x;
   const RowGeom g = make_geom(a.H, a.W);
-  const size_t off = (size_t)row * (size_t)(a.H * a.W);
+  constexpr bool NT_ST = (NT & 1) != 0, NT_LD = (NT & 2) != 0;
 
-  float4 v[NV];
-  if (BF_IN) load_row_bf16<NV>(reinterpret_cast<const unsigned short*>(a.logits[plane]) + off, lane, g.n4, v, EXP ? -INFINITY : 0.0f);
-  else load_row<NV>(reinterpret_cast<const float*>(a.logits[plane]) + off, lane, g.n4, v, EXP ? -INFINITY : 0.0f);
-
-  float inv = 1.0f;
-  if (EXP) {
-    float m = -INFINITY;
+  float4 v[RPW][NV];
 #pragma unroll
-    for (int i = 0; i < NV; ++i) m = fmaxf(m, fmaxf(fmaxf(v[i].x, v[i].y), fmaxf(v[i].z, v[i].w)));
-    m = wave_max(m);
-    float s = 0.0f;
+  for (int k = 0; k < RPW; ++k) {
+    const int row = blockIdx.x * RPW + k;
+    const size_t off = (size_t)(row < a.rows ? row : 0) * (size_t)(a.H * a.W);
+    if (BF_IN) load_row_bf16<NV, NT_LD>(reinterpret_cast<const unsigned short*>(a.logits[plane]) + off, lane, g.n4, v[k], EXP ? -INFINITY : 0.0f);
+    else load_row<NV, NT_LD>(reinterpret_cast<const float*>(a.logits[plane]) + off, lane, g.n4, v[k], EXP ? -INFINITY : 0.0f);
+  }
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      v[i].x = expf(v[i].x - m); v[i].y = expf(v[i].y - m); v[i].z = expf(v[i].z - m); v[i].w = expf(v[i].w - m);
-      s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  for (int k = 0; k < RPW; ++k) {
+    const int row = blockIdx.x * RPW + k;
+    const bool live = row < a.rows;                 // (wave-uniform; a dead row recomputes row 0 and stores nothing)
+    const size_t off = (size_t)(live ? row : 0) * (size_t)(a.H * a.W);
+    if (EXP) row_softmax<NV>(v[k]);
+    if (EXP && a.heatmaps[plane] != nullptr && live) {      // (stored before the expectation sums: the stores drain under them)
+      if (BF_OUT) store_row_bf16<NV, NT_ST>(reinterpret_cast<unsigned short*>(a.heatmaps[plane]) + off, lane, g.n4, v[k]);
+      else store_row<NV, NT_ST>(reinterpret_cast<float*>(a.heatmaps[plane]) + off, lane, g.n4, v[k]);
     }
-    s = wave_sum(s);
-    const float rs = 1.0f / s;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) { v[i].x *= rs; v[i].y *= rs; v[i].z *= rs; v[i].w *= rs; }
-  }
-  (void)inv;
 
-  float sx = 0.0f, sy = 0.0f;
-#pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    int h, w0;
-    elem_hw(g, i, lane, h, w0);
-    const float y = cell_coord(h, g.two_over_h, g.first_h);
-    const float x0 = cell_coord(w0, g.two_over_w, g.first_w);
-    const float rs = (v[i].x + v[i].y) + (v[i].z + v[i].w);
-    sy = fmaf(rs, y, sy);
-    sx += v[i].x * x0 + v[i].y * (x0 + g.two_over_w) + v[i].z * (x0 + 2.0f * g.two_over_w) + v[i].w * (x0 + 3.0f * g.two_over_w);
-  }
-  sx = wave_sum(sx);
-  sy = wave_sum(sy);
-
-  if (EXP && a.heatmaps[plane] != nullptr) {
-    if (BF_OUT) store_row_bf16<NV>(reinterpret_cast<unsigned short*>(a.heatmaps[plane]) + off, lane, g.n4, v);
-    else store_row<NV>(reinterpret_cast<float*>(a.heatmaps[plane]) + off, lane, g.n4, v);
-  }
-  if (lane == 0) {
-    s_mu[plane][0] = sx; s_mu[plane][1] = sy;
-    if (a.plane_coords != nullptr) {
-      float* pc = a.plane_coords + ((size_t)plane * a.rows + row) * 2;
-      pc[0] = sx; pc[1] = sy;
+    float sx, sy;
+    row_expectation<NV>(v[k], g, lane, sx, sy);
+    if (lane == 0) {
+      s_mu[k][plane][0] = sx; s_mu[k][plane][1] = sy;
+      if (a.plane_coords != nullptr && live) {
+        float* pc = a.plane_coords + ((size_t)plane * a.rows + row) * 2;
+        pc[0] = sx; pc[1] = sy;
+      }
     }
   }
   if (a.n_planes == 3 && a.xyz != nullptr) {
     __syncthreads();
-    if (threadIdx.x == 0) {
-      float* o = a.xyz + (size_t)row * 3;
-      o[0] = s_mu[0][0];
-      o[1] = s_mu[0][1];
-      o[2] = 0.5f * (s_mu[1][0] + s_mu[2][1]);     // models/margipose_model.py:259
+    if (threadIdx.x < RPW && (int)(blockIdx.x * RPW + threadIdx.x) < a.rows) {
+      const int k = threadIdx.x;
+      float* o = a.xyz + (size_t)(blockIdx.x * RPW + k) * 3;
+      o[0] = s_mu[k][0][0];
+      o[1] = s_mu[k][0][1];
+      o[2] = 0.5f * (s_mu[k][1][0] + s_mu[k][2][1]);     // models/margipose_model.py:259
     }
   }
 }
@@ -233,33 +286,9 @@ __global__ __launch_bounds__(kBasThreads) void bn_add_softmax_k(BnAddSoftmaxArgs
       const int idx = i * 64 + lane;
       v[i] = (idx < g.n4) ? reinterpret_cast<const float4*>(row)[idx] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
     }
-    float m = -INFINITY;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) m = fmaxf(m, fmaxf(fmaxf(v[i].x, v[i].y), fmaxf(v[i].z, v[i].w)));
-    m = wave_max(m);
-    float s_ = 0.0f;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      v[i].x = expf(v[i].x - m); v[i].y = expf(v[i].y - m); v[i].z = expf(v[i].z - m); v[i].w = expf(v[i].w - m);
-      s_ += (v[i].x + v[i].y) + (v[i].z + v[i].w);
-    }
-    s_ = wave_sum(s_);
-    const float rs_ = 1.0f / s_;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) { v[i].x *= rs_; v[i].y *= rs_; v[i].z *= rs_; v[i].w *= rs_; }
-    float sx = 0.0f, sy = 0.0f;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      int h, w0;
-      elem_hw(g, i, lane, h, w0);
-      const float y = cell_coord(h, g.two_over_h, g.first_h);
-      const float x0 = cell_coord(w0, g.two_over_w, g.first_w);
-      const float rsum = (v[i].x + v[i].y) + (v[i].z + v[i].w);
-      sy = fmaf(rsum, y, sy);
-      sx += v[i].x * x0 + v[i].y * (x0 + g.two_over_w) + v[i].z * (x0 + 2.0f * g.two_over_w) + v[i].w * (x0 + 3.0f * g.two_over_w);
-    }
-    sx = wave_sum(sx);
-    sy = wave_sum(sy);
+    row_softmax<NV>(v);
+    float sx, sy;
+    row_expectation<NV>(v, g, lane, sx, sy);
     const size_t r = (size_t)b * a.J + j;
     if (BF_OUT) store_row_bf16<NV>(reinterpret_cast<unsigned short*>(a.heat[blockIdx.y]) + r * a.P, lane, g.n4, v);
     else store_row<NV>(reinterpret_cast<float*>(a.heat[blockIdx.y]) + r * a.P, lane, g.n4, v);
@@ -651,15 +680,41 @@ extern "C" int mpose_softmax_dsnt_fwd(const void* const* logits, void* const* he
   for (int p = 0; p < n_planes; ++p) { a.logits[p] = logits[p]; a.heatmaps[p] = heatmaps ? heatmaps[p] : nullptr; }
   a.plane_coords = plane_coords; a.xyz = xyz; a.n_planes = n_planes; a.rows = rows; a.H = H; a.W = W;
   hipStream_t s = (hipStream_t)stream;
+  // MPOSE_TAIL_VARIANT = rows per workgroup (1, 2) + 16 * NT bits (timing runs: tools/bench_tail.py; every variant is bit-identical).
+  // Default: sizes whose logits + heatmaps exceed the 256 MB Infinity Cache stream (non-temporal both ways, two rows per workgroup);
+  // smaller ones keep plain accesses -- their heatmaps are re-read from the cache by the next stage's combiner and the loss kernels.
+  static const int forced = [] { const char* e = getenv("MPOSE_TAIL_VARIANT"); return e ? atoi(e) : -1; }();
+  const size_t bytes = (size_t)rows * n_planes * H * W * (io_dtype == 0 ? 8 : (io_dtype == 1 ? 4 : 6));
+  const int variant = forced >= 0 ? forced : (bytes > (size_t)256 << 20 ? 2 + 16 * 3 : 1);
+  const int rpw = (variant & 15) == 2 && nv <= 9 ? 2 : 1, nt = (variant >> 4) & 3;
+  const int grid = (rows + rpw - 1) / rpw;
+#define MPOSE_TAIL_LAUNCH(BI, BO)                                                                                              \
+  do {                                                                                                                         \
+    if (rpw == 2) {                                                                                                            \
+      if (nv == 4) { if (nt == 3) softmax_dsnt_fwd_k<4, BI, BO, true, 2, 3><<<grid, 64 * n_planes, 0, s>>>(a);                \
+                     else if (nt == 1) softmax_dsnt_fwd_k<4, BI, BO, true, 2, 1><<<grid, 64 * n_planes, 0, s>>>(a);           \
+                     else softmax_dsnt_fwd_k<4, BI, BO, true, 2, 0><<<grid, 64 * n_planes, 0, s>>>(a); }                     \
+      else { if (nt == 3) softmax_dsnt_fwd_k<9, BI, BO, true, 2, 3><<<grid, 64 * n_planes, 0, s>>>(a);                        \
+             else if (nt == 1) softmax_dsnt_fwd_k<9, BI, BO, true, 2, 1><<<grid, 64 * n_planes, 0, s>>>(a);                   \
+             else softmax_dsnt_fwd_k<9, BI, BO, true, 2, 0><<<grid, 64 * n_planes, 0, s>>>(a); }                             \
+    } else if (nt == 3) {                                                                                                      \
+      MPOSE_DISPATCH_NV(nv, (softmax_dsnt_fwd_k<NV, BI, BO, true, 1, 3><<<grid, 64 * n_planes, 0, s>>>(a)));                  \
+    } else if (nt == 1) {                                                                                                      \
+      MPOSE_DISPATCH_NV(nv, (softmax_dsnt_fwd_k<NV, BI, BO, true, 1, 1><<<grid, 64 * n_planes, 0, s>>>(a)));                  \
+    } else {                                                                                                                   \
+      MPOSE_DISPATCH_NV(nv, (softmax_dsnt_fwd_k<NV, BI, BO, true, 1, 0><<<grid, 64 * n_planes, 0, s>>>(a)));                  \
+    }                                                                                                                          \
+  } while (0)
   if (io_dtype == 0) {
-    MPOSE_DISPATCH_NV(nv, (softmax_dsnt_fwd_k<NV, false, false, true><<<rows, 64 * n_planes, 0, s>>>(a)));
+    MPOSE_TAIL_LAUNCH(false, false);
   } else if (io_dtype == 1) {
-    MPOSE_DISPATCH_NV(nv, (softmax_dsnt_fwd_k<NV, true, true, true><<<rows, 64 * n_planes, 0, s>>>(a)));
+    MPOSE_TAIL_LAUNCH(true, true);
   } else if (io_dtype == 2) {
-    MPOSE_DISPATCH_NV(nv, (softmax_dsnt_fwd_k<NV, false, true, true><<<rows, 64 * n_planes, 0, s>>>(a)));
+    MPOSE_TAIL_LAUNCH(false, true);
   } else {
     return MPOSE_EINVAL;
   }
+#undef MPOSE_TAIL_LAUNCH
   return launch_status();
 }
 

@@ -24,16 +24,21 @@ def timeit(fn, iters=50, warm=5):
 def main():
     L = _lib.lib()
     res = []
-    for B, F, bf16 in ((64, 32, False), (64, 32, True), (32, 32, False), (2048, 32, False), (2048, 32, True), (512, 64, False)):
+    fwd_only = '--fwd-only' in sys.argv          # (tools/tail_variants.sh: the forward kernel at the cache-defeating sizes only)
+    cases = ((2048, 32, False), (2048, 32, True), (910, 48, False), (512, 64, False)) if fwd_only else \
+        ((64, 32, False), (64, 32, True), (32, 32, False), (2048, 32, False), (2048, 32, True), (512, 64, False))
+    for B, F, bf16 in cases:
         rows = B * 17; n = F * F; E = rows * 3 * n
         dt = torch.bfloat16 if bf16 else torch.float32
         lg = [(torch.randn(B, 17, F, F, device='cuda') * 4).to(dt) for _ in range(3)]
         hm = [torch.empty_like(l) for l in lg]
         xyz = torch.empty(B, 17, 3, device='cuda')
-        t = timeit(lambda: L.mpose_softmax_dsnt_fwd(ptr_array(lg), ptr_array(hm), None, ptr(xyz), 3, rows, F, F, int(bf16), stream_ptr()))
+        t = timeit(lambda: L.mpose_softmax_dsnt_fwd(ptr_array(lg), ptr_array(hm), None, ptr(xyz), 3, rows, F, F, int(bf16), stream_ptr()),
+                   iters=200 if fwd_only else 50)
         bpe = 2 if bf16 else 4
-        res.append(dict(kernel='softmax_dsnt_fwd', B=B, F=F, dtype=str(dt), us=t * 1e6, GBps=E * 2 * bpe / t / 1e9))
-        if bf16:
+        res.append(dict(kernel='softmax_dsnt_fwd', B=B, F=F, dtype=str(dt), us=t * 1e6, GBps=E * 2 * bpe / t / 1e9,
+                        frac_of_8TBps=E * 2 * bpe / t / 8e12, variant=os.environ.get('MPOSE_TAIL_VARIANT', 'default')))
+        if bf16 or fwd_only:
             continue
         tgt = torch.rand(B, 17, 3, device='cuda') * 2 - 1
         losses = torch.empty(B, 17, device='cuda'); dl = torch.ones(B, 17, device='cuda') / (B * 17)
