@@ -84,7 +84,9 @@ def parse():
     ap.add_argument('--graph', action='store_true', help='replay the captured HIP graph of the iteration (train_helpers.GraphedTrainStep) instead '
                     'of enqueueing ~1000 launches per step from Python.  Bit-identical results; the step is GPU-bound, and a replay '
                     'measured ~1 %% SLOWER than eager launches (37.2 vs 36.8 ms, one box), so the benchmark default is eager')
-    ap.add_argument('--eager', action='store_true', help='(default) kept for scripts')
+    ap.add_argument('--eager', action='store_true', help='issue every launch from Python (the default replays the iteration from a launch '
+                    'plan: train_helpers.PlannedTrainStep -- the same schedule without its host cost)')
+    ap.add_argument('--no-plan', action='store_true', help='same as --eager')
     ap.add_argument('--conv-dtype', default='f32', choices=['f32', 'f16', 'bf16'], help="BASELINE configs[4]'s reduced-precision "
                     "convolutions -- 'f16': every convolution on fp16-rounded operands, one MFMA product (model.conv_dtype = "
                     "torch.float16; with --stages 5 --size 384 that is configs[4]'s workload); 'bf16': round 2's variant (columns' "
@@ -304,7 +306,7 @@ def main():
         raise SystemExit(self_launch(args))
     from margipose_amd import dsntnn, parallel
     from margipose_amd.engine import KernelTimer
-    from margipose_amd.train_helpers import DeviceSGD, GraphedTrainStep
+    from margipose_amd.train_helpers import DeviceSGD, GraphedTrainStep, PlannedTrainStep
     from margipose_amd.models import CanonicalSkeletonDesc, MargiPoseModel
     rank, world, local_rank = parallel.init_from_env()
     if world != args.gpus:
@@ -361,9 +363,23 @@ def main():
             torch.cuda.synchronize()
             use_graph = False
 
+    # Default dispatch on one GPU: the iteration recorded once as a LAUNCH PLAN (csrc/plan.hip) and re-issued from a C loop -- the
+    # eager two-stream schedule, kernel for kernel, without ~700 Python-issued launches per step (15 ms of host time on the pool's
+    # fast hosts, 28 ms on its slow ones, where the eager step is host-bound).  --eager issues every launch from Python.
+    planned = None
+    if graphed is None and not args.eager and not args.no_plan and world == 1 and os.environ.get('MPOSE_PLAN', '1') != '0':
+        try:
+            planned = PlannedTrainStep(model, opt, x, target, mask, warmup=2)
+        except Exception as e:          # a failed recording must not cost the measurement: fall back to eager launches
+            sys.stderr.write('bench.py: launch-plan recording failed (%s: %s); running eagerly\n' % (type(e).__name__, e))
+            torch.cuda.synchronize()
+            planned = None
+
     def step():
         if graphed is not None:
             return graphed()[1]
+        if planned is not None:
+            return planned()[1]
         return eager_step()
 
     for _ in range(args.warmup):
@@ -387,10 +403,13 @@ def main():
         model.inner.engine().timer = None
         torch.cuda.synchronize()
         ssum = survey.summary()
-        sconv = {k: v for k, v in ssum.items() if k.startswith('conv:') or k.startswith('wgrad:')}
+        if os.environ.get('MPOSE_SURVEY_DUMP'):       # every launch label of the survey step (tools/: where a step goes, label by label)
+            with open(os.environ['MPOSE_SURVEY_DUMP'], 'w') as f:
+                json.dump(ssum, f, indent=1)
+        sconv ={k: v for k, v in ssum.items() if k.startswith('conv:') or k.startswith('wgrad:')}
         if sconv:
             top_label = max(sconv.items(), key=lambda kv: kv[1]['total_ms'])[0]
-            if graphed is None:
+            if graphed is None and planned is None:
                 timer = KernelTimer(only=[top_label])
                 model.inner.engine().timer = timer
     barrier()
@@ -448,7 +467,10 @@ def main():
                             '%s (reference option, models/margipose_model.py:119-137; torchvision layers restated, unpinned, '
                             'random init)' % args.stem if args.stem.startswith('resnet') else
                             'patch8 (in-repo deterministic stem; the InceptionV4 stem is available with --stem inceptionv4)'), 'parallelism': 'dp%d' % world, 'overlap_wgrad': (not args.no_overlap_wgrad) and (world == 1 or model.inner.engine().dp_overlap()),
-                   'step_dispatch': 'hip graph replay (train_helpers.GraphedTrainStep)' if use_graph else 'eager launches',
+                   'step_dispatch': 'hip graph replay (train_helpers.GraphedTrainStep)' if use_graph else (
+                       'launch plan replay (train_helpers.PlannedTrainStep, csrc/plan.hip): %d recorded launches and %d cross-stream waits '
+                       're-issued per step from one C loop, same two-stream schedule as the eager step' % (planned.n_launches, planned.n_waits)
+                       if planned is not None else 'eager launches (Python / ctypes)'),
                    'conv_engine': {0: 'conv_igemm_k / conv_wgrad_k (conv.hip), six bf16 products per fp32 multiply-add',
                                    1: 'plane engine (conv_p.hip)',
                                    2: 'conv_igemm_k / conv_wgrad_k (conv.hip), three fp16 products per fp32 multiply-add of per-tensor-scaled, '

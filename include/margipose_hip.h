@@ -592,6 +592,37 @@ int mpose_sgd_step(const mpose_sgd_job* jobs_dev, int n_jobs, int64_t max_n, con
 /* dst[0..3] = {a, b, c, d} on the stream (how the host hands the next step's hyper-parameters to a replayed graph). */
 int mpose_set4(float* dst, float a, float b, float c, float d, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Launch plans (csrc/plan.hip): the launches of a training iteration (reference bin/train_3d.py:154-186) recorded once and
+ * re-issued from one C loop -- the eager schedule (same kernels, argument values, streams and cross-stream dependencies)
+ * without its host cost.  Every launch of this library passes through one wrapper; between mpose_plan_begin and mpose_plan_end
+ * it is also recorded.  `streams`: the HIP streams the iteration uses, streams[0] the main one; a launch or wait on any other
+ * stream makes mpose_plan_end fail.  Recording is process-wide (autograd issues the backward pass from its own thread); one
+ * recording at a time.  The recorded iteration executes normally.  A replay is valid while every buffer the recorded launches
+ * touch lives at its recorded address, and only for what the LIBRARY launched: kernels of other libraries are not recorded.
+ * mpose_plan_replay issues ops [first_op, ...) on `streams` (same count as recorded) until the end or the next break
+ * (mpose_plan_break: a point where the host must act, e.g. issue a collective) and stores the index to continue from.
+ * mpose_stream_wait(waiter, signaler): `waiter` waits for everything enqueued on `signaler` so far (event record + stream
+ * wait); recorded like a launch.  None of these calls synchronises with the device. */
+int mpose_plan_begin(void* const* streams, int n_streams);
+int mpose_plan_recording(void);
+int mpose_plan_end(void** plan_out);
+int mpose_plan_abort(void);
+int mpose_plan_break(void);
+int mpose_plan_size(void* plan, int* n_launch, int* n_wait, int* n_break);
+int mpose_plan_replay(void* plan, void* const* streams, int n_streams, int first_op, int* next_op);
+int mpose_plan_destroy(void* plan);
+int mpose_stream_wait(void* waiter, void* signaler);
+/* What an iteration otherwise takes from the tensor library, as recordable launches: a 32-bit fill and a copy (n_bytes % 4 == 0),
+ * p[i] += v over n device int64s (the BatchNorms' num_batches_tracked), out = a + b over n floats (a == NULL: 0 + b: the stage-loss sum of
+ * models/margipose_model.py:238-252), and average_loss's backward d_losses = mask * (grad[0] / out2[1]) (dsntnn.py:99-121; out2 =
+ * mpose_average_loss_fwd's {mean, denominator}; mask may be NULL). */
+int mpose_fill_u32(void* dst, unsigned value, int64_t n_bytes, void* stream);
+int mpose_copy_bytes(const void* src, void* dst, int64_t n_bytes, void* stream);
+int mpose_add_i64(int64_t* p, int64_t v, int64_t n, void* stream);
+int mpose_add_f32(const float* a, const float* b, float* out, int64_t n, void* stream);
+int mpose_average_loss_bwd(const float* grad, const float* out2, const float* mask, float* d_losses, int64_t n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

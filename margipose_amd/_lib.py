@@ -17,7 +17,7 @@ c_int = ctypes.c_int
 c_float = ctypes.c_float
 c_int64 = ctypes.c_int64
 
-ABI_VERSION = 13         # must equal mpose_abi_version() of the library (csrc/tail.hip)
+ABI_VERSION = 14         # must equal mpose_abi_version() of the library (csrc/tail.hip)
 MAX_GROUP = 3
 MAX_TAPS = 12
 MAX_CLASSES = 8
@@ -54,6 +54,39 @@ def check(rc, what):
 def stream_ptr():
     # (torch.cuda.current_stream() costs ~9 us of Python per call -- 8 ms of an 890-launch training step; the raw query is 0.3 us)
     return c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
+
+
+def raw_stream(stream):
+    """The hipStream_t of a torch.cuda.Stream as a void pointer."""
+    return c_void_p(stream.cuda_stream)
+
+
+def stream_wait(waiter, signaler):
+    """`waiter` (a torch.cuda.Stream) waits for everything enqueued on `signaler` so far -- Stream.wait_stream through the library
+    (mpose_stream_wait: event record + stream wait), so that a launch plan being recorded sees the dependency (csrc/plan.hip)."""
+    check(lib().mpose_stream_wait(raw_stream(waiter), raw_stream(signaler)), 'mpose_stream_wait')
+
+
+def fill_zero(t):
+    """t.zero_() as a launch of this library (recordable by a launch plan; ATen's fill is not)."""
+    n = t.numel() * t.element_size()
+    if n:
+        check(lib().mpose_fill_u32(c_void_p(t.data_ptr()), 0, c_int64(n), stream_ptr()), 'mpose_fill_u32')
+    return t
+
+
+def copy_into(dst, src):
+    """dst.copy_(src) for contiguous device tensors of equal byte size, as a launch of this library."""
+    n = src.numel() * src.element_size()
+    if n != dst.numel() * dst.element_size() or not (src.is_contiguous() and dst.is_contiguous()):
+        raise MposeError('copy_into needs contiguous tensors of equal size')
+    if n:
+        check(lib().mpose_copy_bytes(c_void_p(src.data_ptr()), c_void_p(dst.data_ptr()), c_int64(n), stream_ptr()), 'mpose_copy_bytes')
+    return dst
+
+
+def plan_recording():
+    return bool(lib().mpose_plan_recording())
 
 
 def dev_f32(t, name='tensor'):

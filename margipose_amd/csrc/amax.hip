@@ -78,13 +78,13 @@ extern "C" int mpose_absmax(const mpose_absmax_operands* ops, int n_tensors, int
   long blocks = (a.total4 + 256 * 8 - 1) / (256 * 8);
   const long cap = 1024 / n_tensors > 128 ? 1024 / n_tensors : 128;
   if (blocks > cap) blocks = cap;
-  absmax_k<<<dim3((unsigned)blocks, n_tensors), 256, 0, (hipStream_t)stream>>>(a);
+  launch(absmax_k, dim3(dim3((unsigned)blocks, n_tensors)), dim3(256), 0, (hipStream_t)stream, a);
   return launch_status();
 }
 
 extern "C" int mpose_weights_absmax(const mpose_pack_job* jobs_dev, int n_jobs, void* stream) {
   if (n_jobs <= 0) return 0;
-  weights_amax_zero_k<<<(n_jobs + 255) / 256, 256, 0, (hipStream_t)stream>>>(jobs_dev, n_jobs);
-  weights_absmax_k<<<dim3(16, n_jobs), 256, 0, (hipStream_t)stream>>>(jobs_dev);
+  launch(weights_amax_zero_k, dim3((n_jobs + 255) / 256), dim3(256), 0, (hipStream_t)stream, jobs_dev, n_jobs);
+  launch(weights_absmax_k, dim3(dim3(16, n_jobs)), dim3(256), 0, (hipStream_t)stream, jobs_dev);
   return launch_status();
 }

@@ -353,8 +353,8 @@ extern "C" int mpose_sizeof(int which) {
 // train: bit 0 = batch statistics; bit 1 = the jobs carry MPOSE_CONV_STATS_PART rows (1024 threads per job); bit 2 = write the jobs' bounds
 extern "C" int mpose_bn_finalize(const mpose_bn_job* jobs_dev, int n_jobs, int train, float eps, float momentum, void* stream) {
   if (n_jobs <= 0) return 0;
-  if (train & 2) bn_finalize_k<<<dim3(n_jobs, 4), 1024, 0, (hipStream_t)stream>>>(jobs_dev, train & 7, eps, momentum);
-  else bn_finalize_k<<<n_jobs, 256, 0, (hipStream_t)stream>>>(jobs_dev, train & 7, eps, momentum);
+  if (train & 2) launch(bn_finalize_k, dim3(dim3(n_jobs, 4)), dim3(1024), 0, (hipStream_t)stream, jobs_dev, train & 7, eps, momentum);
+  else launch(bn_finalize_k, dim3(n_jobs), dim3(256), 0, (hipStream_t)stream, jobs_dev, train & 7, eps, momentum);
   return launch_status();
 }
 
@@ -368,12 +368,12 @@ extern "C" int mpose_bn_add_fwd(const mpose_bn_add_operands* ops, int n_groups, 
   if (a.total4 == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   if (layout == 0) {
-    bn_add_nhwc_k<true><<<dim3(amax_grid(grid_for(a.total4, 256), ops[0].out_amax != nullptr), n_groups), 256, 0, s>>>(a);
+    launch(bn_add_nhwc_k<true>, dim3(dim3(amax_grid(grid_for(a.total4, 256), ops[0].out_amax != nullptr), n_groups)), dim3(256), 0, s, a);
   } else if (layout == 2) {             // no ReLU on branch a: bn2(x) + bn_d(shortcut) of a ResNet downsample block
-    bn_add_nhwc_k<false><<<dim3(amax_grid(grid_for(a.total4, 256), ops[0].out_amax != nullptr), n_groups), 256, 0, s>>>(a);
+    launch(bn_add_nhwc_k<false>, dim3(dim3(amax_grid(grid_for(a.total4, 256), ops[0].out_amax != nullptr), n_groups)), dim3(256), 0, s, a);
   } else {
     if (c_keep < 1 || c_keep > C) return MPOSE_EINVAL;
-    bn_add_nchw_k<<<dim3(grid_for((long)B * pixels_per_image, 256), n_groups), 256, 0, s>>>(a, B);
+    launch(bn_add_nchw_k, dim3(dim3(grid_for((long)B * pixels_per_image, 256), n_groups)), dim3(256), 0, s, a, B);
   }
   return launch_status();
 }
@@ -391,7 +391,7 @@ extern "C" int mpose_bn_bwd_reduce(const mpose_bn_bwd_reduce_operands* ops, int 
   if (blocks > 512) blocks = 512;
   a.pix_per_block = (int)((a.npix + blocks - 1) / blocks);
   const int lds = rows_per_pass * C * 4 * 8;
-  bn_bwd_reduce_k<<<dim3(blocks, n_groups), 256, lds, (hipStream_t)stream>>>(a);
+  launch(bn_bwd_reduce_k, dim3(dim3(blocks, n_groups)), dim3(256), lds, (hipStream_t)stream, a);
   return launch_status();
 }
 
@@ -429,9 +429,9 @@ extern "C" int mpose_bn_bwd_reduce_ws(const mpose_bn_bwd_reduce_operands* ops, i
   const int rows_per_pass = 256 / (C / 4);
   const int lds = rows_per_pass * C * 4 * 8;
   hipStream_t s = (hipStream_t)stream;
-  bn_bwd_reduce_k<<<dim3((unsigned)blocks, n_groups), 256, lds, s>>>(a);
-  if (reduce_wide(n_groups, C)) bn_bwd_reduce_finish_k<16><<<dim3((C * 4 + 15) / 16, n_groups), 256, 0, s>>>(a, (int)blocks);
-  else bn_bwd_reduce_finish_k<64><<<dim3((C * 4 + 63) / 64, n_groups), 256, 0, s>>>(a, (int)blocks);
+  launch(bn_bwd_reduce_k, dim3(dim3((unsigned)blocks, n_groups)), dim3(256), lds, s, a);
+  if (reduce_wide(n_groups, C)) launch(bn_bwd_reduce_finish_k<16>, dim3(dim3((C * 4 + 15) / 16, n_groups)), dim3(256), 0, s, a, (int)blocks);
+  else launch(bn_bwd_reduce_finish_k<64>, dim3(dim3((C * 4 + 63) / 64, n_groups)), dim3(256), 0, s, a, (int)blocks);
   return launch_status();
 }
 
@@ -439,8 +439,8 @@ extern "C" int mpose_bn_bwd_reduce_ws(const mpose_bn_bwd_reduce_operands* ops, i
 // bit 3 = write the jobs' bounds (bound_out)
 extern "C" int mpose_bn_bwd_coef(const mpose_bn_bwd_coef_job* jobs_dev, int n_jobs, int mode, void* stream) {
   if (n_jobs <= 0) return 0;
-  if (mode & 4) bn_bwd_coef_k<<<dim3(n_jobs, 4), 1024, 0, (hipStream_t)stream>>>(jobs_dev, mode & 11);
-  else bn_bwd_coef_k<<<n_jobs, 256, 0, (hipStream_t)stream>>>(jobs_dev, mode & 11);
+  if (mode & 4) launch(bn_bwd_coef_k, dim3(dim3(n_jobs, 4)), dim3(1024), 0, (hipStream_t)stream, jobs_dev, mode & 11);
+  else launch(bn_bwd_coef_k, dim3(n_jobs), dim3(256), 0, (hipStream_t)stream, jobs_dev, mode & 11);
   return launch_status();
 }
 
@@ -452,21 +452,21 @@ extern "C" int mpose_bn_bwd_apply(const mpose_bn_bwd_apply_operands* ops, int n_
   a.C = C;
   a.total4 = (long)B * pixels_per_image * C / 4;
   if (a.total4 == 0) return 0;
-  bn_bwd_apply_k<<<dim3(amax_grid(grid_for(a.total4, 256), ops[0].da_amax != nullptr), n_groups), 256, 0, (hipStream_t)stream>>>(a);
+  launch(bn_bwd_apply_k, dim3(dim3(amax_grid(grid_for(a.total4, 256), ops[0].da_amax != nullptr), n_groups)), dim3(256), 0, (hipStream_t)stream, a);
   return launch_status();
 }
 
 extern "C" int mpose_bn_relu_fwd(const float* x, const float* scale, const float* shift, float* out, int64_t n, int C, void* stream) {
   if (n < 0 || (C & 3) || C <= 0 || (n % C)) return MPOSE_EINVAL;
   if (n == 0) return 0;
-  bn_relu_k<<<grid_for(n / 4, 256), 256, 0, (hipStream_t)stream>>>(x, scale, shift, out, n / 4, C);
+  launch(bn_relu_k, dim3(grid_for(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, x, scale, shift, out, n / 4, C);
   return launch_status();
 }
 
 extern "C" int mpose_relu_bwd(const float* g, const float* y, float* gm, int64_t n, void* stream) {
   if (n < 0 || (n & 3)) return MPOSE_EINVAL;
   if (n == 0) return 0;
-  relu_bwd_k<<<grid_for(n / 4, 256), 256, 0, (hipStream_t)stream>>>(reinterpret_cast<const float4*>(g), reinterpret_cast<const float4*>(y),
+  launch(relu_bwd_k, dim3(grid_for(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const float4*>(g), reinterpret_cast<const float4*>(y),
                                                                     reinterpret_cast<float4*>(gm), n / 4);
   return launch_status();
 }

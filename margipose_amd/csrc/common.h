@@ -2,6 +2,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
+#include <tuple>
+#include <type_traits>
 #include "../../include/margipose_hip.h"
 
 namespace mpose {
@@ -249,5 +252,30 @@ struct MutPtr3 {
 };
 
 inline int launch_status() { return (int)hipGetLastError(); }
+
+// ---- every kernel launch of the library goes through launch(): it is the point where a LAUNCH PLAN records (csrc/plan.hip:
+// mpose_plan_begin ... mpose_plan_end keeps, per launch, the kernel, the geometry, a copy of the argument values and which of the
+// plan's streams it went to; mpose_plan_replay re-issues the list from one C loop -- a training iteration's ~700 launches for
+// 2-3 ms of host time instead of 15-28 ms of Python, on the same two streams with the same dependencies as the eager schedule).
+// Recording is process-wide, not per thread: autograd runs the backward pass's launches on its own device thread.
+struct Plan;
+extern std::atomic<Plan*> g_plan_rec;
+void plan_record_launch(Plan* plan, const void* fn, dim3 grid, dim3 block, unsigned lds, hipStream_t stream, void* const* argv,
+                        const unsigned* sizes, int n_args);
+
+template <class... P, class... A>
+inline void launch(void (*kernel)(P...), dim3 grid, dim3 block, size_t lds, hipStream_t stream, A&&... args) {
+  static_assert(sizeof...(P) == sizeof...(A), "launch(): argument count differs from the kernel's parameter list");
+  std::tuple<std::remove_cv_t<std::remove_reference_t<P>>...> params{static_cast<P>(args)...};      // the values exactly as the kernel takes them
+  std::apply([&](auto&... e) {
+    void* argv[] = {static_cast<void*>(&e)...};
+    Plan* rec = g_plan_rec.load(std::memory_order_acquire);
+    if (rec != nullptr) {
+      const unsigned sizes[] = {(unsigned)sizeof(e)...};
+      plan_record_launch(rec, reinterpret_cast<const void*>(kernel), grid, block, (unsigned)lds, stream, argv, sizes, (int)sizeof...(P));
+    }
+    (void)hipLaunchKernel(reinterpret_cast<const void*>(kernel), grid, block, argv, lds, stream);      // (errors: launch_status())
+  }, params);
+}
 
 }  // namespace mpose

@@ -1115,7 +1115,7 @@ int launch_conv(const ConvArgs& a0, int n_groups, hipStream_t s) {
   //  the 64-channel 3x3, durations within 1 %; the feature extractor's wide launches, several channel tiles per pixel tile with an
   //  unsplit K, measured 17-25 % SLOWER in this order and keep the plain one: tools/pmc_xcd.sh)
   a.xcd_order = (ROWG && !xcd_off && (grid.x & 7u) == 0 && grid.x >= 16) ? 1 : 0;
-  conv_igemm_k<RN, MODE, KS, PRO, NPL, ROWG><<<grid, 256, lds, s>>>(a);
+  launch(conv_igemm_k<RN, MODE, KS, PRO, NPL, ROWG>, dim3(grid), dim3(256), lds, s, a);
   return launch_status();
 }
 
@@ -1545,7 +1545,7 @@ int launch_wgrad_p(const WgradArgs& a, hipStream_t s) {
       return MPOSE_EINVAL;
     attr_set = true;
   }
-  conv_wgrad_k<KB, NB, F16><<<dim3(8 * a.chunk), 256, lds, s>>>(a);
+  launch(conv_wgrad_k<KB, NB, F16>, dim3(dim3(8 * a.chunk)), dim3(256), lds, s, a);
   return launch_status();
 }
 template <int KB, int NB>
@@ -1965,7 +1965,7 @@ extern "C" int mpose_pack_weights(const mpose_pack_job* jobs_dev, int n_jobs, in
   int bx = (max_elems_per_job + 256 * 8 - 1) / (256 * 8);
   if (bx < 1) bx = 1;
   if (bx > 256) bx = 256;
-  pack_weights_k<<<dim3(bx, n_jobs), 256, 0, (hipStream_t)stream>>>(jobs_dev);
+  launch(pack_weights_k, dim3(dim3(bx, n_jobs)), dim3(256), 0, (hipStream_t)stream, jobs_dev);
   return launch_status();
 }
 
@@ -1974,6 +1974,6 @@ extern "C" int mpose_unpack_wgrads(const mpose_unpack_job* jobs_dev, int n_jobs,
   int bx = (max_elems_per_job / 9 + 256 * 2 - 1) / (256 * 2);      // ~ (k, n) pairs of the largest job / 512
   if (bx < 1) bx = 1;
   if (bx > 256) bx = 256;
-  unpack_wgrads_k<<<dim3(bx, n_jobs), 256, 0, (hipStream_t)stream>>>(jobs_dev);
+  launch(unpack_wgrads_k, dim3(dim3(bx, n_jobs)), dim3(256), 0, (hipStream_t)stream, jobs_dev);
   return launch_status();
 }

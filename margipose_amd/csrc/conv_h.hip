@@ -1146,7 +1146,7 @@ int launch_h2r(ConvHRArgs a, int cmax, int n_groups, hipStream_t s) {
   dim3 grid(a.n_mtiles, (cmax + BN - 1) / BN, n_groups);
   a.part_row0 = mpose_part_phase.row0;
   a.part_rows = mpose_part_phase.total > 0 ? mpose_part_phase.total : (int)grid.x;
-  conv_h2r_k<RN, MODE><<<grid, 256, lds, s>>>(a);
+  launch(conv_h2r_k<RN, MODE>, dim3(grid), dim3(256), lds, s, a);
   return launch_status();
 }
 
@@ -1180,7 +1180,7 @@ int launch_h2(const ConvHArgs& a0, int n_groups, hipStream_t s) {
   dim3 grid(a.n_mtiles * a.g.n_classes, (cmax + BN - 1) / BN, n_groups);
   a.part_row0 = mpose_part_phase.row0;
   a.part_rows = mpose_part_phase.total > 0 ? mpose_part_phase.total : (int)grid.x;
-  conv_h2_k<WM, WN, RM, RN, KST, NBUF, MODE, DUAL><<<grid, 256, lds, s>>>(a);
+  launch(conv_h2_k<WM, WN, RM, RN, KST, NBUF, MODE, DUAL>, dim3(grid), dim3(256), lds, s, a);
   return launch_status();
 }
 

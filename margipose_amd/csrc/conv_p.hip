@@ -512,7 +512,7 @@ int launch_planes(const ConvPArgs& a0, int n_groups, hipStream_t s) {
   a.n_mtiles = (a.M + BM - 1) / BM;
   const int cmax = a.g.Cout1 > a.g.Cout0 && MODE == 1 ? a.g.Cout1 : a.g.Cout0;
   dim3 grid(a.n_mtiles * a.g.n_classes, (cmax + BN - 1) / BN, n_groups);
-  conv_planes_k<WM, WN, RM, RN, NBUF, MODE, NPL><<<grid, 256, lds, s>>>(a);
+  launch(conv_planes_k<WM, WN, RM, RN, NBUF, MODE, NPL>, dim3(grid), dim3(256), lds, s, a);
   return launch_status();
 }
 

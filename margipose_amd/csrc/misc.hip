@@ -601,7 +601,7 @@ extern "C" int mpose_space_to_depth8(const float* x, float* out, int B, int S, v
   if (B < 0 || S <= 0 || (S % 8)) return MPOSE_EINVAL;
   if (B == 0) return 0;
   const long total4 = (long)B * (S / 8) * (S / 8) * 48;
-  space_to_depth8_k<false><<<grid_for(total4, 256), 256, 0, (hipStream_t)stream>>>(x, out, B, S);
+  launch(space_to_depth8_k<false>, dim3(grid_for(total4, 256)), dim3(256), 0, (hipStream_t)stream, x, out, B, S);
   return launch_status();
 }
 
@@ -609,7 +609,7 @@ extern "C" int mpose_depth_to_space8(const float* g, float* dx, int B, int S, vo
   if (B < 0 || S <= 0 || (S % 8)) return MPOSE_EINVAL;
   if (B == 0) return 0;
   const long total4 = (long)B * (S / 8) * (S / 8) * 48;
-  space_to_depth8_k<true><<<grid_for(total4, 256), 256, 0, (hipStream_t)stream>>>(g, dx, B, S);
+  launch(space_to_depth8_k<true>, dim3(grid_for(total4, 256)), dim3(256), 0, (hipStream_t)stream, g, dx, B, S);
   return launch_status();
 }
 
@@ -624,7 +624,7 @@ extern "C" int mpose_axis_permute(const float* const* in, float* const* out, con
   a.B = B; a.S = S; a.C = C;
   const long total4 = (long)B * S * S * C / 4;
   if (total4 == 0) return 0;
-  axis_permute_k<<<dim3(grid_for(total4, 256), n_groups), 256, 0, (hipStream_t)stream>>>(a);
+  launch(axis_permute_k, dim3(dim3(grid_for(total4, 256), n_groups)), dim3(256), 0, (hipStream_t)stream, a);
   return launch_status();
 }
 
@@ -647,7 +647,7 @@ static int combiner_fwd_impl(const void* const* hm, int hm_bf16, const float* w,
   for (int p = 0; p < 3; ++p) a.hm[p] = static_cast<const float*>(hm[p]);
   a.w = w; a.inp = inp; a.out = out; a.B = B; a.J = J; a.HW = HW; a.Q = 3 * J;
   const int lds = (a.Q * CC + a.Q * CT) * 4;
-  combiner_fwd_k<<<B * (HW / CT), 256, lds, (hipStream_t)stream>>>(a);
+  launch(combiner_fwd_k, dim3(B * (HW / CT)), dim3(256), lds, (hipStream_t)stream, a);
   return launch_status();
 }
 
@@ -664,14 +664,14 @@ extern "C" int mpose_combiner_bwd(const float* const* hm, const float* w, const 
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  combiner_bwd_k<<<n_partial, 256, lds, (hipStream_t)stream>>>(a);
+  launch(combiner_bwd_k, dim3(n_partial), dim3(256), lds, (hipStream_t)stream, a);
   return launch_status();
 }
 
 extern "C" int mpose_add(const float* x, const float* y, float* out, int64_t n, void* stream) {
   if (n < 0 || (n & 3)) return MPOSE_EINVAL;
   if (n == 0) return 0;
-  add_k<<<grid_for(n / 4, 256 * 4), 256, 0, (hipStream_t)stream>>>(reinterpret_cast<const float4*>(x), reinterpret_cast<const float4*>(y),
+  launch(add_k, dim3(grid_for(n / 4, 256 * 4)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const float4*>(x), reinterpret_cast<const float4*>(y),
                                                                   reinterpret_cast<float4*>(out), n / 4);
   return launch_status();
 }
@@ -683,14 +683,14 @@ extern "C" int mpose_nchw_to_nhwc_pad(const float* const* in, float* const* out,
   for (int i = 0; i < n_groups; ++i) { a.in[i] = in[i]; a.out[i] = out[i]; }
   a.B = B; a.J = J; a.P = P; a.Cpad = Cpad;
   if ((long)B * P == 0) return 0;
-  nchw_to_nhwc_pad_k<<<dim3(grid_for((long)B * P, 256), n_groups), 256, 0, (hipStream_t)stream>>>(a);
+  launch(nchw_to_nhwc_pad_k, dim3(dim3(grid_for((long)B * P, 256), n_groups)), dim3(256), 0, (hipStream_t)stream, a);
   return launch_status();
 }
 
 extern "C" int mpose_reduce_partials(const float* src, float* dst, int n_partial, int64_t n, int accumulate, void* stream) {
   if (n_partial < 1 || n < 0) return MPOSE_EINVAL;
   if (n == 0) return 0;
-  reduce_partials_k<<<(unsigned)((n + 31) / 32), 256, 0, (hipStream_t)stream>>>(src, dst, n_partial, n, accumulate);
+  launch(reduce_partials_k, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, (hipStream_t)stream, src, dst, n_partial, n, accumulate);
   return launch_status();
 }
 
@@ -707,7 +707,7 @@ extern "C" int mpose_pool3_fwd(const float* in, const float* scale, const float*
   a.in = in; a.scale = scale; a.shift = shift; a.out = out; a.B = B; a.IH = IH; a.IW = IW; a.C = C; a.ld = out_ld; a.kind = kind;
   const long total = (long)B * a.OH * a.OW * (C / 4);
   if (total == 0) return 0;
-  pool3_fwd_k<<<grid_for(total, 256), 256, 0, (hipStream_t)stream>>>(a);
+  launch(pool3_fwd_k, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, a);
   return launch_status();
 }
 
@@ -718,7 +718,7 @@ extern "C" int mpose_pool3_bwd(const float* in, const float* scale, const float*
   a.in = in; a.scale = scale; a.shift = shift; a.g = g; a.out = d_in; a.B = B; a.IH = IH; a.IW = IW; a.C = C; a.ld = g_ld; a.kind = kind;
   const long total = (long)B * IH * IW * (C / 4);
   if (total == 0) return 0;
-  pool3_bwd_k<<<grid_for(total, 256), 256, 0, (hipStream_t)stream>>>(a);
+  launch(pool3_bwd_k, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, a);
   return launch_status();
 }
 
@@ -730,15 +730,15 @@ extern "C" int mpose_maxpool3_bwd_ws(const float* in, const float* scale, const 
   a.in = in; a.scale = scale; a.shift = shift; a.g = g; a.out = d_in; a.B = B; a.IH = IH; a.IW = IW; a.C = C; a.ld = g_ld; a.kind = 0;
   const long total_o = (long)B * a.OH * a.OW * (C / 4), total_i = (long)B * IH * IW * (C / 4);
   if (total_i == 0) return 0;
-  maxpool3_argmax_k<<<grid_for(total_o, 256), 256, 0, (hipStream_t)stream>>>(a, static_cast<unsigned char*>(workspace));
-  maxpool3_bwd_arg_k<<<grid_for(total_i, 256), 256, 0, (hipStream_t)stream>>>(a, static_cast<const unsigned char*>(workspace));
+  launch(maxpool3_argmax_k, dim3(grid_for(total_o, 256)), dim3(256), 0, (hipStream_t)stream, a, static_cast<unsigned char*>(workspace));
+  launch(maxpool3_bwd_arg_k, dim3(grid_for(total_i, 256)), dim3(256), 0, (hipStream_t)stream, a, static_cast<const unsigned char*>(workspace));
   return launch_status();
 }
 
 extern "C" int mpose_image_to_nhwc(const float* x, float* out, int B, int C, int H, int W, int Cpad, void* stream) {
   if (C < 1 || C > Cpad || (Cpad & 3)) return MPOSE_EINVAL;
   if ((long)B * H * W == 0) return 0;
-  image_to_nhwc_k<<<grid_for((long)B * H * W, 256), 256, 0, (hipStream_t)stream>>>(x, out, B, C, (long)H * W, Cpad);
+  launch(image_to_nhwc_k, dim3(grid_for((long)B * H * W, 256)), dim3(256), 0, (hipStream_t)stream, x, out, B, C, (long)H * W, Cpad);
   return launch_status();
 }
 
@@ -752,7 +752,7 @@ extern "C" int mpose_frames_u8(const unsigned char* frames, const float* mean3, 
     sc[c] = 1.0f / (255.0f * std3[c]);
     sh[c] = -mean3[c] / std3[c];
   }
-  frames_u8_k<<<grid_for((long)B * H * W, 256), 256, 0, (hipStream_t)stream>>>(frames, out, B, (long)H * W, Cpad, sc[0], sc[1], sc[2],
+  launch(frames_u8_k, dim3(grid_for((long)B * H * W, 256)), dim3(256), 0, (hipStream_t)stream, frames, out, B, (long)H * W, Cpad, sc[0], sc[1], sc[2],
                                                                                  sh[0], sh[1], sh[2]);
   return launch_status();
 }
@@ -771,8 +771,8 @@ extern "C" int mpose_im2col_k3s2(const void* img, int is_u8, const float* mean3,
     }
   }
   const long total = (long)B * (H / 2) * (W / 2) * 8;
-  if (is_u8) im2col_k3s2_k<true><<<grid_for(total, 256), 256, 0, (hipStream_t)stream>>>(img, out, B, H, W, sc[0], sc[1], sc[2], sh[0], sh[1], sh[2]);
-  else im2col_k3s2_k<false><<<grid_for(total, 256), 256, 0, (hipStream_t)stream>>>(img, out, B, H, W, 1.f, 1.f, 1.f, 0.f, 0.f, 0.f);
+  if (is_u8) launch(im2col_k3s2_k<true>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, img, out, B, H, W, sc[0], sc[1], sc[2], sh[0], sh[1], sh[2]);
+  else launch(im2col_k3s2_k<false>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, img, out, B, H, W, 1.f, 1.f, 1.f, 0.f, 0.f, 0.f);
   return launch_status();
 }
 
@@ -790,28 +790,28 @@ extern "C" int mpose_im2col_s2(const void* img, int is_u8, const float* mean3, c
     }
   }
   const long total = (long)B * (H / 2) * (W / 2) * (Cpad / 4);
-  if (is_u8) im2col_s2_k<true><<<grid_for(total, 256), 256, 0, (hipStream_t)stream>>>(img, out, B, H, W, k, Cpad, sc[0], sc[1], sc[2], sh[0], sh[1], sh[2]);
-  else im2col_s2_k<false><<<grid_for(total, 256), 256, 0, (hipStream_t)stream>>>(img, out, B, H, W, k, Cpad, 1.f, 1.f, 1.f, 0.f, 0.f, 0.f);
+  if (is_u8) launch(im2col_s2_k<true>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, img, out, B, H, W, k, Cpad, sc[0], sc[1], sc[2], sh[0], sh[1], sh[2]);
+  else launch(im2col_s2_k<false>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, img, out, B, H, W, k, Cpad, 1.f, 1.f, 1.f, 0.f, 0.f, 0.f);
   return launch_status();
 }
 
 extern "C" int mpose_col2im_s2(const float* dpatches, float* dx, int B, int H, int W, int k, int Cpad, void* stream) {
   if (!dpatches || !dx || (H & 1) || (W & 1) || H <= 0 || W <= 0 || k < 1 || !(k & 1) || Cpad < 3 * k * k) return MPOSE_EINVAL;
   if (B == 0) return 0;
-  col2im_s2_k<<<grid_for((long)B * 3 * H * W, 256), 256, 0, (hipStream_t)stream>>>(dpatches, dx, B, H, W, k, Cpad);
+  launch(col2im_s2_k, dim3(grid_for((long)B * 3 * H * W, 256)), dim3(256), 0, (hipStream_t)stream, dpatches, dx, B, H, W, k, Cpad);
   return launch_status();
 }
 
 extern "C" int mpose_col2im_k3s2(const float* dpatches, float* dx, int B, int H, int W, void* stream) {
   if (!dpatches || !dx || (H & 1) || (W & 1) || H <= 0 || W <= 0) return MPOSE_EINVAL;
   if (B == 0) return 0;
-  col2im_k3s2_k<<<grid_for((long)B * 3 * H * W, 256), 256, 0, (hipStream_t)stream>>>(dpatches, dx, B, H, W);
+  launch(col2im_k3s2_k, dim3(grid_for((long)B * 3 * H * W, 256)), dim3(256), 0, (hipStream_t)stream, dpatches, dx, B, H, W);
   return launch_status();
 }
 
 extern "C" int mpose_nhwc_to_image(const float* g, float* dx, int B, int C, int H, int W, int Cpad, void* stream) {
   if (C < 1 || C > Cpad || (Cpad & 3)) return MPOSE_EINVAL;
   if ((long)B * H * W == 0) return 0;
-  nhwc_to_image_k<<<grid_for((long)B * H * W, 256), 256, 0, (hipStream_t)stream>>>(g, dx, B, C, (long)H * W, Cpad);
+  launch(nhwc_to_image_k, dim3(grid_for((long)B * H * W, 256)), dim3(256), 0, (hipStream_t)stream, g, dx, B, C, (long)H * W, Cpad);
   return launch_status();
 }

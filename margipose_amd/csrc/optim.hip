@@ -54,7 +54,7 @@ using namespace mpose;
 // of steps ahead of the device without a staging buffer being overwritten under a pending copy.
 extern "C" int mpose_set4(float* dst, float a, float b, float c, float d, void* stream) {
   if (!dst) return MPOSE_EINVAL;
-  set4_k<<<1, 1, 0, (hipStream_t)stream>>>(dst, a, b, c, d);
+  launch(set4_k, dim3(1), dim3(1), 0, (hipStream_t)stream, dst, a, b, c, d);
   return launch_status();
 }
 
@@ -64,6 +64,6 @@ extern "C" int mpose_sgd_step(const mpose_sgd_job* jobs_dev, int n_jobs, int64_t
   long bx = (max_n / 4 + 256 * 4 - 1) / (256 * 4);
   if (bx < 1) bx = 1;
   if (bx > 64) bx = 64;
-  sgd_step_k<<<dim3((unsigned)bx, (unsigned)n_jobs), 256, 0, (hipStream_t)stream>>>(jobs_dev, hyper_dev);
+  launch(sgd_step_k, dim3(dim3((unsigned)bx, (unsigned)n_jobs)), dim3(256), 0, (hipStream_t)stream, jobs_dev, hyper_dev);
   return launch_status();
 }

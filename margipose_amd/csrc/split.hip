@@ -369,7 +369,7 @@ extern "C" int mpose_split_planes(const mpose_split_operands* ops, int n_groups,
     if (!ops[i].src || !ops[i].planes || (ops[i].scale && !ops[i].shift)) return MPOSE_EINVAL;
   }
   a.npix = npix; a.C = C; a.relu = relu;
-  split_planes_k<<<plane_grid(npix, C, n_groups), 256, 0, (hipStream_t)stream>>>(a);
+  launch(split_planes_k, dim3(plane_grid(npix, C, n_groups)), dim3(256), 0, (hipStream_t)stream, a);
   return launch_status();
 }
 
@@ -384,8 +384,8 @@ extern "C" int mpose_split_h2(const mpose_split_h2_operands* ops, int n_groups, 
     if (!ops[i].src || !ops[i].planes || !ops[i].amax || (ops[i].scale && !ops[i].shift)) return MPOSE_EINVAL;
   }
   a.npix = npix; a.C = C; a.relu = relu;
-  if ((C & 31) == 0) split_h2_lines_k<<<plane_grid(npix, C, n_groups), 256, 0, (hipStream_t)stream>>>(a);
-  else split_h2_k<<<plane_grid(npix, C, n_groups), 256, 0, (hipStream_t)stream>>>(a);
+  if ((C & 31) == 0) launch(split_h2_lines_k, dim3(plane_grid(npix, C, n_groups)), dim3(256), 0, (hipStream_t)stream, a);
+  else launch(split_h2_k, dim3(plane_grid(npix, C, n_groups)), dim3(256), 0, (hipStream_t)stream, a);
   return launch_status();
 }
 
@@ -400,7 +400,7 @@ extern "C" int mpose_bn_add_planes(const mpose_bn_add_operands* ops, void* const
     if (!planes[i] || !ops[i].a || !ops[i].b) return MPOSE_EINVAL;
   }
   a.npix = npix; a.C = C;
-  bn_add_planes_k<<<plane_grid(npix, C, n_groups), 256, 0, (hipStream_t)stream>>>(a);
+  launch(bn_add_planes_k, dim3(plane_grid(npix, C, n_groups)), dim3(256), 0, (hipStream_t)stream, a);
   return launch_status();
 }
 
@@ -414,7 +414,7 @@ extern "C" int mpose_bn_add_h2(const mpose_bn_add_operands* ops, void* const* h2
     if (!h2[i] || !ops[i].a || !ops[i].b || !ops[i].out_amax) return MPOSE_EINVAL;
   }
   a.npix = npix; a.C = C;
-  bn_add_h2_k<<<plane_grid(npix, C, n_groups), 256, 0, (hipStream_t)stream>>>(a);
+  launch(bn_add_h2_k, dim3(plane_grid(npix, C, n_groups)), dim3(256), 0, (hipStream_t)stream, a);
   return launch_status();
 }
 
@@ -431,7 +431,7 @@ extern "C" int mpose_bn_bwd_apply_h2(const mpose_bn_bwd_apply_operands* ops, voi
     if ((ops[i].b != nullptr) != (ops[0].b != nullptr) || (ops[i].db_amax != nullptr) != (ops[0].db_amax != nullptr)) return MPOSE_EINVAL;
   }
   a.npix = npix; a.C = C;
-  bn_bwd_apply_h2_k<<<dim3((unsigned)((npix + 127) / 128), (unsigned)(C / 32), (unsigned)n_groups), 256, 0, (hipStream_t)stream>>>(a);
+  launch(bn_bwd_apply_h2_k, dim3(dim3((unsigned)((npix + 127) / 128), (unsigned)(C / 32), (unsigned)n_groups)), dim3(256), 0, (hipStream_t)stream, a);
   return launch_status();
 }
 
@@ -448,6 +448,6 @@ extern "C" int mpose_bn_bwd_apply_planes(const mpose_bn_bwd_apply_operands* ops,
     if (ops[i].b && !ops[i].coef_b) return MPOSE_EINVAL;
   }
   a.npix = npix; a.C = C;
-  bn_bwd_apply_planes_k<<<plane_grid(npix, C, n_groups), 256, 0, (hipStream_t)stream>>>(a);
+  launch(bn_bwd_apply_planes_k, dim3(plane_grid(npix, C, n_groups)), dim3(256), 0, (hipStream_t)stream, a);
   return launch_status();
 }

@@ -308,7 +308,7 @@ static int launch_bn_add_softmax(const BnAddSoftmaxArgs& a, int n_groups, int ld
       return MPOSE_EINVAL;
     raised = true;
   }
-  bn_add_softmax_k<NV, BF_OUT><<<dim3(a.B, n_groups, (a.J + 3) / 4), kBasThreads, lds, s>>>(a);
+  launch(bn_add_softmax_k<NV, BF_OUT>, dim3(dim3(a.B, n_groups, (a.J + 3) / 4)), dim3(kBasThreads), lds, s, a);
   return 0;
 }
 
@@ -669,7 +669,7 @@ using namespace mpose;
     default: return MPOSE_EINVAL;              \
   }
 
-extern "C" int mpose_abi_version(void) { return 13; }   // 2: bf16-plane packed weights, mpose_conv_operands.in1, wgrad tiles, frames/im2col entry points; 3: im2col/col2im_s2, bn_add layout 2; 4: mpose_bn_bwd_coef(eval_mode); 5: plane engine (conv_p.hip, split.hip), pack job layout; 6: mpose_sgd_step, coef job dconv_bias; 7: mpose_bn_bwd_reduce_ws; 8: fused output stage of the plane engine (mpose_conv_operands.epi_*, add_*, out0_planes); 9: MPOSE_CONV_F16X3 (amax fields, pack layout 2, mpose_absmax, mpose_weights_absmax); 10: channel extremes (mpose_conv_operands.mm0, mpose_bn_job.minmax / amax_out), row-of-taps weight gradient; 11: per-axis slot strides (mpose_conv_geom.in_mul_x / out_mul_x), MPOSE_MAX_CLASSES 8; 12: BatchNorm finalisation by the convolution launch's last workgroup (mpose_conv_operands.fin*); 13: MPOSE_CONV_H2_IN (conv_h.hip: producer-split fp16 planes, pack layout 3, mpose_split_h2, out0_amax without the fused stage)
+extern "C" int mpose_abi_version(void) { return 14; }   // 2: bf16-plane packed weights, mpose_conv_operands.in1, wgrad tiles, frames/im2col entry points; 3: im2col/col2im_s2, bn_add layout 2; 4: mpose_bn_bwd_coef(eval_mode); 5: plane engine (conv_p.hip, split.hip), pack job layout; 6: mpose_sgd_step, coef job dconv_bias; 7: mpose_bn_bwd_reduce_ws; 8: fused output stage of the plane engine (mpose_conv_operands.epi_*, add_*, out0_planes); 9: MPOSE_CONV_F16X3 (amax fields, pack layout 2, mpose_absmax, mpose_weights_absmax); 10: channel extremes (mpose_conv_operands.mm0, mpose_bn_job.minmax / amax_out), row-of-taps weight gradient; 11: per-axis slot strides (mpose_conv_geom.in_mul_x / out_mul_x), MPOSE_MAX_CLASSES 8; 12: BatchNorm finalisation by the convolution launch's last workgroup (mpose_conv_operands.fin*); 13: MPOSE_CONV_H2_IN (conv_h.hip: producer-split fp16 planes, pack layout 3, mpose_split_h2, out0_amax without the fused stage); 14: launch plans (plan.hip: mpose_plan_*, mpose_stream_wait, recordable fills / copy / loss arithmetic)
 
 extern "C" int mpose_softmax_dsnt_fwd(const void* const* logits, void* const* heatmaps, float* plane_coords, float* xyz,
                                       int n_planes, int rows, int H, int W, int io_dtype, void* stream) {
@@ -691,18 +691,18 @@ extern "C" int mpose_softmax_dsnt_fwd(const void* const* logits, void* const* he
 #define MPOSE_TAIL_LAUNCH(BI, BO)                                                                                              \
   do {                                                                                                                         \
     if (rpw == 2) {                                                                                                            \
-      if (nv == 4) { if (nt == 3) softmax_dsnt_fwd_k<4, BI, BO, true, 2, 3><<<grid, 64 * n_planes, 0, s>>>(a);                \
-                     else if (nt == 1) softmax_dsnt_fwd_k<4, BI, BO, true, 2, 1><<<grid, 64 * n_planes, 0, s>>>(a);           \
-                     else softmax_dsnt_fwd_k<4, BI, BO, true, 2, 0><<<grid, 64 * n_planes, 0, s>>>(a); }                     \
-      else { if (nt == 3) softmax_dsnt_fwd_k<9, BI, BO, true, 2, 3><<<grid, 64 * n_planes, 0, s>>>(a);                        \
-             else if (nt == 1) softmax_dsnt_fwd_k<9, BI, BO, true, 2, 1><<<grid, 64 * n_planes, 0, s>>>(a);                   \
-             else softmax_dsnt_fwd_k<9, BI, BO, true, 2, 0><<<grid, 64 * n_planes, 0, s>>>(a); }                             \
+      if (nv == 4) { if (nt == 3) launch(softmax_dsnt_fwd_k<4, BI, BO, true, 2, 3>, dim3(grid), dim3(64 * n_planes), 0, s, a);                \
+                     else if (nt == 1) launch(softmax_dsnt_fwd_k<4, BI, BO, true, 2, 1>, dim3(grid), dim3(64 * n_planes), 0, s, a);           \
+                     else launch(softmax_dsnt_fwd_k<4, BI, BO, true, 2, 0>, dim3(grid), dim3(64 * n_planes), 0, s, a); }                     \
+      else { if (nt == 3) launch(softmax_dsnt_fwd_k<9, BI, BO, true, 2, 3>, dim3(grid), dim3(64 * n_planes), 0, s, a);                        \
+             else if (nt == 1) launch(softmax_dsnt_fwd_k<9, BI, BO, true, 2, 1>, dim3(grid), dim3(64 * n_planes), 0, s, a);                   \
+             else launch(softmax_dsnt_fwd_k<9, BI, BO, true, 2, 0>, dim3(grid), dim3(64 * n_planes), 0, s, a); }                             \
     } else if (nt == 3) {                                                                                                      \
-      MPOSE_DISPATCH_NV(nv, (softmax_dsnt_fwd_k<NV, BI, BO, true, 1, 3><<<grid, 64 * n_planes, 0, s>>>(a)));                  \
+      MPOSE_DISPATCH_NV(nv, (launch(softmax_dsnt_fwd_k<NV, BI, BO, true, 1, 3>, dim3(grid), dim3(64 * n_planes), 0, s, a)));                  \
     } else if (nt == 1) {                                                                                                      \
-      MPOSE_DISPATCH_NV(nv, (softmax_dsnt_fwd_k<NV, BI, BO, true, 1, 1><<<grid, 64 * n_planes, 0, s>>>(a)));                  \
+      MPOSE_DISPATCH_NV(nv, (launch(softmax_dsnt_fwd_k<NV, BI, BO, true, 1, 1>, dim3(grid), dim3(64 * n_planes), 0, s, a)));                  \
     } else {                                                                                                                   \
-      MPOSE_DISPATCH_NV(nv, (softmax_dsnt_fwd_k<NV, BI, BO, true, 1, 0><<<grid, 64 * n_planes, 0, s>>>(a)));                  \
+      MPOSE_DISPATCH_NV(nv, (launch(softmax_dsnt_fwd_k<NV, BI, BO, true, 1, 0>, dim3(grid), dim3(64 * n_planes), 0, s, a)));                  \
     }                                                                                                                          \
   } while (0)
   if (io_dtype == 0) {
@@ -743,7 +743,7 @@ extern "C" int mpose_bn_add_softmax_fwd(const mpose_bn_add_operands* ops, void* 
 extern "C" int mpose_coords_merge(const float* plane_coords, float* xyz, int rows, void* stream) {
   if (rows < 0 || !plane_coords || !xyz) return MPOSE_EINVAL;
   if (rows == 0) return 0;
-  coords_merge_k<<<(rows + 255) / 256, 256, 0, (hipStream_t)stream>>>(plane_coords, xyz, rows);
+  launch(coords_merge_k, dim3((rows + 255) / 256), dim3(256), 0, (hipStream_t)stream, plane_coords, xyz, rows);
   return launch_status();
 }
 
@@ -755,7 +755,7 @@ extern "C" int mpose_dsnt_fwd(const float* const* heatmaps, float* plane_coords,
   SoftmaxArgs a{};
   for (int p = 0; p < n_planes; ++p) { a.logits[p] = heatmaps[p]; a.heatmaps[p] = nullptr; }
   a.plane_coords = plane_coords; a.xyz = xyz; a.n_planes = n_planes; a.rows = rows; a.H = H; a.W = W;
-  MPOSE_DISPATCH_NV(nv, (softmax_dsnt_fwd_k<NV, false, false, false><<<rows, 64 * n_planes, 0, (hipStream_t)stream>>>(a)));
+  MPOSE_DISPATCH_NV(nv, (launch(softmax_dsnt_fwd_k<NV, false, false, false>, dim3(rows), dim3(64 * n_planes), 0, (hipStream_t)stream, a)));
   return launch_status();
 }
 
@@ -768,7 +768,7 @@ extern "C" int mpose_dsnt_bwd(const float* d_plane_coords, float* const* d_heatm
   a.d_plane_coords = d_plane_coords;
   for (int p = 0; p < n_planes; ++p) a.d_hm[p] = d_heatmaps[p];
   a.rows = rows; a.H = H; a.W = W; a.accumulate = accumulate;
-  MPOSE_DISPATCH_NV(nv, (dsnt_bwd_k<NV><<<rows, 64 * n_planes, 0, (hipStream_t)stream>>>(a)));
+  MPOSE_DISPATCH_NV(nv, (launch(dsnt_bwd_k<NV>, dim3(rows), dim3(64 * n_planes), 0, (hipStream_t)stream, a)));
   return launch_status();
 }
 
@@ -782,7 +782,7 @@ extern "C" int mpose_softmax_bwd(const float* const* heatmaps, const float* cons
     a.hm[p] = heatmaps[p]; a.g1[p] = g1[p]; a.g2[p] = g2 ? g2[p] : nullptr; a.dlogits[p] = dlogits[p];
   }
   a.n = n;
-  MPOSE_DISPATCH_NV(nv, (softmax_bwd_k<NV><<<rows, 64 * n_planes, 0, (hipStream_t)stream>>>(a)));
+  MPOSE_DISPATCH_NV(nv, (launch(softmax_bwd_k<NV>, dim3(rows), dim3(64 * n_planes), 0, (hipStream_t)stream, a)));
   return launch_status();
 }
 
@@ -803,7 +803,7 @@ extern "C" int mpose_stage_loss_fwd(const float* const* heatmaps, const float* t
   if (rows == 0) return 0;
   a.losses = losses; a.xyz_out = xyz_out;
   const int nv = pick_nv(H * W);
-  MPOSE_DISPATCH_NV(nv, (stage_loss_fwd_k<NV><<<rows, 64 * 3, 0, (hipStream_t)stream>>>(a)));
+  MPOSE_DISPATCH_NV(nv, (launch(stage_loss_fwd_k<NV>, dim3(rows), dim3(64 * 3), 0, (hipStream_t)stream, a)));
   return launch_status();
 }
 
@@ -817,7 +817,7 @@ extern "C" int mpose_stage_loss_bwd(const float* const* heatmaps, const float* t
   a.xyz_in = xyz; a.dloss = dloss;
   for (int p = 0; p < 3; ++p) a.g[p] = g[p];
   const int nv = pick_nv(H * W);
-  MPOSE_DISPATCH_NV(nv, (stage_loss_bwd_k<NV><<<rows, 64 * 3, 0, (hipStream_t)stream>>>(a)));
+  MPOSE_DISPATCH_NV(nv, (launch(stage_loss_bwd_k<NV>, dim3(rows), dim3(64 * 3), 0, (hipStream_t)stream, a)));
   return launch_status();
 }
 
@@ -826,7 +826,7 @@ extern "C" int mpose_js_fwd(const float* heatmaps, const float* mu, float* js, i
   if (rows == 0) return 0;
   JsArgs a{heatmaps, mu, nullptr, js, nullptr, H, W, sigma};
   const int nv = pick_nv(H * W);
-  MPOSE_DISPATCH_NV(nv, (js_k<NV, false><<<rows, 64, 0, (hipStream_t)stream>>>(a)));
+  MPOSE_DISPATCH_NV(nv, (launch(js_k<NV, false>, dim3(rows), dim3(64), 0, (hipStream_t)stream, a)));
   return launch_status();
 }
 
@@ -836,12 +836,12 @@ extern "C" int mpose_js_bwd(const float* heatmaps, const float* mu, const float*
   if (rows == 0) return 0;
   JsArgs a{heatmaps, mu, djs, nullptr, g, H, W, sigma};
   const int nv = pick_nv(H * W);
-  MPOSE_DISPATCH_NV(nv, (js_k<NV, true><<<rows, 64, 0, (hipStream_t)stream>>>(a)));
+  MPOSE_DISPATCH_NV(nv, (launch(js_k<NV, true>, dim3(rows), dim3(64), 0, (hipStream_t)stream, a)));
   return launch_status();
 }
 
 extern "C" int mpose_average_loss_fwd(const float* losses, const float* mask, float* out2, int n, void* stream) {
   if (n < 0) return MPOSE_EINVAL;
-  average_loss_k<<<1, 256, 0, (hipStream_t)stream>>>(losses, mask, out2, n);
+  launch(average_loss_k, dim3(1), dim3(256), 0, (hipStream_t)stream, losses, mask, out2, n);
   return launch_status();
 }

@@ -528,7 +528,7 @@ int launch_rows_ppx(WgRowsArgs& a, hipStream_t s) {
   a.n_ntiles = (a.Cout + C::NT - 1) / C::NT;
   a.total = a.n_units * a.n_ktiles * a.n_ntiles * a.n_split * a.n_groups;
   a.chunk = (a.total + 7) / 8;
-  conv_wgrad_rows_k<WK, WN, KB, NB, PRO, PAIR, X1><<<dim3(8 * a.chunk), C::NTH, C::LDS, s>>>(a);
+  launch(conv_wgrad_rows_k<WK, WN, KB, NB, PRO, PAIR, X1>, dim3(dim3(8 * a.chunk)), dim3(C::NTH), C::LDS, s, a);
   return launch_status();
 }
 template <int WK, int WN, int KB, int NB, bool PRO, bool PAIR>

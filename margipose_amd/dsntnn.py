@@ -133,10 +133,35 @@ class _AverageLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad):
         out2, m = ctx.saved_tensors
-        scale = grad / out2[1]
-        if m is None:
-            return scale.expand(ctx.shape).contiguous(), None
-        return m * scale, None
+        g = dev_f32(grad.contiguous(), 'grad')
+        d = torch.empty(ctx.shape, dtype=torch.float32, device=g.device)      # mask * (grad / denominator), one launch
+        check(lib().mpose_average_loss_bwd(ptr(g), ptr(out2), ptr(m), ptr(d), _lib.c_int64(d.numel()), stream_ptr()),
+              'mpose_average_loss_bwd')
+        return d, None
+
+
+class _AddLosses(torch.autograd.Function):
+    """a + b of two per-location loss tensors (a is None: 0 + b) -- the reference's `losses = 0; losses += ...` over stages
+    (models/margipose_model.py:238-252) as launches of the library, so that a launch plan records them."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        bb = dev_f32(b.contiguous(), 'losses')
+        aa = dev_f32(a.contiguous(), 'losses') if a is not None else None
+        if aa is not None and aa.shape != bb.shape:
+            raise _lib.MposeError('loss tensors of different shapes')
+        out = torch.empty_like(bb)
+        check(lib().mpose_add_f32(ptr(aa), ptr(bb), ptr(out), _lib.c_int64(bb.numel()), stream_ptr()), 'mpose_add_f32')
+        ctx.has_a = aa is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        return (grad if ctx.has_a else None), grad
+
+
+def add_losses(a, b):
+    return _AddLosses.apply(a, b)
 
 
 def euclidean_losses(actual, target):

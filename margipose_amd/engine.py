@@ -950,7 +950,7 @@ class Engine:
             # (a LOWER queue priority for the side stream was tried -- MPOSE_SIDE_PRIO -- see DESIGN 6.0)
             self.side_stream = torch.cuda.Stream(device=main.device, priority=int(os.environ.get('MPOSE_SIDE_PRIO', '0')))
         side = self.side_stream
-        side.wait_stream(main)
+        _lib.stream_wait(side, main)
         with torch.cuda.stream(side):
             self.wgrad(g, ops, n_split)
             self._unpack_now(unpack)
@@ -1069,9 +1069,9 @@ class Engine:
         sp = tb['sp_ptr']
         self.pack_weights(cmode)
         if f16:
-            self.amax_f.zero_()
+            _lib.fill_zero(self.amax_f)        # (fills through the library: a launch plan records them, csrc/plan.hip)
         if train:
-            self.stat_arena.zero_()
+            _lib.fill_zero(self.stat_arena)
         elif self.stem is None:
             self.finalize(tb, 0, 1 + self.T * 90, False)     # scale/shift from the running statistics
         else:
@@ -1336,7 +1336,7 @@ class Engine:
                 hms[p].append(heat[p])
             ctx['blocks'].append(stage_saved)
         if train:
-            self._nbt.add_(1)
+            check(L.mpose_add_i64(c_void_p(self._nbt.data_ptr()), c_int64(1), c_int64(self._nbt.numel()), st()), 'mpose_add_i64')
         return hms, xyz, ctx
 
     # ------------------------------------------------------------------ several forwards in flight
@@ -1372,7 +1372,7 @@ class Engine:
         self.pack_weights(cmode)
         outs, ctx['stem_ctx'] = self.stem.forward(x, train, save, cmode in (2, 3), features=features)
         if train and features is None:
-            self._nbt += 1
+            check(lib().mpose_add_i64(c_void_p(self._nbt.data_ptr()), c_int64(1), c_int64(self._nbt.numel()), stream_ptr()), 'mpose_add_i64')
         return outs, ctx
 
     def graph_backward(self, ctx, grads, need_dx):
@@ -1383,7 +1383,7 @@ class Engine:
                                    'operation: a parameter of the model changed between forward and backward')
         self._restore_arenas(ctx)
         tb = self._tables_for(ctx['B'], ctx['F'])
-        self.gflat.zero_()
+        _lib.fill_zero(self.gflat)
         if self._packed_for != ctx['cmode']:
             self.pack_weights(ctx['cmode'])
         works = []
@@ -1434,8 +1434,8 @@ class Engine:
         f32 = dict(dtype=torch.float32, device=dev)
         J = self.J
         tb = self._tables_for(B, F)
-        self.gflat.zero_()
-        self.stat_arena.zero_()        # forward sums are consumed (mean/invstd live in the float arena)
+        _lib.fill_zero(self.gflat)
+        _lib.fill_zero(self.stat_arena)        # forward sums are consumed (mean/invstd live in the float arena)
         goff = dict((id(p), o) for p, o in zip(self.param_list(), self._grad_offsets))
         coef_base = tb['coef'].data_ptr()
         cmode = ctx['cmode']
@@ -1445,7 +1445,7 @@ class Engine:
         if self._packed_for != cmode:      # a forward on another engine ran in between: the parameters are unchanged (checked
             self.pack_weights(cmode)       # above), so this restores exactly the packing of this context's forward
         if f16:
-            self.amax_b.zero_()
+            _lib.fill_zero(self.amax_b)
 
         # (the backward's sums as partial rows too; an eval-mode forward has ctx['spart'] False but its backward may still use them)
         spart = bool(self.part_stats() and not planes)
@@ -1467,7 +1467,7 @@ class Engine:
             g1 = [g_hms[p][t] for p in range(3)]
             if all(g is None for g in g1) and g_comb is None and D is None:
                 continue
-            g1 = [_lib.dev_f32(g.contiguous(), 'grad') if g is not None else torch.zeros_like(heat[p]) for p, g in enumerate(g1)]
+            g1 = [_lib.dev_f32(g.contiguous(), 'grad') if g is not None else _lib.fill_zero(torch.empty_like(heat[p])) for p, g in enumerate(g1)]
             dlog = [torch.empty_like(h) for h in heat]
             check(L.mpose_softmax_bwd(ptr_array(heat), ptr_array(g1), ptr_array(g_comb) if g_comb is not None else None,
                                       ptr_array(dlog), 3, B * J, F * F, st()), 'mpose_softmax_bwd')
@@ -1677,7 +1677,7 @@ class Engine:
         """Stage `bucket`'s weight-gradient partials -> flat gradient slice (one unpack launch over its job range), then,
         under data parallelism, one asynchronous all-reduce of that slice that overlaps the rest of the backward."""
         if self.overlap_wgrad and self.side_stream is not None:
-            torch.cuda.current_stream().wait_stream(self.side_stream)
+            _lib.stream_wait(torch.cuda.current_stream(), self.side_stream)
         self._side_keep.clear()            # (their memory may now be recycled by main-stream allocations)
         if n_jobs > 0 and not self.inline_unpack:
             check(lib().mpose_unpack_wgrads(c_void_p(tb['unpack'].data_ptr() + first_job * UNPACK_DT.itemsize), n_jobs,

@@ -128,7 +128,7 @@ class _BackboneFn(torch.autograd.Function):
         g_hms = [list(grads[p * T:(p + 1) * T]) for p in range(3)]
         # (ctx.ectx stays: with retain_graph=True the node may run again; the saved activations go when the graph does)
         gflat, dx = engine.backward(ctx.ectx, hms, g_hms, ctx.needs_input_grad[2])
-        flat = gflat.clone()
+        flat = _lib.copy_into(torch.empty_like(gflat), gflat)      # (a launch of the library: a launch plan records it)
         if engine.dp is not None:       # the per-stage buckets were summed over replicas during the backward pass
             flat.div_(engine.dp[1])
         out = engine.grads_from_flat(flat)
@@ -214,10 +214,11 @@ class MargiPoseModel(nn.Module):
         pix = self._pixelwise_flag()
         target = target_var.narrow(-1, 0, 3).contiguous() if target_var.size(-1) >= 3 else \
             torch.cat([target_var.narrow(-1, 0, 2), torch.zeros_like(target_var.narrow(-1, 0, 1))], -1).contiguous()
-        losses = 0
+        losses = None
         for xy_hm, zy_hm, xz_hm in zip(self.xy_heatmaps, self.zy_heatmaps, self.xz_heatmaps):
-            # one fused launch per stage: JS of the plane(s) + DSNT + z-merge + Euclidean
-            losses = losses + dsntnn.stage_losses(xy_hm, zy_hm, xz_hm, target, 1.0, pix, three_d)
+            # one fused launch per stage: JS of the plane(s) + DSNT + z-merge + Euclidean; `losses = 0; losses += ...` (reference
+            # :238-252) with the additions as launches of the library
+            losses = dsntnn.add_losses(losses, dsntnn.stage_losses(xy_hm, zy_hm, xz_hm, target, 1.0, pix, three_d))
         return losses
 
     def forward_2d_losses(self, out_var, target_var):

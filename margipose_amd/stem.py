@@ -384,11 +384,11 @@ class _GraphStem:
         f32 = dict(dtype=torch.float32, device=dev)
         tb = self.tables(B, S)
         if train:
-            self.s_arena.zero_()
+            _lib.fill_zero(self.s_arena)       # (fills / copies through the library: a launch plan records them)
         else:
             eng.finalize_table(tb['fin'], 0, tb['n_fin'], False)
         if f16:
-            self.amax_f.zero_()
+            _lib.fill_zero(self.amax_f)
         cflags = eng.conv_flags(2) if f16 else 0       # (three-product form, or its single-product reduced-precision variant)
         measured = set()
         raw = {}
@@ -484,11 +484,11 @@ class _GraphStem:
         st = stream_ptr
         f32 = dict(dtype=torch.float32, device=dev)
         tb = self.tables(B, S)
-        self.s_arena.zero_()
+        _lib.fill_zero(self.s_arena)
         f16 = ctx.get('f16', False)
         cflags = ctx.get('cflags', 32 if f16 else 0)
         if f16:
-            self.amax_b.zero_()
+            _lib.fill_zero(self.amax_b)
         if self.out_nodes is not None:
             dact = dict((n.name, g) for n, g in zip(self.out_nodes, D) if g is not None)
         else:
@@ -519,7 +519,7 @@ class _GraphStem:
                 if isinstance(op, _AddOp):     # both addends receive d_raw (w.r.t. their affine / activated values)
                     for t in (op.a, op.b):
                         if t.name not in dact:       # (the identity path has other consumers that accumulate into it later)
-                            dact[t.name] = d_raw.clone() if (t is op.a and op.relu_a) else d_raw
+                            dact[t.name] = _lib.copy_into(torch.empty_like(d_raw), d_raw) if (t is op.a and op.relu_a) else d_raw
                         else:
                             acc = dact[t.name]
                             check(L.mpose_add(ptr(acc), ptr(d_raw), ptr(acc), c_int64(acc.numel()), st()), 'mpose_add')
@@ -528,7 +528,7 @@ class _GraphStem:
                 Hs, Ws = src.hw(S)
                 want_dsrc = (not src.is_image) or need_dx
                 if want_dsrc and src.name not in dact:
-                    dact[src.name] = torch.zeros(B, Hs, Ws, src.C, **f32)
+                    dact[src.name] = _lib.fill_zero(torch.empty(B, Hs, Ws, src.C, **f32))
                 sc = None if src.is_image else self.fptr(src, 0)
                 sh = None if src.is_image else self.fptr(src, 1)
                 if isinstance(op, _ConvOp):

@@ -6,7 +6,7 @@ import bisect
 
 import torch
 
-from . import dsntnn
+from . import _lib, dsntnn
 
 
 class PiecewiseLinearSchedule:
@@ -230,6 +230,14 @@ class DeviceSGD:
             # nothing executes during capture: the job table is filled by finish_capture() with the gradients' addresses inside
             # the graph's memory pool, and the hyper-parameters are uploaded by the caller before every replay
             table = self._graph_table
+        elif _lib.plan_recording():
+            # a launch plan is being recorded (PlannedTrainStep): this iteration executes, so the table is bound to its gradient
+            # tensors now; the hyper-parameters were uploaded before the recording began (they must not be part of it: a replay
+            # would write this iteration's values over the ones before_replay() just uploaded)
+            self._fill_table(self._graph_table)
+            table = self._graph_table
+            self._steps += 1
+            torch.autograd.graph.increment_version(self.params)
         else:
             self.upload_hyper()
             self._fill_table(self._eager_table)
@@ -314,6 +322,104 @@ class GraphedTrainStep:
             self.opt.before_replay()
         self.graph.replay()
         return self.out, self.loss
+
+
+class PlannedTrainStep:
+    """One training iteration (the same sequence as GraphedTrainStep: model(x) -> forward_loss -> zero_grad -> backward ->
+    optimiser.step, reference bin/train_3d.py:154-186) recorded ONCE as a launch plan (csrc/plan.hip) and re-issued from one C
+    loop: the eager schedule exactly -- same kernels, same argument values, the weight-gradient launches on the side stream
+    with the same dependencies -- for ~3 ms of host time instead of 15-28 ms of Python.  (A HIP graph of the iteration replays
+    its two streams serially on this runtime: 25.3 against 23.9 ms, profiles/r5_graph_replay_ab.txt; on the pool's slow hosts
+    the eager loop is host-bound: 28.7 ms.)
+
+        step = PlannedTrainStep(model, optimiser, x, target, mask)          # example tensors fix the shapes
+        out, loss = step(x, target, mask)                                    # copies the batch in, replays
+
+    What makes a replay valid: every tensor of the recorded iteration lives in a private allocator pool that stays reserved for
+    this object (the replayed launches write the same addresses); everything the iteration computes is a launch of this library
+    (the engine's fills and copies, the stage-loss sum, average_loss's backward, DeviceSGD) -- kernels of the tensor library
+    are not recorded; the backward pass is seeded with a persistent tensor of ones.  `optimiser` must be a DeviceSGD (its
+    hyper-parameters live in device memory and may change every step); `valid_depth` must select one loss for the whole batch.
+    Side effects of the constructor: like GraphedTrainStep it runs `warmup` + 1 real iterations on the example batch."""
+
+    def __init__(self, model, optimiser, x, target, mask, valid_depth=None, warmup=2):
+        import ctypes
+        if not isinstance(optimiser, DeviceSGD):
+            raise _lib.MposeError('PlannedTrainStep needs a DeviceSGD optimiser (torch optimisers launch kernels a plan cannot record)')
+        self.model, self.opt = model, optimiser
+        self.x, self.target, self.mask = x.clone(), target.clone(), mask.clone()
+        self.valid_depth = [1] * x.shape[0] if valid_depth is None else [int(v) for v in valid_depth]
+        if 0 in self.valid_depth and 1 in self.valid_depth:
+            raise _lib.MposeError('PlannedTrainStep: a per-sample mix of 2D and 3D losses is composed with tensor-library kernels')
+        eng = model.inner.engine()
+        if eng.dp is not None:
+            raise _lib.MposeError('PlannedTrainStep: the data-parallel all-reduces are issued by the host inside the backward pass')
+        self._one = torch.ones((), dtype=torch.float32, device=x.device)
+        self._plan = None
+        for _ in range(max(1, warmup)):          # (creates the engine's arenas, job tables and side stream; raises kernels' LDS limits)
+            self._iteration()
+        torch.cuda.synchronize()
+        L = _lib.lib()
+        self._side = eng.side_stream if eng.overlap_wgrad else None
+        dev = x.device.index if x.device.index is not None else torch.cuda.current_device()
+        self._pool = torch.cuda.MemPool()
+        optimiser.upload_hyper()                  # (outside the recording, see DeviceSGD.step)
+        arr = self._stream_array()
+        # every thread's allocations (autograd runs the backward pass on its own) go to the private pool while recording
+        torch._C._cuda_beginAllocateToPool(dev, self._pool.id)
+        try:
+            _lib.check(L.mpose_plan_begin(arr, len(arr)), 'mpose_plan_begin')
+            try:
+                self.out, self.loss = self._iteration()
+            except BaseException:
+                L.mpose_plan_abort()
+                raise
+            plan = ctypes.c_void_p()
+            _lib.check(L.mpose_plan_end(ctypes.byref(plan)), 'mpose_plan_end (a launch went to a stream outside the plan?)')
+            self._plan = plan
+        finally:
+            torch._C._cuda_endAllocateToPool(dev, self._pool.id)
+            torch._C._cuda_releasePool(dev, self._pool.id)
+        n = [ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)]
+        L.mpose_plan_size(self._plan, ctypes.byref(n[0]), ctypes.byref(n[1]), ctypes.byref(n[2]))
+        self.n_launches, self.n_waits = n[0].value, n[1].value
+        torch.cuda.synchronize()
+
+    def _stream_array(self):
+        import ctypes
+        streams = [torch.cuda.current_stream()] + ([self._side] if self._side is not None else [])
+        return (ctypes.c_void_p * len(streams))(*[s.cuda_stream for s in streams])
+
+    def _iteration(self):
+        out = self.model(self.x)
+        loss = forward_loss(self.model, out, self.target, self.mask, self.valid_depth)
+        self.opt.zero_grad(set_to_none=True)
+        loss.backward(self._one)
+        self.opt.step()
+        return out, loss
+
+    def __call__(self, x=None, target=None, mask=None):
+        import ctypes
+        if x is not None:
+            self.x.copy_(x, non_blocking=True)
+        if target is not None:
+            self.target.copy_(target, non_blocking=True)
+        if mask is not None:
+            self.mask.copy_(mask, non_blocking=True)
+        self.opt.before_replay()
+        arr = self._stream_array()
+        nxt = ctypes.c_int(0)
+        _lib.check(_lib.lib().mpose_plan_replay(self._plan, arr, len(arr), 0, ctypes.byref(nxt)), 'mpose_plan_replay')
+        return self.out, self.loss
+
+    def __del__(self):
+        try:
+            if self._plan is not None:
+                torch.cuda.synchronize()
+                _lib.lib().mpose_plan_destroy(self._plan)
+                self._plan = None
+        except Exception:
+            pass
 
 
 class BatchStager:

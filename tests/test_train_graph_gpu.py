@@ -78,6 +78,80 @@ def test_graphed_iterations_equal_eager_iterations(stem):
         assert torch.equal(a, b), k
 
 
+@pytest.mark.parametrize('stem,overlap', [('patch8', True), ('inceptionv4', True), ('patch8', False)])
+def test_planned_iterations_equal_eager_iterations(stem, overlap):
+    """train_helpers.PlannedTrainStep: the iteration recorded once as a launch plan (csrc/plan.hip) and re-issued from a C loop
+    on the eager schedule's two streams gives the same losses and the same weights, bit for bit, as the reference's loop run
+    eagerly -- with the weight gradients on the side stream (the default) and on the main stream."""
+    from margipose_amd.train_helpers import DeviceSGD, PlannedTrainStep, make_1cycle, training_step
+    T, seed, B, n_iter = 1, 55, 2, 4
+    x, target, mask = W.seeded_inputs(seed, B)
+    batches = [W.seeded_inputs(seed + 1 + i, B) for i in range(n_iter)]
+    m_e = _model(T, seed, x, stem)
+    m_p = copy.deepcopy(m_e)
+    m_e.inner.engine().overlap_wgrad = overlap
+    m_p.inner.engine().overlap_wgrad = overlap
+    opt_e = DeviceSGD(m_e.parameters(), lr=0.05, momentum=0.9)
+    sch_e = make_1cycle(opt_e, 20, 0.05, 0.9)
+    losses_e = []
+    for xb, tb, mb in batches:
+        _, loss = training_step(m_e, sch_e, xb.cuda(), tb.cuda(), mb.cuda(), [1] * B)
+        losses_e.append(float(loss.detach()))
+    # planned: recorded once (the constructor's iterations run on the state, which is restored afterwards)
+    opt_p = DeviceSGD(m_p.parameters(), lr=0.05, momentum=0.9)
+    sch_p = make_1cycle(opt_p, 20, 0.05, 0.9)
+    state = copy.deepcopy(m_p.state_dict())
+    step = PlannedTrainStep(m_p, opt_p, x.cuda(), target.cuda(), mask.cuda())
+    assert step.n_launches > 100 and (step.n_waits > 0) == overlap, (step.n_launches, step.n_waits)
+    m_p.load_state_dict(state)
+    opt_p._bufs.zero_(); opt_p._steps = 0
+    # (other users of the allocator between replays must not disturb the plan's buffers: they live in a private pool)
+    junk = [torch.randn(1 << 20, device='cuda') for _ in range(8)]
+    losses_p = []
+    for xb, tb, mb in batches:
+        sch_p.batch_step()
+        _, loss = step(xb.cuda(), tb.cuda(), mb.cuda())
+        losses_p.append(float(loss))
+        junk = [torch.randn(1 << 20, device='cuda') for _ in range(8)]
+    assert losses_e == losses_p, (losses_e, losses_p)
+    for (k, a), (_, b) in zip(m_e.state_dict().items(), m_p.state_dict().items()):
+        assert torch.equal(a, b), k
+    # the parameters' .grad tensors follow the replays (they are views of the recorded iteration's gradient buffer)
+    for pe, pp in zip(m_e.parameters(), m_p.parameters()):
+        assert torch.equal(pe.grad, pp.grad)
+
+
+def test_training_iteration_launches_only_library_kernels():
+    """What a launch plan cannot record must not be in the iteration: every device kernel of one eager training iteration (forward,
+    3D loss, backward, DeviceSGD) is a launch of libmargipose_hip.so -- no fills, copies or elementwise kernels of the tensor library."""
+    from torch.profiler import ProfilerActivity, profile
+    from margipose_amd import dsntnn
+    from margipose_amd.train_helpers import DeviceSGD, forward_loss
+    T, seed, B = 2, 56, 2
+    x, target, mask = [t.cuda() for t in W.seeded_inputs(seed, B)]
+    m = _model(T, seed, x.cpu(), 'inceptionv4')
+    opt = DeviceSGD(m.parameters(), lr=0.05, momentum=0.9)
+    one = torch.ones((), device='cuda')
+
+    def iteration():
+        out = m(x)
+        loss = forward_loss(m, out, target, mask, [1] * B)
+        opt.zero_grad(set_to_none=True)
+        loss.backward(one)
+        opt.step()
+
+    for _ in range(3):
+        iteration()
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        iteration()
+        torch.cuda.synchronize()
+    names = [e.name for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA]
+    assert len(names) > 100
+    foreign = sorted(set(n for n in names if 'mpose' not in n and 'Memcpy HtoD' not in n))
+    assert not foreign, foreign
+
+
 def test_batch_stager_pinned_double_buffer():
     """train_helpers.BatchStager (reference bin/train_3d.py:158-161 done with pinned double buffers on a copy stream): values
     arrive intact for float and uint8 frames, slots rotate, and the consumer needs no host synchronisation."""
