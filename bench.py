@@ -367,7 +367,7 @@ def main():
     # eager two-stream schedule, kernel for kernel, without ~700 Python-issued launches per step (15 ms of host time on the pool's
     # fast hosts, 28 ms on its slow ones, where the eager step is host-bound).  --eager issues every launch from Python.
     planned = None
-    if graphed is None and not args.eager and not args.no_plan and world == 1 and os.environ.get('MPOSE_PLAN', '1') != '0':
+    if graphed is None and not args.eager and not args.no_plan and os.environ.get('MPOSE_PLAN', '1') != '0':
         try:
             planned = PlannedTrainStep(model, opt, x, target, mask, warmup=2)
         except Exception as e:          # a failed recording must not cost the measurement: fall back to eager launches

@@ -277,6 +277,9 @@ typedef struct {
  * the launch runs units * n_groups * n_split workgroups, one per CU at a time (the caller sizes n_split so that
  * this is close to a multiple of 256, and the partial-sum buffer as n_split * packed-fp32 weight size). */
 int mpose_conv_wgrad_tiles(const mpose_conv_geom* geom);
+/* Workgroups of that launch that share a CU (1, or 3 for the narrow tiles of the row-of-taps kernel): a round of the launch is
+ * 256 * this many workgroups. */
+int mpose_conv_wgrad_occupancy(const mpose_conv_geom* geom);
 
 /* d > 1: the geometry is a stride-1 convolution dilated by d along x (every tap's dx a multiple of d), whose weight gradient
  * mpose_conv_wgrad computes as d launches over the residues of x mod d -- IF n_split is a multiple of d; each residue then
@@ -621,6 +624,7 @@ int mpose_fill_u32(void* dst, unsigned value, int64_t n_bytes, void* stream);
 int mpose_copy_bytes(const void* src, void* dst, int64_t n_bytes, void* stream);
 int mpose_add_i64(int64_t* p, int64_t v, int64_t n, void* stream);
 int mpose_add_f32(const float* a, const float* b, float* out, int64_t n, void* stream);
+int mpose_copy_div_f32(const float* src, float* dst, float divisor, int64_t n, void* stream);      /* dst = src / divisor */
 int mpose_average_loss_bwd(const float* grad, const float* out2, const float* mask, float* d_losses, int64_t n, void* stream);
 
 #ifdef __cplusplus

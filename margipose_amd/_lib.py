@@ -89,6 +89,19 @@ def plan_recording():
     return bool(lib().mpose_plan_recording())
 
 
+PLAN_HOST_OPS = None        # while train_helpers.PlannedTrainStep records: the host actions of the iteration, in order
+
+
+def plan_host(fn):
+    """Run fn() -- a host action inside an iteration that a launch plan cannot record (issuing a collective, waiting for one).
+    While a plan is being recorded the point is marked (mpose_plan_break) and fn is kept: a replay stops there, calls fn() and
+    continues.  fn must only touch buffers that live as long as the plan."""
+    if PLAN_HOST_OPS is not None and plan_recording():
+        check(lib().mpose_plan_break(), 'mpose_plan_break')
+        PLAN_HOST_OPS.append(fn)
+    return fn()
+
+
 def dev_f32(t, name='tensor'):
     """Validate a device fp32 contiguous tensor and return it."""
     if not isinstance(t, torch.Tensor):

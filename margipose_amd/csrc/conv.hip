@@ -1215,9 +1215,9 @@ int launch_conv_ks(const ConvArgs& a, int mode, int cmax, int n_groups, hipStrea
     return launch_conv_ks_p<RN, 1, false>(a, mode, cmax, n_groups, s);
   }
   if (a.flags & MPOSE_CONV_F16X3) {
-    if constexpr (RN > 1) {
-      if (rowg_env() && rowg_eligible(a.g)) return launch_conv_ks_p<RN, 2, true>(a, mode, cmax, n_groups, s);
-    }
+    // (round 5: the 32-wide tiles too -- the feature extractor's 32-channel 3x3 layers and the columns' last 32-channel block spent
+    //  their loop on the split, nine times per input element; MPOSE_CONV_ROWG=2 restores the per-tap loop for them)
+    if (rowg_env() && (RN > 1 || rowg_env() != 2) && rowg_eligible(a.g)) return launch_conv_ks_p<RN, 2, true>(a, mode, cmax, n_groups, s);
     return launch_conv_ks_p<RN, 2, false>(a, mode, cmax, n_groups, s);
   }
   return launch_conv_ks_p<RN, 3, false>(a, mode, cmax, n_groups, s);
@@ -1651,6 +1651,7 @@ int mpose_conv_h2_launch(const mpose_conv_geom* geom, const mpose_conv_operands*
                          int cmax, void* stream);          // conv_h.hip
 int mpose_wgrad_rows_units(const mpose_conv_geom* geom);                                                                       // wgrad.hip
 int mpose_wgrad_rows_launch(const mpose_conv_geom* geom, const mpose_wgrad_operands* ops, int n_groups, int n_split, void* stream);
+int mpose_wgrad_rows_occupancy(const mpose_conv_geom* geom);
 
 // in_mul_x / out_mul_x = 0 ("as along y") filled in: what the kernels and the checks below read
 static mpose_conv_geom normalised(const mpose_conv_geom* g) {
@@ -1879,6 +1880,17 @@ extern "C" int mpose_conv_wgrad_tiles(const mpose_conv_geom* geom_) {
   int entries = 0;
   for (int c = 0; c < geom->n_classes; ++c) entries += geom->cls[c].n_taps;
   return entries * (geom->Cin / (32 * wgrad_blocks(geom->Cin))) * (geom->Cout0 / (32 * wgrad_blocks(geom->Cout0)));
+}
+
+extern "C" int mpose_conv_wgrad_occupancy(const mpose_conv_geom* geom_) {
+  if (check_geom(geom_)) return -1;
+  const mpose_conv_geom gn = normalised(geom_);
+  if (mpose_wgrad_rows_units(&gn)) return mpose_wgrad_rows_occupancy(&gn);
+  {
+    mpose_conv_geom pg;
+    if (x_phases(gn, &pg) > 1 && mpose_wgrad_rows_units(&pg)) return mpose_wgrad_rows_occupancy(&pg);
+  }
+  return 1;
 }
 
 extern "C" int mpose_conv_wgrad(const mpose_conv_geom* geom_, const mpose_wgrad_operands* ops, int n_groups, int n_split,

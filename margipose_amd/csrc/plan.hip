@@ -122,6 +122,12 @@ __global__ __launch_bounds__(256) void average_loss_bwd_k(const float* __restric
   d[i] = mask != nullptr ? __fmul_rn(mask[i], scale) : scale;
 }
 
+// dst = src / divisor (IEEE division: what Tensor.div_ computes -- the mean over data-parallel replicas of the summed gradients)
+__global__ __launch_bounds__(256) void copy_div_f32_k(const float* __restrict__ s, float* __restrict__ d, float divisor, long n) {
+  const long stride = (long)gridDim.x * 256;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) d[i] = __fdiv_rn(s[i], divisor);
+}
+
 static inline unsigned grid_of(long n, int per_block, unsigned cap) {
   const long g = (n + per_block - 1) / per_block;
   return (unsigned)(g < 1 ? 1 : (g > (long)cap ? (long)cap : g));
@@ -293,5 +299,12 @@ extern "C" int mpose_average_loss_bwd(const float* grad, const float* out2, cons
   if (n < 0 || !grad || !out2 || !d_losses) return MPOSE_EINVAL;
   if (n == 0) return 0;
   launch(average_loss_bwd_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, grad, out2, mask, d_losses, (long)n);
+  return launch_status();
+}
+
+extern "C" int mpose_copy_div_f32(const float* src, float* dst, float divisor, int64_t n, void* stream) {
+  if (n < 0 || !src || !dst) return MPOSE_EINVAL;
+  if (n == 0) return 0;
+  launch(copy_div_f32_k, dim3(grid_of(n, 256 * 4, 8192)), dim3(256), 0, (hipStream_t)stream, src, dst, divisor, (long)n);
   return launch_status();
 }

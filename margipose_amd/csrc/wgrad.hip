@@ -632,6 +632,13 @@ int mpose_wgrad_rows_units(const mpose_conv_geom* geom) {
   return n * ((geom->Cin + kt - 1) / kt) * ((geom->Cout0 + nt - 1) / nt);
 }
 
+// Workgroups of the row form that share a CU for this geometry: the narrow tiles (shapes 2, 3: <= 114 + 48 registers, 44 KB of LDS)
+// run three per CU, the wide ones one.
+int mpose_wgrad_rows_occupancy(const mpose_conv_geom* geom) {
+  const int shape = rows_shape(geom->Cin, geom->Cout0);
+  return (shape == 2 || shape == 3) ? 3 : 1;
+}
+
 // Called by mpose_conv_wgrad (conv.hip) after it validated geometry and operands.  Returns MPOSE_ENOSYS when the row form does
 // not apply (the caller then runs conv_wgrad_k).
 int mpose_wgrad_rows_launch(const mpose_conv_geom* geom, const mpose_wgrad_operands* ops, int n_groups, int n_split, void* stream) {

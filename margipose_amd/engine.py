@@ -51,6 +51,10 @@ COEF_DT = np.dtype([('sums', 'u8'), ('gamma', 'u8'), ('mean', 'u8'), ('invstd', 
                     ('sg_col', 'i4'), ('dconv_bias', 'u8'), ('part', 'u8'), ('n_part', 'i4'), ('part_ld', 'i4'),
                     ('g_amax', 'u8'), ('bound_out', 'u8')], align=True)
 
+# Weight-gradient pixel splits sized for the workgroups that share a CU (the narrow row-of-taps tiles run three per CU): alone, the
+# feature extractor's 32-channel layers go 245 -> 148 us and the columns' 17-joint block 57 -> 41 us, but in the step the wider launches
+# crowd the main stream's convolutions out of the CUs they share (23.51 -> 23.85 ms, tools/ab_sweep.sh): off by default.
+_WG_OCC = os.environ.get('MPOSE_WG_OCC', '0') != '0'
 _WG_FIXED = float(os.environ.get('MPOSE_WG_FIXED', '3.0'))     # fixed per-workgroup cost of a weight-gradient launch, in 128-pixel row units (Engine._n_split)
 AMAX_SLOT = 16 * 64          # floats per activation amax slot (MPOSE_AMAX_SUBSLOTS * MPOSE_AMAX_STRIDE)
 _SIZES_CHECKED = False
@@ -358,6 +362,7 @@ class Engine:
         self._key_tensors = None
         self._bn_bound = []
         self.timer = None            # optional KernelTimer (bench.py)
+        self._dp_works = []          # in-flight gradient all-reduces of the current backward pass (data parallel)
         self.side_stream = None      # weight-gradient GEMMs run here, off the data-gradient critical path
         self._side_keep = []         # tensors the side stream still reads (released at the next bucket boundary)
         # (measured: no faster -- the step is bound by the sum of the heavy kernels' work, not by the main stream's chain of launches -- off)
@@ -992,7 +997,8 @@ class Engine:
                 raise _lib.MposeError('mpose_conv_wgrad_tiles rejected the geometry %s' % getattr(g, '_name', '?'))
             slots = g.B * g.GH * (32 if width32 else g.GW)
             d = max(1, int(lib().mpose_conv_wgrad_phases(ctypes.byref(g))))       # x-dilated kernels: d launches, n_split / d each
-            nsp = g._n_split = d * self._n_split(slots // d, tiles, groups)
+            occ = max(1, int(lib().mpose_conv_wgrad_occupancy(ctypes.byref(g)))) if _WG_OCC else 1
+            nsp = g._n_split = d * self._n_split(slots // d, tiles, groups, occ)
         return nsp
 
     def finalize(self, tb, first, n, train, part=False, bounds=False):
@@ -1198,8 +1204,7 @@ class Engine:
                     if self.fwd_side_stream is None or self.fwd_side_stream.device != main.device:
                         self.fwd_side_stream = torch.cuda.Stream(device=main.device)
                     side = self.fwd_side_stream
-                    ready = torch.cuda.Event()
-                    ready.record(main)               # the input planes (and last step's readers of sc / the partial rows) are done here
+                    _lib.stream_wait(side, main)     # the input planes (and last step's readers of sc / the partial rows) are done here
                     ops1 = []
                     for c, (b, op) in enumerate(zip(grp, ops)):
                         o1 = ConvOperands()
@@ -1212,7 +1217,6 @@ class Engine:
                     self.conv(self.geom('f_in3_regular', B, Hin, b0), ops, cflags)
                     self.finalize(tb, self.fin_index(t, i, 0), 3, True, spart)
                     with torch.cuda.stream(side):
-                        side.wait_event(ready)
                         self.conv(self.geom('f_in1_regular', B, Hin, b0), ops1, cflags)
                         self.finalize(tb, self.fin_index(t, i, 1), 3, True, spart)
                 else:
@@ -1277,7 +1281,7 @@ class Engine:
                 self.conv(self.geom('f_conv2', B, Hout, b0), ops,
                           pflags | (16 if (fuse2 or fuse2_h) else 0) | (256 if spart else 0) | (128 if blk_h2 else 0))
                 if sc_side:                  # the shortcut and its BatchNorm vectors are read from here on
-                    torch.cuda.current_stream().wait_stream(side)
+                    _lib.stream_wait(torch.cuda.current_stream(), side)
                 add_h2 = h2f and self.h2_next(t, i)      # this block's sum is the next (H2) block's input: planes written here
                 if train and not fin_fused:
                     self.finalize(tb, self.fin_index(t, i, 2), 3, True, spart, bounds=add_h2)
@@ -1386,11 +1390,12 @@ class Engine:
         _lib.fill_zero(self.gflat)
         if self._packed_for != ctx['cmode']:
             self.pack_weights(ctx['cmode'])
-        works = []
+        works = self._dp_works
+        del works[:]
         dx = self.stem.backward(ctx['stem_ctx'], grads, need_dx)
         self._finish_bucket(tb, 0, 0, tb['n_unpack'], works)
-        for w in works:
-            w.wait()
+        if self.dp is not None:
+            _lib.plan_host(self._wait_collectives)
         ctx['done'] = True
         return self.gflat, dx
 
@@ -1459,7 +1464,8 @@ class Engine:
             mode = eval_bn | (0 if (spart and not from_sums) else 2) | (4 if (spart and not from_sums) else 0) | (8 if bounds else 0)
             check(L.mpose_bn_bwd_coef(c_void_p(coef_base + first * COEF_DT.itemsize), n, mode, st()), 'mpose_bn_bwd_coef')
 
-        works = []          # in-flight gradient all-reduces (data parallel), one per finished bucket
+        works = self._dp_works          # in-flight gradient all-reduces (data parallel), one per finished bucket
+        del works[:]
         D = None            # gradient w.r.t. the stage input, cumulative over later stages (:195 is `inp = inp + ...`)
         g_comb = None
         for t in reversed(range(self.T)):
@@ -1668,10 +1674,15 @@ class Engine:
                     check(L.mpose_depth_to_space8(ptr(d_s2d), ptr(dx), B, ctx['x_shape'][2], st()), 'mpose_depth_to_space8')
             # ---- the stem's packed partial sums -> torch-layout gradients; last bucket ----
             self._finish_bucket(tb, self.T, self.T * 90, tb['n_unpack'] - self.T * 90, works)
-        for w in works:
-            w.wait()                   # (stream-ordered for RCCL: the current stream waits for the collective)
+        if self.dp is not None:
+            _lib.plan_host(self._wait_collectives)                   # (stream-ordered for RCCL: the current stream waits for the collective)
         ctx['done'] = True
         return self.gflat, dx
+
+    def _wait_collectives(self):
+        for w in self._dp_works:
+            w.wait()                   # (stream-ordered for RCCL: the current stream waits for the collective)
+        del self._dp_works[:]
 
     def _finish_bucket(self, tb, bucket, first_job, n_jobs, works):
         """Stage `bucket`'s weight-gradient partials -> flat gradient slice (one unpack launch over its job range), then,
@@ -1685,22 +1696,24 @@ class Engine:
         if self.dp is not None:
             lo, hi = self._buckets[bucket]
             if hi > lo:
-                works.append(torch.distributed.all_reduce(self.gflat[lo:hi], op=torch.distributed.ReduceOp.SUM,
-                                                          group=self.dp[0], async_op=True))
+                sl, grp = self.gflat[lo:hi], self.dp[0]
+                # (a host action: a launch plan marks the point and re-issues the collective there on every replay)
+                _lib.plan_host(lambda: works.append(torch.distributed.all_reduce(sl, op=torch.distributed.ReduceOp.SUM, group=grp, async_op=True)))
 
     @staticmethod
-    def _n_split(slots, tiles=27, groups=3):
+    def _n_split(slots, tiles=27, groups=3, occ=1):
         """Split-K factor of the weight-gradient GEMMs.  `tiles` = (tap entries) x (Cin tiles) x (Cout tiles) of ONE
         column (mpose_conv_wgrad_tiles); the launch has `groups` columns and runs tiles*groups*n workgroups, one
         per CU at a time.  Pick the n whose last round of 256 is fullest, discounted by the fixed per-workgroup cost
         (LDS reduction, pipeline fill) so that short row ranges are not split further than they pay for."""
         rows = max(1, slots // 32)
         best, best_score = 1, -1.0
-        for n in range(1, 65):
+        per_round = 256 * occ          # (`occ` workgroups share a CU: the narrow tiles of the row-of-taps kernel, mpose_conv_wgrad_occupancy)
+        for n in range(1, 64 * occ + 1):
             if n > 1 and rows < 8 * n:
                 break
             wgs = tiles * groups * n
-            eff = wgs / (256.0 * ((wgs + 255) // 256))
+            eff = wgs / (float(per_round) * ((wgs + per_round - 1) // per_round))
             work = rows / (4.0 * n)
             score = eff * work / (work + _WG_FIXED)
             if score > best_score + 1e-9:

@@ -128,9 +128,12 @@ class _BackboneFn(torch.autograd.Function):
         g_hms = [list(grads[p * T:(p + 1) * T]) for p in range(3)]
         # (ctx.ectx stays: with retain_graph=True the node may run again; the saved activations go when the graph does)
         gflat, dx = engine.backward(ctx.ectx, hms, g_hms, ctx.needs_input_grad[2])
-        flat = _lib.copy_into(torch.empty_like(gflat), gflat)      # (a launch of the library: a launch plan records it)
-        if engine.dp is not None:       # the per-stage buckets were summed over replicas during the backward pass
-            flat.div_(engine.dp[1])
+        if engine.dp is not None:       # the per-stage buckets were summed over replicas during the backward pass: the mean
+            flat = torch.empty_like(gflat)
+            _lib.check(_lib.lib().mpose_copy_div_f32(_lib.ptr(gflat), _lib.ptr(flat), _lib.c_float(float(engine.dp[1])), _lib.c_int64(gflat.numel()),
+                                                     _lib.stream_ptr()), 'mpose_copy_div_f32')
+        else:
+            flat = _lib.copy_into(torch.empty_like(gflat), gflat)      # (a launch of the library: a launch plan records it)
         out = engine.grads_from_flat(flat)
         return (None, None, dx) + tuple(out)
 

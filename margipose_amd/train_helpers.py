@@ -340,6 +340,8 @@ class PlannedTrainStep:
     (the engine's fills and copies, the stage-loss sum, average_loss's backward, DeviceSGD) -- kernels of the tensor library
     are not recorded; the backward pass is seeded with a persistent tensor of ones.  `optimiser` must be a DeviceSGD (its
     hyper-parameters live in device memory and may change every step); `valid_depth` must select one loss for the whole batch.
+    Data parallel: the all-reduces of the gradient buckets are host actions -- the plan breaks at each, a replay issues them again
+    between two segments (the same places the eager backward pass issues them).
     Side effects of the constructor: like GraphedTrainStep it runs `warmup` + 1 real iterations on the example batch."""
 
     def __init__(self, model, optimiser, x, target, mask, valid_depth=None, warmup=2):
@@ -352,15 +354,13 @@ class PlannedTrainStep:
         if 0 in self.valid_depth and 1 in self.valid_depth:
             raise _lib.MposeError('PlannedTrainStep: a per-sample mix of 2D and 3D losses is composed with tensor-library kernels')
         eng = model.inner.engine()
-        if eng.dp is not None:
-            raise _lib.MposeError('PlannedTrainStep: the data-parallel all-reduces are issued by the host inside the backward pass')
         self._one = torch.ones((), dtype=torch.float32, device=x.device)
         self._plan = None
         for _ in range(max(1, warmup)):          # (creates the engine's arenas, job tables and side stream; raises kernels' LDS limits)
             self._iteration()
         torch.cuda.synchronize()
         L = _lib.lib()
-        self._side = eng.side_stream if eng.overlap_wgrad else None
+        self._sides = [s for s in ((eng.side_stream if eng.overlap_wgrad else None), eng.fwd_side_stream) if s is not None]
         dev = x.device.index if x.device.index is not None else torch.cuda.current_device()
         self._pool = torch.cuda.MemPool()
         optimiser.upload_hyper()                  # (outside the recording, see DeviceSGD.step)
@@ -369,11 +369,16 @@ class PlannedTrainStep:
         torch._C._cuda_beginAllocateToPool(dev, self._pool.id)
         try:
             _lib.check(L.mpose_plan_begin(arr, len(arr)), 'mpose_plan_begin')
+            # data parallel: the all-reduces of the gradient buckets and the wait for them are host actions (Engine._finish_bucket):
+            # the plan breaks there and a replay calls them again, in order
+            self._host_ops = _lib.PLAN_HOST_OPS = []
             try:
                 self.out, self.loss = self._iteration()
             except BaseException:
                 L.mpose_plan_abort()
                 raise
+            finally:
+                _lib.PLAN_HOST_OPS = None
             plan = ctypes.c_void_p()
             _lib.check(L.mpose_plan_end(ctypes.byref(plan)), 'mpose_plan_end (a launch went to a stream outside the plan?)')
             self._plan = plan
@@ -383,11 +388,13 @@ class PlannedTrainStep:
         n = [ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)]
         L.mpose_plan_size(self._plan, ctypes.byref(n[0]), ctypes.byref(n[1]), ctypes.byref(n[2]))
         self.n_launches, self.n_waits = n[0].value, n[1].value
+        if n[2].value != len(self._host_ops):
+            raise _lib.MposeError('PlannedTrainStep: %d breaks recorded for %d host actions' % (n[2].value, len(self._host_ops)))
         torch.cuda.synchronize()
 
     def _stream_array(self):
         import ctypes
-        streams = [torch.cuda.current_stream()] + ([self._side] if self._side is not None else [])
+        streams = [torch.cuda.current_stream()] + self._sides
         return (ctypes.c_void_p * len(streams))(*[s.cuda_stream for s in streams])
 
     def _iteration(self):
@@ -409,7 +416,11 @@ class PlannedTrainStep:
         self.opt.before_replay()
         arr = self._stream_array()
         nxt = ctypes.c_int(0)
-        _lib.check(_lib.lib().mpose_plan_replay(self._plan, arr, len(arr), 0, ctypes.byref(nxt)), 'mpose_plan_replay')
+        replay = _lib.lib().mpose_plan_replay
+        _lib.check(replay(self._plan, arr, len(arr), 0, ctypes.byref(nxt)), 'mpose_plan_replay')
+        for host_op in self._host_ops:              # (data parallel: issue / wait for the bucket's all-reduce, then go on)
+            host_op()
+            _lib.check(replay(self._plan, arr, len(arr), nxt.value, ctypes.byref(nxt)), 'mpose_plan_replay')
         return self.out, self.loss
 
     def __del__(self):

@@ -435,6 +435,8 @@ def test_data_parallel_rccl_single_rank():
     out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'dp_nccl_single.py')], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                          timeout=600).stdout.decode(errors='replace')
     assert 'DP_NCCL_SINGLE_OK' in out, out[-3000:]
+    # (round 5) the same step re-issued from a launch plan: the collectives are host actions between two recorded segments
+    assert 'DP_NCCL_PLAN_OK' in out, out[-3000:]
 
 
 def test_bench_launches_its_own_ranks():

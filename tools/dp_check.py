@@ -104,6 +104,20 @@ if rank == 0:
     # free running (each implementation on its own ReLU piece): the rule of tests/test_grad_parity_gpu.py -- within FREE_RATIO = 3 x
     # the reference's own fp32 deviation (which sites flip is luck; check (1) above is the exact statement about the averaging)
     assert np.median(e_gpu) <= max(1e-4, 3.0 * np.median(e_ref)) and np.quantile(e_gpu, 0.99) <= max(1e-4, 3.0 * np.quantile(e_ref, 0.99))
+# (3) the same data-parallel step from a launch plan (train_helpers.PlannedTrainStep): the bucket all-reduces are host actions the
+#     plan breaks at; a replay must reproduce the eager data-parallel gradients bit for bit
+from margipose_amd.train_helpers import DeviceSGD, PlannedTrainStep
+m.load_state_dict(state)
+xs, ts, ms = [t.to(dev) for t in shard(rank)]
+opt0 = DeviceSGD(m.parameters(), lr=0.0, momentum=0.0)
+pstep = PlannedTrainStep(m, opt0, xs, ts, ms, warmup=1)
+assert len(pstep._host_ops) == T + 2, len(pstep._host_ops)
+pstep(xs, ts, ms)
+torch.cuda.synchronize()
+for k, p in m.named_parameters():
+    assert torch.equal(p.grad, dp_g[k]), (k, float((p.grad - dp_g[k]).abs().max()))
+print('rank %d: planned data-parallel step == eager data-parallel step (%d launches, %d host actions)' % (rank, pstep.n_launches, len(pstep._host_ops)))
+del pstep
 dist.barrier()
 if rank == 0:
     print('DP_CHECK_OK')

@@ -54,6 +54,25 @@ assert l_dp == l_plain
 for a, b in zip(g_plain, g_dp):
     assert torch.equal(a, b), float((a - b).abs().max())
 print('DP_NCCL_SINGLE_OK buckets=%s (eager schedule)' % calls, flush=True)
+# the same step from a LAUNCH PLAN (train_helpers.PlannedTrainStep): the plan breaks at every bucket's all-reduce and at the final
+# wait, a replay issues the collectives again from the host between two segments of recorded launches
+from margipose_amd.train_helpers import PlannedTrainStep
+m.load_state_dict(state)
+opt0 = DeviceSGD(m.parameters(), lr=0.0, momentum=0.0)          # (lr 0: the iterations leave the weights where they are)
+pstep = PlannedTrainStep(m, opt0, x, tgt, mask, warmup=1)
+assert len(pstep._host_ops) == T + 2, len(pstep._host_ops)       # T + 1 buckets and the wait for them
+calls = []
+dist.all_reduce = counting
+for _ in range(2):
+    out, loss = pstep(x, tgt, mask)
+dist.all_reduce = orig
+torch.cuda.synchronize()
+assert len(calls) == 2 * (T + 1), calls
+assert float(loss) == l_plain, (float(loss), l_plain)
+for a, p in zip(g_plain, m.parameters()):
+    assert torch.equal(a, p.grad), float((a - p.grad).abs().max())
+print('DP_NCCL_PLAN_OK launches=%d waits=%d host_ops=%d' % (pstep.n_launches, pstep.n_waits, len(pstep._host_ops)), flush=True)
+del pstep
 if os.environ.get('MPOSE_DP_GRAPH') != '1':
     os._exit(0)                          # (skip the process-group teardown: nothing to synchronise with)
 # MPOSE_DP_GRAPH=1: the same step, collectives included, captured as ONE HIP graph and replayed (a runtime whose RCCL cannot be

@@ -46,3 +46,15 @@ iv = sorted(qs[mq]); gaps = [iv[i + 1][0] - iv[i][1] for i in range(len(iv) - 1)
 print('  main queue %s: sum of gaps %.2f ms/step, median gap %.2f us, gaps > 5 us: %d/step (%.2f ms)' % (
     mq, sum(g for g in gaps if g > 0) / nlast / 1e6, sorted(gaps)[len(gaps) // 2] / 1e3, sum(1 for g in gaps if g > 5000) / nlast,
     sum(g for g in gaps if g > 5000) / nlast / 1e6))
+# forward / backward phases of the last step (the backward begins with the first loss-backward kernel)
+last0 = ends[-2]
+st_ = [r for r in rows if r['s'] >= last0 and r['e'] <= ends[-1]]
+bwd0 = min((r['s'] for r in st_ if 'stage_loss_bwd_k' in r['Kernel_Name'] or 'average_loss_bwd_k' in r['Kernel_Name']), default=None)
+if bwd0 is not None:
+    for name, lo, hi in (('forward + loss', last0, bwd0), ('backward + update', bwd0, ends[-1])):
+        ph = [r for r in st_ if lo <= r['s'] < hi]
+        u = union([(r['s'], min(r['e'], hi)) for r in ph])
+        small = sum(r['e'] - r['s'] for r in ph if r['e'] - r['s'] < 12000)
+        print('  %-18s wall %.2f ms, some kernel running %.2f, idle %.2f; kernel-time sum %.2f; launches %d (%d under 12 us: %.2f ms)' % (
+            name, (hi - lo) / 1e6, u / 1e6, (hi - lo - u) / 1e6, sum(r['e'] - r['s'] for r in ph) / 1e6, len(ph),
+            sum(1 for r in ph if r['e'] - r['s'] < 12000), small / 1e6))
