@@ -193,6 +193,53 @@ def fused_tail_microbench(device, B, bf16_out=False, launches=200):
             'kernel': 'bn_add_softmax_k (residual sum + flat_softmax + dsnt, 3 columns, B=%d, %s heatmaps)' % (B, 'bf16' if bf16_out else 'fp32')}
 
 
+def train_tail_microbench(device, B, launches=200):
+    """The training tail's other three launches per stage: stage_loss_fwd_k (3 x JS + DSNT + z-merge + Euclidean: the
+    heatmaps read once, 4 E bytes, E = 3 B 17 F^2), stage_loss_bwd_k (heatmaps read, their gradient written: 8 E) and softmax_bwd_k
+    (heatmaps + the loss gradient + the next stage's combiner gradient read, the logits' gradient written: 16 E; 12 E at the last
+    stage).  Same method as tail_microbench: back-to-back launches between two HIP events, nothing subtracted."""
+    from margipose_amd import _lib
+    F, J = 32, 17
+    L = _lib.lib()
+    hm = [torch.softmax(torch.randn(B, J, F * F, device=device) * 4, -1).view(B, J, F, F).contiguous() for _ in range(3)]
+    tgt = (torch.rand(B, J, 3, device=device) * 2 - 1).contiguous()
+    losses = torch.empty(B, J, device=device)
+    xyz = torch.empty(B, J, 3, device=device)
+    g = torch.full((B, J), 1.0 / (B * J), device=device)
+    d_hm = [torch.empty_like(h) for h in hm]
+    g_comb = [torch.randn_like(h) * 1e-3 for h in hm]
+    d_log = [torch.empty_like(h) for h in hm]
+    E = 3 * B * J * F * F
+    cf = _lib.c_float
+
+    def fwd():
+        _lib.check(L.mpose_stage_loss_fwd(_lib.ptr_array(hm), _lib.ptr(tgt), _lib.ptr(losses), _lib.ptr(xyz), B * J, F, F, cf(1.0), 1, 1, 0,
+                                          _lib.stream_ptr()), 'stage_loss_fwd')
+
+    def bwd():
+        _lib.check(L.mpose_stage_loss_bwd(_lib.ptr_array(hm), _lib.ptr(tgt), _lib.ptr(xyz), _lib.ptr(g), _lib.ptr_array(d_hm), B * J, F, F, cf(1.0),
+                                          1, 1, 0, _lib.stream_ptr()), 'stage_loss_bwd')
+
+    def sbwd():
+        _lib.check(L.mpose_softmax_bwd(_lib.ptr_array(hm), _lib.ptr_array(d_hm), _lib.ptr_array(g_comb), _lib.ptr_array(d_log), 3, B * J, F * F,
+                                       _lib.stream_ptr()), 'softmax_bwd')
+
+    out = {}
+    for name, fn, nbytes in (('stage_loss_fwd_k', fwd, 4 * E), ('stage_loss_bwd_k', bwd, 8 * E), ('softmax_bwd_k', sbwd, 16 * E)):
+        for _ in range(5):
+            fn()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        s.record()
+        for _ in range(launches):
+            fn()
+        e.record()
+        torch.cuda.synchronize()
+        sec = s.elapsed_time(e) * 1e-3 / launches
+        out[name] = {'us_per_launch': sec * 1e6, 'bytes_per_launch': nbytes, 'achieved_GBps': nbytes / sec / 1e9, 'frac': nbytes / sec / 1e9 / PEAK_HBM_GBPS}
+    return out
+
+
 def configs4_leg(device, steps=8, warmup=3, batch=32):
     """BASELINE configs[4] on one GPU, short: 5-stage MargiPose at 384 x 384 (48 x 48 heatmaps), convolution operands rounded to
     fp16 (one MFMA product per multiply-add, fp32 accumulate), same loss and optimiser as the headline step.  One extra step runs
@@ -539,6 +586,9 @@ def main():
                 fused_tail_microbench(device, B), note='replaces bn_add_nchw_k + softmax_dsnt_fwd_k; latency-bound'),
             'configs[1] inference, B=64 bf16 heatmaps, as launched by the step (fused with the residual sum)': dict(
                 fused_tail_microbench(device, 64, bf16_out=True), note='latency-bound')}
+        res['tail_training'] = {
+            'configs[2] training, B=%d fp32 (latency-bound: working set in Infinity Cache)' % B: train_tail_microbench(device, B),
+            'B=2048 fp32 (beyond the Infinity Cache: the HBM-roofline point)': train_tail_microbench(device, 2048, launches=50)}
     if allreduce is not None:
         res['allreduce_buckets'] = {'buckets': allreduce, 'xgmi_peak_GBps_per_gpu': 7 * 153.0, 'total_bytes': sum(b['bytes'] for b in allreduce),
                                     'total_ms_if_serial': sum(b['ms'] for b in allreduce)}

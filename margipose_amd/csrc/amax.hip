@@ -55,7 +55,17 @@ __global__ __launch_bounds__(256) void weights_absmax_k(const mpose_pack_job* __
   const long n = (long)j.N * j.K * j.T;
   if ((long)blockIdx.x * 256 >= n) return;
   float m = 0.f;
-  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) m = fmaxf(m, fabsf(j.src[e]));
+  if ((reinterpret_cast<uintptr_t>(j.src) & 15) == 0) {       // 16-byte loads, then the (at most three) trailing elements
+    const long n4 = n >> 2;
+    const float4* s4 = reinterpret_cast<const float4*>(j.src);
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n4; e += (long)gridDim.x * 256) {
+      const float4 v = s4[e];
+      m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (unsigned)(n & 3)) m = fmaxf(m, fabsf(j.src[(n4 << 2) + threadIdx.x]));
+  } else {
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) m = fmaxf(m, fabsf(j.src[e]));
+  }
   block_amax_commit_one(m, j.amax);
 }
 

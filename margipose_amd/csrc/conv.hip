@@ -1568,8 +1568,79 @@ inline int wgrad_blocks(int c) { return c % 128 == 0 ? 4 : (c % 96 == 0 ? 3 : (c
 // ---------------------------------------------------------------------------------------------
 // dst layout (bf16): [T][Kpad/16][plane 3][Npad][half 2][8]  -- one 16-byte MFMA B fragment per (n, half);
 // layout 1 (conv_p.hip): [T][Kpad/16][plane 3][half 2][Npad][8] -- 64 consecutive columns of a half = one 1 KiB DMA
-__global__ __launch_bounds__(256) void pack_weights_k(const mpose_pack_job* __restrict__ jobs) {
+// Jobs the tiled packer takes (round 5): the fp16 two-plane layouts of weights whose taps are contiguous and whose k or n index is
+// the next-faster one -- every Conv2d / ConvTranspose2d weight, forward and data-gradient view, up to 12 taps.
+constexpr int kPackTiledMaxT = 12;
+constexpr int kPackU = 9;
+__device__ __forceinline__ bool pack_tiled_ok(const mpose_pack_job& j) {
+  return (j.layout == 2 || j.layout == 3) && j.st == 1 && j.T >= 1 && j.T <= kPackTiledMaxT && (j.sk == j.T || j.sn == j.T) && (j.Kpad & 15) == 0;
+}
+
+// One workgroup per (16 k, 64 n) tile and all taps: the tile is read in SOURCE order (runs of 16 T or 64 T contiguous floats:
+// every line is used whole -- the element-wise packer below walks a tap at a time and fetches every line once per tap), turned in
+// LDS, and written as 16-byte fragments in the packed order.  Same values, bit for bit, as pack_weights_k.
+__global__ __launch_bounds__(256) void pack_weights_tiled_k(const mpose_pack_job* __restrict__ jobs) {
+  __shared__ float tile[kPackTiledMaxT * 16 * 65];          // [t][k_lo][n] (+1: the turn's reads spread over the banks)
   const mpose_pack_job j = jobs[blockIdx.y];
+  if (!pack_tiled_ok(j)) return;
+  const int T = j.T, k16n = j.Kpad / 16, nblk = (j.Npad + 63) / 64;
+  const float w_mul = j.amax != nullptr ? pow2f(f16_scale_exp(*j.amax)) : 1.f;
+  const long plane = (long)j.Npad * 16;
+  const bool k_fast = j.sk == j.T;              // (k, t) contiguous for a fixed n; otherwise (n, t) contiguous for a fixed k
+  for (int tl = blockIdx.x; tl < k16n * nblk; tl += gridDim.x) {
+    const int k16 = tl / nblk, n0 = (tl - k16 * nblk) * 64, k0 = k16 * 16;
+    const int run = (k_fast ? 16 : 64) * T, n_run = k_fast ? 64 : 16;
+    __syncthreads();                            // (the previous tile's readers are done)
+    // 16 threads walk a run (64 bytes per row and instruction), 16 runs per pass; kPackU loads of a thread in flight at a time
+    const float inv_t = 1.0f / (float)T;
+    const int lane16 = threadIdx.x & 15, row16 = threadIdx.x >> 4;
+    for (int o = row16; o < n_run; o += 16) {
+      for (int r0 = lane16; r0 < run; r0 += 16 * kPackU) {
+        float v[kPackU];
+        int rr[kPackU];
+#pragma unroll
+        for (int u = 0; u < kPackU; ++u) {
+          const int r = r0 + 16 * u;
+          rr[u] = r;
+          const int inner = (int)(((float)r + 0.5f) * inv_t), tt = r - inner * T;     // (exact: r < 64 * 12)
+          const int nn = k_fast ? o : inner, kl = k_fast ? inner : o;
+          v[u] = 0.f;
+          if (r < run && n0 + nn < j.N && k0 + kl < j.K) v[u] = j.src[(long)(n0 + nn) * j.sn + (long)(k0 + kl) * j.sk + tt];
+        }
+#pragma unroll
+        for (int u = 0; u < kPackU; ++u) {
+          const int r = rr[u];
+          if (r < run) {
+            const int inner = (int)(((float)r + 0.5f) * inv_t), tt = r - inner * T;
+            const int nn = k_fast ? o : inner, kl = k_fast ? inner : o;
+            tile[(tt * 16 + kl) * 65 + nn] = v[u];
+          }
+        }
+      }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < T * 128; i += 256) {          // (t, half, n): one 16-byte fragment per plane
+      const int t = i >> 7, half = (i >> 6) & 1, nn = i & 63;
+      if (n0 + nn >= j.Npad) continue;
+      f16x8 h, l;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const float vs = tile[(t * 16 + half * 8 + q) * 65 + nn] * w_mul;
+        const _Float16 hh = (_Float16)vs;
+        h[q] = hh;
+        l[q] = (_Float16)(vs - (float)hh);
+      }
+      _Float16* d = reinterpret_cast<_Float16*>(j.dst) + ((long)(t * k16n + k16) * 2) * plane +
+                    (j.layout == 3 ? ((long)half * j.Npad + n0 + nn) * 8 : (long)(n0 + nn) * 16 + half * 8);
+      *reinterpret_cast<f16x8*>(d) = h;
+      *reinterpret_cast<f16x8*>(d + plane) = l;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void pack_weights_k(const mpose_pack_job* __restrict__ jobs, int skip_tiled) {
+  const mpose_pack_job j = jobs[blockIdx.y];
+  if (skip_tiled && pack_tiled_ok(j)) return;      // (pack_weights_tiled_k's)
   const long total = (long)j.T * j.Kpad * j.Npad;
   __bf16* dst = reinterpret_cast<__bf16*>(j.dst);
   const long plane = (long)j.Npad * 16;
@@ -1977,7 +2048,9 @@ extern "C" int mpose_pack_weights(const mpose_pack_job* jobs_dev, int n_jobs, in
   int bx = (max_elems_per_job + 256 * 8 - 1) / (256 * 8);
   if (bx < 1) bx = 1;
   if (bx > 256) bx = 256;
-  launch(pack_weights_k, dim3(dim3(bx, n_jobs)), dim3(256), 0, (hipStream_t)stream, jobs_dev);
+  static const int tiled = [] { const char* e = getenv("MPOSE_PACK_TILED"); return e ? atoi(e) : 1; }();      // (0: the element-wise packer alone, A/B runs)
+  if (tiled) launch(pack_weights_tiled_k, dim3(dim3(bx > 48 ? 48 : bx, n_jobs)), dim3(256), 0, (hipStream_t)stream, jobs_dev);
+  launch(pack_weights_k, dim3(dim3(tiled && bx > 32 ? 32 : bx, n_jobs)), dim3(256), 0, (hipStream_t)stream, jobs_dev, tiled);
   return launch_status();
 }
 

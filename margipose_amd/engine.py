@@ -382,10 +382,11 @@ class Engine:
         # BOUND on the tensor's magnitude that the finalize / coefficient kernels derive before the pass runs (mpose_bn_job.bound_out,
         # mpose_bn_bwd_coef_job.bound_out) -- no measuring, no separate split pass.  (Batch statistics bound a normalised value;
         # running statistics do not: eval-mode forwards measure and split.)  MPOSE_H2_FUSE=0: measure + mpose_split_h2 everywhere;
-        # 1 (default): the residual sum only -- the fused BatchNorm-backward application moves 300 MB (three inputs, two fp32 outputs
+        # 1 (round 4's default): the residual sum only -- the fused BatchNorm-backward application moves 300 MB (three inputs, two fp32 outputs
         # that the weight gradients still read, the planes), past the Infinity Cache, and measured 55 us against 27 + 16 us for
-        # mpose_bn_bwd_apply + mpose_split_h2; 2: both.
-        self.h2_fuse = int(os.environ.get('MPOSE_H2_FUSE', '1'))
+        # mpose_bn_bwd_apply + mpose_split_h2; 2: both.  Round 5: 2 is the default -- kernel for kernel it is slower, in the step
+        # (launch-plan dispatch, one launch and one read pass fewer per H2 block) it measured 23.39 -> 23.25 ms (tools/ab_sweep.sh).
+        self.h2_fuse = int(os.environ.get('MPOSE_H2_FUSE', '2'))
         # the last ResidualBlock's residual sum, flat_softmax and dsnt as ONE launch per stage (mpose_bn_add_softmax_fwd: an image's
         # logits stay in LDS); heatmaps and coordinates are bit-identical to the two-launch path (MPOSE_TAIL_FUSE=0)
         self.tail_fuse = os.environ.get('MPOSE_TAIL_FUSE', '1') != '0'
@@ -566,6 +567,8 @@ class Engine:
                 jobs_h2[2 * i + d]['layout'] = 3
         # [0] conv_igemm_k, six bf16 products; [1] plane engine; [2] conv_igemm_k, three fp16 products; [3] the same + the H2 engine
         self._pack_jobs = tuple(_jobs_to_device(j, device) for j in (jobs, jobs_p, jobs_h, jobs_h2))
+        # (the forward and the data-gradient job of a convolution read the same weight and share its amax slot: measured once)
+        self._amax_jobs = tuple(_jobs_to_device(np.ascontiguousarray(j[0::2]), device) for j in (jobs, jobs_p, jobs_h, jobs_h2))
         self._packed_for = None      # which of the three the packed arena currently holds
         self._pack_max = mx
         self._tables = {}
@@ -1009,7 +1012,7 @@ class Engine:
     def pack_weights(self, cmode):
         jobs = self._pack_jobs[cmode]
         if cmode in (2, 3):
-            check(lib().mpose_weights_absmax(ptr(jobs), 2 * len(self._convs), stream_ptr()), 'mpose_weights_absmax')
+            check(lib().mpose_weights_absmax(ptr(self._amax_jobs[cmode]), len(self._convs), stream_ptr()), 'mpose_weights_absmax')
         check(lib().mpose_pack_weights(ptr(jobs), 2 * len(self._convs), self._pack_max, stream_ptr()), 'mpose_pack_weights')
         self._packed_for = cmode
 

@@ -559,3 +559,48 @@ def test_split_k_launch_plan_in_a_fresh_process():
                            env=env, capture_output=True, text=True, timeout=600, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         assert r.returncode == 0, plan + r.stdout[-2000:] + r.stderr[-2000:]
         assert ' passed' in r.stdout
+
+
+@pytest.mark.parametrize('layout', [2, 3])
+@pytest.mark.parametrize('cout,cin,T,transposed', [(128, 128, 9, False), (192, 128, 9, True), (17, 128, 9, False), (128, 51, 1, False),
+                                                   (96, 64, 7, False), (64, 160, 1, True), (32, 27, 1, False), (64, 3, 49, False)])
+def test_packed_weight_layouts_bit_for_bit(layout, cout, cin, T, transposed):
+    """mpose_pack_weights, layouts 2 and 3 of include/margipose_hip.h, against a numpy statement of them: [T][Kpad/16][h, l][Npad][2][8]
+    (layout 3: [T][Kpad/16][h, l][2][Npad][8]) fp16 of w * 2^k, h = rn16(w 2^k), l = rn16(w 2^k - h), k from the tensor's largest
+    magnitude -- for the forward view of Conv2d / ConvTranspose2d weights (round 5's tiled packer: source-order reads, an LDS turn,
+    16-byte fragment stores) and a 49-tap case the element-wise packer keeps."""
+    import numpy as np
+    from margipose_amd import _lib, engine as eng
+    L = _lib.lib()
+    rng = np.random.default_rng(cout * 1000 + cin * 10 + T)
+    shape = (cin, cout, T) if transposed else (cout, cin, T)
+    w_np = (rng.standard_normal(shape) * rng.choice([1e-3, 1.0, 30.0])).astype(np.float32)
+    w = torch.from_numpy(w_np).cuda()
+    npad = (cout + 63) // 64 * 64
+    kpad = (cin + 31) // 32 * 32
+    packed = torch.full((T * kpad * npad,), float('nan'), dtype=torch.float32, device='cuda')      # 2 planes x 2 bytes = 4 bytes per element
+    amax = torch.zeros(1, dtype=torch.float32, device='cuda')
+    jobs = np.zeros(1, dtype=eng.PACK_DT)
+    j = jobs[0]
+    j['src'], j['dst'], j['amax'] = w.data_ptr(), packed.data_ptr(), amax.data_ptr()
+    j['N'], j['K'], j['T'], j['Npad'], j['Kpad'], j['layout'] = cout, cin, T, npad, kpad, layout
+    j['sn'], j['sk'], j['st'] = (T, cout * T, 1) if transposed else (cin * T, T, 1)
+    dev = eng._jobs_to_device(jobs, 'cuda')
+    _lib.check(L.mpose_weights_absmax(_lib.ptr(dev), 1, _lib.stream_ptr()), 'weights_absmax')
+    _lib.check(L.mpose_pack_weights(_lib.ptr(dev), 1, T * kpad * npad, _lib.stream_ptr()), 'pack')
+    torch.cuda.synchronize()
+    assert float(amax) == float(np.abs(w_np).max())
+    e = (np.float32(np.abs(w_np).max()).view(np.uint32) >> 23) & 0xff
+    k = 141 - int(min(max(e, 27), 254))
+    wnk = np.zeros((npad, kpad, T), np.float32)                       # [n][k][t], zero padded
+    wnk[:cout, :cin] = w_np.transpose(1, 0, 2) if transposed else w_np
+    vs = wnk * np.float32(2.0 ** k)
+    h = vs.astype(np.float16)
+    l = (vs - h.astype(np.float32)).astype(np.float16)
+    pl = np.stack([h, l], 0).reshape(2, npad, kpad // 16, 2, 8, T)     # [plane][n][k16][half][8][t]
+    if layout == 2:
+        want = pl.transpose(5, 2, 0, 1, 3, 4)                           # [t][k16][plane][n][half][8]
+    else:
+        want = pl.transpose(5, 2, 0, 3, 1, 4)                           # [t][k16][plane][half][n][8]
+    got = packed.cpu().numpy().view(np.float16).reshape(want.shape)
+    assert np.array_equal(got.view(np.uint16), np.ascontiguousarray(want).view(np.uint16))
