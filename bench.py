@@ -315,6 +315,23 @@ def inference_microbench(model, device, size):
             model(x)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        # the same forward from a launch plan (train_helpers.PlannedInference): no Python between its ~250 launches
+        planned_ips, plan_note = None, None
+        try:
+            from margipose_amd.train_helpers import PlannedInference
+            pf = PlannedInference(model, x)
+            for _ in range(2):
+                pf()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                pf()
+            torch.cuda.synchronize()
+            planned_ips = 64 * n / (time.perf_counter() - t0)
+            plan_note = '%d launches re-issued from one C loop' % pf.n_launches
+            del pf
+        except Exception as e:
+            plan_note = 'recording failed: %s: %s' % (type(e).__name__, e)
         model.heatmap_dtype = torch.bfloat16       # configs[1] as worded: bf16 heatmap storage + fp32 soft-argmax
         for _ in range(2):
             model(x)
@@ -328,6 +345,7 @@ def inference_microbench(model, device, size):
     model.train()
     return {'images_per_sec': 64 * n / dt, 'batch': 64, 'ms_per_forward': 1e3 * dt / n, 'dtype': 'f32',
             'images_per_sec_bf16_heatmaps': 64 * n / dt16,
+            'images_per_sec_launch_plan': planned_ips, 'launch_plan': plan_note,
             'note': 'eval-mode forward (running-stat BatchNorm), heatmaps + coordinates for all stages; the bf16 figure stores '
                     'the heatmaps as bf16 (fp32 convolutions and soft-argmax): they are <1% of the bytes, so it is the same rate'}
 

@@ -12,6 +12,11 @@ HIPCC_FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++20', '-fPIC', '-Wall', '
                '-Wno-unused-variable', '-Wno-unused-but-set-variable', '-fno-slp-vectorize']
 
 
+# per-source extra flags.  tail.hip: no fusion of a multiply and an add that the source keeps apart (the soft-argmax row arithmetic is
+# shared by two kernels whose results must agree bit for bit; see the comment above row_softmax there)
+EXTRA_FLAGS = {'tail.hip': ['-ffp-contract=on']}
+
+
 def _hipcc():
     exe = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
     if not os.path.exists(exe):
@@ -45,7 +50,7 @@ def build(force=False, verbose=False):
         if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), t_hdr):
             objs.append(obj)
             continue
-        cmd = [_hipcc()] + HIPCC_FLAGS + ['-Rpass-analysis=kernel-resource-usage', '-c', src, '-o', obj]
+        cmd = [_hipcc()] + HIPCC_FLAGS + EXTRA_FLAGS.get(os.path.basename(src), []) + ['-Rpass-analysis=kernel-resource-usage', '-c', src, '-o', obj]
         if verbose:
             print(' '.join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

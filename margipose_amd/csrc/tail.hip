@@ -119,8 +119,12 @@ __device__ __forceinline__ void elem_hw(const RowGeom& g, int i, int lane, int& 
 }
 
 // The row arithmetic of flat_softmax (dsntnn.py:124-130) and dsnt (dsntnn.py:84-96), shared by softmax_dsnt_fwd_k and
-// bn_add_softmax_k.  Every multiply-add is spelled out (fmaf / __fmul_rn / __fadd_rn) so that the compiler's contraction choices
-// cannot differ between the kernels that inline it: their heatmaps and coordinates are bit-identical by construction.
+// bn_add_softmax_k.  This FILE is compiled with -ffp-contract=on (margipose_amd/build.py): under hipcc's default, `fast`, the
+// backend fuses any multiply with any add it meets, whatever the source says -- __fmul_rn / __fadd_rn are plain operators to it -- and
+// it turned `x * rs + y * rs` into fma(x, rs, y * rs) in one of the two kernels and not in the other (round 5: the last bit of 15 % of
+// the coordinates differed; a `#pragma clang fp contract(off)` does not reach the backend's fusion).  With `on` only a source
+// expression `a * b + c` is fused (and the explicit fmaf calls): the two kernels run the same roundings, heatmaps and coordinates are
+// bit-identical (tests/test_tail_gpu.py::test_fused_residual_sum_softmax_is_bit_identical).
 template <int NV>
 __device__ __forceinline__ void row_softmax(float4 (&v)[NV]) {
   float m = -INFINITY;
@@ -353,11 +357,27 @@ __device__ __forceinline__ float js_term(float p, float gq) {
   const float lg = logf((gq + kEps) / (m + kEps));
   return 0.5f * (p * lp + gq * lg);
 }
+// The forward VALUE of the same integrand with the hardware's reciprocal and log2 (v_rcp_f32 / v_log_f32, ~1 ulp each): the ratio is
+// formed first, so the log's argument is right to 2^-23 and the term to ~1e-7 absolute -- the loss value feeds no gradient (the
+// backward recomputes its own terms from the heatmaps with js_dp's exact forms), and at ~15 instead of ~90 instructions per element
+// the forward loss kernel is bound by its bytes, not by its transcendentals (round 5: 270 -> ~100 us at B = 2048).
+__device__ __forceinline__ float js_term_fast(float p, float gq) {
+  const float m = 0.5f * (p + gq);
+  const float rm = __builtin_amdgcn_rcpf(m + kEps);
+  const float lp = __builtin_amdgcn_logf((p + kEps) * rm) * 0.69314718055994530942f;
+  const float lg = __builtin_amdgcn_logf((gq + kEps) * rm) * 0.69314718055994530942f;
+  return 0.5f * (p * lp + gq * lg);
+}
 __device__ __forceinline__ float js_dp(float p, float gq) {
   const float m = 0.5f * (p + gq);
   const float lp = logf((p + kEps) / (m + kEps));
   return 0.5f * (lp + p / (p + kEps) - m / (m + kEps));
 }
+
+#ifndef MPOSE_FAST_LOSS_VALUE
+#define MPOSE_FAST_LOSS_VALUE 1
+#endif
+constexpr bool kFastLossValue = MPOSE_FAST_LOSS_VALUE != 0;      // (stage_loss_fwd_k's JS terms; 0: the exact forms, as the gradient uses)
 
 struct LossArgs {
   const float* hm[MPOSE_MAX_GROUP];
@@ -422,7 +442,7 @@ __global__ __launch_bounds__(64 * MPOSE_MAX_GROUP) void stage_loss_fwd_k(LossArg
         if (a.pixelwise && (i * 64 + lane) < g.n4) {
           float gxv = gx_fixed[c];
           if (!fixed_cols) { const float d = x - q.tx; gxv = expf(d * d * q.kx); }
-          js += js_term(pv[c], gy * gxv);
+          js += kFastLossValue ? js_term_fast(pv[c], gy * gxv) : js_term(pv[c], gy * gxv);
         }
       }
     }

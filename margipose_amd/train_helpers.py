@@ -433,6 +433,78 @@ class PlannedTrainStep:
             pass
 
 
+class PlannedInference:
+    """`model(x)` in eval mode under torch.no_grad() (reference bin/infer_single.py:66, bin/eval_3d.py:61) recorded once as a launch
+    plan and re-issued from one C loop, like PlannedTrainStep: the forward's ~250 launches for a fraction of a millisecond of host
+    time.  Returns the recorded output tensor (coordinates); `model.xy_heatmaps / zy_heatmaps / xz_heatmaps` are the recorded
+    heatmap tensors and follow the replays.  The model's weights and running statistics may change between calls (they are read at
+    replay time), its shapes, modes (`heatmap_dtype`, `conv_dtype`) and device may not."""
+
+    def __init__(self, model, x, warmup=2):
+        import ctypes
+        if model.training:
+            raise _lib.MposeError('PlannedInference records an eval-mode forward: call model.eval() first')
+        self.model = model
+        self.x = x.clone()
+        self._plan = None
+        with torch.no_grad():
+            for _ in range(max(1, warmup)):
+                model(self.x)
+        torch.cuda.synchronize()
+        L = _lib.lib()
+        eng = model.inner.engine() if hasattr(model, 'inner') else model.engine()
+        self._sides = [s for s in (eng.fwd_side_stream,) if s is not None]
+        dev = x.device.index if x.device.index is not None else torch.cuda.current_device()
+        self._pool = torch.cuda.MemPool()
+        arr = self._stream_array()
+        torch._C._cuda_beginAllocateToPool(dev, self._pool.id)
+        try:
+            _lib.check(L.mpose_plan_begin(arr, len(arr)), 'mpose_plan_begin')
+            try:
+                with torch.no_grad():
+                    self.out = model(self.x)
+                self._heatmaps = tuple(getattr(model, k, None) for k in ('xy_heatmaps', 'zy_heatmaps', 'xz_heatmaps'))
+            except BaseException:
+                L.mpose_plan_abort()
+                raise
+            plan = ctypes.c_void_p()
+            _lib.check(L.mpose_plan_end(ctypes.byref(plan)), 'mpose_plan_end (a launch went to a stream outside the plan?)')
+            self._plan = plan
+        finally:
+            torch._C._cuda_endAllocateToPool(dev, self._pool.id)
+            torch._C._cuda_releasePool(dev, self._pool.id)
+        n = [ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)]
+        L.mpose_plan_size(self._plan, ctypes.byref(n[0]), ctypes.byref(n[1]), ctypes.byref(n[2]))
+        self.n_launches, self.n_waits = n[0].value, n[1].value
+        torch.cuda.synchronize()
+
+    def _stream_array(self):
+        import ctypes
+        streams = [torch.cuda.current_stream()] + self._sides
+        return (ctypes.c_void_p * len(streams))(*[s.cuda_stream for s in streams])
+
+    def __call__(self, x=None):
+        import ctypes
+        if x is not None:
+            self.x.copy_(x, non_blocking=True)
+        arr = self._stream_array()
+        nxt = ctypes.c_int(0)
+        _lib.check(_lib.lib().mpose_plan_replay(self._plan, arr, len(arr), 0, ctypes.byref(nxt)), 'mpose_plan_replay')
+        for k, v in zip(('xy_heatmaps', 'zy_heatmaps', 'xz_heatmaps'), self._heatmaps):      # (an eager forward in between re-bound them)
+            if v is not None:
+                setattr(self.model, k, v)
+        return self.out
+
+    def __del__(self):
+        try:
+            if self._plan is not None:
+                torch.cuda.synchronize()
+                _lib.lib().mpose_plan_destroy(self._plan)
+                self._plan = None
+        except Exception:
+            pass
+
+
 class BatchStager:
     """Host -> device staging of training batches (reference bin/train_3d.py:158-161: `batch['input'].to(device, float32)`,
     `batch['target']...`, `batch['joint_mask']...`, synchronous and from pageable memory), done the way the device wants it:

@@ -59,3 +59,27 @@ def test_graft_entry_build_runs():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     mod.build()
+
+
+def test_launch_plan_lifecycle_without_a_device():
+    """csrc/plan.hip's host side needs no GPU until something is launched: begin / recording / break / end / size / replay of an
+    empty plan / destroy, one recording at a time, end without begin refused."""
+    from margipose_amd import build
+    lib = ctypes.CDLL(build.build())
+    streams = (ctypes.c_void_p * 2)(None, ctypes.c_void_p(8).value)
+    plan = ctypes.c_void_p()
+    assert lib.mpose_plan_recording() == 0
+    assert lib.mpose_plan_end(ctypes.byref(plan)) != 0                  # nothing is being recorded
+    assert lib.mpose_plan_begin(streams, 2) == 0
+    assert lib.mpose_plan_recording() == 1
+    assert lib.mpose_plan_begin(streams, 2) != 0                        # one recording at a time
+    assert lib.mpose_plan_break() == 0
+    assert lib.mpose_plan_end(ctypes.byref(plan)) == 0 and plan.value
+    assert lib.mpose_plan_recording() == 0
+    n = [ctypes.c_int(-1) for _ in range(3)]
+    assert lib.mpose_plan_size(plan, ctypes.byref(n[0]), ctypes.byref(n[1]), ctypes.byref(n[2])) == 0
+    assert [v.value for v in n] == [0, 0, 1]
+    nxt = ctypes.c_int(-1)
+    assert lib.mpose_plan_replay(plan, streams, 3, 0, ctypes.byref(nxt)) != 0      # stream count differs from the recording's
+    assert lib.mpose_plan_destroy(plan) == 0
+    assert lib.mpose_plan_begin(streams, 2) == 0 and lib.mpose_plan_abort() == 0 and lib.mpose_plan_recording() == 0

@@ -70,13 +70,14 @@ def mask_flips(a, b):
 
 
 @pytest.mark.parametrize('T,B,engine', [(1, 2, 'auto'), (2, 2, 'auto'), (1, 8, 'auto'), (1, 2, 'planes'), (1, 2, 'bf16x6'), (1, 2, 'igemm'),
-                                        (1, 2, 'h2split'), (1, 3, 'h2fuse2'), (1, 2, 'inceptionv4')])
+                                        (1, 2, 'h2split'), (1, 3, 'h2fuse2'), (1, 2, 'h2fuse1'), (1, 2, 'inceptionv4')])
 def test_grads_on_the_same_relu_piece(T, B, engine):
     """engine 'auto' = what training runs by default (three fp16 products: conv_h2r_k on producer-split planes for the regular
     128-channel blocks with the residual sum writing the next block's planes under an a-priori bound, conv_igemm_k elsewhere, the
     row-of-taps weight gradient); 'igemm' = conv_igemm_k everywhere (round 3's default); 'h2split' = the H2 engine with every operand
     measured and split by mpose_split_h2; 'h2fuse2' = also the BatchNorm-backward application writing its planes under the
-    coefficient kernel's bound (odd batch: ragged tiles); 'planes'
+    coefficient kernel's bound (odd batch: ragged tiles; since round 5 this is what 'auto' runs) and 'h2fuse1' = round 4's default, the
+    residual sum alone writing planes; 'planes'
     forces the plane engine (conv_planes_k: pre-split operands, six bf16 products, two accumulators) through the same step;
     'bf16x6' = conv_igemm_k / conv_wgrad_k with six bf16 products (round 1's arithmetic).  (Three stages on a common piece: the
     configuration-size test below.  The free-running fp64 pass -- how many ReLU sites sit on another piece, and what that alone
@@ -104,6 +105,9 @@ def test_grads_on_the_same_relu_piece(T, B, engine):
     elif engine == 'h2fuse2':
         m.inner.engine().h2_fuse = 2
         tag += '_h2fuse2'
+    elif engine == 'h2fuse1':
+        m.inner.engine().h2_fuse = 1
+        tag += '_h2fuse1'
     gpu, masks, loss_gpu, _ = gpu_step(m, x, target, mask)
     ref64, loss64 = oracle_grads(sd, T, x, target, mask, torch.float64, masks=masks)
     ref32, _ = oracle_grads(sd, T, x, target, mask, torch.float32, masks=masks)

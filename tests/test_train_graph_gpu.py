@@ -152,6 +152,42 @@ def test_training_iteration_launches_only_library_kernels():
     assert not foreign, foreign
 
 
+@pytest.mark.parametrize('bf16', [False, True])
+def test_planned_inference_equals_eager_forward(bf16):
+    """train_helpers.PlannedInference: the eval-mode forward recorded as a launch plan returns, for new inputs and after the weights
+    changed, exactly what the eager forward returns (coordinates and every stage's heatmaps), fp32 and bf16 heatmap storage; and the
+    eager forward it records launches only library kernels."""
+    from torch.profiler import ProfilerActivity, profile
+    from margipose_amd.train_helpers import PlannedInference
+    T, seed, B = 2, 57, 3
+    xs = [W.seeded_inputs(seed + i, B)[0].cuda() for i in range(3)]
+    m = _model(T, seed, xs[0].cpu(), 'inceptionv4').eval()
+    if bf16:
+        m.heatmap_dtype = torch.bfloat16
+    with torch.no_grad():
+        m(xs[0])
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            m(xs[0])
+            torch.cuda.synchronize()
+    names = [e.name for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA]
+    assert len(names) > 50 and not sorted(set(n for n in names if 'mpose' not in n)), sorted(set(n for n in names if 'mpose' not in n))
+    pf = PlannedInference(m, xs[0])
+    assert pf.n_launches > 50
+    for it, x in enumerate(xs):
+        if it == 2:          # the weights may move between calls: they are read at replay time
+            with torch.no_grad():
+                for p in m.parameters():
+                    p.mul_(1.01)
+        got = pf(x).clone()
+        got_hm = [h.clone() for h in m.xy_heatmaps + m.zy_heatmaps + m.xz_heatmaps]
+        with torch.no_grad():
+            want = m(x)
+        want_hm = m.xy_heatmaps + m.zy_heatmaps + m.xz_heatmaps
+        assert torch.equal(got, want)
+        assert len(got_hm) == len(want_hm) and all(torch.equal(a, b) for a, b in zip(got_hm, want_hm))
+        assert want_hm[0].dtype == (torch.bfloat16 if bf16 else torch.float32)
+
+
 def test_batch_stager_pinned_double_buffer():
     """train_helpers.BatchStager (reference bin/train_3d.py:158-161 done with pinned double buffers on a copy stream): values
     arrive intact for float and uint8 frames, slots rotate, and the consumer needs no host synchronisation."""
