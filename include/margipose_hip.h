@@ -329,7 +329,7 @@ int mpose_pack_weights(const mpose_pack_job* jobs_dev, int n_jobs, int max_elems
                        void* stream);
 
 typedef struct {
-  const float* src;                    /* packed partial sums (n_split, T, Kpad/4, Npad, 4) */
+  const float* src;                    /* packed partial sums (n_split, T, Kpad/4, Npad, 4), 16-byte aligned */
   float* dst;                          /* torch-layout gradient */
   int N, K, T, Npad, Kpad, n_split;
   int64_t sn, sk, st;

@@ -18,6 +18,8 @@
 namespace mpose {
 namespace {
 
+constexpr int kPartSplit = 6;      // workgroups per job of the partial-row finalize / coefficient launches
+
 // 256 threads per job, or 1024 when the statistics arrive as per-workgroup partial rows (MPOSE_CONV_STATS_PART: a 128-channel
 // job then sums 256 rows with eight row slices of 128 channel lanes, 32 rows per thread, eight loads in flight)
 __global__ __launch_bounds__(1024) void bn_finalize_k(const mpose_bn_job* __restrict__ jobs, int train, float eps, float momentum) {
@@ -353,7 +355,8 @@ extern "C" int mpose_sizeof(int which) {
 // train: bit 0 = batch statistics; bit 1 = the jobs carry MPOSE_CONV_STATS_PART rows (1024 threads per job); bit 2 = write the jobs' bounds
 extern "C" int mpose_bn_finalize(const mpose_bn_job* jobs_dev, int n_jobs, int train, float eps, float momentum, void* stream) {
   if (n_jobs <= 0) return 0;
-  if (train & 2) launch(bn_finalize_k, dim3(dim3(n_jobs, 4)), dim3(1024), 0, (hipStream_t)stream, jobs_dev, train & 7, eps, momentum);
+  // (six workgroups share a job's channels in 32-channel granules: one granule each for the 192-channel layers, four busy for 128)
+  if (train & 2) launch(bn_finalize_k, dim3(dim3(n_jobs, kPartSplit)), dim3(1024), 0, (hipStream_t)stream, jobs_dev, train & 7, eps, momentum);
   else launch(bn_finalize_k, dim3(n_jobs), dim3(256), 0, (hipStream_t)stream, jobs_dev, train & 7, eps, momentum);
   return launch_status();
 }
@@ -439,7 +442,7 @@ extern "C" int mpose_bn_bwd_reduce_ws(const mpose_bn_bwd_reduce_operands* ops, i
 // bit 3 = write the jobs' bounds (bound_out)
 extern "C" int mpose_bn_bwd_coef(const mpose_bn_bwd_coef_job* jobs_dev, int n_jobs, int mode, void* stream) {
   if (n_jobs <= 0) return 0;
-  if (mode & 4) launch(bn_bwd_coef_k, dim3(dim3(n_jobs, 4)), dim3(1024), 0, (hipStream_t)stream, jobs_dev, mode & 11);
+  if (mode & 4) launch(bn_bwd_coef_k, dim3(dim3(n_jobs, kPartSplit)), dim3(1024), 0, (hipStream_t)stream, jobs_dev, mode & 11);
   else launch(bn_bwd_coef_k, dim3(n_jobs), dim3(256), 0, (hipStream_t)stream, jobs_dev, mode & 11);
   return launch_status();
 }

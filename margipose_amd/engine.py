@@ -53,8 +53,13 @@ COEF_DT = np.dtype([('sums', 'u8'), ('gamma', 'u8'), ('mean', 'u8'), ('invstd', 
 
 # Weight-gradient pixel splits sized for the workgroups that share a CU (the narrow row-of-taps tiles run three per CU): alone, the
 # feature extractor's 32-channel layers go 245 -> 148 us and the columns' 17-joint block 57 -> 41 us, but in the step the wider launches
-# crowd the main stream's convolutions out of the CUs they share (23.51 -> 23.85 ms, tools/ab_sweep.sh): off by default.
-_WG_OCC = os.environ.get('MPOSE_WG_OCC', '0') != '0'
+# crowd the main stream's convolutions out of the CUs they share (23.51 -> 23.85 ms, tools/ab_sweep.sh): off by default ('1' = all).
+# '2': only the feature extractor's full-resolution layers (>= 128 x 128 slots, one column), whose weight gradients END the side
+# stream's chain while the main stream waits (profiles/r5_step_listing.txt): also slower, 23.10 against 23.02 ms (r5_ab_sweeps.txt).
+_WG_OCC = int(os.environ.get('MPOSE_WG_OCC', '0'))
+# The columns' weight pack on the side stream during the feature extractor's forward (Engine.pack_weights): bit-identical, and no
+# gain -- 23.10 against 23.11 ms: the pack and the extractor's 128 x 128 layers are both HBM-bound (r5_ab_sweeps.txt).  Off.
+_PACK_SIDE = os.environ.get('MPOSE_PACK_SIDE', '0') != '0'
 _WG_FIXED = float(os.environ.get('MPOSE_WG_FIXED', '3.0'))     # fixed per-workgroup cost of a weight-gradient launch, in 128-pixel row units (Engine._n_split)
 AMAX_SLOT = 16 * 64          # floats per activation amax slot (MPOSE_AMAX_SUBSLOTS * MPOSE_AMAX_STRIDE)
 _SIZES_CHECKED = False
@@ -355,6 +360,8 @@ class Engine:
             self.stem_bn = _BN(inner.in_cnn[1], 128, 128)
             self._convs = [self.stem_conv] + block_convs
             self._bns = [self.stem_bn] + block_bns
+        self._n_stem_convs = len(self.stem.convs) if self.stem is not None else 1      # (first in self._convs: pack_weights' split)
+        self._pack_join = False
         self._geoms = {}
         self._tables = {}
         self._arena_key = None
@@ -1000,7 +1007,10 @@ class Engine:
                 raise _lib.MposeError('mpose_conv_wgrad_tiles rejected the geometry %s' % getattr(g, '_name', '?'))
             slots = g.B * g.GH * (32 if width32 else g.GW)
             d = max(1, int(lib().mpose_conv_wgrad_phases(ctypes.byref(g))))       # x-dilated kernels: d launches, n_split / d each
-            occ = max(1, int(lib().mpose_conv_wgrad_occupancy(ctypes.byref(g)))) if _WG_OCC else 1
+            occ_on = _WG_OCC == 1 or (_WG_OCC == 2 and groups == 1 and g.GH * g.GW >= 128 * 128)
+            occ = max(1, int(lib().mpose_conv_wgrad_occupancy(ctypes.byref(g)))) if occ_on else 1
+            if occ_on and occ == 1 and tiles * groups <= 2:
+                occ = 4        # (a one-tile launch of conv_wgrad_k -- the image's 27 -> 32 channel layer: 64 pixel splits were 64 workgroups)
             nsp = g._n_split = d * self._n_split(slots // d, tiles, groups, occ)
         return nsp
 
@@ -1009,12 +1019,42 @@ class Engine:
         check(lib().mpose_bn_finalize(c_void_p(base), n, int(train) | (2 if (part and train) else 0) | (4 if (bounds and train) else 0),
                                       ctypes.c_float(BN_EPS), ctypes.c_float(BN_MOMENTUM), stream_ptr()), 'mpose_bn_finalize')
 
-    def pack_weights(self, cmode):
-        jobs = self._pack_jobs[cmode]
-        if cmode in (2, 3):
-            check(lib().mpose_weights_absmax(ptr(self._amax_jobs[cmode]), len(self._convs), stream_ptr()), 'mpose_weights_absmax')
-        check(lib().mpose_pack_weights(ptr(jobs), 2 * len(self._convs), self._pack_max, stream_ptr()), 'mpose_pack_weights')
+    def pack_weights(self, cmode, overlap=False):
+        """Measure (three-product form) and pack every convolution weight for engine `cmode`.  overlap=True (a forward with a graph
+        feature extractor in front of the stages): the columns' share -- 90 % of the bytes -- runs on the side stream while the
+        main stream packs the feature extractor's weights and runs it; join_pack() makes the main stream wait before the first
+        stage (0.27 ms of a step's serial head otherwise: profiles/r5_step_listing.txt)."""
+        n, ns = len(self._convs), self._n_stem_convs
+
+        def run(first, count):
+            if count <= 0:
+                return
+            if cmode in (2, 3):
+                check(lib().mpose_weights_absmax(c_void_p(self._amax_jobs[cmode].data_ptr() + first * PACK_DT.itemsize), count, stream_ptr()),
+                      'mpose_weights_absmax')
+            check(lib().mpose_pack_weights(c_void_p(self._pack_jobs[cmode].data_ptr() + 2 * first * PACK_DT.itemsize), 2 * count, self._pack_max,
+                                           stream_ptr()), 'mpose_pack_weights')
+
+        side_ok = (overlap and _PACK_SIDE and self.overlap_wgrad and 0 < ns < n and (self.timer is None or self.timer.selective)
+                   and (self.dp is None or self.dp_overlap()))
+        if side_ok:
+            main = torch.cuda.current_stream()
+            if self.side_stream is None or self.side_stream.device != main.device:
+                self.side_stream = torch.cuda.Stream(device=main.device, priority=int(os.environ.get('MPOSE_SIDE_PRIO', '0')))
+            _lib.stream_wait(self.side_stream, main)       # (the optimiser's update of the weights is on the main stream)
+            with torch.cuda.stream(self.side_stream):
+                run(ns, n - ns)
+            run(0, ns)
+            self._pack_join = True
+        else:
+            run(0, n)
         self._packed_for = cmode
+
+    def join_pack(self):
+        """The main stream waits for the columns' packed weights (pack_weights(overlap=True)); no-op otherwise."""
+        if self._pack_join:
+            _lib.stream_wait(torch.cuda.current_stream(), self.side_stream)
+            self._pack_join = False
 
     # ------------------------------------------------------------------ forward
     def forward(self, x, train, save, hm_bf16=False, features=None):
@@ -1076,7 +1116,7 @@ class Engine:
         # statistics as per-workgroup partial rows (MPOSE_CONV_STATS_PART) instead of fp64 atomics: conv_igemm_k / conv_h2_k only
         spart = ctx['spart'] = bool(train and self.part_stats() and not planes)
         sp = tb['sp_ptr']
-        self.pack_weights(cmode)
+        self.pack_weights(cmode, overlap=self.stem is not None and features is None)
         if f16:
             _lib.fill_zero(self.amax_f)        # (fills through the library: a launch plan records them, csrc/plan.hip)
         if train:
@@ -1113,6 +1153,7 @@ class Engine:
                                       ptr(inp), c_int64(inp.numel()), 128, st()), 'mpose_bn_relu_fwd')
             ctx['s2d'], ctx['stem_raw'], ctx['stem_out'] = s2d, stem_raw, inp
         ctx['inps'] = []
+        self.join_pack()
 
         hms = [[], [], []]
         xyz = None

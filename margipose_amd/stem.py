@@ -25,6 +25,7 @@ restated from the published architecture (He et al. 2015; torchvision's v1.5 Bot
 and, like the InceptionV4 stem, can only be checked against this repo's oracle restatement (parity unpinned).
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -33,6 +34,8 @@ from torch import nn
 from . import _lib
 from ._lib import (BnAddOperands, BnBwdApplyOperands, BnBwdReduceOperands, ConvOperands, WgradOperands, c_int64, c_void_p, check, lib, ptr,
                    stream_ptr)
+
+_FIRST_WRITES = os.environ.get('MPOSE_STEM_FIRST_WRITES', '1') != '0'      # (0: every node gradient starts from a zero fill: A/B runs)
 
 BN_EPS_STEM = 1e-3        # BasicConv2d's BatchNorm2d(eps=0.001)
 
@@ -368,6 +371,13 @@ class _GraphStem:
         self._geoms[key] = g
         return g
 
+    @staticmethod
+    def _d_covers(op):
+        """True when the data-gradient launch of `op` stores every element of the source node's gradient (so that the first
+        contribution needs no zero fill): a plain Conv2d whose kernel is at least as wide as its stride on both axes."""
+        return (not op.transposed and not op.flat and tuple(op.dilation) == (1, 1) and op.kh >= op.stride[0] and op.kw >= op.stride[1]
+                and op.cin == op.src.C)
+
     # ------------------------------------------------------------------ forward
     def forward(self, x, train, save, f16=False, features=None):
         """f16: the convolutions run the three-product fp16 form (engine.py); every node's largest consumer-side magnitude is
@@ -489,6 +499,7 @@ class _GraphStem:
         cflags = ctx.get('cflags', 32 if f16 else 0)
         if f16:
             _lib.fill_zero(self.amax_b)
+        fresh = set()         # nodes whose gradient tensor is allocated but not yet written
         if self.out_nodes is not None:
             dact = dict((n.name, g) for n, g in zip(self.out_nodes, D) if g is not None)
         else:
@@ -528,7 +539,14 @@ class _GraphStem:
                 Hs, Ws = src.hw(S)
                 want_dsrc = (not src.is_image) or need_dx
                 if want_dsrc and src.name not in dact:
-                    dact[src.name] = _lib.fill_zero(torch.empty(B, Hs, Ws, src.C, **f32))
+                    # the gradient of a node is the sum of its consumers' contributions: the first one WRITES it when it is a
+                    # convolution whose data-gradient launch covers every pixel of the source (every output phase has a tap:
+                    # kernel >= stride); anything else (pools accumulate; the image) starts from zeros
+                    dact[src.name] = torch.empty(B, Hs, Ws, src.C, **f32)
+                    if _FIRST_WRITES and isinstance(op, _ConvOp) and not src.is_image and self._d_covers(op):
+                        fresh.add(src.name)
+                    else:
+                        _lib.fill_zero(dact[src.name])
                 sc = None if src.is_image else self.fptr(src, 0)
                 sh = None if src.is_image else self.fptr(src, 1)
                 if isinstance(op, _ConvOp):
@@ -547,7 +565,8 @@ class _GraphStem:
                         o.out0 = dact[src.name].data_ptr()
                         if f16:
                             o.in_amax, o.w0_amax = n.amax_b, op.conv.amax_ptr
-                        eng.conv(self.geom(op, B, S, 'd'), [o], 1 | cflags)       # accumulate
+                        eng.conv(self.geom(op, B, S, 'd'), [o], (0 if src.name in fresh else 1) | cflags)       # (first contribution: write; later ones accumulate)
+                        fresh.discard(src.name)
                 elif want_dsrc and op.kind == 0:
                     ws = torch.empty(B * H * H * src.C, dtype=torch.uint8, device=dev)       # window arg-max positions
                     check(L.mpose_maxpool3_bwd_ws(ptr(raw[src.name]), c_void_p(sc), c_void_p(sh), c_void_p(d_raw.data_ptr() + 4 * op.c0),

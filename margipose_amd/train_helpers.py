@@ -453,7 +453,7 @@ class PlannedInference:
         torch.cuda.synchronize()
         L = _lib.lib()
         eng = model.inner.engine() if hasattr(model, 'inner') else model.engine()
-        self._sides = [s for s in (eng.fwd_side_stream,) if s is not None]
+        self._sides = [s for s in (eng.side_stream, eng.fwd_side_stream) if s is not None]      # (side_stream: the columns' weight pack)
         dev = x.device.index if x.device.index is not None else torch.cuda.current_device()
         self._pool = torch.cuda.MemPool()
         arr = self._stream_array()
