@@ -280,6 +280,10 @@ int mpose_conv_wgrad_tiles(const mpose_conv_geom* geom);
 /* Workgroups of that launch that share a CU (1, or 3 for the narrow tiles of the row-of-taps kernel): a round of the launch is
  * 256 * this many workgroups. */
 int mpose_conv_wgrad_occupancy(const mpose_conv_geom* geom);
+/* Waves per workgroup of that launch: 4, or 1 / 2 for the 32-channel tiles of the row-of-taps kernel (32 -> 32, 32 -> 64: the
+ * feature extractor's first layers) -- a workgroup there takes a quarter / half of a wide one's footprint, so the caller may
+ * split the pixels 4 / 2 times further for the same share of the chip. */
+int mpose_conv_wgrad_waves(const mpose_conv_geom* geom);
 
 /* d > 1: the geometry is a stride-1 convolution dilated by d along x (every tap's dx a multiple of d), whose weight gradient
  * mpose_conv_wgrad computes as d launches over the residues of x mod d -- IF n_split is a multiple of d; each residue then

@@ -1730,6 +1730,7 @@ int mpose_conv_h2_launch(const mpose_conv_geom* geom, const mpose_conv_operands*
                          int cmax, void* stream);          // conv_h.hip
 int mpose_wgrad_rows_units(const mpose_conv_geom* geom);                                                                       // wgrad.hip
 int mpose_wgrad_rows_launch(const mpose_conv_geom* geom, const mpose_wgrad_operands* ops, int n_groups, int n_split, void* stream);
+int mpose_wgrad_rows_waves(const mpose_conv_geom* geom);
 int mpose_wgrad_rows_occupancy(const mpose_conv_geom* geom);
 
 // in_mul_x / out_mul_x = 0 ("as along y") filled in: what the kernels and the checks below read
@@ -1970,6 +1971,17 @@ extern "C" int mpose_conv_wgrad_occupancy(const mpose_conv_geom* geom_) {
     if (x_phases(gn, &pg) > 1 && mpose_wgrad_rows_units(&pg)) return mpose_wgrad_rows_occupancy(&pg);
   }
   return 1;
+}
+
+extern "C" int mpose_conv_wgrad_waves(const mpose_conv_geom* geom_) {
+  if (check_geom(geom_)) return -1;
+  const mpose_conv_geom gn = normalised(geom_);
+  if (mpose_wgrad_rows_units(&gn)) return mpose_wgrad_rows_waves(&gn);
+  {
+    mpose_conv_geom pg;
+    if (x_phases(gn, &pg) > 1 && mpose_wgrad_rows_units(&pg)) return mpose_wgrad_rows_waves(&pg);
+  }
+  return 4;
 }
 
 extern "C" int mpose_conv_wgrad(const mpose_conv_geom* geom_, const mpose_wgrad_operands* ops, int n_groups, int n_split,

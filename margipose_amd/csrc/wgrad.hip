@@ -135,9 +135,9 @@ struct Cfg {
 };
 
 template <int WK, int WN, int KB, int NB, bool PRO, bool PAIR, bool X1>
-__global__ __launch_bounds__(64 * WK * WN, WK * WN / 4) void conv_wgrad_rows_k(WgRowsArgs a) {
+__global__ __launch_bounds__(64 * WK * WN, WK * WN >= 4 ? WK * WN / 4 : 2) void conv_wgrad_rows_k(WgRowsArgs a) {
   using C = Cfg<WK, WN, KB, NB>;
-  static_assert(C::NW == 4 || C::NW == 8, "one or two waves per SIMD");
+  static_assert(C::NW == 1 || C::NW == 2 || C::NW == 4 || C::NW == 8, "one or two waves per SIMD; one / two waves per workgroup for the 32-channel tiles");
   constexpr int KT = C::KT, NT = C::NT, QX = C::QX, QG = C::QG, NXI = C::NXI, NGI = C::NGI, NPX = C::NPX, PX = C::PX, PG = C::PG, NTH = C::NTH;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -548,8 +548,19 @@ int launch_rows(WgRowsArgs& a, hipStream_t s) {
 // 32 x 32), 3 = 64 x 64 (2x2 waves of 32 x 32).  MPOSE_WGRAD_192=1 (experiments) runs shapes 0 / 1 with EIGHT waves per workgroup
 // (two per SIMD; 2x4 waves of 64 x 32 / 96 x 32, tiles 128 x 128 / 192 x 128): measured slower -- 95 vs 88 us on the 128-channel
 // layers -- because eight waves read 1.75x the fragment bytes from LDS for the same MFMAs (profiles/r3_wgrad_loop_parts.txt).
+// 4 = 32 x 32 as ONE wave, 5 = 32 x 64 as two (round 5): the feature extractor's 32-channel layers at 128 x 128 ran shape 3 with
+// one / two of its four waves working -- a step of the kernel is latency-bound at that width (two octets staged per barrier), so
+// the launch's duration follows its number of workgroups, not their size: a quarter / half of the footprint per workgroup lets the
+// caller split the pixels 4x / 2x further on the same CUs (mpose_conv_wgrad_waves).
+inline bool narrow_env() {
+  static int v = -2;
+  if (v == -2) { const char* e = getenv("MPOSE_WGRAD_NARROW"); v = e ? atoi(e) : 1; }
+  return v != 0;
+}
 inline int rows_shape(int cin, int cout) {
   if (cin % 192 == 0 && cout % 64 == 0) return 1;
+  if (narrow_env() && cin <= 32 && cout <= 32) return 4;
+  if (narrow_env() && cin <= 32 && cout <= 64) return 5;
   if (cout <= 32) return cin > 64 ? 2 : 3;
   if (cin <= 64 && cout <= 64) return 3;
   return 0;
@@ -564,6 +575,8 @@ inline void shape_tiles(int shape, int& kt, int& nt) {
     case 1: kt = 192; nt = wide192() ? 128 : 64; break;
     case 2: kt = 128; nt = 32; break;
     case 3: kt = 64; nt = 64; break;
+    case 4: kt = 32; nt = 32; break;
+    case 5: kt = 32; nt = 64; break;
     default: kt = 128; nt = 128; break;
   }
 }
@@ -636,7 +649,13 @@ int mpose_wgrad_rows_units(const mpose_conv_geom* geom) {
 // run three per CU, the wide ones one.
 int mpose_wgrad_rows_occupancy(const mpose_conv_geom* geom) {
   const int shape = rows_shape(geom->Cin, geom->Cout0);
-  return (shape == 2 || shape == 3) ? 3 : 1;
+  return (shape >= 2 && shape <= 5) ? 3 : 1;
+}
+
+// Waves per workgroup of the row form for this geometry (4; 1 / 2 for the 32-channel tiles).
+int mpose_wgrad_rows_waves(const mpose_conv_geom* geom) {
+  const int shape = rows_shape(geom->Cin, geom->Cout0);
+  return shape == 4 ? 1 : (shape == 5 ? 2 : 4);
 }
 
 // Called by mpose_conv_wgrad (conv.hip) after it validated geometry and operands.  Returns MPOSE_ENOSYS when the row form does
@@ -672,6 +691,8 @@ int mpose_wgrad_rows_launch(const mpose_conv_geom* geom, const mpose_wgrad_opera
     case 1: return wide192() ? launch_rows<2, 4, 3, 1>(a, s) : launch_rows<2, 2, 3, 1>(a, s);
     case 2: return launch_rows<4, 1, 1, 1>(a, s);
     case 3: return launch_rows<2, 2, 1, 1>(a, s);
+    case 4: return launch_rows<1, 1, 1, 1>(a, s);
+    case 5: return launch_rows<1, 2, 1, 1>(a, s);
     default: return wide192() ? launch_rows<2, 4, 2, 1>(a, s) : launch_rows<2, 2, 2, 2>(a, s);
   }
 }

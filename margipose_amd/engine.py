@@ -371,6 +371,10 @@ class Engine:
         self.timer = None            # optional KernelTimer (bench.py)
         self._dp_works = []          # in-flight gradient all-reduces of the current backward pass (data parallel)
         self.side_stream = None      # weight-gradient GEMMs run here, off the data-gradient critical path
+        # True: the backward pass hands autograd views of the flat gradient buffer itself instead of a per-step copy of it (51 us for
+        # 178 MB at B = 32) -- the gradients are then valid until the NEXT backward pass overwrites them.  PlannedTrainStep sets it
+        # while it records: its iteration reads the gradients (the optimiser) before it runs the next backward.
+        self.grad_views = False
         self._side_keep = []         # tensors the side stream still reads (released at the next bucket boundary)
         # (measured: no faster -- the step is bound by the sum of the heavy kernels' work, not by the main stream's chain of launches -- off)
         self.fuse_finalize = os.environ.get('MPOSE_FUSE_FINALIZE', '0') != '0'
@@ -1009,8 +1013,13 @@ class Engine:
             d = max(1, int(lib().mpose_conv_wgrad_phases(ctypes.byref(g))))       # x-dilated kernels: d launches, n_split / d each
             occ_on = _WG_OCC == 1 or (_WG_OCC == 2 and groups == 1 and g.GH * g.GW >= 128 * 128)
             occ = max(1, int(lib().mpose_conv_wgrad_occupancy(ctypes.byref(g)))) if occ_on else 1
-            if occ_on and occ == 1 and tiles * groups <= 2:
-                occ = 4        # (a one-tile launch of conv_wgrad_k -- the image's 27 -> 32 channel layer: 64 pixel splits were 64 workgroups)
+            if occ == 1 and tiles * groups <= 2:
+                # a one-tile launch of conv_wgrad_k -- the image's 27 -> 32 channel layer, the LAST weight gradient of a step, which the
+                # main stream waits for with nothing left to run: 64 pixel splits were 64 workgroups (122 us)
+                occ = 4
+            waves = int(lib().mpose_conv_wgrad_waves(ctypes.byref(g)))
+            if 0 < waves < 4:
+                occ = max(occ, 4 // waves)     # one- / two-wave workgroups (the 32-channel tiles): 4 / 2 of them are one wide workgroup's footprint
             nsp = g._n_split = d * self._n_split(slots // d, tiles, groups, occ)
         return nsp
 

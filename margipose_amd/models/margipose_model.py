@@ -132,6 +132,8 @@ class _BackboneFn(torch.autograd.Function):
             flat = torch.empty_like(gflat)
             _lib.check(_lib.lib().mpose_copy_div_f32(_lib.ptr(gflat), _lib.ptr(flat), _lib.c_float(float(engine.dp[1])), _lib.c_int64(gflat.numel()),
                                                      _lib.stream_ptr()), 'mpose_copy_div_f32')
+        elif engine.grad_views:         # (PlannedTrainStep: the iteration's owner reads .grad before the next backward runs)
+            flat = gflat
         else:
             flat = _lib.copy_into(torch.empty_like(gflat), gflat)      # (a launch of the library: a launch plan records it)
         out = engine.grads_from_flat(flat)

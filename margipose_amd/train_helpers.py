@@ -356,8 +356,16 @@ class PlannedTrainStep:
         eng = model.inner.engine()
         self._one = torch.ones((), dtype=torch.float32, device=x.device)
         self._plan = None
-        for _ in range(max(1, warmup)):          # (creates the engine's arenas, job tables and side stream; raises kernels' LDS limits)
-            self._iteration()
+        # the recorded iteration's .grad tensors are views of the engine's flat gradient buffer (no per-step copy of it: the
+        # optimiser launch reads them before the next backward pass overwrites them); eager iterations afterwards copy again
+        views_before, eng.grad_views = eng.grad_views, True
+        self._restore_views = lambda: setattr(eng, 'grad_views', views_before)
+        try:
+            for _ in range(max(1, warmup)):      # (creates the engine's arenas, job tables and side stream; raises kernels' LDS limits)
+                self._iteration()
+        except BaseException:
+            self._restore_views()
+            raise
         torch.cuda.synchronize()
         L = _lib.lib()
         self._sides = [s for s in ((eng.side_stream if eng.overlap_wgrad else None), eng.fwd_side_stream) if s is not None]
@@ -383,6 +391,7 @@ class PlannedTrainStep:
             _lib.check(L.mpose_plan_end(ctypes.byref(plan)), 'mpose_plan_end (a launch went to a stream outside the plan?)')
             self._plan = plan
         finally:
+            self._restore_views()
             torch._C._cuda_endAllocateToPool(dev, self._pool.id)
             torch._C._cuda_releasePool(dev, self._pool.id)
         n = [ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)]

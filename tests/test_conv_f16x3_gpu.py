@@ -308,7 +308,10 @@ def _wgrad_errs(dw, x, go, fn, shape):
 
 @pytest.mark.parametrize('B,H,cin,cout,n_split,pro,gkind', [(2, 32, 128, 128, 3, False, 'normal'), (4, 16, 192, 192, 2, True, 'tiny'),
                                                          (1, 16, 64, 96, 1, False, 'heavy'), (3, 8, 32, 32, 4, True, 'normal'),
-                                                         (2, 24, 128, 64, 5, False, 'tiny'), (2, 16, 96, 128, 2, True, 'heavy')])
+                                                         (2, 24, 128, 64, 5, False, 'tiny'), (2, 16, 96, 128, 2, True, 'heavy'),
+                                                         # (the one- and two-wave workgroups of the 32-channel tiles; 24: an odd number of octets per row)
+                                                         (2, 16, 32, 64, 3, False, 'heavy'), (2, 24, 32, 32, 5, False, 'tiny'),
+                                                         (1, 24, 32, 64, 2, True, 'normal')])
 def test_weight_gradient_fp32_equivalent(B, H, cin, cout, n_split, pro, gkind):
     from margipose_amd import _lib, engine as eng
     L = _lib.lib()
