@@ -13,6 +13,7 @@
 //   (x is centred per element: folding -c1*mean into c2 makes c1*x + c2 a cancelling pair whose rounded constant is a
 //   per-channel BIAS on every pixel -- it showed up as a 3-5x excess on sums of dx over pixels, e.g. the shortcut BatchNorm's
 //   bias gradient one block further down, in the round-2 gradient-parity bisect.)
+#include <stdlib.h>
 #include "common.h"
 
 namespace mpose {
@@ -403,7 +404,10 @@ extern "C" int mpose_bn_bwd_reduce(const mpose_bn_bwd_reduce_operands* ops, int 
 static bool reduce_wide(int n_groups, int C) { return n_groups == 1 && C >= 256; }      // one wide BatchNorm (see bn_bwd_reduce_finish_k)
 
 static long reduce_ws_blocks(int n_groups, long npix, int C) {
-  const long cap = n_groups >= 3 ? 384 : (n_groups == 2 ? 512 : 1024);
+  // (one group that is not a wide BatchNorm -- the feature extractor's nodes: 256 workgroups, one per CU; with 1024 the finishing
+  //  pass walked four times the partials for nothing gained in the main one: -0.1 ... -0.17 ms per step, profiles/r5_ab_sweeps.txt)
+  static const long cap1 = [] { const char* e = getenv("MPOSE_REDUCE_CAP1"); return e ? atol(e) : 256L; }();      // (A/B runs)
+  const long cap = n_groups >= 3 ? 384 : (n_groups == 2 ? 512 : (reduce_wide(n_groups, C) ? 1024 : cap1));
   // (wide: a workgroup's pass covers 256 / (C/4) <= 4 pixel rows at a time; 32 pixels each keeps >= 4 workgroups per CU in flight)
   long blocks = reduce_wide(n_groups, C) ? (npix + 31) / 32 : (npix + 63) / 64;
   if (blocks > cap) blocks = cap;

@@ -60,6 +60,7 @@ _WG_OCC = int(os.environ.get('MPOSE_WG_OCC', '0'))
 # The columns' weight pack on the side stream during the feature extractor's forward (Engine.pack_weights): bit-identical, and no
 # gain -- 23.10 against 23.11 ms: the pack and the extractor's 128 x 128 layers are both HBM-bound (r5_ab_sweeps.txt).  Off.
 _PACK_SIDE = os.environ.get('MPOSE_PACK_SIDE', '0') != '0'
+_GFLAT_FILL = int(os.environ.get('MPOSE_GFLAT_FILL', '0'))
 _WG_FIXED = float(os.environ.get('MPOSE_WG_FIXED', '3.0'))     # fixed per-workgroup cost of a weight-gradient launch, in 128-pixel row units (Engine._n_split)
 AMAX_SLOT = 16 * 64          # floats per activation amax slot (MPOSE_AMAX_SUBSLOTS * MPOSE_AMAX_STRIDE)
 _SIZES_CHECKED = False
@@ -1492,7 +1493,15 @@ class Engine:
         f32 = dict(dtype=torch.float32, device=dev)
         J = self.J
         tb = self._tables_for(B, F)
-        _lib.fill_zero(self.gflat)
+        # When the last stage's heatmaps carry a gradient every stage runs, and every element of the flat gradient buffer a parameter
+        # owns is WRITTEN by this pass (weights: mpose_unpack_wgrads with accumulate = 0; BatchNorm: the coefficient kernels;
+        # combiners: mpose_reduce_partials): no zero fill then (24 us for 178 MB).  A stage without any gradient is skipped and
+        # its parameters keep the fill's zeros.  MPOSE_GFLAT_FILL=1 always fills, =2 fills with NaNs instead of skipping
+        # (test_every_gradient_element_is_written: no gradient may keep one)
+        if _GFLAT_FILL == 1 or all(g_hms[p][self.T - 1] is None for p in range(3)):
+            _lib.fill_zero(self.gflat)
+        elif _GFLAT_FILL == 2:
+            check(lib().mpose_fill_u32(c_void_p(self.gflat.data_ptr()), 0x7fc00000, c_int64(4 * self.gflat.numel()), stream_ptr()), 'mpose_fill_u32')
         _lib.fill_zero(self.stat_arena)        # forward sums are consumed (mean/invstd live in the float arena)
         goff = dict((id(p), o) for p, o in zip(self.param_list(), self._grad_offsets))
         coef_base = tb['coef'].data_ptr()

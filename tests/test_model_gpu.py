@@ -486,6 +486,29 @@ def test_unused_stage_gets_zero_grads():
 
 
 @pytest.mark.parametrize('stem', ['patch8', 'inceptionv4'])
+def test_every_gradient_element_is_written(stem, monkeypatch):
+    """The backward pass does not zero the flat gradient buffer when every stage runs (engine.py, MPOSE_GFLAT_FILL): with the
+    buffer poisoned with NaNs first, no parameter's gradient may keep one, and the gradients equal those of a zero-filled run
+    bit for bit."""
+    import copy
+    from margipose_amd import engine as eng_mod
+    from margipose_amd.models import CanonicalSkeletonDesc, MargiPoseModel
+    torch.manual_seed(11)
+    m0 = MargiPoseModel(CanonicalSkeletonDesc, 2, True, stem, 'jsd').cuda().train()
+    m1 = copy.deepcopy(m0)
+    x = torch.randn(2, 3, 256, 256, device='cuda')
+    tgt = torch.rand(2, 17, 3, device='cuda') * 2 - 1
+    grads = []
+    for m, mode in ((m0, 1), (m1, 2)):
+        monkeypatch.setattr(eng_mod, '_GFLAT_FILL', mode)
+        m.forward_3d_losses(m(x), tgt).mean().backward()
+        grads.append(dict((k, p.grad.clone()) for k, p in m.named_parameters()))
+    for k, g in grads[1].items():
+        assert bool(torch.isfinite(g).all()), k
+        assert torch.equal(g, grads[0][k]), k
+
+
+@pytest.mark.parametrize('stem', ['patch8', 'inceptionv4'])
 def test_uint8_frames_are_normalised_on_device(stem):
     """uint8 RGB frames in -> same result as `ImageSpecs.convert` (to_tensor + (x - mean) / std, reference
     data_specs.py:6-13,38-39) done on the host and fed as float32 (normalisation fused into the first load)."""
