@@ -67,15 +67,17 @@ constexpr unsigned kBig = 0x40000000u;       // added to a voffset (up to three 
 constexpr int MAX_UNITS = 8;
 
 struct RowUnit {
-  int8_t dy, ntap, acc, pad;       // ntap == 3: taps dx = -1, 0, +1; ntap == 1: dx = 0
+  int8_t dy, ntap, acc, pad;       // ntap == 3: taps dx = -1, 0, +1 (widx < 0: not a tap of the kernel, computed and dropped); ntap == 1: dx = 0
   int8_t widx[4];
+  int x_off, g_off;                // byte offsets of the unit's VIEW of the input / the gradient (strided geometries, see build_units)
 };
 
 struct WgRowsArgs {
   mpose_wgrad_operands op[MPOSE_MAX_GROUP];
   int H, W, n_rows;                // slot grid == input == output spatial size; n_rows = B * H
   int Cin, Cout;                   // storage channel counts
-  int x_pix, g_pix0, g_pix1;       // pixel strides in BYTES
+  int x_pix, g_pix0, g_pix1;       // pixel strides in BYTES (of the views the slot grid walks: 2 pixels of the tensor for a stride-2 side)
+  int x_row, g_row0, g_row1;       // row strides in BYTES of the same views
   unsigned x_bytes, g_bytes0, g_bytes1;
   int npad;
   int n_widx0, n_widx1;
@@ -245,16 +247,19 @@ __global__ __launch_bounds__(64 * WK * WN, WK * WN >= 4 ? WK * WN / 4 : 2) void 
   const int n_octets = (v_end - v_begin) * n_oct;
   const int n_steps = (n_octets + 1) >> 1;
   const bool exp_still = (a.exp_flags & 4) != 0;          // (timing experiment: every step re-reads the first octets -> cache-resident operands)
+  const int x_rowb = a.x_row, g_rowb = second ? a.g_row1 : a.g_row0;
   const unsigned x_step = exp_still ? 0u : (unsigned)(8 * x_pix), g_step = exp_still ? 0u : (unsigned)(8 * g_pix);
-  const unsigned x_jump = exp_still ? 0u : (unsigned)(ady * a.W * x_pix), g_jump = exp_still ? 0u : (unsigned)(ady * a.W * g_pix);
+  const unsigned x_jump = exp_still ? 0u : (unsigned)(ady * x_rowb), g_jump = exp_still ? 0u : (unsigned)(ady * g_rowb);
+  // (a view's rows need not follow each other in memory -- every second row and pixel of a tensor: the gap is added at a row's end)
+  const unsigned x_gap = exp_still ? 0u : (unsigned)(x_rowb - a.W * x_pix), g_gap = exp_still ? 0u : (unsigned)(g_rowb - a.W * g_pix);
   struct Cursor { unsigned xs, gs; int vy, o, left; };    // left = octets still to hand out (<= 0: dummy octets, gradient reads 0)
   Cursor cur;
   {
     const int hv = Hv > 0 ? Hv : 1;
     const int b = v_begin / hv;
     cur.vy = v_begin - b * hv; cur.o = 0; cur.left = n_octets;
-    cur.xs = (unsigned)((b * a.H + cur.vy + x_row0) * a.W * x_pix);
-    cur.gs = (unsigned)((b * a.H + cur.vy + g_row0) * a.W * g_pix);
+    cur.xs = (unsigned)((b * a.H + cur.vy + x_row0) * x_rowb + u.x_off);
+    cur.gs = (unsigned)((b * a.H + cur.vy + g_row0) * g_rowb + u.g_off);
   }
   struct Oct { unsigned xs, gs, hl, hr, gpen; };     // body offsets (bytes), halo offsets (or kBig), gradient penalty (0 / kBig)
   auto take = [&](Cursor& c) {
@@ -265,8 +270,8 @@ __global__ __launch_bounds__(64 * WK * WN, WK * WN >= 4 ? WK * WN / 4 : 2) void 
     o.gpen = c.left > 0 ? 0u : kBig;
     const bool row_done = c.o + 1 == n_oct;
     const bool img_done = row_done && c.vy + 1 == Hv;
-    c.xs += x_step + (img_done ? x_jump : 0u);
-    c.gs += g_step + (img_done ? g_jump : 0u);
+    c.xs += x_step + (row_done ? x_gap : 0u) + (img_done ? x_jump : 0u);
+    c.gs += g_step + (row_done ? g_gap : 0u) + (img_done ? g_jump : 0u);
     c.left -= 1;
     c.o = row_done ? 0 : c.o + 1;
     c.vy = img_done ? 0 : c.vy + (row_done ? 1 : 0);
@@ -287,8 +292,8 @@ __global__ __launch_bounds__(64 * WK * WN, WK * WN >= 4 ? WK * WN / 4 : 2) void 
       oo.o[0].gpen = pen; oo.o[1].gpen = pen;
       const bool row_done = c.o + 2 == n_oct;
       const bool img_done = row_done && c.vy + 1 == Hv;
-      c.xs = xs1 + x_step + (img_done ? x_jump : 0u);
-      c.gs += 2 * g_step + (img_done ? g_jump : 0u);
+      c.xs = xs1 + x_step + (row_done ? x_gap : 0u) + (img_done ? x_jump : 0u);
+      c.gs += 2 * g_step + (row_done ? g_gap : 0u) + (img_done ? g_jump : 0u);
       c.left -= 2;
       c.o = row_done ? 0 : c.o + 2;
       c.vy = img_done ? 0 : c.vy + (row_done ? 1 : 0);
@@ -493,6 +498,7 @@ __global__ __launch_bounds__(64 * WK * WN, WK * WN >= 4 ? WK * WN / 4 : 2) void 
     const int k4_total = a.Cin >> 2;
 #pragma unroll
     for (int t = 0; t < NTAP; ++t) {
+      if (u.widx[t] < 0) continue;           // (a position of the row the kernel has no tap at)
       float* base = dw + ((long)(split * n_widx + u.widx[t]) * k4_total) * a.npad * 4;
 #pragma unroll
       for (int kb = 0; kb < KB; ++kb)
@@ -581,6 +587,11 @@ inline void shape_tiles(int shape, int& kt, int& nt) {
   }
 }
 
+inline bool strided_env() {      // MPOSE_WGRAD_STRIDED=0: the stride-2 geometries stay on conv_wgrad_k (A/B runs)
+  static int v = -2;
+  if (v == -2) { const char* e = getenv("MPOSE_WGRAD_STRIDED"); v = e ? atoi(e) : 1; }
+  return v != 0;
+}
 int rows_env() {               // MPOSE_WGRAD_ROWS=0: conv_wgrad_k everywhere (A/B runs); 2: the row form also for launches of single taps
   static int v = -2;
   if (v == -2) { const char* e = getenv("MPOSE_WGRAD_ROWS"); v = e ? atoi(e) : 1; }
@@ -588,36 +599,62 @@ int rows_env() {               // MPOSE_WGRAD_ROWS=0: conv_wgrad_k everywhere (A
 }
 
 // Kernel rows / single taps of a geometry, or -1 when the row form does not apply (then conv.hip's conv_wgrad_k runs).
+//
+// What the kernel walks is a slot grid on which a VIEW of the input and a VIEW of the gradient are correlated at shifts |dx| <= 1:
+//   * stride 1: both views are the tensors;
+//   * a stride-2 Conv2d (in_mul = 2; round 5): input pixel 2 gy + dy = 2 (gy + ay) + ry -- the taps split by the residues (ry, rx)
+//     of their offsets, and residue (ry, rx) sees the view "every second row and pixel of the input, starting at (ry, rx)" at the
+//     shifts (ay, ax): 3 x 3 with padding 1 = one single tap, two pairs {-1, 0} and two rows of pairs;
+//   * a stride-2 ConvTranspose2d (out_mul = 2, one class per output phase): the same with the GRADIENT as the strided side -- class
+//     (oy, ox) pairs the input at (gy + dy, gx + dx) with every second row and pixel of the gradient starting at (oy, ox).
+// A unit = (class, accumulator, residue, ay) with its taps ax in {-1, 0, +1}; a pair runs as a row of three whose missing tap is
+// computed and dropped (widx -1).
 int build_units(const mpose_conv_geom* g, RowUnit* units, int* n_widx0, int* n_widx1) {
-  if (g->n_classes != 1 || g->in_mul != 1 || g->out_mul != 1 || g->in_mul_x != 1 || g->out_mul_x != 1 || g->IH != g->GH || g->IW != g->GW || g->OH != g->GH || g->OW != g->GW)
-    return -1;
-  if ((g->GW & 7) || (g->Cin & 3) || g->cls[0].oy || g->cls[0].ox) return -1;
-  const mpose_tap_class& c = g->cls[0];
-  int n_units = 0, max0 = -1, max1 = -1;
-  for (int acc = 0; acc < 2; ++acc)
-    for (int dy = -8; dy <= 8; ++dy) {          // (dilated kernels: rows 2, 4 pixels apart)
-      int widx[3] = {-1, -1, -1}, cnt = 0;
-      for (int t = 0; t < c.n_taps; ++t) {
-        const mpose_tap& tp = c.taps[t];
-        if ((tp.acc != 0) != (acc != 0) || tp.dy != dy) continue;
-        if (tp.dx < -1 || tp.dx > 1 || widx[tp.dx + 1] >= 0) return -1;
-        widx[tp.dx + 1] = tp.widx;
-        ++cnt;
-      }
-      if (!cnt) continue;
-      if (n_units == MAX_UNITS) return -1;
-      RowUnit u{};
-      u.dy = (int8_t)dy; u.acc = (int8_t)acc;
-      if (cnt == 3) { u.ntap = 3; u.widx[0] = (int8_t)widx[0]; u.widx[1] = (int8_t)widx[1]; u.widx[2] = (int8_t)widx[2]; }
-      else if (cnt == 1 && widx[1] >= 0) { u.ntap = 1; u.widx[0] = (int8_t)widx[1]; }
-      else return -1;
-      units[n_units++] = u;
+  const int im = g->in_mul, om = g->out_mul;
+  if (g->in_mul_x != im || g->out_mul_x != om) return -1;
+  if (!((im == 1 && om == 1) || (strided_env() && ((im == 2 && om == 1) || (im == 1 && om == 2))))) return -1;
+  if (g->IH != g->GH * im || g->IW != g->GW * im || g->OH != g->GH * om || g->OW != g->GW * om) return -1;
+  if ((g->GW & 7) || (g->Cin & 3) || g->n_classes != om * om) return -1;
+  const int in_ld = g->in_ld > 0 ? g->in_ld : g->Cin;
+  const int g_ld0 = g->out_ld0 > 0 ? g->out_ld0 : g->Cout0, g_ld1 = g->out_ld1 > 0 ? g->out_ld1 : g->Cout1;
+  auto fmod_ = [](int v, int m) { return ((v % m) + m) % m; };
+  int n_units = 0, max0 = -1, max1 = -1, matched = 0, total = 0;
+  for (int ci = 0; ci < g->n_classes; ++ci) {
+    const mpose_tap_class& c = g->cls[ci];
+    if (c.oy < 0 || c.oy >= om || c.ox < 0 || c.ox >= om) return -1;
+    total += c.n_taps;
+    for (int acc = 0; acc < 2; ++acc)
+      for (int ry = 0; ry < im; ++ry)
+        for (int rx = 0; rx < im; ++rx)
+          for (int ay = -8; ay <= 8; ++ay) {          // (dilated kernels: rows 2, 4 pixels apart)
+            int widx[3] = {-1, -1, -1}, cnt = 0;
+            for (int t = 0; t < c.n_taps; ++t) {
+              const mpose_tap& tp = c.taps[t];
+              const int ty = fmod_(tp.dy, im), tx = fmod_(tp.dx, im);
+              if ((tp.acc != 0) != (acc != 0) || ty != ry || tx != rx || (tp.dy - ty) / im != ay) continue;
+              const int ax = (tp.dx - tx) / im;
+              if (ax < -1 || ax > 1 || widx[ax + 1] >= 0 || tp.widx < 0) return -1;
+              widx[ax + 1] = tp.widx;
+              ++cnt;
+            }
+            if (!cnt) continue;
+            matched += cnt;
+            if (n_units == MAX_UNITS) return -1;
+            RowUnit u{};
+            u.dy = (int8_t)ay; u.acc = (int8_t)acc;
+            if (cnt == 1 && widx[1] >= 0) { u.ntap = 1; u.widx[0] = (int8_t)widx[1]; }
+            else if (im == 1 && om == 1 && cnt != 3) return -1;      // (stride 1: whole rows or single taps, as before)
+            else { u.ntap = 3; u.widx[0] = (int8_t)widx[0]; u.widx[1] = (int8_t)widx[1]; u.widx[2] = (int8_t)widx[2]; }
+            u.x_off = (ry * g->IW + rx) * in_ld * 4;
+            u.g_off = (c.oy * g->OW + c.ox) * (acc ? g_ld1 : g_ld0) * 4;
+            units[n_units++] = u;
+          }
+    for (int t = 0; t < c.n_taps; ++t) {
+      const mpose_tap& tp = c.taps[t];
+      if (tp.acc) { if (tp.widx > max1) max1 = tp.widx; } else if (tp.widx > max0) max0 = tp.widx;
     }
-  for (int t = 0; t < c.n_taps; ++t) {
-    const mpose_tap& tp = c.taps[t];
-    if (tp.dy < -8 || tp.dy > 8) return -1;
-    if (tp.acc) { if (tp.widx > max1) max1 = tp.widx; } else if (tp.widx > max0) max0 = tp.widx;
   }
+  if (matched != total) return -1;         // (a tap further than eight rows away)
   *n_widx0 = max0 + 1;
   *n_widx1 = max1 + 1;
   // a launch of single taps only (1x1 convolutions, k x 1 columns) stages as much per step as a kernel row for a third of the
@@ -674,12 +711,14 @@ int mpose_wgrad_rows_launch(const mpose_conv_geom* geom, const mpose_wgrad_opera
   const int in_ld = geom->in_ld > 0 ? geom->in_ld : geom->Cin;
   const int g_ld0 = geom->out_ld0 > 0 ? geom->out_ld0 : geom->Cout0;
   const int g_ld1 = geom->out_ld1 > 0 ? geom->out_ld1 : geom->Cout1;
-  a.x_pix = in_ld * 4; a.g_pix0 = g_ld0 * 4; a.g_pix1 = g_ld1 * 4;
-  const long npix = (long)geom->B * geom->GH * geom->GW;
-  if (npix * in_ld * 4 >= (long)kBig || npix * (g_ld0 > g_ld1 ? g_ld0 : g_ld1) * 4 >= (long)kBig) return MPOSE_ENOSYS;
-  a.x_bytes = (unsigned)((npix - 1) * in_ld * 4 + (long)geom->Cin * 4);
-  a.g_bytes0 = (unsigned)((npix - 1) * g_ld0 * 4 + (long)geom->Cout0 * 4);
-  a.g_bytes1 = acc1 ? (unsigned)((npix - 1) * g_ld1 * 4 + (long)geom->Cout1 * 4) : 0u;
+  const int im = geom->in_mul, om = geom->out_mul;           // (the views of a strided side: every im-th / om-th row and pixel)
+  a.x_pix = in_ld * 4 * im; a.g_pix0 = g_ld0 * 4 * om; a.g_pix1 = g_ld1 * 4 * om;
+  a.x_row = geom->IW * in_ld * 4 * im; a.g_row0 = geom->OW * g_ld0 * 4 * om; a.g_row1 = geom->OW * g_ld1 * 4 * om;
+  const long npix_i = (long)geom->B * geom->IH * geom->IW, npix_o = (long)geom->B * geom->OH * geom->OW;
+  if (npix_i * in_ld * 4 >= (long)kBig || npix_o * (g_ld0 > g_ld1 ? g_ld0 : g_ld1) * 4 >= (long)kBig) return MPOSE_ENOSYS;
+  a.x_bytes = (unsigned)((npix_i - 1) * in_ld * 4 + (long)geom->Cin * 4);
+  a.g_bytes0 = (unsigned)((npix_o - 1) * g_ld0 * 4 + (long)geom->Cout0 * 4);
+  a.g_bytes1 = acc1 ? (unsigned)((npix_o - 1) * g_ld1 * 4 + (long)geom->Cout1 * 4) : 0u;
   a.npad = geom->Npad0;
   a.n_split = n_split;
   a.rows_per_split = (a.n_rows + n_split - 1) / n_split;

@@ -526,7 +526,10 @@ class _GraphStem:
             if f16:
                 ao.da_amax = n.amax_b
             check(L.mpose_bn_bwd_apply((BnBwdApplyOperands * 3)(ao), 1, H * W, B, n.C, 0, 0, st()), 'mpose_bn_bwd_apply')
-            for op in n.producers:
+            # (convolutions whose data-gradient can WRITE a source node's gradient go first: a pool reading the same source -- the
+            #  max-pool / strided-convolution pairs of Mixed_3a and Mixed_5a -- then accumulates into it, and nobody zero-fills)
+            prods = sorted(n.producers, key=lambda op: 0 if (_FIRST_WRITES and isinstance(op, _ConvOp) and self._d_covers(op)) else 1)
+            for op in prods:
                 if isinstance(op, _AddOp):     # both addends receive d_raw (w.r.t. their affine / activated values)
                     for t in (op.a, op.b):
                         if t.name not in dact:       # (the identity path has other consumers that accumulate into it later)

@@ -354,6 +354,31 @@ def test_weight_gradient_stride2_with_fused_shortcut():
     _check(*_wgrad_errs(dw1, x, go1, lambda a, w: F.conv2d(a, w, stride=2), (cout, cin, 1, 1)))
 
 
+@pytest.mark.parametrize('n_split', [1, 3])
+def test_weight_gradient_transposed_stride2_with_fused_shortcut(n_split):
+    """ConvTranspose2d(192, 128, 3, stride 2, padding 1, output_padding 1) + the 1x1 transposed shortcut of the columns' up block
+    (reference models/margipose_model.py:67-82): the weight gradient of the four output-phase classes -- on the row-of-taps kernel the
+    GRADIENT is the strided side (every second row and pixel, one view per class; csrc/wgrad.hip build_units)."""
+    from margipose_amd import _lib, engine as eng
+    L = _lib.lib()
+    B, H, cin, cout = 2, 16, 192, 128
+    rng = np.random.default_rng(78 + n_split)
+    x = torch.from_numpy(rng.standard_normal((B, cin, H, H))).float()
+    go = torch.from_numpy(rng.standard_normal((B, cout, 2 * H, 2 * H)) * 1e-3).float()
+    go1 = torch.from_numpy(rng.standard_normal((B, cout, 2 * H, 2 * H)) * 2.0).float()
+    npad = (cout + 63) // 64 * 64
+    g = eng._geom(B, H, cin, 2 * H, cout, cout, H, 1, 2, eng._up_classes(True), npad, npad)
+    to = lambda t: t.permute(0, 2, 3, 1).contiguous().cuda()
+    xg, gg, gg1 = to(x), to(go), to(go1)
+    amaxes = torch.cat([_amax(L, _lib, [xg], cin), _amax(L, _lib, [gg, gg1], cout)])
+    dw, dw1 = _wgrad(L, _lib, eng, g, xg, gg, cout, cin, 9, npad, n_split, amaxes, gout1=gg1, cout1=cout)
+    # (the partials are [widx][k = input channel][n = gradient channel]: the helper unpacks (n, k, tap); ConvTranspose2d's weight is (k, n, ..))
+    _check(*_wgrad_errs(dw.permute(1, 0, 2).contiguous(), x, go,
+                        lambda a, w: F.conv_transpose2d(a, w, stride=2, padding=1, output_padding=1), (cin, cout, 3, 3)))
+    _check(*_wgrad_errs(dw1.permute(1, 0, 2).contiguous(), x, go1,
+                        lambda a, w: F.conv_transpose2d(a, w, stride=2, output_padding=1), (cin, cout, 1, 1)))
+
+
 @pytest.mark.parametrize('B,H,cin,cout,add,f16', [(2, 32, 128, 128, True, True), (4, 16, 192, 192, False, True), (3, 8, 32, 32, True, True),
                                                  (1, 12, 64, 96, True, False)])
 def test_fused_output_stage(B, H, cin, cout, add, f16):

@@ -11,3 +11,8 @@ bash tools/profile.sh r5 > gpurun_out/profile_r5.log 2>&1; tail -5 gpurun_out/pr
 bash tools/step_stats.sh r5 > gpurun_out/step_families_r5.txt 2>&1; head -3 gpurun_out/step_families_r5.txt
 # 2 ranks sharing the GPU through gloo (functional check of the DP bench path)
 MPOSE_SINGLE_DEVICE=1 MPOSE_DIST_BACKEND=gloo timeout 600 python bench.py --gpus 2 --steps 4 --warmup 2 --no-cpu-baseline 2>&1 | tail -1 | cut -c1-400
+# timeline of the default (launch plan, two streams) schedule + the launch-by-launch listing of its last step
+bash tools/trace_step.sh r5 > gpurun_out/timeline_r5.txt 2>&1
+python tools/step_listing.py $(find gpurun_out/tl_r5/trace -name "*kernel_trace.csv" | head -1) > gpurun_out/step_listing_r5.txt; rm -rf gpurun_out/tl_r5/trace
+# the driver's form of the bench
+timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/bench_driver_form.json 2>/dev/null; cut -c1-300 gpurun_out/bench_driver_form.json
