@@ -603,7 +603,12 @@ def main():
             'configs[2] training, B=%d fp32, as launched by the step (fused with the residual sum)' % B: dict(
                 fused_tail_microbench(device, B), note='replaces bn_add_nchw_k + softmax_dsnt_fwd_k; latency-bound'),
             'configs[1] inference, B=64 bf16 heatmaps, as launched by the step (fused with the residual sum)': dict(
-                fused_tail_microbench(device, 64, bf16_out=True), note='latency-bound')}
+                fused_tail_microbench(device, 64, bf16_out=True), note='latency-bound'),
+            'B=2048 fp32, fused with the residual sum (beyond the Infinity Cache: the fused form\'s HBM-roofline point)': dict(
+                fused_tail_microbench(device, 2048, launches=30),
+                note='the all-joints form of bn_add_softmax_k (one workgroup per image and column, every 128-byte channel line of the two '
+                     'padded-to-32-channel inputs read once): 17 of the 32 stored channels are algorithmic bytes, so the line fetches '
+                     'bound it at 204 / 324 of the rate a dense stream reaches')}
         res['tail_training'] = {
             'configs[2] training, B=%d fp32 (latency-bound: working set in Infinity Cache)' % B: train_tail_microbench(device, B),
             'B=2048 fp32 (beyond the Infinity Cache: the HBM-roofline point)': train_tail_microbench(device, 2048, launches=50)}

@@ -438,7 +438,10 @@ int mpose_bn_add_h2(const mpose_bn_add_operands* ops, void* const* h2, int n_gro
 /* The last ResidualBlock's residual sum (mpose_bn_add_fwd layout 1: models/margipose_model.py:34-40) fused with flat_softmax + dsnt:
  * heatmaps[g] (B, J, H, W) = flat_softmax(relu(a_scale*a + a_shift) + (b_scale*b + b_shift)) over the first J of the C NHWC channels
  * of ops[g].a / ops[g].b, plane_coords (n_groups, B*J, 2) = dsnt(heatmaps) (may be NULL); the logits never reach memory, and the
- * heatmaps are bit-identical to the two-launch path's.  io_dtype: 0 fp32 heatmaps, 2 bf16 heatmaps.  H*W <= 4096, W % 4 == 0, C % 4 == 0. */
+ * heatmaps are bit-identical to the two-launch path's.  io_dtype: 0 fp32 heatmaps, 2 bf16 heatmaps.  H*W <= 4096, W % 4 == 0, C % 4 == 0.
+ * Two forms, chosen by the launcher: one workgroup per (image, group, four joints) while the inputs are small (they are re-read
+ * from the Infinity Cache by the five joint groups), one per (image, group) with all J rows in LDS -- every 128-byte channel line
+ * read once, eight lanes per line -- beyond 64 MB of inputs when C == 32 and J * (H*W + 4) * 4 bytes fit in 144 KB of LDS. */
 int mpose_bn_add_softmax_fwd(const mpose_bn_add_operands* ops, void* const* heatmaps, float* plane_coords, int n_groups,
                              int B, int H, int W, int C, int J, int io_dtype, void* stream);
 /* xyz (rows, 3) from plane_coords (3, rows, 2): MargiPoseModel.heatmaps_to_coords' merge, z = (zy.x + xz.y) / 2

@@ -243,12 +243,79 @@ struct BnAddSoftmaxArgs {
 
 constexpr int kBasThreads = 256, kBasPad = 4, kBasU = 4;     // row pitch P + 4 floats: float4-aligned rows, the turn's stores spread over banks
 
-template <int NV, bool BF_OUT>
+// ALLJ (round 5): one workgroup per (image, column) with ALL J rows in LDS (70 KB at 32 x 32, 17 joints) -- it reads the first
+// ceil(J/4) float4s of every pixel's channel line of both tensors, i.e. every line ONCE, where the four-joint form reads each line
+// from five workgroups (fine while the inputs stay in the Infinity Cache; 8x over-fetch from HBM beyond it: 0.10 of the HBM rate at
+// B = 2048).  The launcher picks it when the inputs exceed the cache; below, its 96 workgroups would leave CUs idle (18.4 us
+// against the four-joint form's 9.7 at B = 32).  Same expressions, same row arithmetic: bit-identical heatmaps.
+template <int NV, bool BF_OUT, bool ALLJ>
 __global__ __launch_bounds__(kBasThreads) void bn_add_softmax_k(BnAddSoftmaxArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float tile[];          // [4][P + kBasPad]: the workgroup's four joints
+  extern __shared__ __attribute__((aligned(16))) float tile[];          // [4][P + kBasPad]: the workgroup's four joints ([J][..]: ALLJ)
   const mpose_bn_add_operands& op = a.op[blockIdx.y];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int c0 = blockIdx.z * 4, pitch = a.P + kBasPad;                  // the float4 column of channels c0..c0+3
+  const int pitch = a.P + kBasPad;
+  if constexpr (ALLJ) {
+    // Lanes walk (pixel, float4 of the channel line): eight consecutive lanes share a 128-byte line, the ones whose float4 lies past
+    // the J-th channel load nothing -- a wave instruction touches 8 lines.  (One float4 per lane at a 128-byte stride touches 64
+    // lines per instruction: that form reached 2 TB/s of line traffic.)  a.C == 32 (the launcher checks); a thread's float4 column
+    // is the same in every pass (256 % 8 == 0): its coefficients are loaded once.
+    const size_t img0 = (size_t)b * a.P * a.C;
+    const int chunk = tid & 7, c0 = chunk * 4;
+    const bool live = c0 < a.J;
+    float sa[4], ta[4], sb[4], tb[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int cc = min(c0 + e, a.J - 1);
+      sa[e] = op.a_scale[cc]; ta[e] = op.a_shift[cc]; sb[e] = op.b_scale[cc]; tb[e] = op.b_shift[cc];
+    }
+    constexpr int U = 8;
+    const int n_items = a.P * 8;
+    for (int base = 0; base < n_items; base += kBasThreads * U) {
+      float4 x[U], y[U];              // every load of the pass in flight before the first use
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = base + u * kBasThreads + tid;
+        if (live && i < n_items) {
+          x[u] = *reinterpret_cast<const float4*>(op.a + img0 + (size_t)i * 4);
+          y[u] = *reinterpret_cast<const float4*>(op.b + img0 + (size_t)i * 4);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = base + u * kBasThreads + tid;
+        if (live && i < n_items) {
+          const int px = i >> 3;
+          const float xs[4] = {x[u].x, x[u].y, x[u].z, x[u].w}, ys[4] = {y[u].x, y[u].y, y[u].z, y[u].w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (c0 + e < a.J) tile[(c0 + e) * pitch + px] = fmaxf(fmaf(xs[e], sa[e], ta[e]), 0.f) + fmaf(ys[e], sb[e], tb[e]);
+        }
+      }
+    }
+    __syncthreads();
+    const RowGeom g = make_geom(a.H, a.W);
+    for (int j = wave; j < a.J; j += kBasThreads / 64) {      // a wave per joint, four joints at a time
+      const float* row = tile + j * pitch;
+      float4 v[NV];
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int idx = i * 64 + lane;
+        v[i] = (idx < g.n4) ? reinterpret_cast<const float4*>(row)[idx] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+      }
+      row_softmax<NV>(v);
+      float sx, sy;
+      row_expectation<NV>(v, g, lane, sx, sy);
+      const size_t r = (size_t)b * a.J + j;
+      if (BF_OUT) store_row_bf16<NV>(reinterpret_cast<unsigned short*>(a.heat[blockIdx.y]) + r * a.P, lane, g.n4, v);
+      else store_row<NV>(reinterpret_cast<float*>(a.heat[blockIdx.y]) + r * a.P, lane, g.n4, v);
+      if (lane == 0 && a.plane_coords != nullptr) {
+        float* pc = a.plane_coords + ((size_t)blockIdx.y * a.B * a.J + r) * 2;
+        pc[0] = sx; pc[1] = sy;
+      }
+    }
+    return;
+  }
+  const int c0 = blockIdx.z * 4;                                         // the float4 column of channels c0..c0+3
   const size_t img = (size_t)b * a.P * a.C + c0;
   float sa[4], ta[4], sb[4], tb[4];
 #pragma unroll
@@ -303,16 +370,28 @@ __global__ __launch_bounds__(kBasThreads) void bn_add_softmax_k(BnAddSoftmaxArgs
   }
 }
 
+constexpr int kBasAllJLds = 144 * 1024;      // LDS the all-joints form may take (a workgroup per CU then)
 template <int NV, bool BF_OUT>
-static int launch_bn_add_softmax(const BnAddSoftmaxArgs& a, int n_groups, int lds, hipStream_t s) {
-  static bool raised = false;            // (per instantiation; the attribute is per function and sticky)
+static int launch_bn_add_softmax(const BnAddSoftmaxArgs& a, int n_groups, int lds, bool allj, hipStream_t s) {
+  static bool raised = false, raised_all = false;            // (per instantiation; the attribute is per function and sticky)
+  if (allj) {
+    const int lds_all = a.J * (a.P + kBasPad) * 4;
+    if (!raised_all) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&bn_add_softmax_k<NV, BF_OUT, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              kBasAllJLds) != hipSuccess)
+        return MPOSE_EINVAL;
+      raised_all = true;
+    }
+    launch(bn_add_softmax_k<NV, BF_OUT, true>, dim3(dim3(a.B, n_groups, 1)), dim3(kBasThreads), lds_all, s, a);
+    return 0;
+  }
   if (lds > 48 * 1024 && !raised) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&bn_add_softmax_k<NV, BF_OUT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&bn_add_softmax_k<NV, BF_OUT, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             72 * 1024) != hipSuccess)
       return MPOSE_EINVAL;
     raised = true;
   }
-  launch(bn_add_softmax_k<NV, BF_OUT>, dim3(dim3(a.B, n_groups, (a.J + 3) / 4)), dim3(kBasThreads), lds, s, a);
+  launch(bn_add_softmax_k<NV, BF_OUT, false>, dim3(dim3(a.B, n_groups, (a.J + 3) / 4)), dim3(kBasThreads), lds, s, a);
   return 0;
 }
 
@@ -753,9 +832,16 @@ extern "C" int mpose_bn_add_softmax_fwd(const mpose_bn_add_operands* ops, void* 
   }
   a.plane_coords = plane_coords; a.B = B; a.P = P; a.C = C; a.J = J; a.H = H; a.W = W;
   const int nv = pick_nv(P);
+  // the all-joints form (every channel line read once, coalesced) when the two inputs of the launch's columns are large enough to
+  // keep its B * n_groups workgroups busy and all J rows fit in LDS; MPOSE_TAIL_ALLJ=0 / 1 forces the choice (A/B runs)
+  static const int allj_env = [] { const char* e = getenv("MPOSE_TAIL_ALLJ"); return e ? atoi(e) : -1; }();
+  const bool fits = (long)J * (P + kBasPad) * 4 <= kBasAllJLds && C == 32;
+  // (measured crossover at 32 x 32, three columns: B = 64 -- 50 MB of inputs -- 16.6 us four-joint / 21.9 us all-joints,
+  //  B = 128 -- 100 MB -- 55.7 / 28.3 us; B = 2048: 1659 / 423 us, the two launches it replaces: 1317 us)
+  const bool allj = fits && (allj_env >= 0 ? allj_env != 0 : (long)n_groups * 2 * B * P * C * 4 > (64l << 20));
   int rc = 0;
-  if (io_dtype == 0) { MPOSE_DISPATCH_NV(nv, (rc = launch_bn_add_softmax<NV, false>(a, n_groups, lds, (hipStream_t)stream))); }
-  else { MPOSE_DISPATCH_NV(nv, (rc = launch_bn_add_softmax<NV, true>(a, n_groups, lds, (hipStream_t)stream))); }
+  if (io_dtype == 0) { MPOSE_DISPATCH_NV(nv, (rc = launch_bn_add_softmax<NV, false>(a, n_groups, lds, allj, (hipStream_t)stream))); }
+  else { MPOSE_DISPATCH_NV(nv, (rc = launch_bn_add_softmax<NV, true>(a, n_groups, lds, allj, (hipStream_t)stream))); }
   if (rc) return rc;
   return launch_status();
 }

@@ -1095,7 +1095,9 @@ class Engine:
         Sm = F // 2
         # (the fused tail reads one float4 of each pixel's channel line per workgroup: fine while the two inputs of the three columns
         #  stay in the 256 MB Infinity Cache, 8x over-fetch from HBM beyond -- measured 1.57 ms at B = 2048)
-        tail_fused = self.tail_fuse and (F & 3) == 0 and F * F <= 4096 and 6 * B * F * F * 32 * 4 <= (128 << 20)
+        # (beyond 128 MB the library takes the kernel's all-joints form -- every line read once -- when the J rows fit in LDS)
+        tail_fused = (self.tail_fuse and (F & 3) == 0 and F * F <= 4096 and
+                      (6 * B * F * F * 32 * 4 <= (128 << 20) or self.J * (F * F + 4) * 4 <= 144 * 1024))
         if 192 % Sm != 0 or (Sm % 4) != 0 or (F * F) % 64 != 0 or F * F > 4096:
             raise _lib.MposeError('unsupported input size %d (mid size %d must divide 192 and be a multiple of 4)' % (S, Sm))
         if save and Sm % 8 != 0:       # the weight-gradient kernel walks slot rows in octets (mpose_conv_wgrad: GW % 8 == 0)

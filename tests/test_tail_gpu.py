@@ -153,16 +153,19 @@ def test_bf16_heatmap_io(D):
         np.testing.assert_allclose(h.float().cpu().numpy(), r, rtol=8e-3, atol=1e-30)  # bf16 rounding of outputs
 
 
-@pytest.mark.parametrize('F,bf16', [(32, False), (32, True), (48, False), (16, False), (64, False)])
-def test_fused_residual_sum_softmax_is_bit_identical(F, bf16):
+@pytest.mark.parametrize('F,bf16,B', [(32, False, 5), (32, True, 5), (48, False, 5), (16, False, 5), (64, False, 5),
+                                      # inputs beyond 128 MB: the launcher takes the all-joints form (every channel line read once)
+                                      (32, False, 180), (16, True, 700)])
+def test_fused_residual_sum_softmax_is_bit_identical(F, bf16, B):
     """mpose_bn_add_softmax_fwd (the last ResidualBlock's sum + flat_softmax + dsnt, logits kept in LDS) against the two launches
-    it replaces (mpose_bn_add_fwd layout 1, then mpose_softmax_dsnt_fwd): same heatmaps and coordinates, bit for bit."""
+    it replaces (mpose_bn_add_fwd layout 1, then mpose_softmax_dsnt_fwd): same heatmaps and coordinates, bit for bit -- in the
+    four-joints-per-workgroup form and in the all-joints form the launcher picks when the inputs exceed the Infinity Cache."""
     from margipose_amd import _lib
     from margipose_amd._lib import BnAddOperands
     L = _lib.lib()
-    rng = np.random.default_rng(11 + F)
-    B, C, J = 5, 32, 17
-    g = lambda *s: torch.tensor(rng.standard_normal(s), dtype=torch.float32, device='cuda')
+    gen = torch.Generator(device='cuda').manual_seed(11 + F + B)
+    C, J = 32, 17
+    g = lambda *s: torch.randn(*s, generator=gen, device='cuda', dtype=torch.float32)
     a = [g(B, F, F, C) * 3 for _ in range(3)]
     b = [g(B, F, F, C) * 2 for _ in range(3)]
     co = [[g(C) for _ in range(4)] for _ in range(3)]

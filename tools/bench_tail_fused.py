@@ -2,7 +2,8 @@ import torch, numpy as np, ctypes
 from margipose_amd import _lib
 from margipose_amd._lib import BnAddOperands
 L=_lib.lib()
-B,F,C,J=32,32,32,17
+import sys
+B,F,C,J=(int(sys.argv[1]) if len(sys.argv) > 1 else 32),32,32,17
 a=[torch.randn(B,F,F,C,device='cuda') for _ in range(3)]; b=[torch.randn(B,F,F,C,device='cuda') for _ in range(3)]
 v=[torch.randn(C,device='cuda') for _ in range(4)]
 lg=[torch.empty(B,J,F,F,device='cuda') for _ in range(3)]; h=[torch.empty(B,J,F,F,device='cuda') for _ in range(3)]
@@ -18,8 +19,10 @@ def one():
 def one_only():
     L.mpose_bn_add_softmax_fwd(ops,_lib.ptr_array(h),_lib.ptr(pc),3,B,F,F,C,J,0,st)
 for name,f in (('two',two),('fused+merge',one),('fused',one_only)):
-    for _ in range(20): f()
+    N = 200 if B <= 256 else 20
+    for _ in range(5): f()
     torch.cuda.synchronize(); e0=torch.cuda.Event(enable_timing=True); e1=torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(200): f()
-    e1.record(); torch.cuda.synchronize(); print(name, e0.elapsed_time(e1)/200*1000,'us')
+    for _ in range(N): f()
+    e1.record(); torch.cuda.synchronize(); us = e0.elapsed_time(e1)/N*1000
+    print(name, us, 'us', '%.3f of 8 TB/s on 12 B per heatmap element' % (3*B*J*F*F*12/us/1e6/8000))
