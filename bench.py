@@ -316,7 +316,7 @@ def inference_microbench(model, device, size):
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         # the same forward from a launch plan (train_helpers.PlannedInference): no Python between its ~250 launches
-        planned_ips, plan_note = None, None
+        planned_ips, plan_note, frozen_ips = None, None, None
         try:
             from margipose_amd.train_helpers import PlannedInference
             pf = PlannedInference(model, x)
@@ -329,6 +329,16 @@ def inference_microbench(model, device, size):
             torch.cuda.synchronize()
             planned_ips = 64 * n / (time.perf_counter() - t0)
             plan_note = '%d launches re-issued from one C loop' % pf.n_launches
+            del pf
+            pf = PlannedInference(model, x, frozen_weights=True)     # (the weights are packed once, not per forward: serving)
+            for _ in range(2):
+                pf()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                pf()
+            torch.cuda.synchronize()
+            frozen_ips = 64 * n / (time.perf_counter() - t0)
             del pf
         except Exception as e:
             plan_note = 'recording failed: %s: %s' % (type(e).__name__, e)
@@ -346,6 +356,7 @@ def inference_microbench(model, device, size):
     return {'images_per_sec': 64 * n / dt, 'batch': 64, 'ms_per_forward': 1e3 * dt / n, 'dtype': 'f32',
             'images_per_sec_bf16_heatmaps': 64 * n / dt16,
             'images_per_sec_launch_plan': planned_ips, 'launch_plan': plan_note,
+            'images_per_sec_launch_plan_frozen_weights': frozen_ips,
             'note': 'eval-mode forward (running-stat BatchNorm), heatmaps + coordinates for all stages; the bf16 figure stores '
                     'the heatmaps as bf16 (fp32 convolutions and soft-argmax): they are <1% of the bytes, so it is the same rate'}
 

@@ -24,7 +24,7 @@ constexpr int kPartSplit = 6;      // workgroups per job of the partial-row fina
 // 256 threads per job, or 1024 when the statistics arrive as per-workgroup partial rows (MPOSE_CONV_STATS_PART: a 128-channel
 // job then sums 256 rows with eight row slices of 128 channel lanes, 32 rows per thread, eight loads in flight)
 __global__ __launch_bounds__(1024) void bn_finalize_k(const mpose_bn_job* __restrict__ jobs, int train, float eps, float momentum) {
-  __shared__ double sh[1024 * 2];
+  __shared__ double sh[1024 * 4];      // (sums + extremes of a slice meet here in one pass: reduce_part_rows_pair)
   // (common.h; bit 1: the statistics are the jobs' partial rows -- gridDim.y workgroups share a job's channels)
   bn_finalize_job<false>(jobs[blockIdx.x], train & 1, eps, momentum, (train & 2) ? sh : nullptr, (int)blockIdx.y, (int)gridDim.y, (train & 4) != 0);
 }
@@ -216,6 +216,9 @@ __global__ __launch_bounds__(1024) void bn_bwd_coef_k(const mpose_bn_bwd_coef_jo
   for (int cblk = c_lo; cblk < c_hi; cblk += nth) {
     const int c = cblk + (int)threadIdx.x;
     double ps[4] = {0.0, 0.0, 0.0, 0.0};
+    // (the channel's constants are requested before the row sums are: see bn_finalize_job)
+    const bool cv = c < c_hi;
+    const float mean_c = cv ? j.mean[c] : 0.f, invstd_c = cv ? j.invstd[c] : 0.f, gamma_c = cv ? j.gamma[c] : 0.f;
     if (from_part) {       // (uniform per workgroup: the helper contains barriers)
       const int nc = c_hi - cblk < nth ? c_hi - cblk : nth;
       if (j.sums_stride == 4) {
@@ -231,7 +234,7 @@ __global__ __launch_bounds__(1024) void bn_bwd_coef_k(const mpose_bn_bwd_coef_jo
     auto pick = [&](int k) { return k == 0 ? ps[0] : (k == 1 ? ps[1] : (k == 2 ? ps[2] : ps[3])); };
     const double sg = from_part ? pick(j.sg_col) : j.sums[(size_t)c * j.sums_stride + j.sg_col];
     const double sgx = from_part ? pick(j.which) : j.sums[(size_t)c * j.sums_stride + j.which];
-    const double mean = (double)j.mean[c], invstd = (double)j.invstd[c], gamma = (double)j.gamma[c];
+    const double mean = (double)mean_c, invstd = (double)invstd_c, gamma = (double)gamma_c;
     const double sgxhat = invstd * (sgx - mean * sg);
     const double c0 = gamma * invstd;
     const double c1 = eval_mode ? 0.0 : -c0 * invstd * (sgxhat / n);

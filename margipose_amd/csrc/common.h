@@ -168,6 +168,55 @@ __device__ __forceinline__ void reduce_part_rows(const float* __restrict__ part,
   }
 }
 
+// reduce_part_rows<2> of `part` and reduce_part_rows<2, true> of `mm_part` (same launch: same row count) in ONE pass: the two
+// buffers' loads are in flight together and the slices meet in LDS once -- same rows in the same order per channel, same results.
+// sh: >= blockDim.x * 4 doubles.
+__device__ __forceinline__ void reduce_part_rows_pair(const float* __restrict__ part, const float* __restrict__ mm_part, int max_rows, int ld,
+                                                      int c0, int nc, double* sh, double (&sum)[2], double (&mx)[2]) {
+  const int nt = blockDim.x;
+  int n_part = *reinterpret_cast<const int*>(part);
+  n_part = n_part < 0 ? 0 : (n_part > max_rows ? max_rows : n_part);
+  int n_mm = *reinterpret_cast<const int*>(mm_part);
+  n_mm = n_mm < 0 ? 0 : (n_mm > max_rows ? max_rows : n_mm);
+  part += kPartHdr;
+  mm_part += kPartHdr;
+  const int cw = ((nc + 63) / 64) * 64;
+  const int S = nt / cw > 0 ? nt / cw : 1;
+  const int t = threadIdx.x, cl = t % cw, sl = t / cw;
+  double a[2] = {0.0, 0.0}, m[2] = {-__builtin_huge_val(), -__builtin_huge_val()};
+  if (sl < S && cl < nc) {
+    const float2* p = reinterpret_cast<const float2*>(part + (size_t)(c0 + cl) * 2);
+    const float2* q = reinterpret_cast<const float2*>(mm_part + (size_t)(c0 + cl) * 2);
+    const int n_both = n_part < n_mm ? n_part : n_mm;
+    int r = sl;
+    for (; r + 7 * S < n_both; r += 8 * S) {         // eight rows of each buffer in flight per thread
+      float2 v[8], w[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { v[u] = p[(size_t)(r + u * S) * ld]; w[u] = q[(size_t)(r + u * S) * ld]; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        a[0] += (double)v[u].x; a[1] += (double)v[u].y;
+        m[0] = fmax(m[0], (double)w[u].x); m[1] = fmax(m[1], (double)w[u].y);
+      }
+    }
+    for (int r2 = r; r2 < n_part; r2 += S) { const float2 v = p[(size_t)r2 * ld]; a[0] += (double)v.x; a[1] += (double)v.y; }
+    for (int r2 = r; r2 < n_mm; r2 += S) { const float2 w = q[(size_t)r2 * ld]; m[0] = fmax(m[0], (double)w.x); m[1] = fmax(m[1], (double)w.y); }
+  }
+  __syncthreads();                                   // (sh may still be read from an earlier call)
+  if (sl < S && cl < nc) {
+    double* d = sh + (size_t)(sl * cw + cl) * 4;
+    d[0] = a[0]; d[1] = a[1]; d[2] = m[0]; d[3] = m[1];
+  }
+  __syncthreads();
+  if (t < nc) {
+    sum[0] = 0.0; sum[1] = 0.0; mx[0] = -__builtin_huge_val(); mx[1] = -__builtin_huge_val();
+    for (int s_ = 0; s_ < S; ++s_) {
+      const double* d = sh + (size_t)(s_ * cw + t) * 4;
+      sum[0] += d[0]; sum[1] += d[1]; mx[0] = fmax(mx[0], d[2]); mx[1] = fmax(mx[1], d[3]);
+    }
+  }
+}
+
 // One mpose_bn_finalize job: BatchNorm statistics -> (scale, shift, mean, invstd), the running-statistics update, and the exact
 // largest relu(scale*x + shift) from the channel extremes.  Run by bn_finalize_k (bn.hip) and -- FRESH -- by the last workgroup
 // of the convolution launch whose epilogues accumulated the statistics (conv.hip): those sums and extremes were written by other
@@ -196,15 +245,21 @@ __device__ __forceinline__ void bn_finalize_job(const mpose_bn_job& j, int train
   for (int cblk = c_lo; cblk < c_hi; cblk += nth) {
     const int c = cblk + (int)threadIdx.x;
     double psum[2] = {0.0, 0.0}, pmm[2] = {0.0, 0.0};
+    // what the channel's result needs besides the statistics, requested BEFORE the row sums are (the launch is a chain of dependent
+    // memory round trips on an otherwise idle chip, ten of them per block of the forward pass: every one that overlaps counts)
+    const bool cv = c < c_hi;
+    const float gamma_c = cv ? j.gamma[c] : 0.f, beta_c = cv ? j.beta[c] : 0.f;
+    const float rmean_c = (cv && j.running_mean != nullptr) ? j.running_mean[c] : 0.f, rvar_c = (cv && j.running_mean != nullptr) ? j.running_var[c] : 0.f;
+    const float cbias_c = (cv && j.conv_bias != nullptr) ? j.conv_bias[c] : 0.f;
     if (from_part) {       // (uniform per workgroup: the helper contains barriers)
       const int nc = c_hi - cblk < nth ? c_hi - cblk : nth;
-      reduce_part_rows<2>(j.part, j.n_part, j.part_ld, cblk, nc, sh, psum);
-      if (want_amax && j.mm_part != nullptr) reduce_part_rows<2, true>(j.mm_part, j.n_part, j.part_ld, cblk, nc, sh, pmm);
+      if (want_amax && j.mm_part != nullptr) reduce_part_rows_pair(j.part, j.mm_part, j.n_part, j.part_ld, cblk, nc, sh, psum, pmm);
+      else reduce_part_rows<2>(j.part, j.n_part, j.part_ld, cblk, nc, sh, psum);
     }
     if (c >= c_hi) continue;
     // The conv kernels are bias-free; a producing conv's bias b only shifts the BN input: batch/running mean
     // of (y + b) = mean(y) + b, and  scale*(y + b) + beta - (mean + b)*scale  ==  scale*y + beta - mean*scale.
-    const double cb = (j.conv_bias != nullptr) ? (double)j.conv_bias[c] : 0.0;
+    const double cb = (double)cbias_c;
     double mean, var;
     if (train) {
       const double n = (double)j.count;
@@ -213,21 +268,21 @@ __device__ __forceinline__ void bn_finalize_job(const mpose_bn_job& j, int train
       if (var < 0.0) var = 0.0;
       if (j.running_mean != nullptr) {
         const double unbiased = (j.count > 1) ? var * n / (n - 1.0) : var;
-        j.running_mean[c] = (float)((1.0 - momentum) * (double)j.running_mean[c] + momentum * (mean + cb));
-        j.running_var[c] = (float)((1.0 - momentum) * (double)j.running_var[c] + momentum * unbiased);
+        j.running_mean[c] = (float)((1.0 - momentum) * (double)rmean_c + momentum * (mean + cb));
+        j.running_var[c] = (float)((1.0 - momentum) * (double)rvar_c + momentum * unbiased);
       }
     } else {
-      mean = (double)j.running_mean[c] - cb;
-      var = (double)j.running_var[c];
+      mean = (double)rmean_c - cb;
+      var = (double)rvar_c;
     }
     const double invstd = 1.0 / sqrt(var + (double)eps);
-    const double sc = (double)j.gamma[c] * invstd;
-    const float scf = (float)sc, shf = (float)((double)j.beta[c] - mean * sc);
+    const double sc = (double)gamma_c * invstd;
+    const float scf = (float)sc, shf = (float)((double)beta_c - mean * sc);
     j.scale[c] = scf;
     j.shift[c] = shf;
     if (j.mean != nullptr) { j.mean[c] = (float)mean; j.invstd[c] = (float)invstd; }
     if (want_bound) {      // |gamma * xhat + beta| <= |gamma| sqrt(n) + |beta|  (+ the partner BatchNorm's: the residual sum)
-      float b_ = fabsf(j.gamma[c]) * root_n + fabsf(j.beta[c]);
+      float b_ = fabsf(gamma_c) * root_n + fabsf(beta_c);
       if (j.bound_gamma2 != nullptr) b_ += fabsf(j.bound_gamma2[c]) * root_n + fabsf(j.bound_beta2[c]);
       bound = fmaxf(bound, b_);
     }

@@ -363,6 +363,8 @@ class Engine:
             self._bns = [self.stem_bn] + block_bns
         self._n_stem_convs = len(self.stem.convs) if self.stem is not None else 1      # (first in self._convs: pack_weights' split)
         self._pack_join = False
+        self._pack_epoch = 0         # counts pack_weights() calls (PlannedInference(frozen_weights=True) notices a repack by someone else)
+        self.pack_frozen = False     # True: a forward whose engine mode the packed arena already holds does not repack (PlannedInference)
         self._geoms = {}
         self._tables = {}
         self._arena_key = None
@@ -1059,6 +1061,7 @@ class Engine:
         else:
             run(0, n)
         self._packed_for = cmode
+        self._pack_epoch += 1
 
     def join_pack(self):
         """The main stream waits for the columns' packed weights (pack_weights(overlap=True)); no-op otherwise."""
@@ -1128,7 +1131,8 @@ class Engine:
         # statistics as per-workgroup partial rows (MPOSE_CONV_STATS_PART) instead of fp64 atomics: conv_igemm_k / conv_h2_k only
         spart = ctx['spart'] = bool(train and self.part_stats() and not planes)
         sp = tb['sp_ptr']
-        self.pack_weights(cmode, overlap=self.stem is not None and features is None)
+        if not (self.pack_frozen and self._packed_for == cmode):
+            self.pack_weights(cmode, overlap=self.stem is not None and features is None)
         if f16:
             _lib.fill_zero(self.amax_f)        # (fills through the library: a launch plan records them, csrc/plan.hip)
         if train:

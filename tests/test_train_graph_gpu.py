@@ -152,8 +152,8 @@ def test_training_iteration_launches_only_library_kernels():
     assert not foreign, foreign
 
 
-@pytest.mark.parametrize('bf16', [False, True])
-def test_planned_inference_equals_eager_forward(bf16):
+@pytest.mark.parametrize('bf16,frozen', [(False, False), (True, False), (False, True)])
+def test_planned_inference_equals_eager_forward(bf16, frozen):
     """train_helpers.PlannedInference: the eval-mode forward recorded as a launch plan returns, for new inputs and after the weights
     changed, exactly what the eager forward returns (coordinates and every stage's heatmaps), fp32 and bf16 heatmap storage; and the
     eager forward it records launches only library kernels."""
@@ -171,8 +171,13 @@ def test_planned_inference_equals_eager_forward(bf16):
             torch.cuda.synchronize()
     names = [e.name for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA]
     assert len(names) > 50 and not sorted(set(n for n in names if 'mpose' not in n)), sorted(set(n for n in names if 'mpose' not in n))
-    pf = PlannedInference(m, xs[0])
+    pf = PlannedInference(m, xs[0], frozen_weights=frozen)
     assert pf.n_launches > 50
+    if frozen:               # (the weight measuring / packing launches are not in the recording, and two calls in a row pack nothing;
+        eng = m.inner.engine()           # the eager forwards and the weight update below are noticed and packed once, before the replay)
+        pf(xs[0]); e0 = eng._pack_epoch
+        pf(xs[1]); assert eng._pack_epoch == e0
+        assert pf.n_launches < PlannedInference(m, xs[0]).n_launches
     for it, x in enumerate(xs):
         if it == 2:          # the weights may move between calls: they are read at replay time
             with torch.no_grad():

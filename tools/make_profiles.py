@@ -30,10 +30,13 @@ for r in rows:
 tail = {}
 for (k, B), v in sorted(by.items(), key=lambda kv: -kv[0][1]):
     fused = 'bn_add_softmax_k' in k
-    bf16 = ('true>' in k) if fused else ('false, true, true' in k)
+    targs = [t.strip() for t in k[k.index('<') + 1:k.rindex('>')].split(',')] if '<' in k else []
+    bf16 = (len(targs) > 1 and targs[1] == 'true') if fused else ('false, true, true' in k)      # (bn_add_softmax_k<NV, BF_OUT, ALLJ>)
     nbytes = 3 * B * 17 * 1024 * ((10 if bf16 else 12) if fused else (6 if bf16 else 8)) + (3 * B * 17 * 8 if fused else B * 17 * 12)
     med = statistics.median(v)
-    tail['%sB=%d %s heatmaps' % ('fused with the residual sum: ' if fused else '', B, 'bf16' if bf16 else 'fp32')] = {
+    allj = fused and len(targs) > 2 and targs[2] == 'true'
+    tail['%sB=%d %s heatmaps' % (('fused with the residual sum (all-joints form): ' if allj else 'fused with the residual sum: ') if fused else '', B,
+                                 'bf16' if bf16 else 'fp32')] = {
         'kernel': k, 'launches': len(v), 'median_us': med, 'mean_us': sum(v) / len(v), 'algorithmic_bytes': nbytes,
         'GBps': nbytes / med / 1e3, 'frac_of_8TBps': nbytes / med / 1e3 / 8000.0}
 json.dump({'_source': 'rocprofv3 --kernel-trace --stats -- python tools/prof_tail.py (the loops of bench.py::tail_microbench); kernel durations by '
