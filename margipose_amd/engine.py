@@ -416,7 +416,10 @@ class Engine:
         # bits down to 2^-18 of the bound, and below that its ABSOLUTE error (bound * 2^-39) is far under fp32's at the tensor's
         # typical magnitude.  MPOSE_STEM_BOUNDS=0: measure every node.
         self.stem_bounds = os.environ.get('MPOSE_STEM_BOUNDS', '1') != '0'
-        self.inline_unpack = os.environ.get('MPOSE_INLINE_UNPACK', '0') != '0'     # (see unpack_after: measured no faster, off)
+        # split-K partials summed right behind each weight-gradient launch, on its stream (unpack_after): with round 3's unpack kernel
+        # no faster (24.77 against 24.71 ms); with round 5's (16-byte loads, eight splits in flight) the launch's 50 MB of partials are
+        # read back out of the Infinity Cache instead of 0.65 GB per stage out of HBM on the main stream: 21.96 -> 21.67 ms.  Default.
+        self.inline_unpack = os.environ.get('MPOSE_INLINE_UNPACK', '1') != '0'
         self.overlap_wgrad = True    # +2.3 % step rate, bit-identical results; launches bracketed by a KernelTimer stay serial
         self.dp = None               # optional (process_group, world_size): gradient all-reduce after backward
         self.input_norm = ([0.485, 0.456, 0.406], [0.229, 0.224, 0.225])    # uint8 frames: ImageSpecs mean / stddev
