@@ -1146,6 +1146,10 @@ inline int pick_ks(const ConvArgs& a, int cmax, int n_groups) {
 #ifdef CV_KS_FORCE          // (launch-plan experiments, debug builds: -DCV_KS_FORCE=<RN * 10 + ks>, e.g. 32 = the 96-wide tiles split two ways)
   if (RN == CV_KS_FORCE / 10 && n_iter >= 2 * (CV_KS_FORCE % 10)) return CV_KS_FORCE % 10;
 #endif
+  // (the same as a run-time switch for A/B sweeps: MPOSE_KS_FORCE=<MODE * 100 + RN * 10 + ks>, e.g. 241 = the two-input launches of the 128-wide tiles unsplit)
+  static const int ks_force = [] { const char* e = getenv("MPOSE_KS_FORCE"); return e ? atoi(e) : 0; }();
+  if (ks_force && MODE == ks_force / 100 && RN == (ks_force / 10) % 10 && n_iter >= 2 * (ks_force % 10) && (ks_force % 10 == 1 || ks_force % 10 == 2 || (ks_force % 10 == 4 && RN > 1)))
+    return ks_force % 10;
   for (int ks = 1; ks <= (RN > 1 ? 4 : 2); ks *= 2) {
     if (ks > 1 && n_iter < 2 * ks) break;
     const long wgs = ((m_nominal + 256 / ks - 1) / (256 / ks)) * a.g.n_classes * ((cmax + 32 * RN - 1) / (32 * RN)) * n_groups;
