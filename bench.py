@@ -266,15 +266,29 @@ def configs4_leg(device, steps=8, warmup=3, batch=32):
         return loss
     for _ in range(warmup):
         step()
+    # (the same dispatch as the headline step: the iteration from a launch plan, so that the figure does not depend on the host)
+    planned, dispatch = None, 'eager launches (Python / ctypes)'
+    if os.environ.get('MPOSE_PLAN', '1') != '0':
+        try:
+            from margipose_amd.train_helpers import PlannedTrainStep
+            planned = PlannedTrainStep(model, opt, x, target, mask, warmup=1)
+            dispatch = 'launch plan replay (%d launches)' % planned.n_launches
+        except Exception as e:
+            sys.stderr.write('bench.py: configs[4] launch-plan recording failed (%s: %s); running eagerly\n' % (type(e).__name__, e))
+            planned = None
+    run = (lambda: planned()[1]) if planned is not None else step
+    for _ in range(2):
+        run()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        loss = step()
+        loss = run()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
+    del planned
     res = {'workload': 'BASELINE configs[4] on 1 GPU: training step, batch %d, 5-stage MargiPose, 384x384 input, 48x48 heatmaps, '
                        'convolutions on fp16-rounded operands (fp32 accumulate; BatchNorm / loss / soft-argmax fp32)' % batch,
-           'images_per_sec': batch / dt, 'ms_per_step': 1e3 * dt, 'steps': steps, 'warmup': warmup, 'dtype': 'f16',
+           'images_per_sec': batch / dt, 'ms_per_step': 1e3 * dt, 'steps': steps, 'warmup': warmup, 'dtype': 'f16', 'step_dispatch': dispatch,
            'final_loss': float(loss.detach())}
     timer = KernelTimer()
     timer.calibrate()
