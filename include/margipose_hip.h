@@ -520,6 +520,12 @@ typedef struct {
 /* mode: bit 0 = eval_mode (running statistics were constants), bit 1 = read `sums` even where a job has `part`,
  * bit 2 = 1024 threads per job (launches whose jobs carry partial rows), bit 3 = write the jobs' bounds (bound_out). */
 int mpose_bn_bwd_coef(const mpose_bn_bwd_coef_job* jobs_dev, int n_jobs, int mode, void* stream);
+/* mpose_bn_bwd_reduce_ws followed by mpose_bn_bwd_coef(jobs, n_coef_jobs, coef_mode) -- coef_mode: bit 0 = eval_mode only; jobs with
+ * sums_stride 4 whose `sums` point into the sums of one of the reduction's groups -- as two launches instead of three: the
+ * reduction's finishing pass runs the coefficient jobs of the channels whose sums it has just completed (same results). */
+int mpose_bn_bwd_reduce_coef_ws(const mpose_bn_bwd_reduce_operands* ops, int n_groups, int pixels_per_image, int B, int C,
+                                void* workspace, int64_t workspace_bytes, const mpose_bn_bwd_coef_job* coef_jobs_dev,
+                                int n_coef_jobs, int coef_mode, void* stream);
 
 /* 3x3 pooling over NHWC with the producer's BN+ReLU applied on the fly (scale/shift may be NULL = identity).
  * kind 0: max pool, stride 2, pad 1 (the reference rewrites MaxPool2d padding to k//2, models/margipose_model.py:111-117);

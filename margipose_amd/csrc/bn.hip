@@ -83,7 +83,28 @@ struct BnReduceArgs {
   long npix;
   int C, pix_per_block;
   double* partials;       // when non-NULL: [group][block][C][4] per-workgroup sums (no atomics; bn_bwd_reduce_finish_k adds them up)
+  // mpose_bn_bwd_reduce_coef_ws: the finishing pass also runs these coefficient jobs (those whose `sums` lie inside a group's sums)
+  const mpose_bn_bwd_coef_job* coef_jobs;
+  int n_coef, coef_eval;
 };
+
+// One channel of a coefficient job from its two sums (bn_bwd_coef_k's arithmetic; `c` is the job's channel index).  Returns c0.
+__device__ __forceinline__ double coef_channel(const mpose_bn_bwd_coef_job& j, int c, double sg, double sgx, int eval_mode, double mean, double invstd,
+                                               double gamma, double* sgxhat_out) {
+  const double n = (double)j.count;
+  const double sgxhat = invstd * (sgx - mean * sg);
+  const double c0 = gamma * invstd;
+  const double c1 = eval_mode ? 0.0 : -c0 * invstd * (sgxhat / n);
+  const double c2 = eval_mode ? 0.0 : -c0 * (sg / n);
+  j.coef[c] = (float)c0;
+  j.coef[j.c_stride + c] = (float)c1;
+  j.coef[2 * j.c_stride + c] = (float)c2;
+  j.coef[3 * j.c_stride + c] = (float)mean;
+  if (j.dgamma != nullptr) { j.dgamma[c] = (float)sgxhat; j.dbeta[c] = (float)sg; }
+  if (j.dconv_bias != nullptr) j.dconv_bias[c] = eval_mode ? (float)(c0 * sg) : 0.f;
+  *sgxhat_out = sgxhat;
+  return c0;
+}
 
 __global__ __launch_bounds__(256) void bn_bwd_reduce_k(BnReduceArgs a) {
   extern __shared__ double sred[];     // [rows_per_pass][C][4]
@@ -186,14 +207,40 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_finish_k(BnReduceArgs a, in
   }
   sl[slice][el] = ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
   __syncthreads();
+  __shared__ double fin[EL];
   if (slice == 0 && e < n_e) {
+    double s;
     if constexpr (SL == 4) {
-      a.op[blockIdx.y].sums[e] = (sl[0][el] + sl[1][el]) + (sl[2][el] + sl[3][el]);
+      s = (sl[0][el] + sl[1][el]) + (sl[2][el] + sl[3][el]);
     } else {
-      double s = 0.0;
+      s = 0.0;
 #pragma unroll
       for (int k = 0; k < SL; k += 4) s += (sl[k][el] + sl[k + 1][el]) + (sl[k + 2][el] + sl[k + 3][el]);
-      a.op[blockIdx.y].sums[e] = s;
+    }
+    a.op[blockIdx.y].sums[e] = s;
+    fin[el] = s;
+  }
+  if (a.coef_jobs == nullptr) return;       // (uniform)
+  // The workgroup holds all four sums of EL / 4 channels: it runs the coefficient jobs that read them (bn_bwd_coef_k's launch, 5-6 us
+  // of pure latency behind this one, 22 times per step) -- same sums, same arithmetic, same results.
+  __syncthreads();
+  if (threadIdx.x < EL / 4) {
+    const int ch = blockIdx.x * (EL / 4) + (int)threadIdx.x;       // channel of the group's sums
+    if (ch < a.C) {
+      const double* base = a.op[blockIdx.y].sums;
+      for (int i = 0; i < a.n_coef; ++i) {
+        const mpose_bn_bwd_coef_job& j = a.coef_jobs[i];
+        if (j.sums_stride != 4) continue;
+        const long rel = (long)(j.sums - base);                     // in doubles
+        if (rel < 0 || (rel & 3)) continue;
+        const long c = (long)ch - (rel >> 2);
+        if (c < 0 || c >= j.C) continue;
+        const double* f = fin + threadIdx.x * 4;
+        const double sg = j.sg_col == 0 ? f[0] : (j.sg_col == 1 ? f[1] : (j.sg_col == 2 ? f[2] : f[3]));
+        const double sgx = j.which == 0 ? f[0] : (j.which == 1 ? f[1] : (j.which == 2 ? f[2] : f[3]));
+        double sgxhat;
+        coef_channel(j, (int)c, sg, sgx, a.coef_eval, (double)j.mean[c], (double)j.invstd[c], (double)j.gamma[c], &sgxhat);
+      }
     }
   }
 }
@@ -234,19 +281,10 @@ __global__ __launch_bounds__(1024) void bn_bwd_coef_k(const mpose_bn_bwd_coef_jo
     auto pick = [&](int k) { return k == 0 ? ps[0] : (k == 1 ? ps[1] : (k == 2 ? ps[2] : ps[3])); };
     const double sg = from_part ? pick(j.sg_col) : j.sums[(size_t)c * j.sums_stride + j.sg_col];
     const double sgx = from_part ? pick(j.which) : j.sums[(size_t)c * j.sums_stride + j.which];
-    const double mean = (double)mean_c, invstd = (double)invstd_c, gamma = (double)gamma_c;
-    const double sgxhat = invstd * (sgx - mean * sg);
-    const double c0 = gamma * invstd;
-    const double c1 = eval_mode ? 0.0 : -c0 * invstd * (sgxhat / n);
-    const double c2 = eval_mode ? 0.0 : -c0 * (sg / n);
+    double sgxhat;
+    const double c0 = coef_channel(j, c, sg, sgx, eval_mode, (double)mean_c, (double)invstd_c, (double)gamma_c, &sgxhat);
     if (want_bound)       // |c0 g + c1 (x - mean) + c2| <= |c0| (gmax + sqrt(n) |mean(g xhat)| + |mean g|):  |x - mean| invstd <= sqrt(n)
       bound = fmaxf(bound, (float)(fabs(c0) * ((double)gmax + (eval_mode ? 0.0 : sqrt(n) * fabs(sgxhat / n) + fabs(sg / n)))));
-    j.coef[c] = (float)c0;
-    j.coef[j.c_stride + c] = (float)c1;
-    j.coef[2 * j.c_stride + c] = (float)c2;
-    j.coef[3 * j.c_stride + c] = (float)mean;
-    if (j.dgamma != nullptr) { j.dgamma[c] = (float)sgxhat; j.dbeta[c] = (float)sg; }
-    if (j.dconv_bias != nullptr) j.dconv_bias[c] = eval_mode ? (float)(c0 * sg) : 0.f;
   }
   if (want_bound) block_amax_commit_one(bound * 1.0001f, j.bound_out);       // (uniform; a bound that is not finite -> +inf, like a NaN maximum)
 }
@@ -424,11 +462,30 @@ extern "C" int64_t mpose_bn_bwd_reduce_ws_bytes(int n_groups, int pixels_per_ima
 
 // Same sums as mpose_bn_bwd_reduce, WRITTEN (not accumulated), through per-workgroup partial sums in a caller-provided workspace
 // of at least mpose_bn_bwd_reduce_ws_bytes(): no atomics, more and smaller workgroups, deterministic order.
+static int reduce_ws_launch(const mpose_bn_bwd_reduce_operands* ops, int n_groups, int pixels_per_image, int B, int C, void* workspace,
+                            int64_t workspace_bytes, const mpose_bn_bwd_coef_job* coef_jobs, int n_coef, int coef_eval, void* stream);
+
 extern "C" int mpose_bn_bwd_reduce_ws(const mpose_bn_bwd_reduce_operands* ops, int n_groups, int pixels_per_image, int B, int C,
                                       void* workspace, int64_t workspace_bytes, void* stream) {
+  return reduce_ws_launch(ops, n_groups, pixels_per_image, B, C, workspace, workspace_bytes, nullptr, 0, 0, stream);
+}
+
+// mpose_bn_bwd_reduce_ws + mpose_bn_bwd_coef (mode: bit 0 = eval_mode; jobs read from `sums`, no bounds) as two launches instead
+// of three: the finishing pass of the reduction runs the coefficient jobs whose `sums` it has just completed.
+extern "C" int mpose_bn_bwd_reduce_coef_ws(const mpose_bn_bwd_reduce_operands* ops, int n_groups, int pixels_per_image, int B, int C,
+                                           void* workspace, int64_t workspace_bytes, const mpose_bn_bwd_coef_job* coef_jobs_dev,
+                                           int n_coef_jobs, int coef_mode, void* stream) {
+  if (!coef_jobs_dev || n_coef_jobs < 1 || (coef_mode & ~1)) return MPOSE_EINVAL;
+  if ((long)B * pixels_per_image == 0) return MPOSE_EINVAL;       // (no finishing pass would run the jobs)
+  return reduce_ws_launch(ops, n_groups, pixels_per_image, B, C, workspace, workspace_bytes, coef_jobs_dev, n_coef_jobs, coef_mode & 1, stream);
+}
+
+static int reduce_ws_launch(const mpose_bn_bwd_reduce_operands* ops, int n_groups, int pixels_per_image, int B, int C, void* workspace,
+                            int64_t workspace_bytes, const mpose_bn_bwd_coef_job* coef_jobs, int n_coef, int coef_eval, void* stream) {
   if (n_groups < 1 || n_groups > MPOSE_MAX_GROUP || (C & 3) || C > 1024 || !workspace) return MPOSE_EINVAL;
   if (workspace_bytes < mpose_bn_bwd_reduce_ws_bytes(n_groups, pixels_per_image, B, C)) return MPOSE_EINVAL;
   BnReduceArgs a{};
+  a.coef_jobs = coef_jobs; a.n_coef = n_coef; a.coef_eval = coef_eval;
   for (int i = 0; i < n_groups; ++i) a.op[i] = ops[i];
   a.npix = (long)B * pixels_per_image;
   if (a.npix == 0) return 0;

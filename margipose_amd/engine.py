@@ -420,6 +420,9 @@ class Engine:
         # no faster (24.77 against 24.71 ms); with round 5's (16-byte loads, eight splits in flight) the launch's 50 MB of partials are
         # read back out of the Infinity Cache instead of 0.65 GB per stage out of HBM on the main stream: 21.96 -> 21.67 ms.  Default.
         self.inline_unpack = os.environ.get('MPOSE_INLINE_UNPACK', '1') != '0'
+        # the coefficient jobs that read a BatchNorm-backward reduction's sums run in its finishing pass (bn_bwd_reduce): 22 launches
+        # of pure latency per step fewer, bit-identical results
+        self.fuse_coef = os.environ.get('MPOSE_FUSE_COEF', '1') != '0'
         self.overlap_wgrad = True    # +2.3 % step rate, bit-identical results; launches bracketed by a KernelTimer stay serial
         self.dp = None               # optional (process_group, world_size): gradient all-reduce after backward
         self.input_norm = ([0.485, 0.456, 0.406], [0.229, 0.224, 0.225])    # uint8 frames: ImageSpecs mean / stddev
@@ -864,16 +867,24 @@ class Engine:
         check(lib().mpose_split_h2((SplitH2Operands * 3)(*ops), len(ops), c_int64(npix), C, int(relu), stream_ptr()), 'mpose_split_h2')
         return outs
 
-    def bn_bwd_reduce(self, rops, pixels_per_image, B, C):
-        """BatchNorm-backward sums of one grouped launch (mpose_bn_bwd_reduce_ws: per-workgroup partials, no atomics)."""
+    def bn_bwd_reduce(self, rops, pixels_per_image, B, C, coef=None):
+        """BatchNorm-backward sums of one grouped launch (mpose_bn_bwd_reduce_ws: per-workgroup partials, no atomics).
+        coef = (device address of the first mpose_bn_bwd_coef_job, jobs, eval_mode): the coefficient jobs that read these sums
+        run in the reduction's finishing pass (mpose_bn_bwd_reduce_coef_ws: one launch fewer, same results); returns True when
+        they did (MPOSE_FUSE_COEF=0, or an empty batch: the caller launches mpose_bn_bwd_coef itself)."""
         L = lib()
         n = len(rops)
         need = int(L.mpose_bn_bwd_reduce_ws_bytes(n, pixels_per_image, B, C))
         ws = getattr(self, '_reduce_ws', None)
         if ws is None or ws.numel() < need or ws.device != self.device:
             self._reduce_ws = ws = torch.empty(max(need, 8 << 20), dtype=torch.uint8, device=self.device)
+        if coef is not None and self.fuse_coef and B * pixels_per_image > 0:
+            check(L.mpose_bn_bwd_reduce_coef_ws((BnBwdReduceOperands * 3)(*rops), n, pixels_per_image, B, C, ptr(ws), c_int64(ws.numel()),
+                                                c_void_p(coef[0]), coef[1], int(coef[2]), stream_ptr()), 'mpose_bn_bwd_reduce_coef_ws')
+            return True
         check(L.mpose_bn_bwd_reduce_ws((BnBwdReduceOperands * 3)(*rops), n, pixels_per_image, B, C, ptr(ws), c_int64(ws.numel()), stream_ptr()),
               'mpose_bn_bwd_reduce_ws')
+        return False
 
     def planes_for(self, train, save):
         """Which engine a forward (and its backward) runs the columns on: see __init__."""
@@ -1577,10 +1588,16 @@ class Engine:
                         ro.a_scale, ro.a_shift = self._bnf_ptr(b.bn2, 0), self._bnf_ptr(b.bn2, 1)     # ReLU after the second BN
                         ro.sums = self._stats_ptr(b.bn2, True)
                         rops.append(ro)
-                    self.bn_bwd_reduce(rops, Hout * Hout, B, Cs)
                 blk_h2 = h2 and b0.h2
                 app_h2 = h2f and blk_h2 and self.h2_fuse >= 2     # bn2's backward application writes d_c2 as planes too, scaled by the coefficient kernel's bound
-                run_coef(jb, 6, from_sums=not sums_done, bounds=app_h2)
+                coef_done = False
+                if not sums_done:
+                    # (the six coefficient jobs of bn2 / bn_s read these sums: they run in the reduction's finishing pass unless they
+                    #  also have to produce the bound of an H2 block's planes)
+                    coef_done = self.bn_bwd_reduce(rops, Hout * Hout, B, Cs,
+                                                   None if app_h2 else (coef_base + jb * COEF_DT.itemsize, 6, eval_bn))
+                if not coef_done:
+                    run_coef(jb, 6, from_sums=not sums_done, bounds=app_h2)
                 d_c2 = [torch.empty(B, Hout, Hout, Cs, **f32) for _ in range(3)]
                 d_sc = [torch.empty(B, Hout, Hout, Cs, **f32) for _ in range(3)]
                 aops = []
@@ -1726,8 +1743,8 @@ class Engine:
                 check(L.mpose_relu_bwd(ptr(D), ptr(ctx['stem_out']), ptr(gm), c_int64(gm.numel()), st()), 'mpose_relu_bwd')
                 ro = BnBwdReduceOperands()
                 ro.g, ro.a, ro.sums = gm.data_ptr(), ctx['stem_raw'].data_ptr(), self._stats_ptr(n, True)
-                self.bn_bwd_reduce([ro], F * F, B, 128)
-                run_coef(self.T * 90, 1)
+                if not self.bn_bwd_reduce([ro], F * F, B, 128, (coef_base + self.T * 90 * COEF_DT.itemsize, 1, eval_bn)):
+                    run_coef(self.T * 90, 1)
                 d_raw = torch.empty_like(D)
                 ao = BnBwdApplyOperands()
                 ao.g, ao.a, ao.coef_a, ao.da = gm.data_ptr(), ctx['stem_raw'].data_ptr(), self._bnf_ptr(n, 4), d_raw.data_ptr()

@@ -514,10 +514,11 @@ class _GraphStem:
             ro.g, ro.a, ro.sums = g.data_ptr(), raw[n.name].data_ptr(), self.sptr(n, True)
             if n.relu:
                 ro.a_scale, ro.a_shift = self.fptr(n, 0), self.fptr(n, 1)
-            eng.bn_bwd_reduce([ro], H * W, B, n.C)
             c0_, nc = tb['coef_range'][n.name]
-            if nc:
-                check(L.mpose_bn_bwd_coef(c_void_p(tb['coef'].data_ptr() + c0_ * eng.COEF_ITEMSIZE), nc, 0 if ctx.get('train', True) else 1, st()), 'mpose_bn_bwd_coef')
+            eval_bn = 0 if ctx.get('train', True) else 1
+            # (the node's coefficient jobs run in the reduction's finishing pass: one launch fewer per node)
+            if not eng.bn_bwd_reduce([ro], H * W, B, n.C, (tb['coef'].data_ptr() + c0_ * eng.COEF_ITEMSIZE, nc, eval_bn) if nc else None) and nc:
+                check(L.mpose_bn_bwd_coef(c_void_p(tb['coef'].data_ptr() + c0_ * eng.COEF_ITEMSIZE), nc, eval_bn, st()), 'mpose_bn_bwd_coef')
             d_raw = torch.empty(B, H, W, n.C, **f32)
             ao = BnBwdApplyOperands()
             ao.g, ao.a, ao.coef_a, ao.da = g.data_ptr(), raw[n.name].data_ptr(), self.fptr(n, 4), d_raw.data_ptr()

@@ -884,6 +884,7 @@ def test_step_switches_leave_the_results_bit_identical(stem):
     eng.fuse_finalize = True
     eng.inline_unpack = True
     eng.tail_fuse = False          # (fourth: the residual sum + soft-argmax as two launches through a logits tensor instead of one)
+    eng.fuse_coef = False          # (fifth: the coefficient jobs as their own launch instead of in the reduction's finishing pass)
     res = []
     for m in (m0, m1):
         out = m(x.cuda())
