@@ -540,6 +540,13 @@ int mpose_pool3_bwd(const float* in, const float* scale, const float* shift, con
  * input element.  Same result bit for bit. */
 int mpose_maxpool3_bwd_ws(const float* in, const float* scale, const float* shift, const float* g, float* d_in,
                           void* workspace, long workspace_bytes, int B, int IH, int IW, int C, int g_ld, void* stream);
+/* The same with the arg-max positions kept from the FORWARD pass: mpose_maxpool3_fwd_arg is mpose_pool3_fwd(kind 0) that also
+ * writes one byte per pooled element (>= B*OH*OW*C bytes; first maximum in row-major order), mpose_maxpool3_bwd_arg the second
+ * pass of mpose_maxpool3_bwd_ws reading them -- the backward pass no longer re-reads the pre-pool tensor.  Same results. */
+int mpose_maxpool3_fwd_arg(const float* in, const float* scale, const float* shift, float* out, void* arg_out, long arg_bytes,
+                           int B, int IH, int IW, int C, int out_ld, void* stream);
+int mpose_maxpool3_bwd_arg(const float* g, const void* arg, long arg_bytes, float* d_in, int B, int IH, int IW, int C, int g_ld,
+                           void* stream);
 /* NCHW (B, C, H, W) -> NHWC (B, H, W, Cpad) zero padded, and the reverse gather for the input gradient. */
 int mpose_image_to_nhwc(const float* x, float* out, int B, int C, int H, int W, int Cpad, void* stream);
 int mpose_nhwc_to_image(const float* g, float* dx, int B, int C, int H, int W, int Cpad, void* stream);

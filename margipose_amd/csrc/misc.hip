@@ -393,6 +393,37 @@ __global__ __launch_bounds__(256) void maxpool3_argmax_k(PoolArgs a, unsigned ch
     *reinterpret_cast<unsigned*>(arg_out + i * 4) = arg[0] | (arg[1] << 8) | (arg[2] << 16) | (arg[3] << 24);
   }
 }
+// The forward max pool that also records the window positions (round 5): a training forward keeps the bytes (1/4 of the pooled
+// output) and its backward skips pass 1 above -- the recomputation re-read the whole pre-pool tensor (26 + 42 us per step).  Same
+// traversal and the same strict `>` as maxpool3_argmax_k, the stored maximum equals pool3_fwd_k's (the taps' order does not matter to it).
+__global__ __launch_bounds__(256) void maxpool3_fwd_arg_k(PoolArgs a, unsigned char* __restrict__ arg_out) {
+  const int c4n = a.C >> 2;
+  const long total = (long)a.B * a.OH * a.OW * c4n;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % c4n) * 4;
+    long r = i / c4n;
+    const int ox = (int)(r % a.OW); r /= a.OW;
+    const int oy = (int)(r % a.OH);
+    const long b = r / a.OH;
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.scale != nullptr) { sc = *reinterpret_cast<const float4*>(a.scale + c); sh = *reinterpret_cast<const float4*>(a.shift + c); }
+    float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    unsigned arg[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int ky = -1; ky <= 1; ++ky)
+#pragma unroll
+      for (int kx = -1; kx <= 1; ++kx) {
+        const int yy = oy * 2 + ky, xx = ox * 2 + kx;
+        if (yy < 0 || yy >= a.IH || xx < 0 || xx >= a.IW) continue;
+        const float4 v4 = pool_act(a, (b * a.IH + yy) * a.IW + xx, c, sc, sh);
+        const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (v[e] > best[e]) { best[e] = v[e]; arg[e] = (unsigned)((ky + 1) * 3 + (kx + 1)); }
+      }
+    *reinterpret_cast<unsigned*>(arg_out + i * 4) = arg[0] | (arg[1] << 8) | (arg[2] << 16) | (arg[3] << 24);
+    *reinterpret_cast<float4*>(a.out + ((b * a.OH + oy) * a.OW + ox) * a.ld + c) = make_float4(best[0], best[1], best[2], best[3]);
+  }
+}
 __global__ __launch_bounds__(256) void maxpool3_bwd_arg_k(PoolArgs a, const unsigned char* __restrict__ arg_in) {
   const int c4n = a.C >> 2;
   const long total = (long)a.B * a.IH * a.IW * c4n;
@@ -732,6 +763,30 @@ extern "C" int mpose_maxpool3_bwd_ws(const float* in, const float* scale, const 
   if (total_i == 0) return 0;
   launch(maxpool3_argmax_k, dim3(grid_for(total_o, 256)), dim3(256), 0, (hipStream_t)stream, a, static_cast<unsigned char*>(workspace));
   launch(maxpool3_bwd_arg_k, dim3(grid_for(total_i, 256)), dim3(256), 0, (hipStream_t)stream, a, static_cast<const unsigned char*>(workspace));
+  return launch_status();
+}
+
+extern "C" int mpose_maxpool3_fwd_arg(const float* in, const float* scale, const float* shift, float* out, void* arg_out, long arg_bytes,
+                                      int B, int IH, int IW, int C, int out_ld, void* stream) {
+  PoolArgs a{};
+  if (pool_dims(0, IH, IW, a.OH, a.OW) || (C & 3) || out_ld < C || (out_ld & 3)) return MPOSE_EINVAL;
+  if (!arg_out || arg_bytes < (long)B * a.OH * a.OW * C) return MPOSE_EINVAL;
+  a.in = in; a.scale = scale; a.shift = shift; a.out = out; a.B = B; a.IH = IH; a.IW = IW; a.C = C; a.ld = out_ld; a.kind = 0;
+  const long total = (long)B * a.OH * a.OW * (C / 4);
+  if (total == 0) return 0;
+  launch(maxpool3_fwd_arg_k, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, a, static_cast<unsigned char*>(arg_out));
+  return launch_status();
+}
+
+extern "C" int mpose_maxpool3_bwd_arg(const float* g, const void* arg, long arg_bytes, float* d_in, int B, int IH, int IW, int C, int g_ld,
+                                      void* stream) {
+  PoolArgs a{};
+  if (pool_dims(0, IH, IW, a.OH, a.OW) || (C & 3) || g_ld < C || (g_ld & 3)) return MPOSE_EINVAL;
+  if (!arg || arg_bytes < (long)B * a.OH * a.OW * C) return MPOSE_EINVAL;
+  a.g = g; a.out = d_in; a.B = B; a.IH = IH; a.IW = IW; a.C = C; a.ld = g_ld; a.kind = 0;
+  const long total_i = (long)B * IH * IW * (C / 4);
+  if (total_i == 0) return 0;
+  launch(maxpool3_bwd_arg_k, dim3(grid_for(total_i, 256)), dim3(256), 0, (hipStream_t)stream, a, static_cast<const unsigned char*>(arg));
   return launch_status();
 }
 

@@ -35,6 +35,7 @@ from . import _lib
 from ._lib import (BnAddOperands, BnBwdApplyOperands, BnBwdReduceOperands, ConvOperands, WgradOperands, c_int64, c_void_p, check, lib, ptr,
                    stream_ptr)
 
+_POOL_ARG = os.environ.get('MPOSE_POOL_ARG', '1') != '0'       # (0: the max pools' window choices are recomputed in the backward pass: A/B runs)
 _FIRST_WRITES = os.environ.get('MPOSE_STEM_FIRST_WRITES', '1') != '0'      # (0: every node gradient starts from a zero fill: A/B runs)
 
 BN_EPS_STEM = 1e-3        # BasicConv2d's BatchNorm2d(eps=0.001)
@@ -427,6 +428,7 @@ class _GraphStem:
         st = stream_ptr
         f32 = dict(dtype=torch.float32, device=next(iter(raw.values())).device)
         done = set(id(op) for op in self.ops[:first_op])
+        pool_args = {}
         for op in self.ops[first_op:]:
             n = op.dst
             if n.name not in raw:
@@ -464,8 +466,16 @@ class _GraphStem:
                 check(L.mpose_bn_add_fwd((BnAddOperands * 3)(ao), 1, H * W, B, n.C, 0 if op.relu_a else 2, 0, st()), 'mpose_bn_add_fwd')
             else:
                 Hs = src.hw(S)[0]       # (pools: square maps only)
-                check(L.mpose_pool3_fwd(ptr(raw[src.name]), c_void_p(sc), c_void_p(sh), c_void_p(raw[n.name].data_ptr() + 4 * op.c0),
-                                        B, Hs, Hs, src.C, n.C, op.kind, st()), 'mpose_pool3_fwd')
+                if save and op.kind == 0 and _POOL_ARG:
+                    # (a differentiable forward keeps the max pool's window choices, a byte per pooled element: its backward then
+                    #  needs neither the pre-pool tensor nor a pass over it)
+                    arg = torch.empty(B * n.hw(S)[0] * n.hw(S)[1] * src.C, dtype=torch.uint8, device=raw[src.name].device)
+                    check(L.mpose_maxpool3_fwd_arg(ptr(raw[src.name]), c_void_p(sc), c_void_p(sh), c_void_p(raw[n.name].data_ptr() + 4 * op.c0),
+                                                   ptr(arg), ctypes.c_long(arg.numel()), B, Hs, Hs, src.C, n.C, st()), 'mpose_maxpool3_fwd_arg')
+                    pool_args[id(op)] = arg
+                else:
+                    check(L.mpose_pool3_fwd(ptr(raw[src.name]), c_void_p(sc), c_void_p(sh), c_void_p(raw[n.name].data_ptr() + 4 * op.c0),
+                                            B, Hs, Hs, src.C, n.C, op.kind, st()), 'mpose_pool3_fwd')
             done.add(id(op))
             if train and all(id(p) in done for p in n.producers):
                 f0, nf = tb['fin_range'][n.name]
@@ -481,7 +491,7 @@ class _GraphStem:
             out = torch.empty(B, S // n7.div, S // n7.div, n7.C, **f32)
             check(L.mpose_bn_relu_fwd(ptr(raw[n7.name]), c_void_p(self.fptr(n7, 0)), c_void_p(self.fptr(n7, 1)), ptr(out),
                                       c_int64(out.numel()), n7.C, st()), 'mpose_bn_relu_fwd')
-        ctx = {'raw': raw, 'B': B, 'S': S, 'train': train, 'f16': f16, 'cflags': cflags, 'measured': measured} if save else None
+        ctx = {'raw': raw, 'B': B, 'S': S, 'train': train, 'f16': f16, 'cflags': cflags, 'measured': measured, 'pool_args': pool_args} if save else None
         return out, ctx
 
     # ------------------------------------------------------------------ backward
@@ -571,6 +581,10 @@ class _GraphStem:
                             o.in_amax, o.w0_amax = n.amax_b, op.conv.amax_ptr
                         eng.conv(self.geom(op, B, S, 'd'), [o], (0 if src.name in fresh else 1) | cflags)       # (first contribution: write; later ones accumulate)
                         fresh.discard(src.name)
+                elif want_dsrc and op.kind == 0 and id(op) in ctx.get('pool_args', {}):
+                    arg = ctx['pool_args'][id(op)]
+                    check(L.mpose_maxpool3_bwd_arg(c_void_p(d_raw.data_ptr() + 4 * op.c0), ptr(arg), ctypes.c_long(arg.numel()), ptr(dact[src.name]),
+                                                   B, Hs, Hs, src.C, n.C, st()), 'mpose_maxpool3_bwd_arg')
                 elif want_dsrc and op.kind == 0:
                     ws = torch.empty(B * H * H * src.C, dtype=torch.uint8, device=dev)       # window arg-max positions
                     check(L.mpose_maxpool3_bwd_ws(ptr(raw[src.name]), c_void_p(sc), c_void_p(sh), c_void_p(d_raw.data_ptr() + 4 * op.c0),
