@@ -9,14 +9,24 @@ N = int(os.environ.get('N', '400'))
 torch.manual_seed(0)
 m = MargiPoseModel(CanonicalSkeletonDesc, 3, True, 'inceptionv4', 'jsd').cuda().train()
 m.inner.engine().overlap_wgrad = os.environ.get('OVERLAP', '1') != '0'
-opt = torch.optim.SGD(m.parameters(), lr=1e-2, momentum=0.9, fused=True)
+PLAN = os.environ.get('PLAN', '0') != '0'      # PLAN=1: the default dispatch of bench.py (DeviceSGD + PlannedTrainStep), lr moving every step
 x = torch.randn(32, 3, 256, 256, device='cuda'); tgt = torch.rand(32, 17, 3, device='cuda') * 2 - 1; mask = torch.ones(32, 17, device='cuda')
+if PLAN:
+    from margipose_amd.train_helpers import DeviceSGD, PlannedTrainStep
+    opt = DeviceSGD(m.parameters(), lr=1e-2, momentum=0.9)
+    planned = PlannedTrainStep(m, opt, x, tgt, mask)
+else:
+    opt = torch.optim.SGD(m.parameters(), lr=1e-2, momentum=0.9, fused=True)
 t0 = time.perf_counter()
 for i in range(1, N + 1):
-    opt.zero_grad(set_to_none=True)
-    loss = dsntnn.average_loss(m.forward_3d_losses(m(x), tgt), mask)
-    loss.backward()
-    opt.step()
+    if PLAN:
+        opt.param_groups[0]['lr'] = 1e-2 * (0.5 + 0.5 * (i % 50) / 50.0)
+        loss = planned()[1]
+    else:
+        opt.zero_grad(set_to_none=True)
+        loss = dsntnn.average_loss(m.forward_3d_losses(m(x), tgt), mask)
+        loss.backward()
+        opt.step()
     if i % int(os.environ.get('EVERY', '100')) == 0:
         torch.cuda.synchronize()
         t1 = time.perf_counter()
