@@ -270,7 +270,10 @@ typedef struct {
   const float* gout0_amax;
   const float* gout1_amax;
   int single_product;                  /* with in_amax (all groups alike): MPOSE_CONV_F16X1's arithmetic -- the h x h product only */
-  int pad_;
+  int planes_in;                       /* with in_amax (all groups alike): `in`, gout0 and gout1 are H8 plane tensors (see MPOSE_CONV_H2_IN:
+                                        * [C/8][plane 2][pixel][8] fp16 of x * 2^k, k from the tensor's amax slot as its producer read it)
+                                        * instead of fp32 NHWC -- stride-1 geometries of whole 32-channel groups, GW % 16 == 0, no
+                                        * prologue (the producer applied it); anything else is MPOSE_EINVAL */
 } mpose_wgrad_operands;
 
 /* Number of (tap, input-channel tile, output-channel tile) work units of one group's weight-gradient launch;
@@ -488,10 +491,13 @@ int mpose_bn_bwd_apply(const mpose_bn_bwd_apply_operands* ops, int n_groups, int
                        int B, int C, int layout, int c_keep, void* stream);
 int mpose_bn_bwd_apply_planes(const mpose_bn_bwd_apply_operands* ops, void* const* da_planes, void* const* db_planes,
                               int n_groups, int64_t npix, int C, void* stream);
-/* mpose_bn_bwd_apply that also writes da as the two fp16 planes of MPOSE_CONV_H2_IN, da_h2[i], scaled as the amax slot
- * ops[i].da_amax prescribes (READ: the bound of mpose_bn_bwd_coef_job.bound_out); db is written as fp32 and its largest
- * magnitude accumulated into ops[i].db_amax as mpose_bn_bwd_apply does. */
-int mpose_bn_bwd_apply_h2(const mpose_bn_bwd_apply_operands* ops, void* const* da_h2, int n_groups, int64_t npix, int C, void* stream);
+/* mpose_bn_bwd_apply that writes da as the two fp16 planes of MPOSE_CONV_H2_IN, da_h2[i], scaled as the amax slot
+ * ops[i].da_amax prescribes (READ: the bound of mpose_bn_bwd_coef_job.bound_out); ops[i].da (fp32) may be NULL.
+ * db_h2 == NULL: db is written as fp32 and its largest magnitude accumulated into ops[i].db_amax as mpose_bn_bwd_apply does.
+ * db_h2 != NULL (all groups alike): db is written as planes too, db_h2[i], scaled as ops[i].db_amax prescribes (READ: a bound,
+ * nothing is accumulated); ops[i].db (fp32) may then be NULL. */
+int mpose_bn_bwd_apply_h2(const mpose_bn_bwd_apply_operands* ops, void* const* da_h2, void* const* db_h2, int n_groups, int64_t npix,
+                          int C, void* stream);
 
 typedef struct {
   const double* sums;                  /* (Cs, 3) from mpose_bn_bwd_reduce, or (Cs, 2) from a conv epilogue */

@@ -17,7 +17,7 @@ c_int = ctypes.c_int
 c_float = ctypes.c_float
 c_int64 = ctypes.c_int64
 
-ABI_VERSION = 15         # must equal mpose_abi_version() of the library (csrc/tail.hip)
+ABI_VERSION = 16         # must equal mpose_abi_version() of the library (csrc/tail.hip)
 MAX_GROUP = 3
 MAX_TAPS = 12
 MAX_CLASSES = 8
@@ -160,7 +160,7 @@ class ConvOperands(ctypes.Structure):
 class WgradOperands(ctypes.Structure):
     _fields_ = [('in_', c_void_p), ('in_scale', c_void_p), ('in_shift', c_void_p),
                 ('gout0', c_void_p), ('gout1', c_void_p), ('dw0', c_void_p), ('dw1', c_void_p),
-                ('in_amax', c_void_p), ('gout0_amax', c_void_p), ('gout1_amax', c_void_p), ('single_product', c_int), ('pad_', c_int)]
+                ('in_amax', c_void_p), ('gout0_amax', c_void_p), ('gout1_amax', c_void_p), ('single_product', c_int), ('planes_in', c_int)]
 
 
 class AbsmaxOperands(ctypes.Structure):

@@ -2020,6 +2020,7 @@ extern "C" int mpose_conv_wgrad(const mpose_conv_geom* geom_, const mpose_wgrad_
     if ((ops[i].in_amax != nullptr) != (ops[0].in_amax != nullptr)) return MPOSE_EINVAL;
     if (ops[i].in_amax && (!ops[i].gout0_amax || (acc1 && !ops[i].gout1_amax))) return MPOSE_EINVAL;
     if ((ops[i].single_product != 0) != (ops[0].single_product != 0) || (ops[i].single_product && !ops[i].in_amax)) return MPOSE_EINVAL;
+    if ((ops[i].planes_in != 0) != (ops[0].planes_in != 0) || (ops[i].planes_in && !ops[i].in_amax)) return MPOSE_EINVAL;
   }
   const int n_rows = geom->B * geom->GH;
   if (n_rows == 0 || a.n_entries == 0) return 0;
@@ -2029,6 +2030,7 @@ extern "C" int mpose_conv_wgrad(const mpose_conv_geom* geom_, const mpose_wgrad_
   // stride-1 geometries in the three-product form: one staged operand pair per kernel ROW of taps (wgrad.hip)
   rc = mpose_wgrad_rows_launch(geom, ops, n_groups, n_split, stream);
   if (rc != MPOSE_ENOSYS) return rc;
+  if (ops[0].planes_in) return MPOSE_EINVAL;       // (plane operands: the row form or nothing)
   {   // x-dilated kernels: one launch of the row form per residue of x, n_split / d partials each (x_phases above)
     mpose_conv_geom pg;
     const int d = x_phases(*geom, &pg);

@@ -672,8 +672,10 @@ __global__ __launch_bounds__(256, 2) void conv_h2r_k(ConvHRArgs a) {
   const int prow = a.part_row0 + (int)blockIdx.x;
   const bool hdr_writer = prow == 0 && blockIdx.y == 0;
 
-#pragma unroll 1
-  for (int set = 0; set < NPASS; ++set) {
+  // (a pass is a lambda so that the two-input form can run its two passes as two straight-line copies: as iterations of one
+  //  loop the accumulators are loop-carried through both K-loop variants, and hipcc then needed 95 registers more than MODE 0)
+  auto one_pass = [&](const int set, auto form_c) __attribute__((always_inline)) {
+    constexpr int FORM = decltype(form_c)::value;      // which K loop a pass may need: 0 either (decided at run time), 1 the three-tap steps, 2 the plain loop
     const int t_lo = set ? n_taps0 : 0;
     const int nt = set ? n_taps - n_taps0 : (MODE ? n_taps0 : n_taps);
     const int ng = (nt + TG - 1) / TG;                               // steps per chunk
@@ -812,7 +814,7 @@ __global__ __launch_bounds__(256, 2) void conv_h2r_k(ConvHRArgs a) {
       issue_batch(ng > 1 ? 0 : 1, ng > 1 ? 1 : 0, 1, n_steps > 1, 0, ng, false); // B(1) (share index ng: no A instruction)
       wait_vmcnt<0>();
       __builtin_amdgcn_s_barrier();
-      if (nt == TG * ng) {
+      if (FORM == 1 || (FORM == 0 && nt == TG * ng)) {
         // ---- full steps of three taps (every 3x3).  The first tap's fragments of a step already sit in a register set:
         //   tap 0, 1:  MFMAs  ||  fragment reads of the next tap
         //   then everything of the step is in registers -> wait for the batch issued one step ago, s_barrier
@@ -934,7 +936,7 @@ __global__ __launch_bounds__(256, 2) void conv_h2r_k(ConvHRArgs a) {
             acc[rm][rn][r] = __builtin_ldexpf(acc[rm][rn][r], shift);
             acx[rm][rn][r] = __builtin_ldexpf(acx[rm][rn][r], shift);
           }
-      continue;
+      return;
     }
 
     // ---- epilogue (branch-free: rows beyond M carry an offset the buffer unit rejects) ----
@@ -962,6 +964,66 @@ __global__ __launch_bounds__(256, 2) void conv_h2r_k(ConvHRArgs a) {
 #pragma unroll
     for (int rn = 0; rn < RN; ++rn) { csum[rn] = csq[rn] = rs0[rn] = rs1[rn] = rs2[rn] = rs3[rn] = 0.f; vmx[rn] = vng[rn] = kNegInf; }
     const unsigned col_off = (unsigned)((n0 + li) * 4);
+    // SUM2 (round 6): the two-input data gradient's epilogue goes through LDS.  With the consumer's four BatchNorm-backward sums
+    // (16 loads of two more tensors per block, in accumulator layout) beside 128 accumulator registers the register form spilled in
+    // every arrangement tried.  Here a wave parks 32 rows x BN columns of results in the (idle) A buffers -- ds_write_b32 in
+    // accumulator layout, row pitch 72 floats: the two row groups of a store land in different bank halves -- and reads them back
+    // row-major, four consecutive channels per lane: the two extra tensors and the output move as 16-byte accesses of whole
+    // 256-byte row segments, and a lane carries four columns' sums over its eight rows.
+    constexpr int EP_PITCH = 72;
+    float4 es0 = make_float4(0.f, 0.f, 0.f, 0.f), es1 = es0, es2 = es0, es3 = es0;
+    const int e_row = lane >> 4, e_col = (lane & 15) * 4;
+    const bool e_ok = e_col < BN && n0 + e_col < cout;
+    if constexpr (SUM2) {
+      static_assert(4 * 32 * EP_PITCH * 4 <= 2 * 4 * SA, "the parked tiles fit in the A buffers");
+      float* tile = reinterpret_cast<float*>(smem) + wave * (32 * EP_PITCH);
+      float4 ems = make_float4(0.f, 0.f, 0.f, 0.f), emt = ems;
+      if (red && e_ok) { ems = *reinterpret_cast<const float4*>(op.red_scale + n0 + e_col); emt = *reinterpret_cast<const float4*>(op.red_shift + n0 + e_col); }
+      const unsigned e_coloff = e_ok ? (unsigned)((n0 + e_col) * 4) : 0xFFFFF000u;
+#pragma unroll
+      for (int rm = 0; rm < ((CH_EXP & 64) ? 0 : 2); ++rm) {
+#pragma unroll
+        for (int rn = 0; rn < RN; ++rn)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            tile[(8 * (r >> 2) + 4 * lh + (r & 3)) * EP_PITCH + rn * 32 + li] = __builtin_ldexpf(acc[rm][rn][r] + acx[rm][rn][r], k_back);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (one wave: its LDS accesses execute in order)
+#pragma unroll
+        for (int h4 = 0; h4 < 2; ++h4) {
+          float4 v[4], xa[4], xb[4];
+          unsigned vo[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int row = e_row + 4 * (h4 * 4 + k);
+            const unsigned ro = sRow[wave * 64 + rm * 32 + row];
+            vo[k] = ro >= 0xFFFFF000u ? ro : ro + e_coloff;       // (a row beyond M, or columns beyond the tensor: rejected by the buffer unit)
+            if (e_coloff >= 0xFFFFF000u) vo[k] = 0xFFFFF000u;
+            v[k] = *reinterpret_cast<const float4*>(tile + row * EP_PITCH + (e_col < BN ? e_col : 0));
+            if (red) {
+              const u32x4 a_ = __builtin_amdgcn_raw_buffer_load_b128(rs_ra, (int)vo[k], 0, 0), b_ = __builtin_amdgcn_raw_buffer_load_b128(rs_rb, (int)vo[k], 0, 0);
+              xa[k] = make_float4(__uint_as_float(a_.x), __uint_as_float(a_.y), __uint_as_float(a_.z), __uint_as_float(a_.w));
+              xb[k] = make_float4(__uint_as_float(b_.x), __uint_as_float(b_.y), __uint_as_float(b_.z), __uint_as_float(b_.w));
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            if (vo[k] >= 0xFFFFF000u) v[k] = make_float4(0.f, 0.f, 0.f, 0.f);      // (idle lanes / rows beyond M add nothing)
+            if (red) {
+              const float gx = fmaf(xa[k].x, ems.x, emt.x) > 0.f ? v[k].x : 0.f, gy = fmaf(xa[k].y, ems.y, emt.y) > 0.f ? v[k].y : 0.f;
+              const float gz = fmaf(xa[k].z, ems.z, emt.z) > 0.f ? v[k].z : 0.f, gw = fmaf(xa[k].w, ems.w, emt.w) > 0.f ? v[k].w : 0.f;
+              es0.x += gx; es0.y += gy; es0.z += gz; es0.w += gw;
+              es1.x = fmaf(gx, xa[k].x, es1.x); es1.y = fmaf(gy, xa[k].y, es1.y); es1.z = fmaf(gz, xa[k].z, es1.z); es1.w = fmaf(gw, xa[k].w, es1.w);
+              es2.x += v[k].x; es2.y += v[k].y; es2.z += v[k].z; es2.w += v[k].w;
+              es3.x = fmaf(v[k].x, xb[k].x, es3.x); es3.y = fmaf(v[k].y, xb[k].y, es3.y); es3.z = fmaf(v[k].z, xb[k].z, es3.z); es3.w = fmaf(v[k].w, xb[k].w, es3.w);
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[k].x), __float_as_uint(v[k].y), __float_as_uint(v[k].z), __float_as_uint(v[k].w)},
+                                                   rs_o, (int)vo[k], 0, 0);
+            if (want_amax) out_amax = fmaxf(fmaxf(out_amax, fmaxf(fabsf(v[k].x), fabsf(v[k].y))), fmaxf(fabsf(v[k].z), fabsf(v[k].w)));
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the tile is rewritten by the next row block)
+      }
+    } else {
 #pragma unroll
     for (int rm = 0; rm < ((CH_EXP & 64) ? 0 : 2); ++rm) {
       unsigned voff[16];
@@ -1033,6 +1095,7 @@ __global__ __launch_bounds__(256, 2) void conv_h2r_k(ConvHRArgs a) {
         }
       }
     }
+    }      // (!SUM2)
     if (want_amax) {       // one look-then-atomic per wave into the workgroup's sub-slot (common.h)
       float m = wave_max(out_amax);
       if (lane == 0) {
@@ -1049,7 +1112,16 @@ __global__ __launch_bounds__(256, 2) void conv_h2r_k(ConvHRArgs a) {
         if (lh == 0) { sMM[(wave * BN + rn * 32 + li) * 2] = a_; sMM[(wave * BN + rn * 32 + li) * 2 + 1] = b_; }
       }
     }
-    if (red) {
+    if (red && SUM2) {       // the four lane groups of a wave hold the same four columns over different rows
+      auto fold = [&](float x) { x += __shfl_xor(x, 16, 64); return x + __shfl_xor(x, 32, 64); };
+      const float4 t0 = make_float4(fold(es0.x), fold(es0.y), fold(es0.z), fold(es0.w)), t1 = make_float4(fold(es1.x), fold(es1.y), fold(es1.z), fold(es1.w));
+      const float4 t2 = make_float4(fold(es2.x), fold(es2.y), fold(es2.z), fold(es2.w)), t3 = make_float4(fold(es3.x), fold(es3.y), fold(es3.z), fold(es3.w));
+      if (lane < 16 && e_col < BN) {
+        float4* d = reinterpret_cast<float4*>(sRed + (wave * BN + e_col) * 4);
+        d[0] = make_float4(t0.x, t1.x, t2.x, t3.x); d[1] = make_float4(t0.y, t1.y, t2.y, t3.y);
+        d[2] = make_float4(t0.z, t1.z, t2.z, t3.z); d[3] = make_float4(t0.w, t1.w, t2.w, t3.w);
+      }
+    } else if (red) {
 #pragma unroll
       for (int rn = 0; rn < RN; ++rn) {
         const float t0 = rs0[rn] + __shfl_xor(rs0[rn], 32, 64), t1 = rs1[rn] + __shfl_xor(rs1[rn], 32, 64);
@@ -1109,6 +1181,13 @@ __global__ __launch_bounds__(256, 2) void conv_h2r_k(ConvHRArgs a) {
         }
       }
     }
+  };
+  if constexpr (SUM2) {      // (the launcher checked: whole kernel rows from the first input, then single taps from the second)
+    one_pass(0, std::integral_constant<int, 1>{});
+    one_pass(1, std::integral_constant<int, 2>{});
+  } else {
+#pragma unroll 1
+    for (int set = 0; set < NPASS; ++set) one_pass(set, std::integral_constant<int, 0>{});
   }
 }
 
@@ -1155,7 +1234,13 @@ int launch_h2r_mode(const ConvHRArgs& a, int mode, int cmax, int n_groups, hipSt
   if (mode == 1) return launch_h2r<RN, 1>(a, cmax, n_groups, s);
   // (MODE 2, the two-input sum: its second pass restages the whole halo tile for one tap per step, and the 64-channel form
   //  spilled 36 bytes per lane beside the consumer-sums epilogue -- conv_h2_k takes it)
-  if (mode == 2) return MPOSE_ENOSYS;
+  if (mode == 2) {           // (conv_h2r_k<., 2>: kernel rows of three taps from the first input, fewer than three taps from the second)
+    int n0 = 0;
+    for (int t = 0; t < a.g.cls[0].n_taps; ++t) n0 += a.g.cls[0].taps[t].acc == 0;
+    const int n1 = a.g.cls[0].n_taps - n0;
+    if (n0 % HR_TG || n0 == 0 || n1 == 0 || n1 >= HR_TG) return MPOSE_ENOSYS;
+    return launch_h2r<RN, 2>(a, cmax, n_groups, s);
+  }
   return launch_h2r<RN, 0>(a, cmax, n_groups, s);
 }
 

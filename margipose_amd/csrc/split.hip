@@ -187,12 +187,14 @@ __global__ __launch_bounds__(256) void bn_add_h2_k(BnAddH2Args a) {
 struct BnApplyH2Args {
   mpose_bn_bwd_apply_operands op[MPOSE_MAX_GROUP];
   void* da_h2[MPOSE_MAX_GROUP];
+  void* db_h2[MPOSE_MAX_GROUP];      // (NULL: db as fp32 only, its largest magnitude measured into db_amax)
   long npix;
   int C;
 };
 
-// da = k0a*[mask]g + k1a*(a - mean_a) + k2a  ->  fp32 + fp16 planes (scale from the bound in da_amax: mpose_bn_bwd_coef_job.bound_out);
-// db = k0b*g + k1b*(b - mean_b) + k2b  ->  fp32, its largest magnitude accumulated into db_amax
+// da = k0a*[mask]g + k1a*(a - mean_a) + k2a  ->  fp32 (optional) + fp16 planes (scale from the bound in da_amax: mpose_bn_bwd_coef_job.bound_out);
+// db = k0b*g + k1b*(b - mean_b) + k2b  ->  fp32 (optional), its largest magnitude accumulated into db_amax -- or, with db_h2 (round 6:
+// the two-input data gradient and the weight gradients read planes too), fp16 planes scaled by the BOUND that db_amax already holds
 __global__ __launch_bounds__(256) void bn_bwd_apply_h2_k(BnApplyH2Args a) {
   constexpr int NPX = 128, NK = NPX / 32;       // pixels per workgroup; pixel rows per thread (all their loads in flight together)
   __shared__ float tile[NPX][kTilePitch];
@@ -201,6 +203,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_h2_k(BnApplyH2Args a) {
   const long p0 = (long)blockIdx.x * NPX;
   const int cg = blockIdx.y * 32, c = cg + (threadIdx.x & 7) * 4;
   const bool has_b = op.b != nullptr, masked = op.a_scale != nullptr;
+  void* const db_planes = a.db_h2[blockIdx.z];
+  const float mul_b = (has_b && db_planes != nullptr) ? pow2f(f16_scale_exp(amax_gather(op.db_amax))) : 0.f;
   const float4 k0 = *reinterpret_cast<const float4*>(op.coef_a + c), k1 = *reinterpret_cast<const float4*>(op.coef_a + a.C + c);
   const float4 k2 = *reinterpret_cast<const float4*>(op.coef_a + 2 * a.C + c), mu = *reinterpret_cast<const float4*>(op.coef_a + 3 * a.C + c);
   float4 ms = make_float4(0.f, 0.f, 0.f, 0.f), mt = ms, q0 = ms, q1 = ms, q2 = ms, qm = ms;
@@ -219,11 +223,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_h2_k(BnApplyH2Args a) {
     y[k] = has_b ? *reinterpret_cast<const float4*>(op.b + p * a.C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   float amax_b = 0.f;
+  float4 dkeep[NK];
 #pragma unroll
   for (int k = 0; k < NK; ++k) {
     const int px = (threadIdx.x >> 3) + 32 * k;
     const long p = p0 + px;
     const bool live = p < a.npix;
+    dkeep[k] = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 ga = g[k];
     if (masked) {
       if (!(fmaf(x[k].x, ms.x, mt.x) > 0.f)) ga.x = 0.f;
@@ -240,14 +246,22 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_h2_k(BnApplyH2Args a) {
       d.x = fmaf(q1.x, y[k].x - qm.x, fmaf(q0.x, g[k].x, q2.x)); d.y = fmaf(q1.y, y[k].y - qm.y, fmaf(q0.y, g[k].y, q2.y));
       d.z = fmaf(q1.z, y[k].z - qm.z, fmaf(q0.z, g[k].z, q2.z)); d.w = fmaf(q1.w, y[k].w - qm.w, fmaf(q0.w, g[k].w, q2.w));
       if (live) {
-        *reinterpret_cast<float4*>(op.db + p * a.C + c) = d;
+        if (op.db != nullptr) *reinterpret_cast<float4*>(op.db + p * a.C + c) = d;
         amax_b = fmaxf(fmaxf(amax_b, fmaxf(fabsf(d.x), fabsf(d.y))), fmaxf(fabsf(d.z), fabsf(d.w)));
       }
+      dkeep[k] = d;
     }
     *reinterpret_cast<float4*>(&tile[px][(threadIdx.x & 7) * 4]) = o;
   }
   tile_to_h2<NPX>(tile, a.da_h2[blockIdx.z], a.npix, p0, cg >> 3, mul);
-  if (has_b && op.db_amax != nullptr) block_amax_commit(amax_b, op.db_amax);      // (uniform per workgroup)
+  if (has_b && db_planes != nullptr) {      // (uniform per workgroup) the second gradient through the same tile
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NK; ++k) *reinterpret_cast<float4*>(&tile[(threadIdx.x >> 3) + 32 * k][(threadIdx.x & 7) * 4]) = dkeep[k];
+    tile_to_h2<NPX>(tile, db_planes, a.npix, p0, cg >> 3, mul_b);
+  } else if (has_b && op.db_amax != nullptr) {
+    block_amax_commit(amax_b, op.db_amax);      // (uniform per workgroup)
+  }
 }
 
 struct SplitArgs {
@@ -418,17 +432,21 @@ extern "C" int mpose_bn_add_h2(const mpose_bn_add_operands* ops, void* const* h2
   return launch_status();
 }
 
-extern "C" int mpose_bn_bwd_apply_h2(const mpose_bn_bwd_apply_operands* ops, void* const* da_h2, int n_groups, int64_t npix, int C,
-                                     void* stream) {
+extern "C" int mpose_bn_bwd_apply_h2(const mpose_bn_bwd_apply_operands* ops, void* const* da_h2, void* const* db_h2, int n_groups,
+                                     int64_t npix, int C, void* stream) {
   if (n_groups < 1 || n_groups > MPOSE_MAX_GROUP || (C & 31) || npix < 0 || npix >= (1l << 31)) return MPOSE_EINVAL;
   if (npix == 0) return 0;
   BnApplyH2Args a{};
   for (int i = 0; i < n_groups; ++i) {
     a.op[i] = ops[i];
     a.da_h2[i] = da_h2[i];
+    a.db_h2[i] = db_h2 ? db_h2[i] : nullptr;
     if (!da_h2[i] || !ops[i].g || !ops[i].a || !ops[i].coef_a || !ops[i].da_amax) return MPOSE_EINVAL;
-    if (ops[i].b && (!ops[i].coef_b || !ops[i].db)) return MPOSE_EINVAL;
-    if ((ops[i].b != nullptr) != (ops[0].b != nullptr) || (ops[i].db_amax != nullptr) != (ops[0].db_amax != nullptr)) return MPOSE_EINVAL;
+    if (ops[i].b && (!ops[i].coef_b || (!ops[i].db && !a.db_h2[i]))) return MPOSE_EINVAL;
+    if (a.db_h2[i] && (!ops[i].b || !ops[i].db_amax)) return MPOSE_EINVAL;       // (planes of db: its bound is read from db_amax)
+    if ((ops[i].b != nullptr) != (ops[0].b != nullptr) || (ops[i].db_amax != nullptr) != (ops[0].db_amax != nullptr) ||
+        (a.db_h2[i] != nullptr) != (a.db_h2[0] != nullptr))
+      return MPOSE_EINVAL;
   }
   a.npix = npix; a.C = C;
   launch(bn_bwd_apply_h2_k, dim3(dim3((unsigned)((npix + 127) / 128), (unsigned)(C / 32), (unsigned)n_groups)), dim3(256), 0, (hipStream_t)stream, a);

@@ -768,7 +768,7 @@ using namespace mpose;
     default: return MPOSE_EINVAL;              \
   }
 
-extern "C" int mpose_abi_version(void) { return 15; }   // 2: bf16-plane packed weights, mpose_conv_operands.in1, wgrad tiles, frames/im2col entry points; 3: im2col/col2im_s2, bn_add layout 2; 4: mpose_bn_bwd_coef(eval_mode); 5: plane engine (conv_p.hip, split.hip), pack job layout; 6: mpose_sgd_step, coef job dconv_bias; 7: mpose_bn_bwd_reduce_ws; 8: fused output stage of the plane engine (mpose_conv_operands.epi_*, add_*, out0_planes); 9: MPOSE_CONV_F16X3 (amax fields, pack layout 2, mpose_absmax, mpose_weights_absmax); 10: channel extremes (mpose_conv_operands.mm0, mpose_bn_job.minmax / amax_out), row-of-taps weight gradient; 11: per-axis slot strides (mpose_conv_geom.in_mul_x / out_mul_x), MPOSE_MAX_CLASSES 8; 12: BatchNorm finalisation by the convolution launch's last workgroup (mpose_conv_operands.fin*); 13: MPOSE_CONV_H2_IN (conv_h.hip: producer-split fp16 planes, pack layout 3, mpose_split_h2, out0_amax without the fused stage); 14: launch plans (plan.hip: mpose_plan_*, mpose_stream_wait, recordable fills / copy / loss arithmetic); 15: mpose_conv_wgrad_waves
+extern "C" int mpose_abi_version(void) { return 16; }   // 2: bf16-plane packed weights, mpose_conv_operands.in1, wgrad tiles, frames/im2col entry points; 3: im2col/col2im_s2, bn_add layout 2; 4: mpose_bn_bwd_coef(eval_mode); 5: plane engine (conv_p.hip, split.hip), pack job layout; 6: mpose_sgd_step, coef job dconv_bias; 7: mpose_bn_bwd_reduce_ws; 8: fused output stage of the plane engine (mpose_conv_operands.epi_*, add_*, out0_planes); 9: MPOSE_CONV_F16X3 (amax fields, pack layout 2, mpose_absmax, mpose_weights_absmax); 10: channel extremes (mpose_conv_operands.mm0, mpose_bn_job.minmax / amax_out), row-of-taps weight gradient; 11: per-axis slot strides (mpose_conv_geom.in_mul_x / out_mul_x), MPOSE_MAX_CLASSES 8; 12: BatchNorm finalisation by the convolution launch's last workgroup (mpose_conv_operands.fin*); 13: MPOSE_CONV_H2_IN (conv_h.hip: producer-split fp16 planes, pack layout 3, mpose_split_h2, out0_amax without the fused stage); 14: launch plans (plan.hip: mpose_plan_*, mpose_stream_wait, recordable fills / copy / loss arithmetic); 15: mpose_conv_wgrad_waves; 16: planes end to end for the H2 blocks (mpose_wgrad_operands.planes_in, mpose_bn_bwd_apply_h2(db_h2), the two-input data gradient on conv_h2r_k)
 
 extern "C" int mpose_softmax_dsnt_fwd(const void* const* logits, void* const* heatmaps, float* plane_coords, float* xyz,
                                       int n_planes, int rows, int H, int W, int io_dtype, void* stream) {

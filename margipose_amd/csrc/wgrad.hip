@@ -86,6 +86,7 @@ struct WgRowsArgs {
   int n_ktiles, n_ntiles;
   int n_split, rows_per_split;
   int n_groups, chunk, total;
+  unsigned x_slab, g_slab;         // PL (operands as H8 planes): bytes of one (channel octet, plane) slab of the input / the gradient = pixels * 16
   int exp_flags;                   // timing experiments (compile-time -DWG_TRAFFIC_EXP=<bits>, 0 in every shipped build): 1 = no operand traffic, 2 = no partial-sum stores, 4 = operands re-read from one place (wrong results)
   FastDiv div_h;
 };
@@ -136,9 +137,13 @@ struct Cfg {
   static_assert(4 * KT / HW <= NTH, "one halo item per thread at most");
 };
 
-template <int WK, int WN, int KB, int NB, bool PRO, bool PAIR, bool X1>
+// PL (round 6): both operands arrive as H8 planes -- [C/8][plane][pixel][8] fp16 of x * 2^k, written once by their producer
+// (split.hip) with the scale their amax slot prescribes: a staging item is one 16-byte load of 8 channels of one plane and one
+// ds_write_b128 into the same [pixel][channel] LDS image the transposing reads want -- no prologue, scale or split VALU at all.
+template <int WK, int WN, int KB, int NB, bool PRO, bool PAIR, bool X1, bool PL = false>
 __global__ __launch_bounds__(64 * WK * WN, WK * WN >= 4 ? WK * WN / 4 : 2) void conv_wgrad_rows_k(WgRowsArgs a) {
   using C = Cfg<WK, WN, KB, NB>;
+  static_assert(!PL || (!PRO && C::KT % 32 == 0 && C::NT % 32 == 0 && C::KT <= C::NTH), "plane operands: no prologue, whole 32-channel groups");
   static_assert(C::NW == 1 || C::NW == 2 || C::NW == 4 || C::NW == 8, "one or two waves per SIMD; one / two waves per workgroup for the 32-channel tiles");
   constexpr int KT = C::KT, NT = C::NT, QX = C::QX, QG = C::QG, NXI = C::NXI, NGI = C::NGI, NPX = C::NPX, PX = C::PX, PG = C::PG, NTH = C::NTH;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -182,9 +187,24 @@ __global__ __launch_bounds__(64 * WK * WN, WK * WN >= 4 ? WK * WN / 4 : 2) void 
   unsigned xb_voff[NXI], xb_lds[NXI], g_voff[NGI], g_lds[NGI];
   bool xb_o[NXI], g_o[NGI];
   float4 xb_sc[NXI], xb_sh[NXI];
+  // (PL: an octet's 2 * KT items of 16 bytes are numbered r = [c8 / 4][plane][pixel / 4][c8 % 4][pixel % 4]: sixteen consecutive
+  //  lanes store 4 pixel rows x 4 channel octets = sixteen different 16-byte bank groups of a plane (row pitch = 64 or 192 mod 256),
+  //  and four consecutive lanes read 64 contiguous bytes of one (octet, plane) slab)
+  auto pl_item = [&](int r, int& j, int& pl, int& c8) { j = (r & 3) | (((r >> 4) & 1) << 2); pl = (r >> 5) & 1; c8 = ((r >> 6) << 2) | ((r >> 2) & 3); };
+  const unsigned x_slab = a.x_slab, g_slab = a.g_slab;
 #pragma unroll
   for (int i = 0; i < NXI; ++i) {
     const int it = tid + NTH * i;
+    if constexpr (PL) {
+      const int o = it / (8 * QX), r = it - o * (8 * QX);
+      int j, pl, c8;
+      pl_item(r, j, pl, c8);
+      const bool ok = it < 16 * QX && k0 + 8 * c8 < a.Cin;
+      xb_o[i] = o != 0;
+      xb_voff[i] = ok && !(a.exp_flags & 1) ? (unsigned)(((k0 >> 3) + c8) * 2 + pl) * x_slab + (unsigned)(j * 16) : kBig;
+      xb_lds[i] = it < 16 * QX ? (unsigned)(pl * C::XPL + (o * NPX + j + 1) * PX + c8 * 16) : (unsigned)(C::XPL_DATA + (tid >> 1) * 16);
+      continue;
+    }
     const int o = it / (8 * QX), r = it - o * (8 * QX), j = r / QX, q = r - j * QX;
     const bool ok = it < 16 * QX && k0 + 4 * q < a.Cin;
     xb_o[i] = o != 0;
@@ -201,6 +221,16 @@ __global__ __launch_bounds__(64 * WK * WN, WK * WN >= 4 ? WK * WN / 4 : 2) void 
 #pragma unroll
   for (int i = 0; i < NGI; ++i) {
     const int it = tid + NTH * i;
+    if constexpr (PL) {
+      const int o = it / (8 * QG), r = it - o * (8 * QG);
+      int j, pl, c8;
+      pl_item(r, j, pl, c8);
+      const bool ok = it < 16 * QG && n0 + 8 * c8 < a.Cout;
+      g_o[i] = o != 0;
+      g_voff[i] = ok && !(a.exp_flags & 1) ? (unsigned)(((n0 >> 3) + c8) * 2 + pl) * g_slab + (unsigned)(j * 16) : kBig;
+      g_lds[i] = it < 16 * QG ? (unsigned)(pl * C::GPL + (o * 8 + j) * PG + c8 * 16) : (unsigned)(C::GPL_DATA + (tid >> 1) * 16);
+      continue;
+    }
     const int o = it / (8 * QG), r = it - o * (8 * QG), j = r / QG, q = r - j * QG;
     const bool ok = it < 16 * QG && n0 + 4 * q < a.Cout;
     g_o[i] = o != 0;
@@ -209,11 +239,14 @@ __global__ __launch_bounds__(64 * WK * WN, WK * WN >= 4 ? WK * WN / 4 : 2) void 
   }
   // halo pixels of the two octets (three-tap units), HW floats per thread: thread t takes (octet, side) = t / TPS, channels
   // (t % TPS) * HW .. + HW-1.  Threads beyond 4 * TPS read nothing (out-of-range offset) and store into the dump area.
-  constexpr int HW = C::HW, TPS = KT / HW;
-  const int h_id = tid / TPS, h_oct = (h_id >> 1) & 1, h_side = h_id & 1, h_c = (tid % TPS) * HW;
+  // (PL: a halo pixel is KT / 4 items of 16 bytes -- (channel octet, plane) -- one per thread: tid = [octet, side][c8][plane])
+  constexpr int HW = PL ? 4 : C::HW, TPS = PL ? KT / 4 : KT / HW;
+  const int h_id = tid / TPS, h_oct = (h_id >> 1) & 1, h_side = h_id & 1, h_c = PL ? ((tid % TPS) >> 1) * 8 : (tid % TPS) * HW;
+  const int h_pl = PL ? (tid % TPS) & 1 : 0;
   const bool h_ok = h_id < 4 && k0 + h_c < a.Cin;
-  const unsigned h_col = (unsigned)((k0 + h_c) * 4);
-  const unsigned h_lds = h_id < 4 ? (unsigned)((h_oct * NPX + (h_side ? NPX - 1 : 0)) * PX + h_c * 2) : (unsigned)(C::XPL_DATA + tid * 8);
+  const unsigned h_col = PL ? (unsigned)(((k0 + h_c) >> 3) * 2 + h_pl) * x_slab : (unsigned)((k0 + h_c) * 4);
+  const unsigned h_lds = h_id < 4 ? (unsigned)(h_pl * C::XPL + (h_oct * NPX + (h_side ? NPX - 1 : 0)) * PX + h_c * 2)
+                                  : (unsigned)(C::XPL_DATA + (PL ? (tid >> 1) * 16 : tid * 8));
   float4 h_sc = make_float4(x_mul, x_mul, x_mul, x_mul), h_sh = make_float4(0.f, 0.f, 0.f, 0.f);
   if (pro && h_ok) {
     const float* ps = op.in_scale + k0 + h_c;
@@ -360,7 +393,11 @@ __global__ __launch_bounds__(64 * WK * WN, WK * WN >= 4 ? WK * WN / 4 : 2) void 
   };
   auto stage_item = [&](auto ic, unsigned char* buf) {
     constexpr int I = decltype(ic)::value;
-    if constexpr (I < I_G) {
+    if constexpr (PL) {                // the producer's bytes as they are (an out-of-range halo or a dummy octet was read as zeros)
+      if constexpr (I < I_G) *reinterpret_cast<float4*>(buf + xb_lds[I]) = raw[I];
+      else if constexpr (I < I_HALO) *reinterpret_cast<float4*>(buf + 2 * C::XPL + g_lds[I - I_G]) = raw[I];
+      else *reinterpret_cast<float4*>(buf + h_lds) = raw[I];
+    } else if constexpr (I < I_G) {
       split_store4(buf, C::XPL, xb_lds[I], prologue4(raw[I], xb_sc[I], xb_sh[I]));
     } else if constexpr (I < I_HALO) {
       float4 v = raw[I];
@@ -521,12 +558,12 @@ __global__ __launch_bounds__(64 * WK * WN, WK * WN >= 4 ? WK * WN / 4 : 2) void 
   else body(std::integral_constant<int, 1>{});
 }
 
-template <int WK, int WN, int KB, int NB, bool PRO, bool PAIR, bool X1>
+template <int WK, int WN, int KB, int NB, bool PRO, bool PAIR, bool X1, bool PL = false>
 int launch_rows_ppx(WgRowsArgs& a, hipStream_t s) {
   using C = Cfg<WK, WN, KB, NB>;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_rows_k<WK, WN, KB, NB, PRO, PAIR, X1>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_rows_k<WK, WN, KB, NB, PRO, PAIR, X1, PL>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS) != hipSuccess)
       return MPOSE_EINVAL;
     attr_set = true;
   }
@@ -534,7 +571,7 @@ int launch_rows_ppx(WgRowsArgs& a, hipStream_t s) {
   a.n_ntiles = (a.Cout + C::NT - 1) / C::NT;
   a.total = a.n_units * a.n_ktiles * a.n_ntiles * a.n_split * a.n_groups;
   a.chunk = (a.total + 7) / 8;
-  launch(conv_wgrad_rows_k<WK, WN, KB, NB, PRO, PAIR, X1>, dim3(dim3(8 * a.chunk)), dim3(C::NTH), C::LDS, s, a);
+  launch(conv_wgrad_rows_k<WK, WN, KB, NB, PRO, PAIR, X1, PL>, dim3(dim3(8 * a.chunk)), dim3(C::NTH), C::LDS, s, a);
   return launch_status();
 }
 template <int WK, int WN, int KB, int NB, bool PRO, bool PAIR>
@@ -726,6 +763,23 @@ int mpose_wgrad_rows_launch(const mpose_conv_geom* geom, const mpose_wgrad_opera
   a.div_h = make_fastdiv((unsigned)geom->GH);
   a.exp_flags = WG_TRAFFIC_EXP;
   hipStream_t s = (hipStream_t)stream;
+  if (ops[0].planes_in) {
+    // operands as H8 planes (mpose_wgrad_operands.planes_in): the stride-1 geometries of the 128-channel tile, dense tensors, whole
+    // channel octets, an even number of pixel octets per row; a pixel is 16 bytes of one (channel octet, plane) slab
+    if (im != 1 || om != 1 || geom->in_ld > 0 || geom->out_ld0 > 0 || geom->out_ld1 > 0 || (geom->GW & 15) || (geom->Cin & 31) ||
+        (geom->Cout0 & 31) || rows_shape(geom->Cin, geom->Cout0) != 0)
+      return MPOSE_EINVAL;
+    for (int i = 0; i < n_groups; ++i)
+      if (!ops[i].planes_in || ops[i].in_scale) return MPOSE_EINVAL;
+    if (npix_i * 4 * geom->Cin >= (long)kBig || npix_o * 4 * geom->Cout0 >= (long)kBig) return MPOSE_EINVAL;
+    a.x_pix = a.g_pix0 = a.g_pix1 = 16;
+    a.x_row = geom->IW * 16; a.g_row0 = a.g_row1 = geom->OW * 16;
+    a.x_slab = (unsigned)(npix_i * 16); a.g_slab = (unsigned)(npix_o * 16);
+    a.x_bytes = (unsigned)(npix_i * 4 * geom->Cin);
+    a.g_bytes0 = a.g_bytes1 = (unsigned)(npix_o * 4 * geom->Cout0);
+    return ops[0].single_product ? launch_rows_ppx<2, 2, 2, 2, false, true, true, true>(a, s)
+                                 : launch_rows_ppx<2, 2, 2, 2, false, true, false, true>(a, s);
+  }
   switch (rows_shape(geom->Cin, geom->Cout0)) {
     case 1: return wide192() ? launch_rows<2, 4, 3, 1>(a, s) : launch_rows<2, 2, 3, 1>(a, s);
     case 2: return launch_rows<4, 1, 1, 1>(a, s);

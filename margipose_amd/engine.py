@@ -401,6 +401,11 @@ class Engine:
         # mpose_bn_bwd_apply + mpose_split_h2; 2: both.  Round 5: 2 is the default -- kernel for kernel it is slower, in the step
         # (launch-plan dispatch, one launch and one read pass fewer per H2 block) it measured 23.39 -> 23.25 ms (tools/ab_sweep.sh).
         self.h2_fuse = int(os.environ.get('MPOSE_H2_FUSE', '2'))
+        # Round 6, planes end to end in the backward pass of the H2 blocks: both BatchNorm-backward applications write fp16 planes
+        # ONLY (d_c2, d_sc, d_c1: no fp32 copies), the two-input data gradient runs on conv_h2r_k (its second input as a second K
+        # loop) and both weight gradients DMA-free-stage the planes (mpose_wgrad_operands.planes_in: no split VALU in their loop);
+        # the forward keeps the planes of x and relu(bn1(c1)) for them.  MPOSE_H2_PLANES=0: round 5's backward (A/B runs).
+        self.h2_planes = os.environ.get('MPOSE_H2_PLANES', '1') != '0'
         # the last ResidualBlock's residual sum, flat_softmax and dsnt as ONE launch per stage (mpose_bn_add_softmax_fwd: an image's
         # logits stay in LDS); heatmaps and coordinates are bit-identical to the two-launch path (MPOSE_TAIL_FUSE=0)
         self.tail_fuse = os.environ.get('MPOSE_TAIL_FUSE', '1') != '0'
@@ -567,7 +572,7 @@ class Engine:
         self.wamax = torch.zeros(len(self._convs), dtype=torch.float32, device=device)
         # (an activation slot is 16 sub-slots 64 floats apart = 1024 floats: include/margipose_hip.h, mpose_absmax)
         self.amax_f = torch.zeros(self.T * 10 * 6 * AMAX_SLOT, dtype=torch.float32, device=device)
-        self.amax_b = torch.zeros(self.T * 10 * 12 * AMAX_SLOT, dtype=torch.float32, device=device)      # (+ 3 per block: the gradient w.r.t. its output)
+        self.amax_b = torch.zeros(self.T * 10 * 15 * AMAX_SLOT, dtype=torch.float32, device=device)      # (+ 3 per block: the gradient w.r.t. its output; + 3: d_a1)
         for i, c in enumerate(self._convs):
             c.amax_ptr = self.wamax.data_ptr() + 4 * i
             if c.layout == 1:                      # a column convolution
@@ -580,8 +585,9 @@ class Engine:
         jobs_h2 = jobs_h.copy()
         h2_convs = {}
         for b in self._all_blocks:
-            if b.h2:
-                h2_convs[id(b.conv_in)] = (0,); h2_convs[id(b.conv_sc)] = (0,); h2_convs[id(b.conv2)] = (0, 1)
+            if b.h2:                 # (h2_planes: the two-input data gradient runs on the H2 engine too)
+                h2_convs[id(b.conv_in)] = h2_convs[id(b.conv_sc)] = (0, 1) if self.h2_planes else (0,)
+                h2_convs[id(b.conv2)] = (0, 1)
         for i, c in enumerate(self._convs):
             for d in h2_convs.get(id(c), ()):
                 jobs_h2[2 * i + d]['layout'] = 3
@@ -736,6 +742,9 @@ class Engine:
                         j['bound_out'] = self._amax_f(t, i + 1, 0, c)
                     if b.h2:                     # the BatchNorm-backward application of bn2: d_c2, the data-gradient's operand
                         cj[base + c]['g_amax'], cj[base + c]['bound_out'] = self._amax_b(t, i, 3, c), self._amax_b(t, i, 0, c)
+                        if self.h2_planes:       # ... of the shortcut's BatchNorm (d_sc) and of bn1 (d_c1, from the largest |d_a1|) too
+                            cj[base + 3 + c]['g_amax'], cj[base + 3 + c]['bound_out'] = self._amax_b(t, i, 3, c), self._amax_b(t, i, 2, c)
+                            cj[base + 6 + c]['g_amax'], cj[base + 6 + c]['bound_out'] = self._amax_b(t, i, 4, c), self._amax_b(t, i, 1, c)
         if self.stats_part:
             for t in range(self.T):
                 for i in range(10):
@@ -931,8 +940,8 @@ class Engine:
         return self.amax_f.data_ptr() + 4 * AMAX_SLOT * (((t * 10 + i) * 2 + which) * 3 + c)
 
     def _amax_b(self, t, i, which, c):
-        """which: 0 d_c2, 1 d_c1, 2 d_sc, 3 the gradient w.r.t. the block's output."""
-        return self.amax_b.data_ptr() + 4 * AMAX_SLOT * (((t * 10 + i) * 4 + which) * 3 + c)
+        """which: 0 d_c2, 1 d_c1, 2 d_sc, 3 the gradient w.r.t. the block's output, 4 d_a1 (the masked data gradient of the second 3x3)."""
+        return self.amax_b.data_ptr() + 4 * AMAX_SLOT * (((t * 10 + i) * 5 + which) * 3 + c)
 
     def h2_next(self, t, i):
         """Block i's residual sum feeds an H2 block directly (no axis permutation in between): it can write that block's planes."""
@@ -1398,6 +1407,8 @@ class Engine:
                               'mpose_bn_add_fwd')
                 if save:
                     stage_saved.append({'x': cur, 'c1': c1, 'sc': sc, 'c2': c2})
+                    if blk_h2 and h2f and self.h2_fuse >= 2 and self.h2_planes:      # the weight gradients read the planes (Engine.h2_planes)
+                        stage_saved[-1]['x_h'], stage_saved[-1]['a1_h'] = cur_h, a1_h
                 cur = outs
             if not tail_fused:
                 logits = cur
@@ -1475,6 +1486,39 @@ class Engine:
 
     def _arena_tensors(self):
         return [self.bnf, self.amax_f] + ([self.stem.f_arena, self.stem.amax_f] if self.stem is not None else [])
+
+    # ------------------------------------------------------------------ launch plans (train_helpers.PlannedTrainStep / PlannedInference)
+    def plan_stamp(self, table_keys=None):
+        """Everything a recorded launch plan (csrc/plan.hip) bakes in BY ADDRESS or by value but that lives outside the plan's
+        private allocator pool: the parameters and BatchNorm buffers as bound right now, the engine's arenas, the per-(B, F) job
+        tables, the BatchNorm-backward reduction workspace (regrown by a larger eager batch), and the switches that decide which
+        launches an iteration consists of.  A replay compares it with the stamp taken at recording time: any difference means
+        the plan would read or write through stale pointers.  `table_keys`: the job tables the recording used (default:
+        all that exist now); tables built later for other batch sizes do not invalidate a plan."""
+        if self._arena_key is None:
+            return None
+        bound = [t for t in self._bn_bound_now() if t is not None] + [c.param for c in self._convs] + list(self.combiners)
+        if self.stem is not None:
+            bound += list(self.stem.extra_params)
+        ws = getattr(self, '_reduce_ws', None)
+        arenas = [self.wpack, self.bnf, self.stat_arena, self.gflat, self.wamax, self.amax_f, self.amax_b, self._nbt]
+        if self.stem is not None:
+            arenas += [t for t in (getattr(self.stem, 'f_arena', None), getattr(self.stem, 'amax_f', None)) if t is not None]
+        tables = tuple((k, id(self._tables.get(k))) for k in (sorted(self._tables) if table_keys is None else table_keys))
+        flags = (self.h2, self.h2_fuse, self.inline_unpack, self.overlap_wgrad, self.fuse_coef, self.tail_fuse, self.stats_part,
+                 self.fuse_finalize, self.sc_side, self.stem_bounds, self.f16x3, self.conv_bf16, self.conv_f16x1,
+                 self.planes_mode, self.dp is not None)
+        return (self._arena_key[0], hash(tuple(t.data_ptr() for t in bound)), tuple(t.data_ptr() for t in arenas),
+                (ws.data_ptr(), ws.numel()) if ws is not None else None, tables, flags)
+
+    def before_replay(self):
+        """A launch-plan replay overwrites the BatchNorm arenas like a forward does: an eager forward whose backward is still to
+        come keeps its values (snapshot), and the arenas then belong to nobody's saved context (the replayed iteration runs its
+        own backward)."""
+        self._snapshot_pending()
+        self._gen += 1
+        self._arena_gen = self._gen
+        self._pending = None
 
     def _snapshot_pending(self):
         """Called before a forward overwrites the BatchNorm arenas: if the previous saved forward has not run its backward
@@ -1590,6 +1634,7 @@ class Engine:
                         rops.append(ro)
                 blk_h2 = h2 and b0.h2
                 app_h2 = h2f and blk_h2 and self.h2_fuse >= 2     # bn2's backward application writes d_c2 as planes too, scaled by the coefficient kernel's bound
+                pl_bwd = app_h2 and self.h2_planes and 'x_h' in sv        # planes end to end: no fp32 d_c2 / d_sc / d_c1 at all
                 coef_done = False
                 if not sums_done:
                     # (the six coefficient jobs of bn2 / bn_s read these sums: they run in the reduction's finishing pass unless they
@@ -1598,22 +1643,24 @@ class Engine:
                                                    None if app_h2 else (coef_base + jb * COEF_DT.itemsize, 6, eval_bn))
                 if not coef_done:
                     run_coef(jb, 6, from_sums=not sums_done, bounds=app_h2)
-                d_c2 = [torch.empty(B, Hout, Hout, Cs, **f32) for _ in range(3)]
-                d_sc = [torch.empty(B, Hout, Hout, Cs, **f32) for _ in range(3)]
+                d_c2 = None if pl_bwd else [torch.empty(B, Hout, Hout, Cs, **f32) for _ in range(3)]
+                d_sc = None if pl_bwd else [torch.empty(B, Hout, Hout, Cs, **f32) for _ in range(3)]
                 aops = []
                 for c, b in enumerate(grp):
                     ao = BnBwdApplyOperands()
                     ao.g, ao.a, ao.b = g[c].data_ptr(), sv['c2'][c].data_ptr(), sv['sc'][c].data_ptr()
                     ao.coef_a, ao.coef_b = self._bnf_ptr(b.bn2, 4), self._bnf_ptr(b.bns, 4)
                     ao.a_scale, ao.a_shift = self._bnf_ptr(b.bn2, 0), self._bnf_ptr(b.bn2, 1)
-                    ao.da, ao.db = d_c2[c].data_ptr(), d_sc[c].data_ptr()
+                    if not pl_bwd:
+                        ao.da, ao.db = d_c2[c].data_ptr(), d_sc[c].data_ptr()
                     if f16:
                         ao.da_amax, ao.db_amax = self._amax_b(t, i, 0, c), self._amax_b(t, i, 2, c)
                     aops.append(ao)
-                if app_h2:           # (da_amax is READ there)
+                if app_h2:           # (da_amax is READ there; with pl_bwd db_amax too: both hold the coefficient kernel's bounds)
                     d_c2_h = [torch.empty(cnt * Cs, **f32) for _ in range(3)]
-                    check(L.mpose_bn_bwd_apply_h2((BnBwdApplyOperands * 3)(*aops), ptr_array(d_c2_h), 3, c_int64(cnt), Cs, st()),
-                          'mpose_bn_bwd_apply_h2')
+                    d_sc_h = [torch.empty(cnt * Cs, **f32) for _ in range(3)] if pl_bwd else None
+                    check(L.mpose_bn_bwd_apply_h2((BnBwdApplyOperands * 3)(*aops), ptr_array(d_c2_h), ptr_array(d_sc_h) if pl_bwd else None,
+                                                  3, c_int64(cnt), Cs, st()), 'mpose_bn_bwd_apply_h2')
                 elif planes:         # the gradients feed a convolution next: written pre-split as well
                     d_c2_p = [self.planes_empty(cnt, Cs) for _ in range(3)]
                     d_sc_p = [self.planes_empty(cnt, Cs) for _ in range(3)]
@@ -1635,31 +1682,44 @@ class Engine:
                     op.mask_src = sv['c1'][c].data_ptr()
                     op.mask_scale, op.mask_shift = self._bnf_ptr(b.bn1, 0), self._bnf_ptr(b.bn1, 1)
                     op.stats0 = sp[(id(b.bn1), 'b')] if spart else self._stats_ptr(b.bn1, True)
+                    if pl_bwd:               # the largest |d_a1|: what bn1's coefficient kernel bounds d_c1 with
+                        op.out0_amax = self._amax_b(t, i, 4, c)
                     ops.append(op)
                 self.conv(self.geom('d_conv2', B, Hout, b0), ops, pflags | (256 if spart else 0) | (128 if blk_h2 else 0))
-                # (3) wgrad of the second 3x3 (its input relu(bn1(c1)) is recomputed while staging)
+                # (3) wgrad of the second 3x3 (its input relu(bn1(c1)) is recomputed while staging; pl_bwd: the forward's planes of it)
                 wops = []
                 for c, b in enumerate(grp):
                     wo = WgradOperands()
-                    wo.in_, wo.in_scale, wo.in_shift = sv['c1'][c].data_ptr(), self._bnf_ptr(b.bn1, 0), self._bnf_ptr(b.bn1, 1)
-                    wo.gout0, wo.dw0 = d_c2[c].data_ptr(), tb['part_ptr'][id(b.conv2)]
+                    if pl_bwd:
+                        wo.in_, wo.gout0, wo.planes_in = sv['a1_h'][c].data_ptr(), d_c2_h[c].data_ptr(), 1
+                    else:
+                        wo.in_, wo.in_scale, wo.in_shift = sv['c1'][c].data_ptr(), self._bnf_ptr(b.bn1, 0), self._bnf_ptr(b.bn1, 1)
+                        wo.gout0 = d_c2[c].data_ptr()
+                    wo.dw0 = tb['part_ptr'][id(b.conv2)]
                     if f16:
                         wo.in_amax, wo.gout0_amax = self._amax_f(t, i, 1, c), self._amax_b(t, i, 0, c)
                         wo.single_product = int(x1)
                     wops.append(wo)
                 g_w2 = self.geom('f_conv2', B, Hout, b0)
-                self.wgrad_async(g_w2, wops, self.wg_n_split(g_w2), sv['c1'] + d_c2, self.unpack_after(tb, [b.conv2 for b in grp]))
+                self.wgrad_async(g_w2, wops, self.wg_n_split(g_w2), (sv['a1_h'] + d_c2_h) if pl_bwd else (sv['c1'] + d_c2),
+                                 self.unpack_after(tb, [b.conv2 for b in grp]))
                 # (4) BN1 backward
-                run_coef(jb + 6, 3)
-                d_c1 = [torch.empty(B, Hout, Hout, Cs, **f32) for _ in range(3)]
+                run_coef(jb + 6, 3, bounds=pl_bwd)
+                d_c1 = None if pl_bwd else [torch.empty(B, Hout, Hout, Cs, **f32) for _ in range(3)]
                 aops = []
                 for c, b in enumerate(grp):
                     ao = BnBwdApplyOperands()
-                    ao.g, ao.a, ao.coef_a, ao.da = d_a1[c].data_ptr(), sv['c1'][c].data_ptr(), self._bnf_ptr(b.bn1, 4), d_c1[c].data_ptr()
+                    ao.g, ao.a, ao.coef_a = d_a1[c].data_ptr(), sv['c1'][c].data_ptr(), self._bnf_ptr(b.bn1, 4)
+                    if not pl_bwd:
+                        ao.da = d_c1[c].data_ptr()
                     if f16:
                         ao.da_amax = self._amax_b(t, i, 1, c)
                     aops.append(ao)
-                if planes:
+                if pl_bwd:           # d_c1 as planes only, scaled by the bound the coefficient kernel just wrote
+                    d_c1_h = [torch.empty(cnt * Cs, **f32) for _ in range(3)]
+                    check(L.mpose_bn_bwd_apply_h2((BnBwdApplyOperands * 3)(*aops), ptr_array(d_c1_h), None, 3, c_int64(cnt), Cs, st()),
+                          'mpose_bn_bwd_apply_h2')
+                elif planes:
                     d_c1_p = [self.planes_empty(cnt, Cs) for _ in range(3)]
                     check(L.mpose_bn_bwd_apply_planes((BnBwdApplyOperands * 3)(*aops), ptr_array(d_c1_p), None, 3, c_int64(cnt), Cs, st()),
                           'mpose_bn_bwd_apply_planes')
@@ -1671,8 +1731,11 @@ class Engine:
                 wops = []
                 for c, b in enumerate(grp):
                     wo = WgradOperands()
-                    wo.in_ = sv['x'][c].data_ptr()
-                    wo.gout0, wo.gout1 = d_c1[c].data_ptr(), d_sc[c].data_ptr()
+                    if pl_bwd:
+                        wo.in_, wo.gout0, wo.gout1, wo.planes_in = sv['x_h'][c].data_ptr(), d_c1_h[c].data_ptr(), d_sc_h[c].data_ptr(), 1
+                    else:
+                        wo.in_ = sv['x'][c].data_ptr()
+                        wo.gout0, wo.gout1 = d_c1[c].data_ptr(), d_sc[c].data_ptr()
                     wo.dw0, wo.dw1 = tb['part_ptr'][id(b.conv_in)], tb['part_ptr'][id(b.conv_sc)]
                     if f16:
                         wo.in_amax = self._amax_f(t, i, 0, _first_same(sv['x'], c))
@@ -1680,16 +1743,20 @@ class Engine:
                         wo.single_product = int(x1)
                     wops.append(wo)
                 g_w1 = self.geom(gname, B, Hin, b0)
-                self.wgrad_async(g_w1, wops, self.wg_n_split(g_w1), list(sv['x']) + d_c1 + d_sc,
+                self.wgrad_async(g_w1, wops, self.wg_n_split(g_w1), (list(sv['x_h']) + d_c1_h + d_sc_h) if pl_bwd else (list(sv['x']) + d_c1 + d_sc),
                                  self.unpack_after(tb, [b.conv_in for b in grp] + [b.conv_sc for b in grp]))
                 # (6) dgrad of conv_in + the shortcut's dgrad: one launch, the shortcut as a tap on a second input
+                din_h2 = blk_h2 and self.h2_planes       # on conv_h2r_k (its weights are packed for it): both inputs as planes
+                if din_h2 and not pl_bwd:                # (an eval-mode backward / MPOSE_H2_FUSE < 2: measured and split like d_c2 above)
+                    d_c1_h = self.split_h2(d_c1, [self._amax_b(t, i, 1, c) for c in range(3)], cnt, Cs)
+                    d_sc_h = self.split_h2(d_sc, [self._amax_b(t, i, 2, c) for c in range(3)], cnt, Cs)
                 d_x = [torch.empty(B, Hin, Hin, b0.cin_s, **f32) for _ in range(3)]
                 kd = {'regular': 'd_in_regular', 'down': 'd_in_down', 'up': 'd_in_up'}[b0.kind]
                 ops = []
                 for c, b in enumerate(grp):
                     op = ConvOperands()
-                    op.in_ = (d_c1_p[c] if planes else d_c1[c]).data_ptr()
-                    op.in1 = (d_sc_p[c] if planes else d_sc[c]).data_ptr()
+                    op.in_ = (d_c1_p[c] if planes else (d_c1_h[c] if din_h2 else d_c1[c])).data_ptr()
+                    op.in1 = (d_sc_p[c] if planes else (d_sc_h[c] if din_h2 else d_sc[c])).data_ptr()
                     op.w0, op.out0 = self._wptr(b.conv_in, True), d_x[c].data_ptr()
                     op.w1 = self._wptr(b.conv_sc, True)
                     if f16:
@@ -1703,7 +1770,7 @@ class Engine:
                     if h2f and self.h2_fuse >= 2 and i >= 1 and self.stage_blocks[t][i - 1][0].h2:     # d_x is an H2 block's g: its largest magnitude for that block's bound
                         op.out0_amax = self._amax_b(t, i - 1, 3, c)
                     ops.append(op)
-                self.conv(self.geom(kd, B, Hout, b0), ops, 2 | pflags | (256 if (spart and fuse_sums) else 0))
+                self.conv(self.geom(kd, B, Hout, b0), ops, 2 | pflags | (256 if (spart and fuse_sums) else 0) | (128 if din_h2 else 0))
                 sums_done = fuse_sums
                 g = d_x
                 if i == 5 and any(sp != 0 for sp in self.spaces):     # the permutation is an involution

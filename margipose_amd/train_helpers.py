@@ -324,6 +324,18 @@ class GraphedTrainStep:
         return self.out, self.loss
 
 
+def _check_stamp(eng, stamp, who, table_keys=None):
+    """A launch plan replays raw device addresses.  Those inside its private allocator pool cannot move; the engine's arenas, job
+    tables and workspaces and the model's parameters can (model.to(), load_state_dict(assign=True), `p.data = ...`, an eager
+    step at a larger batch, a switch flipped on the engine): a replay after such a change would write through stale pointers."""
+    now = eng.plan_stamp(table_keys)
+    if now != stamp:
+        names = ('device', 'parameter / buffer addresses', 'engine arenas', 'reduction workspace', 'job tables', 'engine switches')
+        what = [n for n, a, b in zip(names, now or (None,) * 6, stamp or (None,) * 6) if a != b]
+        raise _lib.MposeError('%s: the recorded launch plan is stale (%s changed since it was recorded); build a new one'
+                              % (who, ', '.join(what) or 'the engine was rebuilt'))
+
+
 class PlannedTrainStep:
     """One training iteration (the same sequence as GraphedTrainStep: model(x) -> forward_loss -> zero_grad -> backward ->
     optimiser.step, reference bin/train_3d.py:154-186) recorded ONCE as a launch plan (csrc/plan.hip) and re-issued from one C
@@ -400,6 +412,9 @@ class PlannedTrainStep:
         if n[2].value != len(self._host_ops):
             raise _lib.MposeError('PlannedTrainStep: %d breaks recorded for %d host actions' % (n[2].value, len(self._host_ops)))
         torch.cuda.synchronize()
+        self._eng = eng
+        self._table_keys = tuple(sorted(eng._tables))
+        self._stamp = eng.plan_stamp(self._table_keys)           # (what the recorded launches point at outside the private pool: checked per replay)
 
     def _stream_array(self):
         import ctypes
@@ -422,6 +437,8 @@ class PlannedTrainStep:
             self.target.copy_(target, non_blocking=True)
         if mask is not None:
             self.mask.copy_(mask, non_blocking=True)
+        _check_stamp(self._eng, self._stamp, 'PlannedTrainStep', self._table_keys)
+        self._eng.before_replay()
         self.opt.before_replay()
         arr = self._stream_array()
         nxt = ctypes.c_int(0)
@@ -494,6 +511,8 @@ class PlannedInference:
         L.mpose_plan_size(self._plan, ctypes.byref(n[0]), ctypes.byref(n[1]), ctypes.byref(n[2]))
         self.n_launches, self.n_waits = n[0].value, n[1].value
         self._stamp = self._weights_stamp()
+        self._table_keys = tuple(sorted(eng._tables))
+        self._addr_stamp = eng.plan_stamp(self._table_keys)
         torch.cuda.synchronize()
 
     def _stream_array(self):
@@ -517,6 +536,8 @@ class PlannedInference:
             self.refresh()
         if x is not None:
             self.x.copy_(x, non_blocking=True)
+        _check_stamp(self._eng, self._addr_stamp, 'PlannedInference', self._table_keys)
+        self._eng.before_replay()
         arr = self._stream_array()
         nxt = ctypes.c_int(0)
         _lib.check(_lib.lib().mpose_plan_replay(self._plan, arr, len(arr), 0, ctypes.byref(nxt)), 'mpose_plan_replay')

@@ -275,10 +275,14 @@ def test_data_gradient_with_relu_mask_and_bn_sums(B, H, C, part):
     assert float(((got - ref).abs() / (ref.abs() + o64.abs().max() * x64.abs().max() * (B * H * H) ** 0.5)).max()) < 1e-5
 
 
-@pytest.mark.parametrize('B,H,cin,cout,ratio', [(2, 32, 128, 128, 1.0), (4, 16, 192, 192, 1e-9), (3, 10, 64, 64, 1e6), (2, 16, 64, 64, 0.0)])
-def test_sum_of_two_inputs_with_consumer_sums_and_amax(B, H, cin, cout, ratio):
+@pytest.mark.parametrize('B,H,cin,cout,ratio,part', [(2, 32, 128, 128, 1.0, False), (2, 32, 128, 128, 0.3, True), (4, 16, 192, 192, 1e-9, False),
+                                                      (3, 10, 64, 64, 1e6, False), (3, 10, 64, 64, 2.0, True), (2, 16, 64, 64, 0.0, False),
+                                                      (5, 8, 32, 32, 1.0, True)])
+def test_sum_of_two_inputs_with_consumer_sums_and_amax(B, H, cin, cout, ratio, part):
     """MPOSE_CONV_SUM_INPUTS (dX = conv_in^T(dC1) + shortcut^T(dSC)) with the inputs at very different magnitudes (0: an all-zero
-    second input is dropped, not overflowed), red_* = the consumer's four BatchNorm-backward sums of what is stored, out0_amax."""
+    second input is dropped, not overflowed), red_* = the consumer's four BatchNorm-backward sums of what is stored, out0_amax.
+    Round 6: the stride-1 shapes run on conv_h2r_k<., 2> (two K loops, the epilogue through LDS; ragged last tiles at H = 10 and 8,
+    the 32-channel tile), red_sums as fp64 atomics and as per-workgroup partial rows."""
     L, _lib, eng = _lib_eng()
     from margipose_amd._lib import ConvOperands
     rng = np.random.default_rng(B + H + cin)
@@ -295,7 +299,8 @@ def test_sum_of_two_inputs_with_consumer_sums_and_amax(B, H, cin, cout, ratio):
     xa = _amax([x0g, x1g], cin)
     x0h, x1h = _split([x0g, x1g], xa, cin)
     out = torch.full((B, H, H, cout), float('nan'), device='cuda')
-    red = torch.zeros(cout, 4, dtype=torch.float64, device='cuda')
+    rows = -(-(B * H * H) // 64)
+    red = torch.full((4 + rows * cout * 4,), float('nan'), device='cuda') if part else torch.zeros(cout, 4, dtype=torch.float64, device='cuda')
     oam = torch.zeros(SLOT, device='cuda')
     scg, shg = sc.cuda(), sh.cuda()
     op = ConvOperands()
@@ -303,8 +308,12 @@ def test_sum_of_two_inputs_with_consumer_sums_and_amax(B, H, cin, cout, ratio):
     op.in_amax, op.in1_amax, op.w0_amax, op.w1_amax = xa[0].data_ptr(), xa[1].data_ptr(), wa0.data_ptr(), wa1.data_ptr()
     op.red_a, op.red_b, op.red_scale, op.red_shift, op.red_sums = rag.data_ptr(), rbg.data_ptr(), scg.data_ptr(), shg.data_ptr(), red.data_ptr()
     op.out0_amax = oam.data_ptr()
-    _lib.check(L.mpose_conv_fwd(ctypes.byref(g), (ConvOperands * 1)(op), 1, 2 | F16X3 | H2, _lib.stream_ptr()), 'conv')
+    _lib.check(L.mpose_conv_fwd(ctypes.byref(g), (ConvOperands * 1)(op), 1, 2 | F16X3 | H2 | (PART if part else 0), _lib.stream_ptr()), 'conv')
     torch.cuda.synchronize()
+    if part:
+        n = int(red[:1].view(torch.int32))
+        assert 0 < n <= rows
+        red = red[4:4 + n * cout * 4].view(n, cout, 4).double().sum(0)
     fn = lambda a0, a1, v0, v1: F.conv2d(a0, v0, padding=1) + F.conv2d(a1, v1)
     _check(*_errs(out, fn(x0.double(), x1.double(), w0.double(), w1.double()), fn(x0, x1, w0, w1)))
     o64 = out.cpu().double().view(-1, cout); a64 = rag.cpu().double().view(-1, cout); b64 = rbg.cpu().double().view(-1, cout)
@@ -313,3 +322,71 @@ def test_sum_of_two_inputs_with_consumer_sums_and_amax(B, H, cin, cout, ratio):
     tol = o64.abs().max() * max(1.0, float(a64.abs().max())) * (B * H * H) ** 0.5
     assert float(((red.cpu() - ref).abs() / (ref.abs() + tol)).max()) < 1e-5
     assert float(oam.max()) == float(out.abs().max())
+
+
+@pytest.mark.parametrize('B,H,n_split,single,loosen', [(2, 32, 3, False, 1.0), (3, 16, 2, False, 64.0), (1, 32, 1, True, 1.0)])
+def test_weight_gradient_from_plane_operands(B, H, n_split, single, loosen):
+    """mpose_wgrad_operands.planes_in (round 6): the row-of-taps weight gradient of a regular 128-channel block reading BOTH operands
+    as the H8 planes their producers wrote -- the 3x3 + fused 1x1 shortcut launch (two gradients, ten taps) and the plain 3x3 --
+    against torch's float64 / float32 gradients (the gate of tests/test_conv_f16x3_gpu.py), with a loose bound in the slots,
+    several pixel splits, an odd number of images, and the single-product (fp16-rounded) arithmetic; and bit for bit against the
+    same launch on the fp32 tensors whose planes those are (same scale exponents, same two pieces: same products)."""
+    L, _lib, eng = _lib_eng()
+    from margipose_amd._lib import WgradOperands
+    C = 128
+    rng = np.random.default_rng(B * 10 + H)
+    x = torch.from_numpy(_data(rng, (B, C, H, H), 'relu')).float()
+    g0 = torch.from_numpy(_data(rng, (B, C, H, H), 'heavy') * 1e-3).float()
+    g1 = torch.from_numpy(rng.standard_normal((B, C, H, H)) * 1e-2).float()
+    xg, g0g, g1g = (t.permute(0, 2, 3, 1).contiguous().cuda() for t in (x, g0, g1))
+    slots = _amax([xg, g0g, g1g], C, loosen=loosen)
+    xh, g0h, g1h = _split([xg, g0g, g1g], slots, C)
+    npad = 128
+    geom = eng._geom(B, H, C, H, C, C, H, 1, 1, [(0, 0, T9(eng) + [(0, 0, 0, 1)])], npad, npad)
+
+    def run(planes):
+        p0 = torch.full((n_split * 9 * C * npad,), float('nan'), device='cuda'); p1 = torch.full((n_split * C * npad,), float('nan'), device='cuda')
+        wo = WgradOperands()
+        src = (xh, g0h, g1h) if planes else (xg, g0g, g1g)
+        wo.in_, wo.gout0, wo.gout1, wo.dw0, wo.dw1 = src[0].data_ptr(), src[1].data_ptr(), src[2].data_ptr(), p0.data_ptr(), p1.data_ptr()
+        wo.in_amax, wo.gout0_amax, wo.gout1_amax = slots[0].data_ptr(), slots[1].data_ptr(), slots[2].data_ptr()
+        wo.single_product, wo.planes_in = int(single), int(planes)
+        _lib.check(L.mpose_conv_wgrad(ctypes.byref(geom), (WgradOperands * 1)(wo), 1, n_split, _lib.stream_ptr()), 'wgrad')
+        outs = []
+        for p, t in ((p0, 9), (p1, 1)):
+            dw = torch.full((C, C, t), float('nan'), device='cuda')
+            jobs = np.zeros(1, dtype=eng.UNPACK_DT)
+            j = jobs[0]
+            j['src'], j['dst'] = p.data_ptr(), dw.data_ptr()
+            j['N'], j['K'], j['T'], j['Npad'], j['Kpad'], j['n_split'] = C, C, t, npad, C, n_split
+            j['sn'], j['sk'], j['st'], j['accumulate'] = C * t, t, 1, 0
+            dev = eng._jobs_to_device(jobs, 'cuda')
+            _lib.check(L.mpose_unpack_wgrads(_lib.ptr(dev), 1, C * C * t, _lib.stream_ptr()), 'unpack')
+            outs.append(dw)
+        torch.cuda.synchronize()
+        return outs
+    dw3, dw1 = run(True)
+    f3, f1 = run(False)
+    assert torch.equal(dw3, f3) and torch.equal(dw1, f1)
+
+    def errs(dw, go, fn, shape):
+        def grad(dtype):
+            w = torch.zeros(shape, dtype=dtype, requires_grad=True)
+            fn(x.to(dtype), w).backward(go.to(dtype))
+            return w.grad.double()
+        ref, f32 = grad(torch.float64), grad(torch.float32)
+        scale = ref.abs().max()
+        return float((dw.cpu().double().reshape(shape) - ref).abs().max() / scale), float((f32 - ref).abs().max() / scale)
+    if not single:
+        _check(*errs(dw3, g0, lambda a, w: F.conv2d(a, w, padding=1), (C, C, 3, 3)))
+        _check(*errs(dw1, g1, lambda a, w: F.conv2d(a, w), (C, C, 1, 1)))
+    else:          # fp16-rounded operands: 2^-11 per factor
+        e3, _ = errs(dw3, g0, lambda a, w: F.conv2d(a, w, padding=1), (C, C, 3, 3))
+        assert e3 < 2e-3, e3
+    # what the row form does not take as planes is refused, not computed on misread bytes
+    wo = WgradOperands()
+    g_bad = eng._geom(B, H, 192, H, 192, 0, H, 1, 1, [(0, 0, T9(eng))], 192)
+    big = torch.zeros(B * H * H * 192, device='cuda')
+    wo.in_, wo.gout0, wo.dw0 = big.data_ptr(), big.data_ptr(), torch.zeros(9 * 192 * 192, device='cuda').data_ptr()
+    wo.in_amax, wo.gout0_amax, wo.planes_in = slots[0].data_ptr(), slots[1].data_ptr(), 1
+    assert L.mpose_conv_wgrad(ctypes.byref(g_bad), (WgradOperands * 1)(wo), 1, 1, _lib.stream_ptr()) != 0

@@ -69,45 +69,23 @@ def mask_flips(a, b):
     return sum(int((a[k] != b[k]).sum()) for k in a), n
 
 
-@pytest.mark.parametrize('T,B,engine', [(1, 2, 'auto'), (2, 2, 'auto'), (1, 8, 'auto'), (1, 2, 'planes'), (1, 2, 'bf16x6'), (1, 2, 'igemm'),
-                                        (1, 2, 'h2split'), (1, 3, 'h2fuse2'), (1, 2, 'h2fuse1'), (1, 2, 'inceptionv4')])
+@pytest.mark.parametrize('T,B,engine', [(1, 3, 'auto'), (2, 2, 'auto'), (1, 8, 'auto'), (1, 2, 'inceptionv4')])
 def test_grads_on_the_same_relu_piece(T, B, engine):
-    """engine 'auto' = what training runs by default (three fp16 products: conv_h2r_k on producer-split planes for the regular
-    128-channel blocks with the residual sum writing the next block's planes under an a-priori bound, conv_igemm_k elsewhere, the
-    row-of-taps weight gradient); 'igemm' = conv_igemm_k everywhere (round 3's default); 'h2split' = the H2 engine with every operand
-    measured and split by mpose_split_h2; 'h2fuse2' = also the BatchNorm-backward application writing its planes under the
-    coefficient kernel's bound (odd batch: ragged tiles; since round 5 this is what 'auto' runs) and 'h2fuse1' = round 4's default, the
-    residual sum alone writing planes; 'planes'
-    forces the plane engine (conv_planes_k: pre-split operands, six bf16 products, two accumulators) through the same step;
-    'bf16x6' = conv_igemm_k / conv_wgrad_k with six bf16 products (round 1's arithmetic).  (Three stages on a common piece: the
-    configuration-size test below.  The free-running fp64 pass -- how many ReLU sites sit on another piece, and what that alone
-    does to the gradients -- runs for ONE case: it is a CPU fp64 backward pass per case and the suite has a time budget.)"""
+    """What training runs (one convolution engine per launch kind since round 6): three fp16 products everywhere; the regular
+    128-channel blocks on conv_h2r_k with planes end to end (forward, both data gradients, both weight gradients read
+    producer-written fp16 planes under a-priori bounds), conv_igemm_k / the row-of-taps weight gradient elsewhere.  B = 3: an odd
+    batch, ragged last tiles.  'inceptionv4' = the same behind the reference's default feature extractor, its ReLU / max-pool pieces
+    controlled too.  (Three stages on a common piece: the configuration-size test below.  The free-running fp64 pass -- how many
+    ReLU sites sit on another piece, and what that alone does to the gradients -- runs for ONE case: it is a CPU fp64 backward
+    pass per case and the suite has a time budget.)"""
     seed = 700 + 10 * T + B
     x, target, mask = W.seeded_inputs(seed + 1000, B)
     rng = np.random.default_rng(seed)
     mask = torch.tensor((rng.uniform(0, 1, (B, 17)) > 0.2).astype(np.float32))
     m, sd = build(T, seed, x, 'inceptionv4' if engine == 'inceptionv4' else 'patch8')
     tag = 'T%d_B%d' % (T, B)
-    if engine == 'inceptionv4':        # the default engine behind the reference's default feature extractor, its ReLU / max-pool pieces controlled too
+    if engine == 'inceptionv4':
         tag += '_inceptionv4'
-    elif engine == 'planes':
-        m.inner.engine().planes_mode = '1'
-        tag += '_planes'
-    elif engine == 'bf16x6':
-        m.inner.engine().f16x3, m.inner.engine().planes_mode = False, '0'
-        tag += '_bf16x6'
-    elif engine == 'igemm':
-        m.inner.engine().h2 = False
-        tag += '_igemm'
-    elif engine == 'h2split':
-        m.inner.engine().h2_fuse = 0
-        tag += '_h2split'
-    elif engine == 'h2fuse2':
-        m.inner.engine().h2_fuse = 2
-        tag += '_h2fuse2'
-    elif engine == 'h2fuse1':
-        m.inner.engine().h2_fuse = 1
-        tag += '_h2fuse1'
     gpu, masks, loss_gpu, _ = gpu_step(m, x, target, mask)
     ref64, loss64 = oracle_grads(sd, T, x, target, mask, torch.float64, masks=masks)
     ref32, _ = oracle_grads(sd, T, x, target, mask, torch.float32, masks=masks)

@@ -86,18 +86,12 @@ def report(name, errs, tol=TOL):
     assert not bad, 'parity failures (%s): %s' % (name, bad[:10])
 
 
-@pytest.mark.parametrize('T,perm,engine', [(1, True, 'auto'), (2, True, 'auto'), (1, False, 'auto'), (1, True, 'planes'), (1, True, 'bf16x6')])
-def test_eval_forward(T, perm, engine):
-    """engine: 'auto' = conv_igemm_k with three fp16 products (the default); 'planes' = the plane engine with BatchNorm, ReLU and
-    the residual sum fused into its epilogues; 'bf16x6' = conv_igemm_k with six bf16 products."""
+@pytest.mark.parametrize('T,perm', [(1, True), (2, True), (1, False)])
+def test_eval_forward(T, perm):
+    """Eval-mode forward: conv_igemm_k with three fp16 products, BatchNorm + ReLU + residual sum in its epilogues."""
     seed, B = 400 + T, 2
     x, target, mask = W.seeded_inputs(seed + 1000, B)
     m = build(T, seed, x, perm).eval()
-    if engine == 'planes':
-        m.inner.engine().planes_mode = '1'
-    elif engine == 'bf16x6':
-        m.inner.engine().f16x3 = False
-        m.inner.engine().planes_mode = '0'
     with torch.no_grad():
         out = m(x.cuda())
         l3 = m.forward_3d_losses(out, target.cuda())
@@ -106,7 +100,7 @@ def test_eval_forward(T, perm, engine):
     for p in ('xy', 'zy', 'xz'):
         for t in range(T):
             errs['hm_%s%d' % (p, t)] = rel(getattr(m, p + '_heatmaps')[t].cpu(), ref[p][t].detach())
-    report('eval_T%d_%d%s' % (T, perm, '' if engine == 'auto' else '_' + engine), errs)
+    report('eval_T%d_%d' % (T, perm), errs)
 
 
 def test_inference_config_batch64_vs_oracle():
@@ -193,17 +187,16 @@ def grad_noise_gate(name, gpu, ref64, ref32, same_piece=None):
     assert stats['zero_grad_abs_max'] < 1e-4, stats
 
 
-@pytest.mark.parametrize('T,B,planes', [(1, 2, False), (2, 2, False), (1, 2, True)])
-def test_train_step_vs_oracle(T, B, planes):
-    """planes=True forces the plane convolution engine (inference's and the bf16 mode's) through an fp32 training step."""
+@pytest.mark.parametrize('T,B', [(1, 2)] + ([(2, 2)] if os.environ.get('MPOSE_LONG_TESTS', '0') != '0' else []))
+def test_train_step_vs_oracle(T, B):
+    """(T = 2 under MPOSE_LONG_TESTS: its forward is test_model_T2_vs_reference_golden's, its gradients
+    tests/test_grad_parity_gpu.py::test_grads_on_the_same_relu_piece[2-2-auto]'s.)"""
     seed = 500 + T
     x, target, mask = W.seeded_inputs(seed + 1000, B)
     rng = np.random.default_rng(seed)
     mask = torch.tensor((rng.uniform(0, 1, (B, 17)) > 0.2).astype(np.float32))
     from margipose_amd import dsntnn
     m = build(T, seed, x).train()
-    if planes:
-        m.inner.engine().planes_mode = '1'
     xg = x.cuda().requires_grad_(True)
     out = m(xg)
     from oracle import piece
@@ -225,7 +218,7 @@ def test_train_step_vs_oracle(T, B, planes):
             errs['buf:' + k] = rel(sd[k].cpu(), v)
         if k.endswith('num_batches_tracked'):
             assert int(sd[k]) == 1
-    name = 'train_T%d_B%d%s' % (T, B, '_planes' if planes else '')
+    name = 'train_T%d_B%d' % (T, B)
     report(name, errs)
     # gradients: gated on the reference's own fp32 noise floor
     gpu = OrderedDict((k, p.grad.cpu()) for k, p in m.named_parameters())
@@ -631,7 +624,8 @@ def test_parameter_update_between_forward_and_backward_is_an_error():
         loss.backward()
 
 
-@pytest.mark.parametrize('stem', ['patch8', 'inceptionv4'])
+@pytest.mark.parametrize('stem', ['patch8', pytest.param('inceptionv4', marks=pytest.mark.skipif(
+    os.environ.get('MPOSE_LONG_TESTS', '0') == '0', reason='suite time budget: MPOSE_LONG_TESTS=1 (tools/final_check.sh) runs it'))])
 def test_backward_through_eval_mode_batchnorm(stem):
     """model.eval() + loss.backward() (reference bin/eval_3d.py:63 computes losses in eval mode; fine-tuning with frozen
     statistics): running statistics are constants, dx = gamma*invstd*g, and the bias of a convolution in front of a
@@ -790,77 +784,13 @@ def test_fp16_convolution_mode_vs_oracle(T, size, stem, B):
     assert m.conv_dtype == torch.float32
 
 
-def test_bf16_convolution_mode_vs_oracle():
-    """model.conv_dtype = torch.bfloat16 against the fp64 ORACLE (round 3's verdict, item 10: the bf16 mode of conv_p.hip had a
-    self-comparison only).  The columns' forward and data-gradient convolutions multiply bf16-rounded operands (8 significant
-    bits: 2^-9 relative rounding per element, 8x the fp16 mode's) in one MFMA pass with fp32 accumulation; the feature extractor,
-    the weight gradients, BatchNorm, losses and soft-argmax stay fp32.  Stated tolerance of the mode, one training step of a
-    2-stage model: coordinates 5e-2 absolute (under one 32x32-heatmap pixel), loss 5 % relative, every gradient tensor of >= 1024
-    elements within cosine 0.90 of the oracle's, their median within 0.97, whole-model gradient norm within 10 %."""
-    from margipose_amd import dsntnn
-    T, B, seed = 2, 4, 850
-    x, target, mask = W.seeded_inputs(seed, B)
-    m, sd = _build_stem(T, seed, x, 'patch8')
-    m.train()
-    m.conv_dtype = torch.bfloat16
-    out = m(x.cuda())
-    loss = dsntnn.average_loss(m.forward_3d_losses(out, target.cuda()), mask.cuda())
-    loss.backward()
-    gpu = OrderedDict((k, p.grad.detach().cpu().double()) for k, p in m.named_parameters())
-    coords, ref_loss, g64 = _oracle_step(sd, x, target, mask, T)
-    e_c = float((out.detach().cpu().double() - coords).abs().max())
-    e_l = abs(float(loss) - ref_loss) / abs(ref_loss)
-    big = [k for k in g64 if g64[k].numel() >= 1024 and float(g64[k].norm()) > 0]
-    cos = {k: float((gpu[k] * g64[k]).sum() / (gpu[k].norm() * g64[k].norm() + 1e-300)) for k in big}
-    worst = min(cos, key=cos.get)
-    n_gpu = float(torch.sqrt(sum((v ** 2).sum() for v in gpu.values())))
-    n_ref = float(torch.sqrt(sum((v ** 2).sum() for v in g64.values())))
-    print('bf16 mode T=%d %s: coords %.2e, loss %.2e, worst cosine %.4f (%s), median cosine %.5f, grad norm ratio %.4f'
-          % (T, 'patch8', e_c, e_l, cos[worst], worst, float(np.median(list(cos.values()))), n_gpu / n_ref))
-    assert e_c < 5e-2 and e_l < 5e-2, (e_c, e_l)
-    assert cos[worst] > 0.90 and float(np.median(list(cos.values()))) > 0.97, (worst, cos[worst])
-    assert abs(n_gpu / n_ref - 1.0) < 0.10
-    assert e_c > 1e-6                        # the mode really is different arithmetic
-
-
-def test_bf16_convolution_mode():
-    """model.conv_dtype = torch.bfloat16 (BASELINE configs[4]: reduced-precision convolutions): the columns' forward and
-    data-gradient convolutions multiply bf16-rounded operands in ONE MFMA pass with fp32 accumulation.  Stated tolerance
-    against the fp32 path (NOT the 1e-4 parity bar; measured on this randomly initialised 2-stage net: 2.4e-2 / 6e-5): coordinates
-    5e-2 absolute (normalised [-1, 1] units, i.e. under one 32x32-heatmap pixel), losses 1 %, gradient direction cosine >= 0.95
-    on the large tensors (measured 0.973 on the worst)."""
-    from margipose_amd import dsntnn
-    T, seed, B = 2, 830, 4
-    x, target, mask = W.seeded_inputs(seed, B)
-    m, _ = _build_stem(T, seed, x, 'patch8')
-    m.train()
-
-    def run():
-        m.zero_grad(set_to_none=True)
-        out = m(x.cuda())
-        loss = dsntnn.average_loss(m.forward_3d_losses(out, target.cuda()), mask.cuda())
-        loss.backward()
-        return out.detach().clone(), float(loss.detach()), [p.grad.clone() for p in m.parameters()]
-    o32, l32, g32 = run()
-    m.conv_dtype = torch.bfloat16
-    assert m.conv_dtype == torch.bfloat16
-    o16, l16, g16 = run()
-    m.conv_dtype = torch.float32
-    o32b, l32b, _ = run()
-    assert float((o16 - o32).abs().max()) < 5e-2 and abs(l16 - l32) < 0.01 * abs(l32), (float((o16 - o32).abs().max()), l16, l32)
-    assert float((o16 - o32).abs().max()) > 1e-6              # the mode really is different arithmetic
-    big = [(a, b) for a, b in zip(g16, g32) if a.numel() >= 1024]
-    cos = min(float((a * b).sum() / (a.norm() * b.norm() + 1e-30)) for a, b in big)
-    assert cos > 0.95, cos
-    assert abs(l32b - l32) <= 1e-5 * abs(l32)                 # and switching back restores the fp32 path
-
-
 @pytest.mark.parametrize('stem', ['patch8', 'inceptionv4'])
 def test_step_switches_leave_the_results_bit_identical(stem):
-    """Two scheduling switches of the engine that change WHO does a piece of work, not its arithmetic: the BatchNorm
-    finalisation run by the producing convolution launch's last workgroup (mpose_conv_operands.fin*; MPOSE_FUSE_FINALIZE) and the
-    split-K partials summed right behind each weight-gradient launch (MPOSE_INLINE_UNPACK).  Loss, every gradient, and the
-    running statistics must equal the default schedule's bit for bit."""
+    """The scheduling switches the engine keeps change WHO does a piece of work, not its arithmetic: the split-K
+    partials summed right behind each weight-gradient launch or once per stage (Engine.inline_unpack), the last block's residual
+    sum + soft-argmax as one launch or two (tail_fuse), the BatchNorm-backward coefficient jobs in the reduction's finishing pass
+    or as their own launch (fuse_coef).  Loss, every gradient, and the running statistics must equal the default schedule's bit
+    for bit."""
     import copy
     from margipose_amd import dsntnn
     from margipose_amd.models import CanonicalSkeletonDesc, MargiPoseModel
@@ -872,19 +802,10 @@ def test_step_switches_leave_the_results_bit_identical(stem):
         torch.manual_seed(seed)
         m0 = MargiPoseModel(CanonicalSkeletonDesc, T, True, stem, 'jsd').cuda().train()
     m1 = copy.deepcopy(m0)
-    # (the launch that finalises its own BatchNorm is conv_igemm_k's: both models run that engine, the default one with the
-    #  statistics as per-workgroup partial rows -- a third "who does it" switch covered by the same bit-for-bit claim)
-    m0.inner.engine().h2 = False
     eng = m1.inner.engine()
-    eng.h2 = False
-    # (a launch that finalises its own BatchNorm does not write the a-priori bound the feature extractor's nodes take their scale
-    #  from by default -- it measures them instead, another power of two, other last bits: both models measure here)
-    m0.inner.engine().stem_bounds = False
-    eng.stem_bounds = False
-    eng.fuse_finalize = True
-    eng.inline_unpack = True
-    eng.tail_fuse = False          # (fourth: the residual sum + soft-argmax as two launches through a logits tensor instead of one)
-    eng.fuse_coef = False          # (fifth: the coefficient jobs as their own launch instead of in the reduction's finishing pass)
+    eng.inline_unpack = False
+    eng.tail_fuse = False
+    eng.fuse_coef = False
     res = []
     for m in (m0, m1):
         out = m(x.cuda())
@@ -926,29 +847,3 @@ def test_rebound_batchnorm_tensors_are_picked_up():
     torch.cuda.synchronize()
     assert not torch.equal(bn.running_mean, before)               # the bound buffer is the one updated
     assert float(old_mean.abs().max()) == 0.0                      # the orphan (initial zeros) is left alone
-
-
-def test_shortcut_on_a_second_stream_is_bit_identical():
-    """Engine.sc_side (MPOSE_SC_SIDE=1): the H2 blocks' 1x1 shortcut convolution and its BatchNorm finalisation as their own
-    launches on a second stream, joined before the residual sum, instead of a second pass of the 3x3's launch.  Same arithmetic
-    per output element and per partial-statistics row: loss, gradients and running statistics equal the default's bit for bit."""
-    import copy
-    from margipose_amd import dsntnn
-    T, B, seed = 1, 2, 471
-    x, target, mask = W.seeded_inputs(seed + 1000, B)
-    m0 = build(T, seed, x).train()
-    m1 = copy.deepcopy(m0)
-    m1.inner.engine().sc_side = True
-    assert m0.inner.engine().h2 and m0.inner.engine().part_stats()
-    res = []
-    for m in (m0, m1):
-        out = m(x.cuda())
-        loss = dsntnn.average_loss(m.forward_3d_losses(out, target.cuda()), mask.cuda())
-        loss.backward()
-        res.append((out.detach().clone(), float(loss.detach())))
-    assert m1.inner.engine().fwd_side_stream is not None            # the path really ran
-    assert res[0][1] == res[1][1] and torch.equal(res[0][0], res[1][0])
-    for (k, a), (_, b) in zip(m0.named_parameters(), m1.named_parameters()):
-        assert torch.equal(a.grad, b.grad), k
-    for (k, a), (_, b) in zip(m0.state_dict().items(), m1.state_dict().items()):
-        assert torch.equal(a, b), k

@@ -121,6 +121,39 @@ def test_planned_iterations_equal_eager_iterations(stem, overlap):
         assert torch.equal(pe.grad, pp.grad)
 
 
+def test_stale_launch_plan_is_refused_and_pending_forwards_survive_a_replay():
+    """A launch plan replays raw addresses.  (1) An eager forward whose backward is still to come keeps its BatchNorm vectors across
+    a replay (Engine.before_replay snapshots them like a forward would): its gradients equal those of the same forward / backward
+    with no replay in between.  (2) A larger eager batch regrows the engine's reduction workspace, a re-bound parameter moves a
+    weight: either makes the recorded addresses stale, and the next replay raises instead of writing through them."""
+    from margipose_amd._lib import MposeError
+    from margipose_amd.train_helpers import DeviceSGD, PlannedTrainStep, forward_loss
+    T, seed, B = 1, 61, 2
+    x, target, mask = W.seeded_inputs(seed, B)
+    m = _model(T, seed, x)
+    opt = DeviceSGD(m.parameters(), lr=0.0, momentum=0.0)          # (lr 0: the replays leave the weights alone)
+    step = PlannedTrainStep(m, opt, x.cuda(), target.cuda(), mask.cuda())
+    xb, tb, mb = (t.cuda() for t in W.seeded_inputs(seed + 1, B))
+
+    def grads(replay_between):
+        out = m(xb)
+        loss = forward_loss(m, out, tb, mb, [1] * B)
+        if replay_between:
+            step()
+        for p in m.parameters():
+            p.grad = None
+        loss.backward()
+        return [p.grad.clone() for p in m.parameters()]
+    g0, g1 = grads(False), grads(True)
+    for a, b in zip(g0, g1):
+        assert torch.equal(a, b)
+    step()                                                           # still valid
+    p0 = next(m.parameters())
+    p0.data = p0.data.clone()                                        # a weight re-bound behind the plan's back
+    with pytest.raises(MposeError, match='stale'):
+        step()
+
+
 def test_training_iteration_launches_only_library_kernels():
     """What a launch plan cannot record must not be in the iteration: every device kernel of one eager training iteration (forward,
     3D loss, backward, DeviceSGD) is a launch of libmargipose_hip.so -- no fills, copies or elementwise kernels of the tensor library."""
