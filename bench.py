@@ -87,10 +87,10 @@ def parse():
     ap.add_argument('--eager', action='store_true', help='issue every launch from Python (the default replays the iteration from a launch '
                     'plan: train_helpers.PlannedTrainStep -- the same schedule without its host cost)')
     ap.add_argument('--no-plan', action='store_true', help='same as --eager')
-    ap.add_argument('--conv-dtype', default='f32', choices=['f32', 'f16', 'bf16'], help="BASELINE configs[4]'s reduced-precision "
+    ap.add_argument('--conv-dtype', default='f32', choices=['f32', 'f16'], help="BASELINE configs[4]'s reduced-precision "
                     "convolutions -- 'f16': every convolution on fp16-rounded operands, one MFMA product (model.conv_dtype = "
-                    "torch.float16; with --stages 5 --size 384 that is configs[4]'s workload); 'bf16': round 2's variant (columns' "
-                    'forward / data-gradient only).  A DIFFERENT workload, reported with its own dtype, never the headline')
+                    "torch.float16; with --stages 5 --size 384 that is configs[4]'s workload).  A DIFFERENT workload, reported with its own "
+                    'dtype, never the headline')
     return ap.parse_args()
 
 
@@ -412,9 +412,7 @@ def main():
     parallel.broadcast_parameters(model)
     parallel.attach(model)
     model.inner.engine().overlap_wgrad = not args.no_overlap_wgrad
-    if args.conv_dtype == 'bf16':
-        model.conv_dtype = torch.bfloat16
-    elif args.conv_dtype == 'f16':
+    if args.conv_dtype == 'f16':
         model.conv_dtype = torch.float16
     # the reference's optimiser, SGD(lr, momentum) (bin/train_3d.py:339), as one launch with device-resident hyper-parameters
     opt = DeviceSGD(model.parameters(), lr=0.01, momentum=0.9)
@@ -545,8 +543,7 @@ def main():
         'metric': 'images/sec fwd+bwd at 256x256, 17 joints (training step: forward + JS/Euclidean loss + backward + SGD)',
         'value': images / dt, 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': {'f32': 'f32 (3xfp16 split operands, fp32 accumulate)', 'f16': 'f16 (operands rounded to fp16, fp32 accumulate; BatchNorm / loss fp32)',
-                  'bf16': 'bf16'}[args.conv_dtype], 'data': 'synthetic',
+        'dtype': {'f32': 'f32 (3xfp16 split operands, fp32 accumulate)', 'f16': 'f16 (operands rounded to fp16, fp32 accumulate; BatchNorm / loss fp32)'}[args.conv_dtype], 'data': 'synthetic',
         'config': {'workload': '%s: training step, per-GPU batch %d, %d-stage MargiPose, %dx%d input, 17 joints, '
                                '%dx%d heatmaps, JS + Euclidean loss, SGD(momentum 0.9)' % (
                                    'BASELINE configs[4] (reduced-precision convolutions)' if args.conv_dtype != 'f32' and args.stages == 5 and args.size == 384
@@ -561,18 +558,17 @@ def main():
                        'launch plan replay (train_helpers.PlannedTrainStep, csrc/plan.hip): %d recorded launches and %d cross-stream waits '
                        're-issued per step from one C loop, same two-stream schedule as the eager step' % (planned.n_launches, planned.n_waits)
                        if planned is not None else 'eager launches (Python / ctypes)'),
-                   'conv_engine': {0: 'conv_igemm_k / conv_wgrad_k (conv.hip), six bf16 products per fp32 multiply-add',
-                                   1: 'plane engine (conv_p.hip)',
-                                   2: 'conv_igemm_k / conv_wgrad_k (conv.hip), three fp16 products per fp32 multiply-add of per-tensor-scaled, '
+                   'conv_engine': {2: 'conv_igemm_k / conv_wgrad_rows_k (conv.hip, wgrad.hip), three fp16 products per fp32 multiply-add of per-tensor-scaled, '
                                       'two-way split operands (MPOSE_CONV_F16X3: fp32-equivalent, tests/test_conv_f16x3_gpu.py)',
-                                   3: 'three fp16 products per fp32 multiply-add (MPOSE_CONV_F16X3) on two engines: conv_h2r_k (conv_h.hip: operands '
-                                      'split once by their producer into two fp16 planes, DMA-fed shared LDS tiles, two workgroups per CU) for the '
-                                      'forward and second-3x3 data-gradient of the regular 128-channel blocks, conv_igemm_k / conv_wgrad_k '
-                                      '(conv.hip) for everything else'}[
+                                   3: 'three fp16 products per fp32 multiply-add (MPOSE_CONV_F16X3): the regular 128-channel blocks on producer-split '
+                                      'fp16 planes end to end -- conv_h2r_k (conv_h.hip: DMA-fed shared LDS tiles, two workgroups per CU) for their '
+                                      'forward and BOTH data gradients, conv_wgrad_rows_k reading the same planes for both weight gradients, the '
+                                      'BatchNorm-backward applications writing planes only; conv_igemm_k / conv_wgrad_rows_k on fp32 tensors for '
+                                      'everything else'}[
                                        model.inner.engine().conv_mode_for(True, True)],
                    'final_loss': loss_value},
     }
-    products = 3.0 if model.inner.engine().conv_mode_for(True, True) in (2, 3) else 6.0
+    products = 3.0
     if args.conv_dtype == 'f16':
         products = 1.0                 # one MFMA product per multiply-add: priced against the full dense 16-bit MFMA peak
     peak_equiv = PEAK_BF16_MFMA_TFLOPS / products
@@ -640,24 +636,6 @@ def main():
     if allreduce is not None:
         res['allreduce_buckets'] = {'buckets': allreduce, 'xgmi_peak_GBps_per_gpu': 7 * 153.0, 'total_bytes': sum(b['bytes'] for b in allreduce),
                                     'total_ms_if_serial': sum(b['ms'] for b in allreduce)}
-    if world == 1 and not args.no_inference and args.conv_dtype == 'f32' and model.inner.engine().conv_mode_for(True, True) == 2:
-        # the same step with the six-product bf16 form of the convolutions (round 1's arithmetic, MPOSE_F16X3=0), for reference
-        eng = model.inner.engine()
-        eng.f16x3 = False
-        for _ in range(2):
-            eager_step()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(5):
-            eager_step()
-        torch.cuda.synchronize()
-        dt6 = (time.perf_counter() - t1) / 5
-        eng.f16x3 = True
-        res['six_product_bf16_form'] = {'images_per_sec': B / dt6, 'ms_per_step': 1e3 * dt6, 'steps': 5,
-                                        'note': 'same training step with every fp32 multiply-add as six bf16 MFMA products of three-way split '
-                                                'operands instead of three fp16 products of two-way split, per-tensor-scaled ones; both forms '
-                                                'pass the same parity gates (tests/test_conv_gpu.py, tests/test_conv_f16x3_gpu.py, '
-                                                'tests/test_grad_parity_gpu.py)'}
     if world == 1 and not args.no_inference:
         res['inference'] = inference_microbench(model, device, args.size)
     if world == 1 and not args.no_inference and not args.no_configs4 and args.conv_dtype == 'f32' and args.stages == 3:

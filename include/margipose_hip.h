@@ -148,16 +148,14 @@ typedef struct {
   /* Fused output stage (inference: BatchNorm with running statistics is a per-channel affine map, so a ResidualBlock needs
    * no elementwise pass at all):
    *     y0 = [relu](epi_scale0 * conv0 + epi_shift0) [+ add_scale * add_src + add_shift]      (MPOSE_CONV_EPI_RELU0)
-   * y0 is written as fp32 NHWC to out0 and -- plane engine only, out0 may then be NULL -- as pre-split planes
-   * P8[Cout0/8][3][B*OH*OW][8] to out0_planes (what the next plane convolution reads); conv.hip's engine can also accumulate
-   * max |y0| into the amax slot out0_amax (what the next MPOSE_CONV_F16X3 convolution needs).  Not combined with
-   * stats0 / mask_src / MPOSE_CONV_ACCUMULATE. */
+   * y0 is written as fp32 NHWC to out0; the launch can also accumulate max |y0| into the amax slot out0_amax (what the next
+   * MPOSE_CONV_F16X3 convolution needs).  Not combined with stats0 / mask_src / MPOSE_CONV_ACCUMULATE. */
   const float* epi_scale0;
   const float* epi_shift0;
   const float* add_src;                /* fp32 NHWC, same shape as out0 (the shortcut branch), or NULL */
   const float* add_scale;
   const float* add_shift;
-  void* out0_planes;
+  void* out0_planes;                   /* reserved (round 2's bf16 plane engine, removed in round 6): must be NULL */
   /* MPOSE_CONV_F16X3: largest magnitudes of the tensors as the K loop sees them -- `in` AFTER the in_scale / in_shift / ReLU
    * prologue and `in1` as activation amax SLOTS (see mpose_absmax), the torch-layout weights behind w0 / w1 as one float each
    * (mpose_weights_absmax).  A value below the true maximum overflows fp16 (inf / NaN results). */
@@ -192,14 +190,10 @@ typedef struct {
 } mpose_conv_operands;
 
 #define MPOSE_CONV_ACCUMULATE 1   /* out0 += result */
-#define MPOSE_CONV_PLANES_IN 4    /* `in` / `in1` are pre-split activations: three bf16 planes (hi, mid, lo) in the blocked
-                                   * layout P8[Cin/8][plane][B*IH*IW][8] (mpose_split_planes and the *_planes outputs of the
-                                   * BatchNorm kernels write it), `w0` / `w1` are packed with layout 1; in_scale must be NULL
-                                   * (the producer already applied BatchNorm + ReLU) and in_ld 0.  Runs conv_p.hip's engine:
-                                   * both operands reach LDS by DMA, two workgroups per CU. */
+#define MPOSE_CONV_PLANES_IN 4    /* reserved: round 2's plane engine on three bf16 planes (conv_p.hip) left the library in round 6 --
+                                   * MPOSE_CONV_H2_IN is its successor on two fp16 planes; the flag is rejected (MPOSE_EINVAL) */
 #define MPOSE_CONV_EPI_RELU0 16    /* with the fused output stage of mpose_conv_operands: ReLU after epi_scale0 / epi_shift0 */
-#define MPOSE_CONV_BF16 8         /* with MPOSE_CONV_PLANES_IN: multiply the hi planes only (bf16 x bf16 -> fp32, one MFMA per
-                                   * fragment pair): the reduced-precision mode of BASELINE configs[4], NOT fp32-equivalent */
+#define MPOSE_CONV_BF16 8         /* reserved (the plane engine's single-pass bf16 mode): rejected; configs[4]'s mode is MPOSE_CONV_F16X1 */
 #define MPOSE_CONV_F16X3 32       /* fp32 convolution as THREE fp16 MFMA products instead of six bf16 ones (conv.hip engine only).
                                    * x * 2^k = h + l with two fp16 values (11 significant bits each, |x - (h+l) 2^-k| <= 2^-22 |x|),
                                    * k = 141 - biased_exponent(amax) (clamped to [-113, 114]) so that the tensor's largest
@@ -346,22 +340,6 @@ typedef struct {
 int mpose_unpack_wgrads(const mpose_unpack_job* jobs_dev, int n_jobs, int max_elems_per_job,
                         void* stream);
 
-/* Pre-split activations for MPOSE_CONV_PLANES_IN (csrc/split.hip): three bf16 planes hi/mid/lo with x = hi + mid + lo
- * (to 2^-27 |x|) in the blocked layout P8[C/8][plane][npix][8]; mpose_planes_bytes gives the buffer size.  Every
- * elementwise pass that feeds a convolution has a variant that writes this layout directly:
- *   mpose_split_planes         planes = split([relu](scale*src + shift)), scale NULL = identity (src NHWC fp32, C % 8 == 0):
- *                              the BatchNorm + ReLU between a ResidualBlock's convolutions (models/margipose_model.py:31-33)
- *   mpose_bn_add_planes        mpose_bn_add_fwd (layout 0) with the sum also (ops[i].out may be NULL: only) written as planes
- *   mpose_bn_bwd_apply_planes  mpose_bn_bwd_apply with da / db also (ops[i].da / .db may be NULL: only) written as planes */
-typedef struct {
-  const float* src;
-  const float* scale;
-  const float* shift;
-  void* planes;
-} mpose_split_operands;
-int64_t mpose_planes_bytes(int64_t npix, int C);
-int mpose_split_planes(const mpose_split_operands* ops, int n_groups, int64_t npix, int C, int relu, void* stream);
-
 /* Producer-split activations for MPOSE_CONV_H2_IN (csrc/split.hip): planes = the two fp16 pieces of
  * [relu](scale * src + shift) * 2^k, k = f16 scale exponent of max over the sub-slots of `amax` (a BOUND the caller guarantees),
  * layout H8[C/8][2][npix][8]; mpose_h2_bytes gives the buffer size (= the fp32 tensor's). */
@@ -431,8 +409,6 @@ typedef struct {
 
 int mpose_bn_add_fwd(const mpose_bn_add_operands* ops, int n_groups, int pixels_per_image, int B,
                      int C, int layout, int c_keep, void* stream);
-int mpose_bn_add_planes(const mpose_bn_add_operands* ops, void* const* planes, int n_groups, int64_t npix, int C,
-                        void* stream);
 /* mpose_bn_add_fwd (layout 0) that also writes the sum as the two fp16 planes of MPOSE_CONV_H2_IN, h2[i], scaled as the amax
  * slot ops[i].out_amax prescribes -- which is READ here (a bound somebody else wrote, see mpose_bn_job.bound_out), never
  * measured.  ops[i].out may be NULL (planes only). */
@@ -489,8 +465,6 @@ typedef struct {
 
 int mpose_bn_bwd_apply(const mpose_bn_bwd_apply_operands* ops, int n_groups, int pixels_per_image,
                        int B, int C, int layout, int c_keep, void* stream);
-int mpose_bn_bwd_apply_planes(const mpose_bn_bwd_apply_operands* ops, void* const* da_planes, void* const* db_planes,
-                              int n_groups, int64_t npix, int C, void* stream);
 /* mpose_bn_bwd_apply that writes da as the two fp16 planes of MPOSE_CONV_H2_IN, da_h2[i], scaled as the amax slot
  * ops[i].da_amax prescribes (READ: the bound of mpose_bn_bwd_coef_job.bound_out); ops[i].da (fp32) may be NULL.
  * db_h2 == NULL: db is written as fp32 and its largest magnitude accumulated into ops[i].db_amax as mpose_bn_bwd_apply does.

@@ -38,8 +38,6 @@ def lib():
         _LIB.mpose_abi_version.restype = c_int
         if _LIB.mpose_abi_version() != ABI_VERSION:
             raise MposeError('libmargipose_hip.so ABI version mismatch')
-        _LIB.mpose_planes_bytes.restype = c_int64
-        _LIB.mpose_planes_bytes.argtypes = [c_int64, c_int]
         _LIB.mpose_bn_bwd_reduce_ws_bytes.restype = c_int64
         _LIB.mpose_h2_bytes.restype = c_int64
         _LIB.mpose_h2_bytes.argtypes = [c_int64, c_int]
@@ -170,10 +168,6 @@ class AbsmaxOperands(ctypes.Structure):
 class BnAddOperands(ctypes.Structure):
     _fields_ = [('a', c_void_p), ('a_scale', c_void_p), ('a_shift', c_void_p),
                 ('b', c_void_p), ('b_scale', c_void_p), ('b_shift', c_void_p), ('out', c_void_p), ('out_amax', c_void_p)]
-
-
-class SplitOperands(ctypes.Structure):
-    _fields_ = [('src', c_void_p), ('scale', c_void_p), ('shift', c_void_p), ('planes', c_void_p)]
 
 
 class SplitH2Operands(ctypes.Structure):

@@ -387,7 +387,7 @@ extern "C" int mpose_sizeof(int which) {
     case 7: return (int)sizeof(mpose_bn_add_operands);
     case 8: return (int)sizeof(mpose_bn_bwd_reduce_operands);
     case 9: return (int)sizeof(mpose_bn_bwd_apply_operands);
-    case 10: return (int)sizeof(mpose_split_operands);
+    case 10: return (int)sizeof(mpose_split_h2_operands);
     case 11: return (int)sizeof(mpose_sgd_job);
     case 12: return (int)sizeof(mpose_absmax_operands);
     default: return -1;
@@ -447,7 +447,7 @@ static bool reduce_wide(int n_groups, int C) { return n_groups == 1 && C >= 256;
 static long reduce_ws_blocks(int n_groups, long npix, int C) {
   // (one group that is not a wide BatchNorm -- the feature extractor's nodes: 256 workgroups, one per CU; with 1024 the finishing
   //  pass walked four times the partials for nothing gained in the main one: -0.1 ... -0.17 ms per step, profiles/r5_ab_sweeps.txt)
-  static const long cap1 = [] { const char* e = getenv("MPOSE_REDUCE_CAP1"); return e ? atol(e) : 256L; }();      // (A/B runs)
+  constexpr long cap1 = 256L;
   const long cap = n_groups >= 3 ? 384 : (n_groups == 2 ? 512 : (reduce_wide(n_groups, C) ? 1024 : cap1));
   // (wide: a workgroup's pass covers 256 / (C/4) <= 4 pixel rows at a time; 32 pixels each keeps >= 4 workgroups per CU in flight)
   long blocks = reduce_wide(n_groups, C) ? (npix + 31) / 32 : (npix + 63) / 64;

@@ -1110,11 +1110,10 @@ int launch_conv(const ConvArgs& a0, int n_groups, hipStream_t s) {
   dim3 grid(a.n_mtiles * a.g.n_classes, (cmax + BN - 1) / BN, n_groups);
   a.part_row0 = mpose_part_phase.row0;
   a.part_rows = mpose_part_phase.total > 0 ? mpose_part_phase.total : (int)grid.x;
-  static const bool xcd_off = [] { const char* e = getenv("MPOSE_IGEMM_XCD"); return e && atoi(e) == 0; }();
   // (row-group launches only -- the columns' convolutions: 308 -> 226 MB per launch on the two-input data gradient, 131 -> 73 MB on
   //  the 64-channel 3x3, durations within 1 %; the feature extractor's wide launches, several channel tiles per pixel tile with an
   //  unsplit K, measured 17-25 % SLOWER in this order and keep the plain one: tools/pmc_xcd.sh)
-  a.xcd_order = (ROWG && !xcd_off && (grid.x & 7u) == 0 && grid.x >= 16) ? 1 : 0;
+  a.xcd_order = (ROWG && (grid.x & 7u) == 0 && grid.x >= 16) ? 1 : 0;
   launch(conv_igemm_k<RN, MODE, KS, PRO, NPL, ROWG>, dim3(grid), dim3(256), lds, s, a);
   return launch_status();
 }
@@ -1141,15 +1140,10 @@ inline int pick_ks(const ConvArgs& a, int cmax, int n_groups) {
   // (round 4: unsplit is the default in training too -- on a common ReLU piece the step's gradients sit at 1.14x the fp32 CPU path's
   //  median error with every 128-channel launch in this form (tests/test_grad_parity_gpu.py, 'igemm' case: 4.0e-6 / max 1.3e-5),
   //  the contract is 1e-4, and the step gains 0.2 ms: 23.68 -> 23.47.  MPOSE_SLIM=1 restores the split for training launches.)
-  static const bool unsplit_ok = [] { const char* e = getenv("MPOSE_SLIM"); return !e || atoi(e) == 2; }();
-  const bool chain_bound = SLIM && NPL == 2 && a.op[0].epi_scale0 == nullptr && !unsplit_ok;      // (one product: a chain of 72)
+  const bool chain_bound = false;      // (round 3 kept training's two-way K split on these launches; round 4 measured the unsplit form inside the gates)
 #ifdef CV_KS_FORCE          // (launch-plan experiments, debug builds: -DCV_KS_FORCE=<RN * 10 + ks>, e.g. 32 = the 96-wide tiles split two ways)
   if (RN == CV_KS_FORCE / 10 && n_iter >= 2 * (CV_KS_FORCE % 10)) return CV_KS_FORCE % 10;
 #endif
-  // (the same as a run-time switch for A/B sweeps: MPOSE_KS_FORCE=<MODE * 100 + RN * 10 + ks>, e.g. 241 = the two-input launches of the 128-wide tiles unsplit)
-  static const int ks_force = [] { const char* e = getenv("MPOSE_KS_FORCE"); return e ? atoi(e) : 0; }();
-  if (ks_force && MODE == ks_force / 100 && RN == (ks_force / 10) % 10 && n_iter >= 2 * (ks_force % 10) && (ks_force % 10 == 1 || ks_force % 10 == 2 || (ks_force % 10 == 4 && RN > 1)))
-    return ks_force % 10;
   for (int ks = 1; ks <= (RN > 1 ? 4 : 2); ks *= 2) {
     if (ks > 1 && n_iter < 2 * ks) break;
     const long wgs = ((m_nominal + 256 / ks - 1) / (256 / ks)) * a.g.n_classes * ((cmax + 32 * RN - 1) / (32 * RN)) * n_groups;
@@ -1205,11 +1199,7 @@ int launch_conv_ks_p(const ConvArgs& a, int mode, int cmax, int n_groups, hipStr
   if (a.op[0].in_scale != nullptr) return launch_conv_kp<RN, 0, true, NPL, ROWG>(a, cmax, n_groups, s);
   return launch_conv_kp<RN, 0, false, NPL, ROWG>(a, cmax, n_groups, s);
 }
-static int rowg_env() {                    // MPOSE_CONV_ROWG=0 disables the row-group loop (A/B runs)
-  static int v = -2;
-  if (v == -2) { const char* e = getenv("MPOSE_CONV_ROWG"); v = e ? atoi(e) : 1; }
-  return v;
-}
+static constexpr int rowg_env() { return 1; }      // (the row-group loop: a run-time switch until round 6)
 template <int RN>
 int launch_conv_ks(const ConvArgs& a, int mode, int cmax, int n_groups, hipStream_t s) {
   if (a.flags & MPOSE_CONV_F16X1) {          // (with MPOSE_CONV_F16X3: same operands and scales, the h x h product only)
@@ -1728,8 +1718,6 @@ using namespace mpose;
 thread_local int* mpose::mpose_dry_rows = nullptr;
 thread_local mpose::PartPhase mpose::mpose_part_phase = {0, 0};
 
-int mpose_conv_planes_launch(const mpose_conv_geom* geom, const mpose_conv_operands* ops, int n_groups, int flags, int mode,
-                             int cmax, void* stream);      // conv_p.hip
 int mpose_conv_h2_launch(const mpose_conv_geom* geom, const mpose_conv_operands* ops, int n_groups, int flags, int mode,
                          int cmax, void* stream);          // conv_h.hip
 int mpose_wgrad_rows_units(const mpose_conv_geom* geom);                                                                       // wgrad.hip
@@ -1814,7 +1802,7 @@ extern "C" int mpose_conv_fwd(const mpose_conv_geom* geom_, const mpose_conv_ope
     if ((ops[i].red_sums != nullptr) != (ops[0].red_sums != nullptr)) return MPOSE_EINVAL;
     if (ops[i].mm0 && ((flags & MPOSE_CONV_PLANES_IN) || !ops[i].stats0)) return MPOSE_EINVAL;
     if ((flags & MPOSE_CONV_H2_IN) && (ops[i].epi_scale0 || ops[i].add_src || ops[i].out0_planes || ops[i].fin_count || ops[i].in_scale ||
-                                       (flags & (MPOSE_CONV_ACCUMULATE | MPOSE_CONV_PLANES_IN | MPOSE_CONV_F16X1)) || !(flags & MPOSE_CONV_F16X3)))
+                                       (flags & (MPOSE_CONV_ACCUMULATE | MPOSE_CONV_PLANES_IN)) || !(flags & MPOSE_CONV_F16X3)))
       return MPOSE_EINVAL;
     if (ops[i].fin_count && ((flags & MPOSE_CONV_PLANES_IN) || !ops[i].fin0 || !ops[i].stats0 || (ops[i].fin1 && (!acc1 || !ops[i].stats1)) ||
                              sum_inputs)) return MPOSE_EINVAL;
@@ -1857,15 +1845,7 @@ extern "C" int mpose_conv_fwd(const mpose_conv_geom* geom_, const mpose_conv_ope
   }
   a.M = geom->B * geom->GH * geom->GW;
   if (a.M == 0) return 0;
-  if (flags & MPOSE_CONV_PLANES_IN) {      // pre-split activations: conv_p.hip
-    if (ops[0].in_scale || (geom->Cout0 % 32) || (acc1 && (geom->Cout1 % 32)) || (geom->Npad0 % 64)) return MPOSE_EINVAL;
-    if (flags & MPOSE_CONV_F16X3) return MPOSE_EINVAL;
-    const int cm = (acc1 && geom->Cout1 > geom->Cout0) ? geom->Cout1 : geom->Cout0;
-    if (cm > geom->Npad0) return MPOSE_EINVAL;
-    const int ldm = geom->out_ld0 > geom->out_ld1 ? geom->out_ld0 : geom->out_ld1;
-    if ((long)geom->B * geom->OH * geom->OW * (ldm > cm ? ldm : cm) * 4 >= 0xFFFFF000l) return MPOSE_EINVAL;
-    return mpose_conv_planes_launch(geom, ops, n_groups, flags, sum_inputs ? 2 : (acc1 ? 1 : 0), cm, stream);
-  }
+  if (flags & MPOSE_CONV_PLANES_IN) return MPOSE_EINVAL;      // (round 2's plane engine left the library in round 6)
   if (flags & MPOSE_CONV_BF16) return MPOSE_EINVAL;
   if ((flags & MPOSE_CONV_F16X1) && !(flags & MPOSE_CONV_F16X3)) return MPOSE_EINVAL;
   if (flags & MPOSE_CONV_F16X3) {
@@ -1919,7 +1899,7 @@ extern "C" int mpose_conv_fwd(const mpose_conv_geom* geom_, const mpose_conv_ope
   // gain is gone (114-120 -> 122, 113 -> 111 us), and at 192 channels the 96-channel tiles are faster (58 vs 65 us).  So:
   // inference launches only -- until round 4, which measured the training step with them: MPOSE_SLIM=2 (every eligible launch,
   // without the rule that keeps training's K split) is now the default; 1: inference launches only (round 3's plan); 0: never.
-  static const int slim = [] { const char* e = getenv("MPOSE_SLIM"); return e ? atoi(e) : 2; }();
+  constexpr int slim = 2;
   // (the single-product mode MPOSE_CONV_F16X1 accumulates a third as often: unsplit everywhere, training included)
   if (slim && (slim == 2 || a.op[0].epi_scale0 != nullptr || (flags & MPOSE_CONV_F16X1)) && mode == 0 && (flags & MPOSE_CONV_F16X3) &&
       (cmax % 128) == 0 && rowg_env() && rowg_eligible(a.g))
@@ -2074,7 +2054,7 @@ extern "C" int mpose_pack_weights(const mpose_pack_job* jobs_dev, int n_jobs, in
   int bx = (max_elems_per_job + 256 * 8 - 1) / (256 * 8);
   if (bx < 1) bx = 1;
   if (bx > 256) bx = 256;
-  static const int tiled = [] { const char* e = getenv("MPOSE_PACK_TILED"); return e ? atoi(e) : 1; }();      // (0: the element-wise packer alone, A/B runs)
+  constexpr int tiled = 1;      // (the tiled packer for the large weights, the element-wise one for the rest)
   if (tiled) launch(pack_weights_tiled_k, dim3(dim3(bx > 48 ? 48 : bx, n_jobs)), dim3(256), 0, (hipStream_t)stream, jobs_dev);
   launch(pack_weights_k, dim3(dim3(tiled && bx > 32 ? 32 : bx, n_jobs)), dim3(256), 0, (hipStream_t)stream, jobs_dev, tiled);
   return launch_status();

@@ -588,22 +588,41 @@ constexpr int HR_TG = 3;          // taps per step
 constexpr int HR_MAXT = 9;        // taps per pass
 constexpr int HR_MAXNG = 6;       // 64-row groups of an A plane-half: 256 + (largest - smallest tap shift) <= 384 pixels
 
-template <int RN, int MODE>
+// LDS layout of conv_h2r_k: two A buffers (a halo tile's (plane, k half) sub-arrays), the B ring of two slots x three taps, the
+// epilogue scratch (cross-wave sums: it aliases the rings once the K loop is done; behind the parked result tiles of MODE 2) and
+// the output-row table at the end.
+template <int RN, int MODE, bool X1>
+struct H2rLds {
+  static constexpr int BN = 32 * RN, BNL = (BN + 63) / 64 * 64, NPLN = X1 ? 1 : 2;
+  static constexpr int SA = (HR_MAXNG * 64 + 16) * 16, ABUF = 2 * NPLN * SA, B_SLOT = HR_TG * 2 * NPLN * BNL * 16;
+  static constexpr int RING = 2 * ABUF + 2 * B_SLOT;
+  static constexpr int EP_TILE = MODE == 2 ? 4 * 32 * 72 * 4 : 0;
+  static constexpr int RED_OFF = 2 * ABUF > EP_TILE ? 2 * ABUF : EP_TILE;
+  static constexpr int RED_END = RED_OFF + 4 * BN * 4 * 4 + 4 * BN * 2 * 4;
+  static constexpr int ROW_OFF = RING > RED_END ? RING : RED_END;
+  static constexpr int BYTES = ROW_OFF + HR_BM * 4;
+};
+
+// X1 (round 6): MPOSE_CONV_F16X1's arithmetic on the same planes -- the h pieces ARE the operands rounded to fp16, so the kernel
+// leaves the l planes where they are: half the DMA instructions and fragment reads, one product per multiply-add, one accumulator.
+template <int RN, int MODE, bool X1 = false>
 __global__ __launch_bounds__(256, 2) void conv_h2r_k(ConvHRArgs a) {
   constexpr bool ACC1 = MODE == 1, SUM2 = MODE == 2;
   constexpr int NPASS = MODE ? 2 : 1;
   constexpr int BM = HR_BM, BN = 32 * RN, BNL = (BN + 63) / 64 * 64, NGN = BNL / 64;
   constexpr int TG = HR_TG;
-  constexpr int B_TAP = 4 * BNL * 16;          // one tap's B tile: [plane][k half][BNL columns][16 B]
+  constexpr int NPLN = X1 ? 1 : 2;             // operand planes the kernel reads
+  constexpr int B_TAP = 2 * NPLN * BNL * 16;   // one tap's B tile: [plane][k half][BNL columns][16 B]
   constexpr int B_SLOT = TG * B_TAP;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int SA = (HR_MAXNG * 64 + 16) * 16;        // bytes of one (plane, half) sub-array: compile-time, so that planes are immediate offsets
-  const int ABUF = 4 * SA;
+  using L = H2rLds<RN, MODE, X1>;
+  constexpr int ABUF = 2 * NPLN * SA;
+  static_assert(ABUF == L::ABUF && B_SLOT == L::B_SLOT, "one LDS layout for the kernel and its launcher");
   unsigned char* sB = smem + 2 * ABUF;                                         // [2 slots][B_SLOT]
-  unsigned* sRow = reinterpret_cast<unsigned*>(sB + 2 * B_SLOT);               // [BM] output row byte offsets
-  float* sRed = reinterpret_cast<float*>(sB);                                  // epilogue scratch, aliases the (then idle) B ring:
+  unsigned* sRow = reinterpret_cast<unsigned*>(smem + L::ROW_OFF);             // [BM] output row byte offsets
+  float* sRed = reinterpret_cast<float*>(smem + L::RED_OFF);                   // epilogue scratch, aliases the (then idle) rings:
   float* sMM = sRed + 4 * BN * 4;                                              //   [4 waves][BN][4] and [4 waves][BN][2]
-  static_assert(4 * BN * 4 * 4 + 4 * BN * 2 * 4 <= 2 * B_SLOT, "epilogue scratch fits in the B ring");
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lh = lane >> 5;
@@ -645,7 +664,7 @@ __global__ __launch_bounds__(256, 2) void conv_h2r_k(ConvHRArgs a) {
     sRow[tid] = (int)m < a.M ? m * (unsigned)out_ld * 4u : 0xFFFFF000u;      // (output grid = slot grid: pixel index = m)
   };
   // the zero rows of both A buffers (never written by the DMA: it covers rows 0 .. NG*64-1)
-  for (int i = tid; i < 2 * 4 * 16; i += 256) {
+  for (int i = tid; i < 2 * 2 * NPLN * 16; i += 256) {
     const int sub = i >> 4, r = i & 15;
     *reinterpret_cast<u32x4*>(smem + sub * SA + (zrow + r) * 16) = u32x4{0u, 0u, 0u, 0u};
   }
@@ -695,7 +714,8 @@ __global__ __launch_bounds__(256, 2) void conv_h2r_k(ConvHRArgs a) {
     }
 
     // ---- loop-invariant addresses of this pass ----
-    const int la = (a.NG + ng - 1) / ng;                            // A instructions per wave and batch
+    const int ngw = X1 ? (2 * a.NG + 3) / 4 : a.NG;                 // A instructions per wave and halo tile (X1: the h plane's two sub-arrays only)
+    const int la = (ngw + ng - 1) / ng;                             // A instructions per wave and batch
     const unsigned bvoff0 = (CH_EXP & 2) ? kOob : (unsigned)((n0 + lane) * 16);
     const int rowb0 = wave * 64 + li, rowb1 = rowb0 + 32;           // tile rows of this lane's two output pixels (before the tap shift)
     // An LDS-DMA instruction costs its wave ~25 cycles when its operands are ready and ~180 when they are computed in line (scalar
@@ -726,7 +746,7 @@ __global__ __launch_bounds__(256, 2) void conv_h2r_k(ConvHRArgs a) {
 #pragma unroll
       for (int ti = 0; ti < TG; ++ti) {
         const int t = gb * TG + ti;
-        if (t < nt) {                                              // (wave-uniform; always true for the 3x3 passes)
+        if (t < nt && (!X1 || wave < 2)) {                         // (wave-uniform; always true for the 3x3 passes.  X1: the h plane's two k halves)
           const unsigned soff = __builtin_amdgcn_readlane(tab_b, t_lo + t) + (unsigned)cb * b_chunk + (unsigned)wave * w_plane_b;
           unsigned char* dst = smem + lds_b0 + bslot * B_SLOT + ti * B_TAP;
           if constexpr (CH_EXP & 512) {       // timing experiment: the B tile by a plain load (no LDS-DMA, results wrong)
@@ -736,7 +756,7 @@ __global__ __launch_bounds__(256, 2) void conv_h2r_k(ConvHRArgs a) {
           else dma16(rs_w0, dst, b_live ? bvoff0 : kOob, b_live ? soff : 0u);
         }
       }
-      const int k_hi = (ja + 1) * la < a.NG ? (ja + 1) * la : a.NG;
+      const int k_hi = (ja + 1) * la < ngw ? (ja + 1) * la : ngw;
       for (int k = ja * la; k < k_hi; ++k) {
         const unsigned q = q0 + (unsigned)__builtin_amdgcn_readlane(tab_arow, k);
         const unsigned vo = (a_live && q < (unsigned)npix && !(CH_EXP & 1)) ? q * 16u : kOob;
@@ -766,13 +786,13 @@ __global__ __launch_bounds__(256, 2) void conv_h2r_k(ConvHRArgs a) {
         const bool ok = (fr_ok[rm] >> (t_lo + t)) & 1u;
         const int r = ok ? row : zrow + (row & 15);
         fa[st][rm][0] = *reinterpret_cast<const f16x8*>(pa + r * 16);
-        fa[st][rm][1] = *reinterpret_cast<const f16x8*>(pa + r * 16 + 2 * SA);
+        if constexpr (!X1) fa[st][rm][1] = *reinterpret_cast<const f16x8*>(pa + r * 16 + 2 * SA);
       }
       const unsigned char* pb = sB + bslot * B_SLOT + ti * B_TAP + (lh * BNL + li) * 16;
 #pragma unroll
       for (int rn = 0; rn < RN; ++rn) {
         fb[st][rn][0] = *reinterpret_cast<const f16x8*>(pb + rn * 32 * 16);
-        fb[st][rn][1] = *reinterpret_cast<const f16x8*>(pb + rn * 32 * 16 + 2 * BNL * 16);
+        if constexpr (!X1) fb[st][rn][1] = *reinterpret_cast<const f16x8*>(pb + rn * 32 * 16 + 2 * BNL * 16);
       }
     };
     auto mfma_tap = [&](auto ST) {                // products outermost: no two consecutive MFMAs on one accumulator
@@ -781,14 +801,16 @@ __global__ __launch_bounds__(256, 2) void conv_h2r_k(ConvHRArgs a) {
         asm volatile("" :: "v"(fa[st][0][0]), "v"(fa[st][0][1]), "v"(fa[st][1][0]), "v"(fa[st][1][1]), "v"(fb[st][0][0]), "v"(fb[st][0][1]));
         return;
       }
+      if constexpr (!X1) {
 #pragma unroll
-      for (int rm = 0; rm < 2; ++rm)
+        for (int rm = 0; rm < 2; ++rm)
 #pragma unroll
-        for (int rn = 0; rn < RN; ++rn) acx[rm][rn] = mfma_f16(fa[st][rm][1], fb[st][rn][0], acx[rm][rn]);
+          for (int rn = 0; rn < RN; ++rn) acx[rm][rn] = mfma_f16(fa[st][rm][1], fb[st][rn][0], acx[rm][rn]);
 #pragma unroll
-      for (int rm = 0; rm < 2; ++rm)
+        for (int rm = 0; rm < 2; ++rm)
 #pragma unroll
-        for (int rn = 0; rn < RN; ++rn) acx[rm][rn] = mfma_f16(fa[st][rm][0], fb[st][rn][1], acx[rm][rn]);
+          for (int rn = 0; rn < RN; ++rn) acx[rm][rn] = mfma_f16(fa[st][rm][0], fb[st][rn][1], acx[rm][rn]);
+      }
 #pragma unroll
       for (int rm = 0; rm < 2; ++rm)
 #pragma unroll
@@ -834,7 +856,7 @@ __global__ __launch_bounds__(256, 2) void conv_h2r_k(ConvHRArgs a) {
         // issue order inside a tap's block: every MFMA gap takes one fragment read (and its address arithmetic) or one DMA
         // instruction of the batch; without the hints hipcc bunches the reads in front of the MFMAs and the DMA behind them
         auto spread_reads = [&]() {
-          if constexpr (SCHED_HINTS) {
+          if constexpr (SCHED_HINTS && !X1) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
               __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -845,7 +867,7 @@ __global__ __launch_bounds__(256, 2) void conv_h2r_k(ConvHRArgs a) {
           }
         };
         auto spread_batch = [&]() {
-          if constexpr (SCHED_HINTS) {
+          if constexpr (SCHED_HINTS && !X1) {
 #pragma unroll
             for (int i = 0; i < 5; ++i) {
               __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -975,7 +997,7 @@ __global__ __launch_bounds__(256, 2) void conv_h2r_k(ConvHRArgs a) {
     const int e_row = lane >> 4, e_col = (lane & 15) * 4;
     const bool e_ok = e_col < BN && n0 + e_col < cout;
     if constexpr (SUM2) {
-      static_assert(4 * 32 * EP_PITCH * 4 <= 2 * 4 * SA, "the parked tiles fit in the A buffers");
+      static_assert(4 * 32 * EP_PITCH * 4 == L::EP_TILE, "the parked tiles' bytes as the LDS layout reserves them");
       float* tile = reinterpret_cast<float*>(smem) + wave * (32 * EP_PITCH);
       float4 ems = make_float4(0.f, 0.f, 0.f, 0.f), emt = ems;
       if (red && e_ok) { ems = *reinterpret_cast<const float4*>(op.red_scale + n0 + e_col); emt = *reinterpret_cast<const float4*>(op.red_shift + n0 + e_col); }
@@ -1208,30 +1230,30 @@ inline bool h2r_eligible(const mpose_conv_geom& g, int* lo_out, int* hi_out) {
   return true;
 }
 
-template <int RN, int MODE>
+template <int RN, int MODE, bool X1 = false>
 int launch_h2r(ConvHRArgs a, int cmax, int n_groups, hipStream_t s) {
-  constexpr int BN = 32 * RN, BNL = (BN + 63) / 64 * 64;
-  constexpr int lds = 2 * 4 * (HR_MAXNG * 64 + 16) * 16 + 2 * HR_TG * 4 * BNL * 16 + HR_BM * 4;
+  constexpr int BN = 32 * RN;
+  constexpr int lds = H2rLds<RN, MODE, X1>::BYTES;
   static_assert(2 * lds <= 160 * 1024, "two workgroups per CU");
   if (a.NG > HR_MAXNG) return MPOSE_ENOSYS;
   a.n_mtiles = (a.M + HR_BM - 1) / HR_BM;
   if (mpose_dry_rows) { *mpose_dry_rows += a.n_mtiles; return 0; }     // (mpose_conv_stat_rows)
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_h2r_k<RN, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_h2r_k<RN, MODE, X1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
       return MPOSE_EINVAL;
     attr_set = true;
   }
   dim3 grid(a.n_mtiles, (cmax + BN - 1) / BN, n_groups);
   a.part_row0 = mpose_part_phase.row0;
   a.part_rows = mpose_part_phase.total > 0 ? mpose_part_phase.total : (int)grid.x;
-  launch(conv_h2r_k<RN, MODE>, dim3(grid), dim3(256), lds, s, a);
+  launch(conv_h2r_k<RN, MODE, X1>, dim3(grid), dim3(256), lds, s, a);
   return launch_status();
 }
 
-template <int RN>
+template <int RN, bool X1 = false>
 int launch_h2r_mode(const ConvHRArgs& a, int mode, int cmax, int n_groups, hipStream_t s) {
-  if (mode == 1) return launch_h2r<RN, 1>(a, cmax, n_groups, s);
+  if (mode == 1) return launch_h2r<RN, 1, X1>(a, cmax, n_groups, s);
   // (MODE 2, the two-input sum: its second pass restages the whole halo tile for one tap per step, and the 64-channel form
   //  spilled 36 bytes per lane beside the consumer-sums epilogue -- conv_h2_k takes it)
   if (mode == 2) {           // (conv_h2r_k<., 2>: kernel rows of three taps from the first input, fewer than three taps from the second)
@@ -1239,9 +1261,9 @@ int launch_h2r_mode(const ConvHRArgs& a, int mode, int cmax, int n_groups, hipSt
     for (int t = 0; t < a.g.cls[0].n_taps; ++t) n0 += a.g.cls[0].taps[t].acc == 0;
     const int n1 = a.g.cls[0].n_taps - n0;
     if (n0 % HR_TG || n0 == 0 || n1 == 0 || n1 >= HR_TG) return MPOSE_ENOSYS;
-    return launch_h2r<RN, 2>(a, cmax, n_groups, s);
+    return launch_h2r<RN, 2, X1>(a, cmax, n_groups, s);
   }
-  return launch_h2r<RN, 0>(a, cmax, n_groups, s);
+  return launch_h2r<RN, 0, X1>(a, cmax, n_groups, s);
 }
 
 template <int WM, int WN, int RM, int RN, int KST, int NBUF, int MODE, bool DUAL>
@@ -1278,7 +1300,7 @@ int launch_h2_mode(const ConvHArgs& a, int mode, int n_groups, hipStream_t s) {
 
 // Tile choice (MPOSE_H2_TILE overrides for timing runs: see the table in the function).
 int launch_h2_shape(const ConvHArgs& a, int mode, int cmax, int n_groups, hipStream_t s) {
-  static const int forced = [] { const char* e = getenv("MPOSE_H2_TILE"); return e ? atoi(e) : 0; }();
+  constexpr int forced = 0;      // (1-4: the tile shapes of round 4's timing runs, kept as the table below)
   if (cmax % 128 == 0) {
     switch (forced) {
       case 1: return launch_h2_mode<2, 2, 2, 2, 1, 4, true>(a, mode, n_groups, s);      // 128 x 128, 16-channel slots, 4 deep
@@ -1313,12 +1335,13 @@ int mpose_conv_h2_launch(const mpose_conv_geom* geom, const mpose_conv_operands*
   a.div_gw = make_fastdiv((unsigned)geom->GW);
   a.div_ghw = make_fastdiv((unsigned)(geom->GH * geom->GW));
   a.flags = flags;
+  const bool x1 = (flags & MPOSE_CONV_F16X1) != 0;
   const long npix = (long)geom->B * geom->IH * geom->IW;
   const long in_bytes = npix * 16 * 2 * (geom->Cin / 8);
   if (in_bytes >= 0xFFFFFF00l - (1l << 20) || geom->in_ld > 0) return MPOSE_EINVAL;       // 32-bit buffer offsets; dense inputs only
   if ((long)geom->Npad0 * 16 * 4 * (geom->Cin / 16) * MPOSE_MAX_TAPS >= 0xFFFFFF00l) return MPOSE_EINVAL;
   a.in_slab = (unsigned)(npix * 16);
-  static const int form = [] { const char* e = getenv("MPOSE_H2_FORM"); return e ? atoi(e) : 1; }();      // 0: the general kernel only (A/B runs)
+  constexpr int form = 1;
   int lo = 0, hi = 0;
   bool opts_ok = true;       // epilogue options per mode (conv_h2r_k): 0: all; 1: statistics + extremes; 2: consumer sums + output amax
   for (int i = 0; i < n_groups; ++i) {
@@ -1333,9 +1356,12 @@ int mpose_conv_h2_launch(const mpose_conv_geom* geom, const mpose_conv_operands*
     r.lo = lo;
     r.NG = (HR_BM + hi - lo + 63) / 64;
     r.a_rows = r.NG * 64 + 16;
-    const int rc = cmax <= 32 ? launch_h2r_mode<1>(r, mode, cmax, n_groups, (hipStream_t)stream)
-                              : launch_h2r_mode<2>(r, mode, cmax, n_groups, (hipStream_t)stream);
-    if (rc != MPOSE_ENOSYS) return rc;
+    // (MPOSE_CONV_F16X1: the 64-channel tile of the stride-1 form only -- the engine's regular blocks)
+    const int rc = x1 ? (cmax <= 32 ? MPOSE_ENOSYS : launch_h2r_mode<2, true>(r, mode, cmax, n_groups, (hipStream_t)stream))
+                      : (cmax <= 32 ? launch_h2r_mode<1>(r, mode, cmax, n_groups, (hipStream_t)stream)
+                                    : launch_h2r_mode<2>(r, mode, cmax, n_groups, (hipStream_t)stream));
+    if (rc != MPOSE_ENOSYS || x1) return rc;
   }
+  if (x1) return MPOSE_ENOSYS;
   return launch_h2_shape(a, mode, cmax, n_groups, (hipStream_t)stream);
 }

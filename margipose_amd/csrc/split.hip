@@ -1,14 +1,8 @@
-// Producers of PRE-SPLIT activations for conv_p.hip (gfx950): every elementwise pass that feeds a convolution writes
-// its result once as three bf16 planes, x = hi + mid + lo (round-to-nearest at every level, the residual subtractions
-// are exact in fp32, |x - (hi+mid+lo)| <= 2^-27 |x|), in the blocked layout
-//       P8[C/8][plane 3][pixel][8]          16 bytes per (pixel, channel octet, plane)
-// -- the convolution engine then needs no VALU work on its operands and fetches them by DMA in 1 KiB contiguous runs.
-//
-// Thread mapping: a workgroup = 64 consecutive pixels x 4 channel octets (wave w = octet 4*blockIdx.y + w, lane = pixel).
-// A lane reads its 8 channels as two float4 (32 contiguous bytes; the four waves of the workgroup together consume whole
-// 128-byte lines of the NHWC source) and writes one 16-byte word per plane: 64 lanes = 1 KiB contiguous per plane.
-// Optional fp32 NHWC copies of the results are written the same way (they feed the weight-gradient kernel and the
-// BatchNorm backward, which still read fp32).
+// Producers of PRE-SPLIT activations for conv_h.hip / wgrad.hip (gfx950): every elementwise pass that feeds a convolution of an H2
+// block writes its result once as two fp16 planes of x * 2^k (h = rn16(x * 2^k), l = rn16(x * 2^k - h): 22 significant bits), k
+// from a BOUND on the tensor's magnitude that exists before the pass runs, in the blocked layout
+//       H8[C/8][plane 2][pixel][8]          16 bytes per (pixel, channel octet, plane): the bytes of the fp32 tensor
+// -- the convolution and weight-gradient kernels then need no VALU work on their operands and fetch them in 1 KiB contiguous runs.
 //
 // Replaces, fused: the BN+ReLU between the two convolutions of a ResidualBlock (reference
 // models/margipose_model.py:31-35), the block's output sum (:39) and the BatchNorm backward applications (autograd).
@@ -17,30 +11,8 @@
 namespace mpose {
 namespace {
 
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ float bf_lo(unsigned p) { return __uint_as_float(p << 16); }
-__device__ __forceinline__ float bf_hi(unsigned p) { return __uint_as_float(p & 0xFFFF0000u); }
-// two fp32 -> three packed bf16 pairs (v_cvt_pk_bf16_f32 rounds to nearest even)
-__device__ __forceinline__ void split2(const float x0, const float x1, unsigned& h, unsigned& m, unsigned& l) {
-  h = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{x0, x1}, bf16x2));
-  const float r0 = x0 - bf_lo(h), r1 = x1 - bf_hi(h);
-  m = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{r0, r1}, bf16x2));
-  const float q0 = r0 - bf_lo(m), q1 = r1 - bf_hi(m);
-  l = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{q0, q1}, bf16x2));
-}
-
-// 8 channels of one pixel -> the three planes of channel octet c8
-__device__ __forceinline__ void store_planes8(void* planes, long npix, int c8, long p, const float (&v)[8]) {
-  uint4 h, m, l;
-  split2(v[0], v[1], h.x, m.x, l.x);
-  split2(v[2], v[3], h.y, m.y, l.y);
-  split2(v[4], v[5], h.z, m.z, l.z);
-  split2(v[6], v[7], h.w, m.w, l.w);
-  uint4* d = reinterpret_cast<uint4*>(planes) + (long)c8 * 3 * npix + p;
-  d[0] = h; d[npix] = m; d[2 * npix] = l;
-}
 __device__ __forceinline__ void load8(const float* __restrict__ src, long p, int C, int c0, float (&v)[8]) {
   const float4 a = *reinterpret_cast<const float4*>(src + p * C + c0);
   const float4 b = *reinterpret_cast<const float4*>(src + p * C + c0 + 4);
@@ -264,107 +236,6 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_h2_k(BnApplyH2Args a) {
   }
 }
 
-struct SplitArgs {
-  mpose_split_operands op[MPOSE_MAX_GROUP];
-  long npix;
-  int C, relu;
-};
-
-// planes = split([relu](scale*x + shift))   (scale NULL: identity)
-__global__ __launch_bounds__(256) void split_planes_k(SplitArgs a) {
-  const mpose_split_operands& op = a.op[blockIdx.z];
-  const int c8 = blockIdx.y * 4 + (threadIdx.x >> 6);
-  const long p = (long)blockIdx.x * 64 + (threadIdx.x & 63);
-  if (c8 * 8 >= a.C || p >= a.npix) return;
-  float v[8];
-  load8(op.src, p, a.C, c8 * 8, v);
-  if (op.scale != nullptr) {
-    float sc[8], sh[8];
-    load_vec8(op.scale, c8 * 8, sc);
-    load_vec8(op.shift, c8 * 8, sh);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = fmaf(v[e], sc[e], sh[e]);
-  }
-  if (a.relu) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
-  }
-  store_planes8(op.planes, a.npix, c8, p, v);
-}
-
-struct BnAddPArgs {
-  mpose_bn_add_operands op[MPOSE_MAX_GROUP];
-  void* planes[MPOSE_MAX_GROUP];
-  long npix;
-  int C;
-};
-
-// out = relu(a_scale*a + a_shift) + (b_scale*b + b_shift)  ->  fp32 NHWC (optional) + planes
-__global__ __launch_bounds__(256) void bn_add_planes_k(BnAddPArgs a) {
-  const mpose_bn_add_operands& op = a.op[blockIdx.z];
-  const int c8 = blockIdx.y * 4 + (threadIdx.x >> 6);
-  const long p = (long)blockIdx.x * 64 + (threadIdx.x & 63);
-  if (c8 * 8 >= a.C || p >= a.npix) return;
-  const int c0 = c8 * 8;
-  float x[8], y[8], sa[8], ta[8], sb[8], tb[8], o[8];
-  load8(op.a, p, a.C, c0, x);
-  load8(op.b, p, a.C, c0, y);
-  load_vec8(op.a_scale, c0, sa); load_vec8(op.a_shift, c0, ta);
-  load_vec8(op.b_scale, c0, sb); load_vec8(op.b_shift, c0, tb);
-#pragma unroll
-  for (int e = 0; e < 8; ++e) o[e] = fmaxf(fmaf(x[e], sa[e], ta[e]), 0.f) + fmaf(y[e], sb[e], tb[e]);
-  if (op.out != nullptr) store8(op.out, p, a.C, c0, o);
-  store_planes8(a.planes[blockIdx.z], a.npix, c8, p, o);
-}
-
-struct BnApplyPArgs {
-  mpose_bn_bwd_apply_operands op[MPOSE_MAX_GROUP];
-  void* da_planes[MPOSE_MAX_GROUP];
-  void* db_planes[MPOSE_MAX_GROUP];
-  long npix;
-  int C;
-};
-
-// da = k0a*[mask]g + k1a*(a - mean_a) + k2a ; db = k0b*g + k1b*(b - mean_b) + k2b  (bn.hip's algebra)  ->  fp32 (optional) + planes
-__global__ __launch_bounds__(256) void bn_bwd_apply_planes_k(BnApplyPArgs a) {
-  const mpose_bn_bwd_apply_operands& op = a.op[blockIdx.z];
-  const int c8 = blockIdx.y * 4 + (threadIdx.x >> 6);
-  const long p = (long)blockIdx.x * 64 + (threadIdx.x & 63);
-  if (c8 * 8 >= a.C || p >= a.npix) return;
-  const int c0 = c8 * 8;
-  float g[8];
-  load8(op.g, p, a.C, c0, g);
-  {
-    float x[8], ga[8], k0[8], k1[8], k2[8], mu[8], o[8];
-    load8(op.a, p, a.C, c0, x);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) ga[e] = g[e];
-    if (op.a_scale != nullptr) {
-      float ms[8], mt[8];
-      load_vec8(op.a_scale, c0, ms); load_vec8(op.a_shift, c0, mt);
-#pragma unroll
-      for (int e = 0; e < 8; ++e)
-        if (!(fmaf(x[e], ms[e], mt[e]) > 0.f)) ga[e] = 0.f;
-    }
-    load_vec8(op.coef_a, c0, k0); load_vec8(op.coef_a + a.C, c0, k1); load_vec8(op.coef_a + 2 * a.C, c0, k2);
-    load_vec8(op.coef_a + 3 * a.C, c0, mu);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = fmaf(k1[e], x[e] - mu[e], fmaf(k0[e], ga[e], k2[e]));
-    if (op.da != nullptr) store8(op.da, p, a.C, c0, o);
-    if (a.da_planes[blockIdx.z] != nullptr) store_planes8(a.da_planes[blockIdx.z], a.npix, c8, p, o);
-  }
-  if (op.b != nullptr) {
-    float x[8], k0[8], k1[8], k2[8], mu[8], o[8];
-    load8(op.b, p, a.C, c0, x);
-    load_vec8(op.coef_b, c0, k0); load_vec8(op.coef_b + a.C, c0, k1); load_vec8(op.coef_b + 2 * a.C, c0, k2);
-    load_vec8(op.coef_b + 3 * a.C, c0, mu);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = fmaf(k1[e], x[e] - mu[e], fmaf(k0[e], g[e], k2[e]));
-    if (op.db != nullptr) store8(op.db, p, a.C, c0, o);
-    if (a.db_planes[blockIdx.z] != nullptr) store_planes8(a.db_planes[blockIdx.z], a.npix, c8, p, o);
-  }
-}
-
 inline dim3 plane_grid(long npix, int C, int n_groups) { return dim3((unsigned)((npix + 63) / 64), (unsigned)((C + 31) / 32), (unsigned)n_groups); }
 
 }  // namespace
@@ -372,20 +243,7 @@ inline dim3 plane_grid(long npix, int C, int n_groups) { return dim3((unsigned)(
 
 using namespace mpose;
 
-extern "C" int64_t mpose_planes_bytes(int64_t npix, int C) { return npix * (int64_t)((C + 7) / 8) * 3 * 16; }
 
-extern "C" int mpose_split_planes(const mpose_split_operands* ops, int n_groups, int64_t npix, int C, int relu, void* stream) {
-  if (n_groups < 1 || n_groups > MPOSE_MAX_GROUP || (C & 7) || npix < 0 || npix >= (1l << 31)) return MPOSE_EINVAL;
-  if (npix == 0) return 0;
-  SplitArgs a{};
-  for (int i = 0; i < n_groups; ++i) {
-    a.op[i] = ops[i];
-    if (!ops[i].src || !ops[i].planes || (ops[i].scale && !ops[i].shift)) return MPOSE_EINVAL;
-  }
-  a.npix = npix; a.C = C; a.relu = relu;
-  launch(split_planes_k, dim3(plane_grid(npix, C, n_groups)), dim3(256), 0, (hipStream_t)stream, a);
-  return launch_status();
-}
 
 extern "C" int64_t mpose_h2_bytes(int64_t npix, int C) { return npix * (int64_t)((C + 7) / 8) * 2 * 16; }
 
@@ -403,20 +261,6 @@ extern "C" int mpose_split_h2(const mpose_split_h2_operands* ops, int n_groups, 
   return launch_status();
 }
 
-extern "C" int mpose_bn_add_planes(const mpose_bn_add_operands* ops, void* const* planes, int n_groups, int64_t npix, int C,
-                                   void* stream) {
-  if (n_groups < 1 || n_groups > MPOSE_MAX_GROUP || (C & 7) || npix < 0 || npix >= (1l << 31)) return MPOSE_EINVAL;
-  if (npix == 0) return 0;
-  BnAddPArgs a{};
-  for (int i = 0; i < n_groups; ++i) {
-    a.op[i] = ops[i];
-    a.planes[i] = planes[i];
-    if (!planes[i] || !ops[i].a || !ops[i].b) return MPOSE_EINVAL;
-  }
-  a.npix = npix; a.C = C;
-  launch(bn_add_planes_k, dim3(plane_grid(npix, C, n_groups)), dim3(256), 0, (hipStream_t)stream, a);
-  return launch_status();
-}
 
 extern "C" int mpose_bn_add_h2(const mpose_bn_add_operands* ops, void* const* h2, int n_groups, int64_t npix, int C, void* stream) {
   if (n_groups < 1 || n_groups > MPOSE_MAX_GROUP || (C & 31) || npix < 0 || npix >= (1l << 31)) return MPOSE_EINVAL;
@@ -453,19 +297,3 @@ extern "C" int mpose_bn_bwd_apply_h2(const mpose_bn_bwd_apply_operands* ops, voi
   return launch_status();
 }
 
-extern "C" int mpose_bn_bwd_apply_planes(const mpose_bn_bwd_apply_operands* ops, void* const* da_planes, void* const* db_planes,
-                                         int n_groups, int64_t npix, int C, void* stream) {
-  if (n_groups < 1 || n_groups > MPOSE_MAX_GROUP || (C & 7) || npix < 0 || npix >= (1l << 31)) return MPOSE_EINVAL;
-  if (npix == 0) return 0;
-  BnApplyPArgs a{};
-  for (int i = 0; i < n_groups; ++i) {
-    a.op[i] = ops[i];
-    a.da_planes[i] = da_planes ? da_planes[i] : nullptr;
-    a.db_planes[i] = db_planes ? db_planes[i] : nullptr;
-    if (!ops[i].g || !ops[i].a || !ops[i].coef_a) return MPOSE_EINVAL;
-    if (ops[i].b && !ops[i].coef_b) return MPOSE_EINVAL;
-  }
-  a.npix = npix; a.C = C;
-  launch(bn_bwd_apply_planes_k, dim3(plane_grid(npix, C, n_groups)), dim3(256), 0, (hipStream_t)stream, a);
-  return launch_status();
-}

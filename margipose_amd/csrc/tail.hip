@@ -779,10 +779,10 @@ extern "C" int mpose_softmax_dsnt_fwd(const void* const* logits, void* const* he
   for (int p = 0; p < n_planes; ++p) { a.logits[p] = logits[p]; a.heatmaps[p] = heatmaps ? heatmaps[p] : nullptr; }
   a.plane_coords = plane_coords; a.xyz = xyz; a.n_planes = n_planes; a.rows = rows; a.H = H; a.W = W;
   hipStream_t s = (hipStream_t)stream;
-  // MPOSE_TAIL_VARIANT = rows per workgroup (1, 2) + 16 * NT bits (timing runs: tools/bench_tail.py; every variant is bit-identical).
-  // Default: sizes whose logits + heatmaps exceed the 256 MB Infinity Cache stream (non-temporal both ways, two rows per workgroup);
+  // variant = rows per workgroup (1, 2) + 16 * NT bits (every variant is bit-identical; profiles/r5_tail_variants.txt).
+  // Sizes whose logits + heatmaps exceed the 256 MB Infinity Cache stream (non-temporal both ways, two rows per workgroup);
   // smaller ones keep plain accesses -- their heatmaps are re-read from the cache by the next stage's combiner and the loss kernels.
-  static const int forced = [] { const char* e = getenv("MPOSE_TAIL_VARIANT"); return e ? atoi(e) : -1; }();
+  constexpr int forced = -1;
   const size_t bytes = (size_t)rows * n_planes * H * W * (io_dtype == 0 ? 8 : (io_dtype == 1 ? 4 : 6));
   const int variant = forced >= 0 ? forced : (bytes > (size_t)256 << 20 ? 2 + 16 * 3 : 1);
   const int rpw = (variant & 15) == 2 && nv <= 9 ? 2 : 1, nt = (variant >> 4) & 3;
@@ -833,8 +833,8 @@ extern "C" int mpose_bn_add_softmax_fwd(const mpose_bn_add_operands* ops, void* 
   a.plane_coords = plane_coords; a.B = B; a.P = P; a.C = C; a.J = J; a.H = H; a.W = W;
   const int nv = pick_nv(P);
   // the all-joints form (every channel line read once, coalesced) when the two inputs of the launch's columns are large enough to
-  // keep its B * n_groups workgroups busy and all J rows fit in LDS; MPOSE_TAIL_ALLJ=0 / 1 forces the choice (A/B runs)
-  static const int allj_env = [] { const char* e = getenv("MPOSE_TAIL_ALLJ"); return e ? atoi(e) : -1; }();
+  // keep its B * n_groups workgroups busy and all J rows fit in LDS
+  constexpr int allj_env = -1;
   const bool fits = (long)J * (P + kBasPad) * 4 <= kBasAllJLds && C == 32;
   // (measured crossover at 32 x 32, three columns: B = 64 -- 50 MB of inputs -- 16.6 us four-joint / 21.9 us all-joints,
   //  B = 128 -- 100 MB -- 55.7 / 28.3 us; B = 2048: 1659 / 423 us, the two launches it replaces: 1317 us)

@@ -595,11 +595,7 @@ int launch_rows(WgRowsArgs& a, hipStream_t s) {
 // one / two of its four waves working -- a step of the kernel is latency-bound at that width (two octets staged per barrier), so
 // the launch's duration follows its number of workgroups, not their size: a quarter / half of the footprint per workgroup lets the
 // caller split the pixels 4x / 2x further on the same CUs (mpose_conv_wgrad_waves).
-inline bool narrow_env() {
-  static int v = -2;
-  if (v == -2) { const char* e = getenv("MPOSE_WGRAD_NARROW"); v = e ? atoi(e) : 1; }
-  return v != 0;
-}
+constexpr bool narrow_env() { return true; }
 inline int rows_shape(int cin, int cout) {
   if (cin % 192 == 0 && cout % 64 == 0) return 1;
   if (narrow_env() && cin <= 32 && cout <= 32) return 4;
@@ -608,11 +604,7 @@ inline int rows_shape(int cin, int cout) {
   if (cin <= 64 && cout <= 64) return 3;
   return 0;
 }
-inline bool wide192() {
-  static int v = -2;
-  if (v == -2) { const char* e = getenv("MPOSE_WGRAD_192"); v = e ? atoi(e) : 0; }
-  return v != 0;
-}
+constexpr bool wide192() { return false; }      // (round 3's eight-wave tiles: measured slower, not instantiated any more)
 inline void shape_tiles(int shape, int& kt, int& nt) {
   switch (shape) {
     case 1: kt = 192; nt = wide192() ? 128 : 64; break;
@@ -624,16 +616,8 @@ inline void shape_tiles(int shape, int& kt, int& nt) {
   }
 }
 
-inline bool strided_env() {      // MPOSE_WGRAD_STRIDED=0: the stride-2 geometries stay on conv_wgrad_k (A/B runs)
-  static int v = -2;
-  if (v == -2) { const char* e = getenv("MPOSE_WGRAD_STRIDED"); v = e ? atoi(e) : 1; }
-  return v != 0;
-}
-int rows_env() {               // MPOSE_WGRAD_ROWS=0: conv_wgrad_k everywhere (A/B runs); 2: the row form also for launches of single taps
-  static int v = -2;
-  if (v == -2) { const char* e = getenv("MPOSE_WGRAD_ROWS"); v = e ? atoi(e) : 1; }
-  return v;
-}
+constexpr bool strided_env() { return true; }      // (the stride-2 geometries as strided views: round 5)
+constexpr int rows_env() { return 1; }      // (2: the row form also for launches of single taps -- measured slower)
 
 // Kernel rows / single taps of a geometry, or -1 when the row form does not apply (then conv.hip's conv_wgrad_k runs).
 //
@@ -781,11 +765,11 @@ int mpose_wgrad_rows_launch(const mpose_conv_geom* geom, const mpose_wgrad_opera
                                  : launch_rows_ppx<2, 2, 2, 2, false, true, false, true>(a, s);
   }
   switch (rows_shape(geom->Cin, geom->Cout0)) {
-    case 1: return wide192() ? launch_rows<2, 4, 3, 1>(a, s) : launch_rows<2, 2, 3, 1>(a, s);
+    case 1: return launch_rows<2, 2, 3, 1>(a, s);
     case 2: return launch_rows<4, 1, 1, 1>(a, s);
     case 3: return launch_rows<2, 2, 1, 1>(a, s);
     case 4: return launch_rows<1, 1, 1, 1>(a, s);
     case 5: return launch_rows<1, 2, 1, 1>(a, s);
-    default: return wide192() ? launch_rows<2, 4, 2, 1>(a, s) : launch_rows<2, 2, 2, 2>(a, s);
+    default: return launch_rows<2, 2, 2, 2>(a, s);
   }
 }

@@ -24,7 +24,7 @@ import torch
 import torch.distributed
 
 from . import _lib
-from ._lib import (BnAddOperands, BnBwdApplyOperands, BnBwdReduceOperands, AbsmaxOperands, ConvGeom, ConvOperands, SplitH2Operands, SplitOperands, WgradOperands, c_int,
+from ._lib import (BnAddOperands, BnBwdApplyOperands, BnBwdReduceOperands, AbsmaxOperands, ConvGeom, ConvOperands, SplitH2Operands, WgradOperands, c_int,
                    c_int64, c_void_p, check, lib, ptr, ptr_array, stream_ptr)
 
 BN_EPS = 1e-5
@@ -51,17 +51,10 @@ COEF_DT = np.dtype([('sums', 'u8'), ('gamma', 'u8'), ('mean', 'u8'), ('invstd', 
                     ('sg_col', 'i4'), ('dconv_bias', 'u8'), ('part', 'u8'), ('n_part', 'i4'), ('part_ld', 'i4'),
                     ('g_amax', 'u8'), ('bound_out', 'u8')], align=True)
 
-# Weight-gradient pixel splits sized for the workgroups that share a CU (the narrow row-of-taps tiles run three per CU): alone, the
-# feature extractor's 32-channel layers go 245 -> 148 us and the columns' 17-joint block 57 -> 41 us, but in the step the wider launches
-# crowd the main stream's convolutions out of the CUs they share (23.51 -> 23.85 ms, tools/ab_sweep.sh): off by default ('1' = all).
-# '2': only the feature extractor's full-resolution layers (>= 128 x 128 slots, one column), whose weight gradients END the side
-# stream's chain while the main stream waits (profiles/r5_step_listing.txt): also slower, 23.10 against 23.02 ms (r5_ab_sweeps.txt).
-_WG_OCC = int(os.environ.get('MPOSE_WG_OCC', '0'))
-# The columns' weight pack on the side stream during the feature extractor's forward (Engine.pack_weights): bit-identical, and no
-# gain -- 23.10 against 23.11 ms: the pack and the extractor's 128 x 128 layers are both HBM-bound (r5_ab_sweeps.txt).  Off.
-_PACK_SIDE = os.environ.get('MPOSE_PACK_SIDE', '0') != '0'
+# MPOSE_GFLAT_FILL=2: the backward pass poisons the flat gradient buffer with NaNs instead of skipping its zero fill
+# (tests/test_model_gpu.py::test_every_gradient_element_is_written); 1: always zero it.
 _GFLAT_FILL = int(os.environ.get('MPOSE_GFLAT_FILL', '0'))
-_WG_FIXED = float(os.environ.get('MPOSE_WG_FIXED', '3.0'))     # fixed per-workgroup cost of a weight-gradient launch, in 128-pixel row units (Engine._n_split)
+_WG_FIXED = 3.0              # fixed per-workgroup cost of a weight-gradient launch, in 128-pixel row units (Engine._n_split)
 AMAX_SLOT = 16 * 64          # floats per activation amax slot (MPOSE_AMAX_SUBSLOTS * MPOSE_AMAX_STRIDE)
 _SIZES_CHECKED = False
 
@@ -74,7 +67,7 @@ def _check_struct_sizes():
     expect = {0: ctypes.sizeof(ConvGeom), 1: ctypes.sizeof(ConvOperands), 2: ctypes.sizeof(WgradOperands),
               3: PACK_DT.itemsize, 4: UNPACK_DT.itemsize, 5: BN_DT.itemsize, 6: COEF_DT.itemsize,
               7: ctypes.sizeof(BnAddOperands), 8: ctypes.sizeof(BnBwdReduceOperands), 9: ctypes.sizeof(BnBwdApplyOperands),
-              10: ctypes.sizeof(SplitOperands), 12: ctypes.sizeof(AbsmaxOperands)}
+              10: ctypes.sizeof(SplitH2Operands), 12: ctypes.sizeof(AbsmaxOperands)}
     for which, size in expect.items():
         got = L.mpose_sizeof(which)
         if got != size:
@@ -174,13 +167,13 @@ class _Conv:
         self.stem = stem
         self.npad_f = _rup(cout, 64)             # forward pack: N = cout, K = cin_s
         self.npad_d = _rup(cin, 64)              # dgrad pack:   N = cin,  K = cout_s
-        # arena sized for the largest packing: three bf16 planes (hi, mid, lo; the six-product form) = 6 bytes per element = 1.5
-        # floats; the default three-product form packs two fp16 planes (4 bytes per element) into the same slot
+        # arena sized for the largest packing: three bf16 planes (hi, mid, lo: the patch8 stem's six-product form) = 6 bytes per
+        # element = 1.5 floats; the three-product form packs two fp16 planes (4 bytes per element) into the same slot
         self.size_f = self.T * cin_s * self.npad_f * 3 // 2
         self.size_d = self.T * cout_s * self.npad_d * 3 // 2
         self.size_g = self.T * cin_s * self.npad_f          # one split-K partial of the weight gradient (fp32)
         self.off_f = self.off_d = self.off_g = -1
-        self.layout = 0                          # packed-weight layout (include/margipose_hip.h): 1 = conv_p.hip's (column convs)
+        self.column = False                      # a convolution of the stages' columns (not the feature extractor's)
 
     def strides(self, dgrad):
         """(sn, sk, st): element strides of (n, k, tap) in the torch-layout weight."""
@@ -198,7 +191,7 @@ class _BN:
         self.f_off = self.s_off = -1             # offsets into the float / double arenas
 
 
-_H2_CHANNELS = tuple(int(v) for v in os.environ.get('MPOSE_H2_CHANNELS', '128').split(',') if v)
+_H2_CHANNELS = (128,)        # regular blocks of these widths run on the H2 engine (192 -> 192 at 16 x 16: 288 tiles on 512 slots, slower: DESIGN 4.5)
 
 
 class _Block:
@@ -327,23 +320,14 @@ class Engine:
         self.combiners = [m.conv.weight for m in inner.hm_combiners]
         self._all_blocks = [b for st in self.stage_blocks for grp in st for b in grp]
         block_convs = [c for b in self._all_blocks for c in (b.conv_in, b.conv2, b.conv_sc)]
-        # Two convolution engines serve the columns.  conv_igemm_k (csrc/conv.hip) reads fp32 activations and splits them in its
-        # K loop; conv_planes_k (csrc/conv_p.hip) reads activations PRE-split into bf16 planes by their producers, both operands
-        # by DMA, two workgroups per CU.  On one box the convolutions themselves take the same time (19.1 vs 19.0 ms per training
-        # step), but in training the weight-gradient kernel still wants fp32 operands, so every producer writes 18 instead of
-        # 12 bytes per element (+2.2 ms per step): fp32 TRAINING stays on conv_igemm_k.  Inference (BatchNorm + ReLU + residual
-        # fused into the plane engine's epilogue, no fp32 round trip) and the single-pass bf16 mode run on the plane engine.
-        # MPOSE_PLANES=1 / 0 forces one engine everywhere (A/B runs).
-        self.planes_mode = os.environ.get('MPOSE_PLANES', 'auto')
-        # conv_igemm_k / conv_wgrad_k multiply as THREE fp16 products of two-way split, per-tensor-scaled operands instead of six
-        # bf16 products of three-way split ones (MPOSE_CONV_F16X3 in include/margipose_hip.h): the same fp32-equivalent accuracy
-        # (tests/test_conv_f16x3_gpu.py) at half the matrix work.  Each operand tensor's largest magnitude is measured by a small
-        # pass (mpose_absmax) before the convolution that reads it.  MPOSE_F16X3=0 keeps the six-product form (A/B runs).
-        self.f16x3 = os.environ.get('MPOSE_F16X3', '1') != '0'
-        self.conv_bf16 = False       # single-pass bf16 convolutions in the columns (MargiPoseModel.conv_dtype, configs[4])
+        # One arithmetic everywhere: an fp32 multiply-add as THREE fp16 products of two-way split, per-tensor-scaled operands
+        # (MPOSE_CONV_F16X3 in include/margipose_hip.h), fp32 accumulation.  Two kernels serve it: conv_igemm_k (csrc/conv.hip)
+        # reads fp32 activations and splits them in its K loop -- the feature extractor, the stride-2 / 192-channel / joint blocks,
+        # inference with its fused epilogues -- and conv_h2r_k (csrc/conv_h.hip) reads operands PRE-split into fp16 planes by their
+        # producers: the regular 128-channel blocks in training (see conv_mode_for).
         self.conv_f16x1 = False      # every convolution on fp16-ROUNDED operands, one product (MPOSE_CONV_F16X1; conv_dtype = float16)
         for c in block_convs:
-            c.layout = 1             # packed-weight layout when the plane engine runs (layout 0 otherwise; see pack_weights)
+            c.column = True
         block_bns = [n for b in self._all_blocks for n in (b.bn1, b.bn2, b.bns)]
         self.stem = None
         fe_name = getattr(inner, 'feature_extractor_name', 'patch8')
@@ -361,8 +345,6 @@ class Engine:
             self.stem_bn = _BN(inner.in_cnn[1], 128, 128)
             self._convs = [self.stem_conv] + block_convs
             self._bns = [self.stem_bn] + block_bns
-        self._n_stem_convs = len(self.stem.convs) if self.stem is not None else 1      # (first in self._convs: pack_weights' split)
-        self._pack_join = False
         self._pack_epoch = 0         # counts pack_weights() calls (PlannedInference(frozen_weights=True) notices a repack by someone else)
         self.pack_frozen = False     # True: a forward whose engine mode the packed arena already holds does not repack (PlannedInference)
         self._geoms = {}
@@ -379,55 +361,36 @@ class Engine:
         # while it records: its iteration reads the gradients (the optimiser) before it runs the next backward.
         self.grad_views = False
         self._side_keep = []         # tensors the side stream still reads (released at the next bucket boundary)
-        # (measured: no faster -- the step is bound by the sum of the heavy kernels' work, not by the main stream's chain of launches -- off)
-        self.fuse_finalize = os.environ.get('MPOSE_FUSE_FINALIZE', '0') != '0'
         # BatchNorm statistics (forward sums, channel extremes, backward sums) leave the convolution launches as per-workgroup
-        # partial rows written with plain stores (MPOSE_CONV_STATS_PART) and are added up by the finalize / coefficient kernels:
-        # the fp64 device-scope atomics they replace cost a 128-channel launch 20 us of ~110 -- 2.8 ms of a 24.6 ms training step
-        # (round 4, same box: 24.6 -> 21.8 ms).  MPOSE_STATS_PART=0 keeps the atomics (A/B runs); the fused finalize needs them.
-        self.stats_part = os.environ.get('MPOSE_STATS_PART', '1') != '0'
-        # Training / differentiable forwards run the forward and the second 3x3's data-gradient of the regular 128-channel blocks
-        # on conv_h2r_k (csrc/conv_h.hip): operands split ONCE into two fp16 planes by an elementwise pass (mpose_split_h2), both
-        # DMA'd into workgroup-shared LDS tiles, two workgroups per CU, no operand arithmetic in the K loop -- 85 instead of
-        # 117 us per 128 -> 128 launch (round 4).  MPOSE_H2=0: conv_igemm_k everywhere (A/B runs).
-        self.h2 = os.environ.get('MPOSE_H2', '1') != '0'
-        # ... and in TRAINING the elementwise passes that produce an H2 block's operands write the fp16 planes themselves (the
-        # residual sum of the block before: mpose_bn_add_h2; the BatchNorm-backward application: mpose_bn_bwd_apply_h2), scaled by a
-        # BOUND on the tensor's magnitude that the finalize / coefficient kernels derive before the pass runs (mpose_bn_job.bound_out,
-        # mpose_bn_bwd_coef_job.bound_out) -- no measuring, no separate split pass.  (Batch statistics bound a normalised value;
-        # running statistics do not: eval-mode forwards measure and split.)  MPOSE_H2_FUSE=0: measure + mpose_split_h2 everywhere;
-        # 1 (round 4's default): the residual sum only -- the fused BatchNorm-backward application moves 300 MB (three inputs, two fp32 outputs
-        # that the weight gradients still read, the planes), past the Infinity Cache, and measured 55 us against 27 + 16 us for
-        # mpose_bn_bwd_apply + mpose_split_h2; 2: both.  Round 5: 2 is the default -- kernel for kernel it is slower, in the step
-        # (launch-plan dispatch, one launch and one read pass fewer per H2 block) it measured 23.39 -> 23.25 ms (tools/ab_sweep.sh).
-        self.h2_fuse = int(os.environ.get('MPOSE_H2_FUSE', '2'))
-        # Round 6, planes end to end in the backward pass of the H2 blocks: both BatchNorm-backward applications write fp16 planes
-        # ONLY (d_c2, d_sc, d_c1: no fp32 copies), the two-input data gradient runs on conv_h2r_k (its second input as a second K
-        # loop) and both weight gradients DMA-free-stage the planes (mpose_wgrad_operands.planes_in: no split VALU in their loop);
-        # the forward keeps the planes of x and relu(bn1(c1)) for them.  MPOSE_H2_PLANES=0: round 5's backward (A/B runs).
+        # partial rows written with plain stores (MPOSE_CONV_STATS_PART) and are added up in a fixed order by the finalize /
+        # coefficient kernels (round 4: the fp64 device-scope atomics they replace cost a 128-channel launch 20 us of ~110).
+        #
+        # Training / differentiable forwards run the regular 128-channel blocks on conv_h2r_k: forward, BOTH data gradients and
+        # (round 6) both weight gradients read fp16 planes that the elementwise pass producing the tensor wrote ONCE -- the residual
+        # sum of the block before (mpose_bn_add_h2), BatchNorm + ReLU (mpose_split_h2), the BatchNorm-backward applications
+        # (mpose_bn_bwd_apply_h2: planes only, no fp32 copy) -- scaled by a BOUND on the tensor's magnitude that the finalize /
+        # coefficient kernels derive before the pass runs (mpose_bn_job.bound_out, mpose_bn_bwd_coef_job.bound_out): no measuring,
+        # no split pass, no operand arithmetic in any K loop.  (Batch statistics bound a normalised value; running statistics do
+        # not: eval-mode forwards that will be differentiated measure and split.)
+        # MPOSE_H2_PLANES=0: round 5's backward for those blocks (fp32 gradients beside the planes, the two-input data gradient and
+        # the weight gradients on the fp32 kernels) -- same-box A/B runs only.
         self.h2_planes = os.environ.get('MPOSE_H2_PLANES', '1') != '0'
         # the last ResidualBlock's residual sum, flat_softmax and dsnt as ONE launch per stage (mpose_bn_add_softmax_fwd: an image's
-        # logits stay in LDS); heatmaps and coordinates are bit-identical to the two-launch path (MPOSE_TAIL_FUSE=0)
-        self.tail_fuse = os.environ.get('MPOSE_TAIL_FUSE', '1') != '0'
-        # Training forward of the H2 blocks: the 1x1 shortcut convolution as its OWN launch on a second stream instead of a second
-        # pass of the 3x3's launch (114 us for the pair against 85-91 for the 3x3 alone: the pass restages every chunk's tile for
-        # one tap and runs a second epilogue).  Nothing needs the shortcut before the block's residual sum, the forward pass has
-        # no other side work, and the 3x3's 768 tiles leave half of the second round's slots idle.
-        self.sc_side = os.environ.get('MPOSE_SC_SIDE', '0') != '0'
-        self.fwd_side_stream = None
+        # logits stay in LDS); heatmaps and coordinates are bit-identical to the two-launch path (tail_fuse = False)
+        self.tail_fuse = True
         # Training forward of the feature extractor: a node whose channels all come out of a BatchNorm takes its amax slot from
         # the finalize kernel's a-priori bound max_c(|gamma_c| sqrt(N) + |beta_c|) instead of a measuring pass (mpose_absmax): 12 of
         # the 16 passes per step.  The bound is 2^5-2^7 above the true maximum at these sizes; a two-piece fp16 operand keeps its 22
         # bits down to 2^-18 of the bound, and below that its ABSOLUTE error (bound * 2^-39) is far under fp32's at the tensor's
-        # typical magnitude.  MPOSE_STEM_BOUNDS=0: measure every node.
-        self.stem_bounds = os.environ.get('MPOSE_STEM_BOUNDS', '1') != '0'
-        # split-K partials summed right behind each weight-gradient launch, on its stream (unpack_after): with round 3's unpack kernel
-        # no faster (24.77 against 24.71 ms); with round 5's (16-byte loads, eight splits in flight) the launch's 50 MB of partials are
-        # read back out of the Infinity Cache instead of 0.65 GB per stage out of HBM on the main stream: 21.96 -> 21.67 ms.  Default.
-        self.inline_unpack = os.environ.get('MPOSE_INLINE_UNPACK', '1') != '0'
+        # typical magnitude.  False: measure every node.
+        self.stem_bounds = True
+        # split-K partials summed right behind each weight-gradient launch, on its stream (unpack_after): the launch's 50 MB of
+        # partials are read back out of the Infinity Cache instead of 0.65 GB per stage out of HBM on the main stream (round 5:
+        # 21.96 -> 21.67 ms).  False: one unpack launch per stage bucket (bit-identical).
+        self.inline_unpack = True
         # the coefficient jobs that read a BatchNorm-backward reduction's sums run in its finishing pass (bn_bwd_reduce): 22 launches
         # of pure latency per step fewer, bit-identical results
-        self.fuse_coef = os.environ.get('MPOSE_FUSE_COEF', '1') != '0'
+        self.fuse_coef = True
         self.overlap_wgrad = True    # +2.3 % step rate, bit-identical results; launches bracketed by a KernelTimer stay serial
         self.dp = None               # optional (process_group, world_size): gradient all-reduce after backward
         self.input_norm = ([0.485, 0.456, 0.406], [0.229, 0.224, 0.225])    # uint8 frames: ImageSpecs mean / stddev
@@ -565,7 +528,6 @@ class Engine:
                 j['sn'], j['sk'], j['st'] = sn, sk, st
                 j['layout'] = 0
                 mx = max(mx, int(j['T']) * int(j['Kpad']) * int(j['Npad']))
-        jobs_p, jobs_h = jobs.copy(), jobs.copy()
         # largest magnitudes (MPOSE_CONV_F16X3): one float per convolution weight, per block (cur[3], a1[3]) for the forward
         # operands -- kept until the backward pass, the weight gradients read the same tensors -- and (d_c2[3], d_c1[3], d_sc[3])
         # for the gradients
@@ -575,14 +537,12 @@ class Engine:
         self.amax_b = torch.zeros(self.T * 10 * 15 * AMAX_SLOT, dtype=torch.float32, device=device)      # (+ 3 per block: the gradient w.r.t. its output; + 3: d_a1)
         for i, c in enumerate(self._convs):
             c.amax_ptr = self.wamax.data_ptr() + 4 * i
-            if c.layout == 1:                      # a column convolution
-                jobs_p[2 * i]['layout'] = jobs_p[2 * i + 1]['layout'] = 1
-            if c.layout == 1 or getattr(c, 'generic', False):      # columns and the feature extractor's graph (not the patch8 stem)
-                jobs_h[2 * i]['layout'] = jobs_h[2 * i + 1]['layout'] = 2
-                jobs_h[2 * i]['amax'] = jobs_h[2 * i + 1]['amax'] = c.amax_ptr
+            if c.column or getattr(c, 'generic', False):      # columns and the feature extractor's graph (not the patch8 stem)
+                jobs[2 * i]['layout'] = jobs[2 * i + 1]['layout'] = 2
+                jobs[2 * i]['amax'] = jobs[2 * i + 1]['amax'] = c.amax_ptr
         # [3]: [2] with layout 3 (conv_h.hip's B tiles) for what the H2 engine runs: forward of conv_in / shortcut / conv2 and the
-        # data-gradient of conv2 of the H2 blocks
-        jobs_h2 = jobs_h.copy()
+        # data-gradients of the H2 blocks
+        jobs_h2 = jobs.copy()
         h2_convs = {}
         for b in self._all_blocks:
             if b.h2:                 # (h2_planes: the two-input data gradient runs on the H2 engine too)
@@ -591,10 +551,10 @@ class Engine:
         for i, c in enumerate(self._convs):
             for d in h2_convs.get(id(c), ()):
                 jobs_h2[2 * i + d]['layout'] = 3
-        # [0] conv_igemm_k, six bf16 products; [1] plane engine; [2] conv_igemm_k, three fp16 products; [3] the same + the H2 engine
-        self._pack_jobs = tuple(_jobs_to_device(j, device) for j in (jobs, jobs_p, jobs_h, jobs_h2))
+        # pack jobs by engine mode (conv_mode_for): 2 = conv_igemm_k everywhere, 3 = the same + the H2 engine's blocks in layout 3
+        self._pack_jobs = {2: _jobs_to_device(jobs, device), 3: _jobs_to_device(jobs_h2, device)}
         # (the forward and the data-gradient job of a convolution read the same weight and share its amax slot: measured once)
-        self._amax_jobs = tuple(_jobs_to_device(np.ascontiguousarray(j[0::2]), device) for j in (jobs, jobs_p, jobs_h, jobs_h2))
+        self._amax_jobs = {2: _jobs_to_device(np.ascontiguousarray(jobs[0::2]), device), 3: _jobs_to_device(np.ascontiguousarray(jobs_h2[0::2]), device)}
         self._packed_for = None      # which of the three the packed arena currently holds
         self._pack_max = mx
         self._tables = {}
@@ -789,7 +749,7 @@ class Engine:
             g = _geom(B, H, ci, H, co, co, H, 1, 1, [(0, 0, t9 + [(0, 0, 0, 1)])], np_f, np_f)
         elif name == 'f_conv2':
             g = _geom(B, H, co, H, co, 0, H, 1, 1, [(0, 0, t9)], np_f)
-        elif name == 'f_in3_regular':    # the 3x3 of f_in_regular alone / its 1x1 shortcut alone (Engine.sc_side)
+        elif name == 'f_in3_regular':    # the 3x3 of f_in_regular alone / its 1x1 shortcut alone (kernel benchmarks)
             g = _geom(B, H, ci, H, co, 0, H, 1, 1, [(0, 0, t9)], np_f)
         elif name == 'f_in1_regular':
             g = _geom(B, H, ci, H, co, 0, H, 1, 1, [(0, 0, [(0, 0, 0, 0)])], np_f)
@@ -840,22 +800,6 @@ class Engine:
             self.timer.stop('conv:' + g._name, t0, g._flops * len(ops))
 
     # ---- pre-split activations (csrc/split.hip) ----
-    def planes_empty(self, npix, C):
-        return torch.empty(npix * (C // 8) * 48, dtype=torch.uint8, device=self.device)
-
-    def split_planes(self, srcs, npix, C, scales=None, shifts=None, relu=False):
-        """fp32 NHWC tensors -> bf16 hi/mid/lo planes of [relu](scale*x + shift); one grouped launch."""
-        outs = [self.planes_empty(npix, C) for _ in srcs]
-        ops = []
-        for i, src in enumerate(srcs):
-            so = SplitOperands()
-            so.src, so.planes = src.data_ptr(), outs[i].data_ptr()
-            if scales is not None:
-                so.scale, so.shift = scales[i], shifts[i]
-            ops.append(so)
-        check(lib().mpose_split_planes((SplitOperands * 3)(*ops), len(ops), c_int64(npix), C, int(relu), stream_ptr()), 'mpose_split_planes')
-        return outs
-
     def split_h2(self, srcs, slots, npix, C, scales=None, shifts=None, relu=False):
         """fp32 NHWC tensors -> two fp16 planes of [relu](scale*x + shift) * 2^k (mpose_split_h2; k from each tensor's amax slot);
         tensors that share storage are split once."""
@@ -880,7 +824,7 @@ class Engine:
         """BatchNorm-backward sums of one grouped launch (mpose_bn_bwd_reduce_ws: per-workgroup partials, no atomics).
         coef = (device address of the first mpose_bn_bwd_coef_job, jobs, eval_mode): the coefficient jobs that read these sums
         run in the reduction's finishing pass (mpose_bn_bwd_reduce_coef_ws: one launch fewer, same results); returns True when
-        they did (MPOSE_FUSE_COEF=0, or an empty batch: the caller launches mpose_bn_bwd_coef itself)."""
+        they did (fuse_coef = False, or an empty batch: the caller launches mpose_bn_bwd_coef itself)."""
         L = lib()
         n = len(rops)
         need = int(L.mpose_bn_bwd_reduce_ws_bytes(n, pixels_per_image, B, C))
@@ -895,28 +839,20 @@ class Engine:
               'mpose_bn_bwd_reduce_ws')
         return False
 
-    def planes_for(self, train, save):
-        """Which engine a forward (and its backward) runs the columns on: see __init__."""
-        if self.planes_mode in ('0', '1'):
-            return self.planes_mode == '1'
-        # (with the three-product fp16 form conv_igemm_k also wins at inference: 4280 vs 3640 images/s at B=64, one box, against
-        #  the plane engine's six-product bf16 form even with its fused BatchNorm / ReLU / residual epilogue)
-        return self.conv_bf16 or (not self.f16x3 and not (train or save))
-
     def conv_mode_for(self, train, save):
-        """0: conv_igemm_k with six bf16 products, 1: plane engine, 2: conv_igemm_k with three fp16 products, 3: 2 with the H2
-        engine on the regular 128-channel blocks (training and differentiable forwards: the unfused block schedule)."""
-        if self.planes_for(train, save):
-            return 1
-        if self.f16x3 and self.h2 and (train or save) and not self.conv_f16x1 and not self.fuse_finalize and self.stages_have_h2():
+        """2: conv_igemm_k everywhere (inference with its fused epilogues); 3: the same with the H2 engine (conv_h2r_k on
+        producer-split fp16 planes) on the regular 128-channel blocks -- training and differentiable forwards, in the fp32-equivalent
+        arithmetic and (round 6) in the fp16-rounded mode, where the kernels read the h planes alone."""
+        if (train or save) and self.stages_have_h2():
             return 3
-        return 2 if self.f16x3 else 0
+        return 2
+
+    def conv_flags(self, cmode):
+        """mpose_conv_fwd flags of the arithmetic: MPOSE_CONV_F16X3 (+ MPOSE_CONV_F16X1 in the fp16-rounded mode)."""
+        return 32 | (64 if self.conv_f16x1 else 0)
 
     def stages_have_h2(self):
         return any(b.h2 for b in self._all_blocks)
-
-    def conv_flags(self, cmode):
-        return (4 | (8 if self.conv_bf16 else 0)) if cmode == 1 else ((32 | (64 if self.conv_f16x1 else 0)) if cmode in (2, 3) else 0)
 
     def absmax(self, tensors, slots, C, scales=None, shifts=None, relu=False):
         """Largest magnitude of each NHWC tensor (after an optional per-channel affine map + ReLU) into its device slot; tensors
@@ -992,8 +928,7 @@ class Engine:
             return
         main = torch.cuda.current_stream()
         if self.side_stream is None or self.side_stream.device != main.device:
-            # (a LOWER queue priority for the side stream was tried -- MPOSE_SIDE_PRIO -- see DESIGN 6.0)
-            self.side_stream = torch.cuda.Stream(device=main.device, priority=int(os.environ.get('MPOSE_SIDE_PRIO', '0')))
+            self.side_stream = torch.cuda.Stream(device=main.device)      # (a lower queue priority was tried in round 5: no gain)
         side = self.side_stream
         _lib.stream_wait(side, main)
         with torch.cuda.stream(side):
@@ -1003,18 +938,9 @@ class Engine:
         # Tensor.record_stream this costs no allocator head-room (reserved memory 8.3 GB instead of 30 GB at B=32)
         self._side_keep.extend(tensors)
 
-    def fuse_fin(self, op, table, counters, job0, job1=None):
-        """The convolution launch finishes the BatchNorm(s) of its output(s) itself (mpose_conv_operands.fin*): job indices into
-        `table` (a device-resident mpose_bn_job array), one ticket counter per first job."""
-        op.fin0 = table.data_ptr() + job0 * BN_DT.itemsize
-        if job1 is not None:
-            op.fin1 = table.data_ptr() + job1 * BN_DT.itemsize
-        op.fin_count = counters.data_ptr() + 4 * job0
-        op.fin_eps, op.fin_momentum = BN_EPS, BN_MOMENTUM
-
     def part_stats(self):
-        """Statistics leave the convolution launches as partial rows (MPOSE_CONV_STATS_PART); the fused finalize needs the atomics."""
-        return self.stats_part and not self.fuse_finalize
+        """Statistics leave the convolution launches as per-workgroup partial rows (MPOSE_CONV_STATS_PART), always."""
+        return True
 
     def finalize_table(self, table, first, n, train, part=False, bounds=False):
         base = table.data_ptr() + first * BN_DT.itemsize
@@ -1037,9 +963,8 @@ class Engine:
                 raise _lib.MposeError('mpose_conv_wgrad_tiles rejected the geometry %s' % getattr(g, '_name', '?'))
             slots = g.B * g.GH * (32 if width32 else g.GW)
             d = max(1, int(lib().mpose_conv_wgrad_phases(ctypes.byref(g))))       # x-dilated kernels: d launches, n_split / d each
-            occ_on = _WG_OCC == 1 or (_WG_OCC == 2 and groups == 1 and g.GH * g.GW >= 128 * 128)
-            occ = max(1, int(lib().mpose_conv_wgrad_occupancy(ctypes.byref(g)))) if occ_on else 1
-            if occ == 1 and tiles * groups <= 2:
+            occ = 1
+            if tiles * groups <= 2:
                 # a one-tile launch of conv_wgrad_k -- the image's 27 -> 32 channel layer, the LAST weight gradient of a step, which the
                 # main stream waits for with nothing left to run: 64 pixel splits were 64 workgroups (122 us)
                 occ = 4
@@ -1054,43 +979,13 @@ class Engine:
         check(lib().mpose_bn_finalize(c_void_p(base), n, int(train) | (2 if (part and train) else 0) | (4 if (bounds and train) else 0),
                                       ctypes.c_float(BN_EPS), ctypes.c_float(BN_MOMENTUM), stream_ptr()), 'mpose_bn_finalize')
 
-    def pack_weights(self, cmode, overlap=False):
-        """Measure (three-product form) and pack every convolution weight for engine `cmode`.  overlap=True (a forward with a graph
-        feature extractor in front of the stages): the columns' share -- 90 % of the bytes -- runs on the side stream while the
-        main stream packs the feature extractor's weights and runs it; join_pack() makes the main stream wait before the first
-        stage (0.27 ms of a step's serial head otherwise: profiles/r5_step_listing.txt)."""
-        n, ns = len(self._convs), self._n_stem_convs
-
-        def run(first, count):
-            if count <= 0:
-                return
-            if cmode in (2, 3):
-                check(lib().mpose_weights_absmax(c_void_p(self._amax_jobs[cmode].data_ptr() + first * PACK_DT.itemsize), count, stream_ptr()),
-                      'mpose_weights_absmax')
-            check(lib().mpose_pack_weights(c_void_p(self._pack_jobs[cmode].data_ptr() + 2 * first * PACK_DT.itemsize), 2 * count, self._pack_max,
-                                           stream_ptr()), 'mpose_pack_weights')
-
-        side_ok = (overlap and _PACK_SIDE and self.overlap_wgrad and 0 < ns < n and (self.timer is None or self.timer.selective)
-                   and (self.dp is None or self.dp_overlap()))
-        if side_ok:
-            main = torch.cuda.current_stream()
-            if self.side_stream is None or self.side_stream.device != main.device:
-                self.side_stream = torch.cuda.Stream(device=main.device, priority=int(os.environ.get('MPOSE_SIDE_PRIO', '0')))
-            _lib.stream_wait(self.side_stream, main)       # (the optimiser's update of the weights is on the main stream)
-            with torch.cuda.stream(self.side_stream):
-                run(ns, n - ns)
-            run(0, ns)
-            self._pack_join = True
-        else:
-            run(0, n)
+    def pack_weights(self, cmode):
+        """Measure and pack every convolution weight for engine mode `cmode` (conv_mode_for): one launch each."""
+        n = len(self._convs)
+        check(lib().mpose_weights_absmax(c_void_p(self._amax_jobs[cmode].data_ptr()), n, stream_ptr()), 'mpose_weights_absmax')
+        check(lib().mpose_pack_weights(c_void_p(self._pack_jobs[cmode].data_ptr()), 2 * n, self._pack_max, stream_ptr()), 'mpose_pack_weights')
         self._packed_for = cmode
         self._pack_epoch += 1
-
-    def join_pack(self):
-        """The main stream waits for the columns' packed weights (pack_weights(overlap=True)); no-op otherwise."""
-        if self._pack_join:
-            _lib.stream_wait(torch.cuda.current_stream(), self.side_stream)
-            self._pack_join = False
 
     # ------------------------------------------------------------------ forward
     def forward(self, x, train, save, hm_bf16=False, features=None):
@@ -1145,19 +1040,14 @@ class Engine:
         # (repacked on every forward, 0.33 ms: a cache keyed on the parameters' version counters would miss `p.data` updates and
         #  anything a replayed graph or a raw kernel such as DeviceSGD writes)
         cmode = ctx['cmode'] = self.conv_mode_for(train, save)
-        planes = cmode == 1
-        f16 = cmode in (2, 3)
         h2 = cmode == 3
-        h2f = ctx['h2f'] = bool(h2 and train and self.h2_fuse)       # the producers of the H2 blocks' operands write the planes themselves
-        # train mode on conv_igemm_k: the convolution launches finalise their own BatchNorms (no mpose_bn_finalize launches)
-        fin_fused = train and not planes and self.fuse_finalize
-        # statistics as per-workgroup partial rows (MPOSE_CONV_STATS_PART) instead of fp64 atomics: conv_igemm_k / conv_h2_k only
-        spart = ctx['spart'] = bool(train and self.part_stats() and not planes)
+        h2f = ctx['h2f'] = bool(h2 and train)       # the producers of the H2 blocks' operands write the planes themselves (a-priori bounds)
+        # statistics as per-workgroup partial rows (MPOSE_CONV_STATS_PART): deterministic, no atomics
+        spart = ctx['spart'] = bool(train)
         sp = tb['sp_ptr']
         if not (self.pack_frozen and self._packed_for == cmode):
-            self.pack_weights(cmode, overlap=self.stem is not None and features is None)
-        if f16:
-            _lib.fill_zero(self.amax_f)        # (fills through the library: a launch plan records them, csrc/plan.hip)
+            self.pack_weights(cmode)
+        _lib.fill_zero(self.amax_f)        # (fills through the library: a launch plan records them, csrc/plan.hip)
         if train:
             _lib.fill_zero(self.stat_arena)
         elif self.stem is None:
@@ -1169,7 +1059,7 @@ class Engine:
             inp = features.permute(0, 2, 3, 1).contiguous()
         elif self.stem is not None:
             # ---- InceptionV4 feature extractor (stem.py) ----
-            inp, ctx['stem_ctx'] = self.stem.forward(x, train, save, f16)
+            inp, ctx['stem_ctx'] = self.stem.forward(x, train, save)
         else:
             # ---- patch8 stem: space-to-depth + 1x1 conv (192->128) + BN + ReLU ----
             if x.dtype == torch.uint8:
@@ -1192,7 +1082,6 @@ class Engine:
                                       ptr(inp), c_int64(inp.numel()), 128, st()), 'mpose_bn_relu_fwd')
             ctx['s2d'], ctx['stem_raw'], ctx['stem_out'] = s2d, stem_raw, inp
         ctx['inps'] = []
-        self.join_pack()
 
         hms = [[], [], []]
         xyz = None
@@ -1206,9 +1095,6 @@ class Engine:
             ctx['inps'].append(inp)
             cur = [inp, inp, inp]
             pflags = ctx['pflags'] = self.conv_flags(cmode)
-            if planes:               # the stage input is read by all three columns: split once
-                inp_p = self.split_planes([inp], B * F * F, 128)[0]
-                cur_p = [inp_p, inp_p, inp_p]
             stage_saved = []
             nxt_h = None
             for i in range(10):
@@ -1221,32 +1107,21 @@ class Engine:
                     spaces = (c_int * 3)(*self.spaces)
                     check(L.mpose_axis_permute(ptr_array(cur), ptr_array(outs), spaces, 3, B, Sm, 192, st()), 'mpose_axis_permute')
                     cur = outs
-                    if planes:
-                        moved = [c for c in range(3) if self.spaces[c] != 0]
-                        new_p = self.split_planes([cur[c] for c in moved], B * Sm * Sm, 192)
-                        cur_p = list(cur_p)
-                        for c, pl in zip(moved, new_p):
-                            cur_p[c] = pl
                 gname = {'regular': 'f_in_regular', 'down': 'f_in_down', 'up': 'f_in_up'}[b0.kind]
                 g1 = self.geom(gname, B, Hin, b0)
                 last = i == 9
                 npix_o = B * Hout * Hout
-                # Inference on the plane engine: BatchNorm with running statistics is a per-channel affine map, so it (and the
-                # ReLU, and the block's residual sum) run in the convolutions' epilogues, which write the next convolution's
-                # pre-split planes directly -- a ResidualBlock is two launches and no elementwise pass (reference :31-40).
-                fused = planes and not train and not save and not self.conv_bf16
-                # The same on conv_igemm_k (three-product form): its epilogue applies bn1 + ReLU (conv2 then reads a plain
-                # tensor: no prologue) or bn2 + ReLU + the shortcut's BatchNorm + the sum, and measures max |.| for the next
-                # convolution's scale as it stores -- fp32 in and out, two launches per block, no elementwise or amax pass.
-                fused_h = f16 and not train and not save and os.environ.get('MPOSE_FUSED_EVAL', '1') != '0'
-                c1 = None if fused else [torch.empty(B, Hout, Hout, b0.cout_s, **f32) for _ in range(3)]
+                # Inference: BatchNorm with running statistics is a per-channel affine map, so it (and the ReLU, and the block's
+                # residual sum) run in the convolutions' epilogues -- the first launch stores relu(bn1(.)) (the second reads a plain
+                # tensor: no prologue), the second relu(bn2(.)) + bn_s(shortcut) -- and both measure max |.| for the next
+                # convolution's scale as they store: two launches per block, no elementwise or amax pass (reference :31-40).
+                fused_h = not train and not save
+                c1 = [torch.empty(B, Hout, Hout, b0.cout_s, **f32) for _ in range(3)]
                 sc = [torch.empty(B, Hout, Hout, b0.cout_s, **f32) for _ in range(3)]
-                if fused:
-                    a1_p = [self.planes_empty(npix_o, b0.cout_s) for _ in range(3)]
-                if f16:                      # (columns reading one tensor -- the stage input -- share its slot)
-                    cur_slot = [self._amax_f(t, i, 0, _first_same(cur, c)) for c in range(3)]
-                    if i == 0:               # later blocks: the previous block's residual add measured its output as it wrote it
-                        self.absmax(cur, cur_slot, b0.cin_s)
+                # (columns reading one tensor -- the stage input -- share its slot)
+                cur_slot = [self._amax_f(t, i, 0, _first_same(cur, c)) for c in range(3)]
+                if i == 0:               # later blocks: the previous block's residual add measured its output as it wrote it
+                    self.absmax(cur, cur_slot, b0.cin_s)
                 blk_h2 = h2 and b0.h2        # this block's forward convolutions read producer-split fp16 planes (conv_h.hip)
                 if blk_h2:
                     if nxt_h is not None:    # (the block before wrote them with its residual sum)
@@ -1256,140 +1131,71 @@ class Engine:
                 ops = []
                 for c, b in enumerate(grp):
                     op = ConvOperands()
-                    op.in_ = (cur_p[c] if planes else (cur_h[c] if blk_h2 else cur[c])).data_ptr()
+                    op.in_ = (cur_h[c] if blk_h2 else cur[c]).data_ptr()
                     op.w0, op.w1 = self._wptr(b.conv_in), self._wptr(b.conv_sc)
-                    if f16:
-                        op.in_amax, op.w0_amax, op.w1_amax = cur_slot[c], b.conv_in.amax_ptr, b.conv_sc.amax_ptr
+                    op.in_amax, op.w0_amax, op.w1_amax = cur_slot[c], b.conv_in.amax_ptr, b.conv_sc.amax_ptr
                     op.out1 = sc[c].data_ptr()
-                    if fused:
-                        op.out0_planes = a1_p[c].data_ptr()
+                    op.out0 = c1[c].data_ptr()
+                    if fused_h:          # c1 holds relu(bn1(conv)) here
                         op.epi_scale0, op.epi_shift0 = self._bnf_ptr(b.bn1, 0), self._bnf_ptr(b.bn1, 1)
-                    else:
-                        op.out0 = c1[c].data_ptr()
-                        if fused_h:          # c1 holds relu(bn1(conv)) here
-                            op.epi_scale0, op.epi_shift0 = self._bnf_ptr(b.bn1, 0), self._bnf_ptr(b.bn1, 1)
-                            op.out0_amax = self._amax_f(t, i, 1, c)
-                    if train and spart:
+                        op.out0_amax = self._amax_f(t, i, 1, c)
+                    if train:
                         op.stats0, op.stats1 = sp[(id(b.bn1), 'f')], sp[(id(b.bns), 'f')]
-                        if f16:
-                            op.mm0 = sp[(id(b.bn1), 'mm')]
-                    elif train:
-                        op.stats0, op.stats1 = self._stats_ptr(b.bn1), self._stats_ptr(b.bns)
-                        if f16:
-                            op.mm0 = self._mm_ptr(b.bn1)
-                        if fin_fused:        # (the launch's last workgroup per column runs the two finalize jobs)
-                            self.fuse_fin(op, tb['fin'], tb['fin_count'], self.fin_index(t, i, 0) + c, self.fin_index(t, i, 1) + c)
+                        op.mm0 = sp[(id(b.bn1), 'mm')]
                     ops.append(op)
-                sc_side = (self.sc_side and blk_h2 and train and spart and not fin_fused and b0.kind == 'regular'
-                           and (self.timer is None or self.timer.selective))
-                if sc_side:
-                    main = torch.cuda.current_stream()
-                    if self.fwd_side_stream is None or self.fwd_side_stream.device != main.device:
-                        self.fwd_side_stream = torch.cuda.Stream(device=main.device)
-                    side = self.fwd_side_stream
-                    _lib.stream_wait(side, main)     # the input planes (and last step's readers of sc / the partial rows) are done here
-                    ops1 = []
-                    for c, (b, op) in enumerate(zip(grp, ops)):
-                        o1 = ConvOperands()
-                        o1.in_, o1.in_amax = op.in_, op.in_amax
-                        o1.w0, o1.w0_amax = op.w1, op.w1_amax
-                        o1.out0, o1.stats0 = op.out1, op.stats1
-                        ops1.append(o1)
-                        op.w1, op.w1_amax, op.out1, op.stats1 = None, None, None, None
-                    cflags = pflags | 256 | 128
-                    self.conv(self.geom('f_in3_regular', B, Hin, b0), ops, cflags)
-                    self.finalize(tb, self.fin_index(t, i, 0), 3, True, spart)
-                    with torch.cuda.stream(side):
-                        self.conv(self.geom('f_in1_regular', B, Hin, b0), ops1, cflags)
-                        self.finalize(tb, self.fin_index(t, i, 1), 3, True, spart)
-                else:
-                    self.conv(g1, ops, pflags | (16 if (fused or fused_h) else 0) | (256 if spart else 0) | (128 if blk_h2 else 0))
-                    if train and not fin_fused:
-                        self.finalize(tb, self.fin_index(t, i, 0), 6, True, spart)
+                self.conv(g1, ops, pflags | (16 if fused_h else 0) | (256 if spart else 0) | (128 if blk_h2 else 0))
+                if train:
+                    self.finalize(tb, self.fin_index(t, i, 0), 6, True, spart)
                 # largest relu(bn1(c1)): what the next K loop (and its weight gradient) will split.  In training bn_finalize just
                 # derived it from c1's channel extremes (the convolution's epilogue took them); otherwise it is measured
-                if f16 and not fused_h and not train:
+                if not fused_h and not train:
                     self.absmax(c1, [self._amax_f(t, i, 1, c) for c in range(3)], b0.cout_s, [self._bnf_ptr(b.bn1, 0) for b in grp],
                                 [self._bnf_ptr(b.bn1, 1) for b in grp], relu=True)
                 if blk_h2:                   # relu(bn1(c1)) * 2^k as two fp16 planes, once (its amax slot: exact, from c1's channel extremes)
                     a1_h = self.split_h2(c1, [self._amax_f(t, i, 1, c) for c in range(3)], npix_o, b0.cout_s,
                                          [self._bnf_ptr(b.bn1, 0) for b in grp], [self._bnf_ptr(b.bn1, 1) for b in grp], relu=True)
-                if planes and not fused:     # relu(bn1(c1)) is written once, pre-split, instead of being recomputed by every tap
-                    a1_p = self.split_planes(c1, npix_o, b0.cout_s, [self._bnf_ptr(b.bn1, 0) for b in grp],
-                                             [self._bnf_ptr(b.bn1, 1) for b in grp], relu=True)
-                fuse2 = fused and not last
                 fuse2_h = fused_h and not last
-                need_f32 = (not fuse2) or (i == 4 and any(sp != 0 for sp in self.spaces))     # the axis permutation reads fp32
-                c2 = None if (fuse2 or fuse2_h) else [torch.empty(B, Hout, Hout, b0.cout_s, **f32) for _ in range(3)]
+                c2 = None if fuse2_h else [torch.empty(B, Hout, Hout, b0.cout_s, **f32) for _ in range(3)]
                 if last:
                     outs = [None] * 3 if tail_fused else [torch.empty(B, self.J, F, F, **f32) for _ in range(3)]
-                elif need_f32:
-                    outs = [torch.empty(B, Hout, Hout, b0.cout_s, **f32) for _ in range(3)]
                 else:
-                    outs = [None, None, None]
-                if fuse2:
-                    nxt_p = [self.planes_empty(npix_o, b0.cout_s) for _ in range(3)]
+                    outs = [torch.empty(B, Hout, Hout, b0.cout_s, **f32) for _ in range(3)]
                 ops = []
                 for c, b in enumerate(grp):
                     op = ConvOperands()
                     op.w0 = self._wptr(b.conv2)
-                    if planes:
-                        op.in_ = a1_p[c].data_ptr()
-                    else:
-                        op.in_ = (a1_h[c] if blk_h2 else c1[c]).data_ptr()
-                        if not fused_h and not blk_h2:
-                            op.in_scale, op.in_shift = self._bnf_ptr(b.bn1, 0), self._bnf_ptr(b.bn1, 1)
-                        if f16:
-                            op.in_amax, op.w0_amax = self._amax_f(t, i, 1, c), b.conv2.amax_ptr
-                    if fuse2:
-                        op.out0_planes = nxt_p[c].data_ptr()
-                        if outs[c] is not None:
-                            op.out0 = outs[c].data_ptr()
-                        op.epi_scale0, op.epi_shift0 = self._bnf_ptr(b.bn2, 0), self._bnf_ptr(b.bn2, 1)
-                        op.add_src, op.add_scale, op.add_shift = sc[c].data_ptr(), self._bnf_ptr(b.bns, 0), self._bnf_ptr(b.bns, 1)
-                    elif fuse2_h:
+                    op.in_ = (a1_h[c] if blk_h2 else c1[c]).data_ptr()
+                    if not fused_h and not blk_h2:
+                        op.in_scale, op.in_shift = self._bnf_ptr(b.bn1, 0), self._bnf_ptr(b.bn1, 1)
+                    op.in_amax, op.w0_amax = self._amax_f(t, i, 1, c), b.conv2.amax_ptr
+                    if fuse2_h:
                         op.out0 = outs[c].data_ptr()
                         op.epi_scale0, op.epi_shift0 = self._bnf_ptr(b.bn2, 0), self._bnf_ptr(b.bn2, 1)
                         op.add_src, op.add_scale, op.add_shift = sc[c].data_ptr(), self._bnf_ptr(b.bns, 0), self._bnf_ptr(b.bns, 1)
                         op.out0_amax = self._amax_f(t, i + 1, 0, c)           # (the axis permutation after block 4 keeps the maximum)
                     else:
                         op.out0 = c2[c].data_ptr()
-                    if train and spart:
+                    if train:
                         op.stats0 = sp[(id(b.bn2), 'f')]
-                    elif train:
-                        op.stats0 = self._stats_ptr(b.bn2)
-                        if fin_fused:
-                            self.fuse_fin(op, tb['fin'], tb['fin_count'], self.fin_index(t, i, 2) + c)
                     ops.append(op)
-                self.conv(self.geom('f_conv2', B, Hout, b0), ops,
-                          pflags | (16 if (fuse2 or fuse2_h) else 0) | (256 if spart else 0) | (128 if blk_h2 else 0))
-                if sc_side:                  # the shortcut and its BatchNorm vectors are read from here on
-                    _lib.stream_wait(torch.cuda.current_stream(), side)
+                self.conv(self.geom('f_conv2', B, Hout, b0), ops, pflags | (16 if fuse2_h else 0) | (256 if spart else 0) | (128 if blk_h2 else 0))
                 add_h2 = h2f and self.h2_next(t, i)      # this block's sum is the next (H2) block's input: planes written here
-                if train and not fin_fused:
+                if train:
                     self.finalize(tb, self.fin_index(t, i, 2), 3, True, spart, bounds=add_h2)
-                if fuse2:
-                    cur_p = nxt_p
-                elif fuse2_h:
-                    pass
-                else:
+                if not fuse2_h:
                     aops = []
                     for c, b in enumerate(grp):
                         ao = BnAddOperands()
                         ao.a, ao.a_scale, ao.a_shift = c2[c].data_ptr(), self._bnf_ptr(b.bn2, 0), self._bnf_ptr(b.bn2, 1)
                         ao.b, ao.b_scale, ao.b_shift = sc[c].data_ptr(), self._bnf_ptr(b.bns, 0), self._bnf_ptr(b.bns, 1)
                         ao.out = outs[c].data_ptr() if outs[c] is not None else None
-                        if f16 and not last:
+                        if not last:
                             ao.out_amax = self._amax_f(t, i + 1, 0, c)       # (the axis permutation after block 4 keeps the maximum)
                         aops.append(ao)
                     if add_h2:               # (out_amax is READ there: the bound bn_finalize just wrote)
                         nxt_h = [torch.empty(npix_o * b0.cout_s, **f32) for _ in range(3)]
                         check(L.mpose_bn_add_h2((BnAddOperands * 3)(*aops), ptr_array(nxt_h), 3, c_int64(npix_o), b0.cout_s, st()),
                               'mpose_bn_add_h2')
-                    elif planes and not last:
-                        cur_p = [self.planes_empty(npix_o, b0.cout_s) for _ in range(3)]
-                        check(L.mpose_bn_add_planes((BnAddOperands * 3)(*aops), ptr_array(cur_p), 3, c_int64(npix_o), b0.cout_s, st()),
-                              'mpose_bn_add_planes')
                     elif last and tail_fused:       # residual sum + flat_softmax + dsnt in one launch: no logits in memory
                         heat = [torch.empty(B, self.J, F, F, dtype=torch.bfloat16 if hm_bf16 else torch.float32, device=x.device)
                                 for _ in range(3)]
@@ -1407,7 +1213,7 @@ class Engine:
                               'mpose_bn_add_fwd')
                 if save:
                     stage_saved.append({'x': cur, 'c1': c1, 'sc': sc, 'c2': c2})
-                    if blk_h2 and h2f and self.h2_fuse >= 2 and self.h2_planes:      # the weight gradients read the planes (Engine.h2_planes)
+                    if blk_h2 and h2f and self.h2_planes:      # the weight gradients read the planes (Engine.h2_planes)
                         stage_saved[-1]['x_h'], stage_saved[-1]['a1_h'] = cur_h, a1_h
                 cur = outs
             if not tail_fused:
@@ -1456,10 +1262,8 @@ class Engine:
             self._pending = weakref.ref(ctx)
             ctx['param_versions'] = [p._version for p in self.param_list()]
         cmode = ctx['cmode'] = self.conv_mode_for(train, save)
-        if cmode == 1:
-            raise _lib.MposeError('graph models run on conv_igemm_k (MPOSE_PLANES=1 is set)')
         self.pack_weights(cmode)
-        outs, ctx['stem_ctx'] = self.stem.forward(x, train, save, cmode in (2, 3), features=features)
+        outs, ctx['stem_ctx'] = self.stem.forward(x, train, save, features=features)
         if train and features is None:
             check(lib().mpose_add_i64(c_void_p(self._nbt.data_ptr()), c_int64(1), c_int64(self._nbt.numel()), stream_ptr()), 'mpose_add_i64')
         return outs, ctx
@@ -1488,7 +1292,7 @@ class Engine:
         return [self.bnf, self.amax_f] + ([self.stem.f_arena, self.stem.amax_f] if self.stem is not None else [])
 
     # ------------------------------------------------------------------ launch plans (train_helpers.PlannedTrainStep / PlannedInference)
-    def plan_stamp(self, table_keys=None):
+    def plan_stamp(self, table_keys=None, backward=True):
         """Everything a recorded launch plan (csrc/plan.hip) bakes in BY ADDRESS or by value but that lives outside the plan's
         private allocator pool: the parameters and BatchNorm buffers as bound right now, the engine's arenas, the per-(B, F) job
         tables, the BatchNorm-backward reduction workspace (regrown by a larger eager batch), and the switches that decide which
@@ -1500,14 +1304,13 @@ class Engine:
         bound = [t for t in self._bn_bound_now() if t is not None] + [c.param for c in self._convs] + list(self.combiners)
         if self.stem is not None:
             bound += list(self.stem.extra_params)
-        ws = getattr(self, '_reduce_ws', None)
+        ws = getattr(self, '_reduce_ws', None) if backward else None      # (a forward-only plan never touches the reduction workspace)
         arenas = [self.wpack, self.bnf, self.stat_arena, self.gflat, self.wamax, self.amax_f, self.amax_b, self._nbt]
         if self.stem is not None:
             arenas += [t for t in (getattr(self.stem, 'f_arena', None), getattr(self.stem, 'amax_f', None)) if t is not None]
         tables = tuple((k, id(self._tables.get(k))) for k in (sorted(self._tables) if table_keys is None else table_keys))
-        flags = (self.h2, self.h2_fuse, self.inline_unpack, self.overlap_wgrad, self.fuse_coef, self.tail_fuse, self.stats_part,
-                 self.fuse_finalize, self.sc_side, self.stem_bounds, self.f16x3, self.conv_bf16, self.conv_f16x1,
-                 self.planes_mode, self.dp is not None)
+        flags = (self.h2_planes, self.inline_unpack, self.overlap_wgrad, self.fuse_coef, self.tail_fuse, self.stem_bounds, self.conv_f16x1,
+                 self.dp is not None)
         return (self._arena_key[0], hash(tuple(t.data_ptr() for t in bound)), tuple(t.data_ptr() for t in arenas),
                 (ws.data_ptr(), ws.numel()) if ws is not None else None, tables, flags)
 
@@ -1570,16 +1373,15 @@ class Engine:
         goff = dict((id(p), o) for p, o in zip(self.param_list(), self._grad_offsets))
         coef_base = tb['coef'].data_ptr()
         cmode = ctx['cmode']
-        planes, f16, h2 = cmode == 1, cmode in (2, 3), cmode == 3
+        h2 = cmode == 3
         pflags = ctx['pflags']         # (the forward's convolution engine and precision)
-        x1 = f16 and bool(pflags & 64)
+        x1 = bool(pflags & 64)
         if self._packed_for != cmode:      # a forward on another engine ran in between: the parameters are unchanged (checked
             self.pack_weights(cmode)       # above), so this restores exactly the packing of this context's forward
-        if f16:
-            _lib.fill_zero(self.amax_b)
+        _lib.fill_zero(self.amax_b)
 
         # (the backward's sums as partial rows too; an eval-mode forward has ctx['spart'] False but its backward may still use them)
-        spart = bool(self.part_stats() and not planes)
+        spart = True
         sp = tb['sp_ptr']
 
         h2f = bool(h2 and ctx.get('h2f', False))
@@ -1619,9 +1421,8 @@ class Engine:
                 if i == 9:
                     sums_done = False        # (g comes from the tail)
                 # this block's data-gradient can take block i-1's sums unless the axis permutation sits between them (after
-                # block 4: it mixes channels and pixels) or the plane engine runs; MPOSE_FUSE_BN_SUMS=0 for A/B runs
-                fuse_sums = (not planes) and i >= 1 and not (i == 5 and any(sp != 0 for sp in self.spaces)) and \
-                    os.environ.get('MPOSE_FUSE_BN_SUMS', '1') != '0'
+                # block 4: it mixes channels and pixels)
+                fuse_sums = i >= 1 and not (i == 5 and any(sp != 0 for sp in self.spaces))
                 # (1) sums of g, g*c2, g*sc -> BN2 / BN_shortcut backward coefficients, dgamma, dbeta -- already taken by the
                 #     data-gradient that produced g (the epilogue of the next block's step (6)) where that was possible
                 if not sums_done:
@@ -1633,7 +1434,7 @@ class Engine:
                         ro.sums = self._stats_ptr(b.bn2, True)
                         rops.append(ro)
                 blk_h2 = h2 and b0.h2
-                app_h2 = h2f and blk_h2 and self.h2_fuse >= 2     # bn2's backward application writes d_c2 as planes too, scaled by the coefficient kernel's bound
+                app_h2 = h2f and blk_h2     # bn2's backward application writes d_c2 as planes too, scaled by the coefficient kernel's bound
                 pl_bwd = app_h2 and self.h2_planes and 'x_h' in sv        # planes end to end: no fp32 d_c2 / d_sc / d_c1 at all
                 coef_done = False
                 if not sums_done:
@@ -1653,19 +1454,13 @@ class Engine:
                     ao.a_scale, ao.a_shift = self._bnf_ptr(b.bn2, 0), self._bnf_ptr(b.bn2, 1)
                     if not pl_bwd:
                         ao.da, ao.db = d_c2[c].data_ptr(), d_sc[c].data_ptr()
-                    if f16:
-                        ao.da_amax, ao.db_amax = self._amax_b(t, i, 0, c), self._amax_b(t, i, 2, c)
+                    ao.da_amax, ao.db_amax = self._amax_b(t, i, 0, c), self._amax_b(t, i, 2, c)
                     aops.append(ao)
                 if app_h2:           # (da_amax is READ there; with pl_bwd db_amax too: both hold the coefficient kernel's bounds)
                     d_c2_h = [torch.empty(cnt * Cs, **f32) for _ in range(3)]
                     d_sc_h = [torch.empty(cnt * Cs, **f32) for _ in range(3)] if pl_bwd else None
                     check(L.mpose_bn_bwd_apply_h2((BnBwdApplyOperands * 3)(*aops), ptr_array(d_c2_h), ptr_array(d_sc_h) if pl_bwd else None,
                                                   3, c_int64(cnt), Cs, st()), 'mpose_bn_bwd_apply_h2')
-                elif planes:         # the gradients feed a convolution next: written pre-split as well
-                    d_c2_p = [self.planes_empty(cnt, Cs) for _ in range(3)]
-                    d_sc_p = [self.planes_empty(cnt, Cs) for _ in range(3)]
-                    check(L.mpose_bn_bwd_apply_planes((BnBwdApplyOperands * 3)(*aops), ptr_array(d_c2_p), ptr_array(d_sc_p), 3, c_int64(cnt),
-                                                      Cs, st()), 'mpose_bn_bwd_apply_planes')
                 else:
                     check(L.mpose_bn_bwd_apply((BnBwdApplyOperands * 3)(*aops), 3, Hout * Hout, B, Cs, 0, 0, st()), 'mpose_bn_bwd_apply')
                 # (2) dgrad of the second 3x3; ReLU mask and the BN1-backward sums happen in its epilogue
@@ -1675,10 +1470,9 @@ class Engine:
                 ops = []
                 for c, b in enumerate(grp):
                     op = ConvOperands()
-                    op.in_ = (d_c2_p[c] if planes else (d_c2_h[c] if blk_h2 else d_c2[c])).data_ptr()
+                    op.in_ = (d_c2_h[c] if blk_h2 else d_c2[c]).data_ptr()
                     op.w0, op.out0 = self._wptr(b.conv2, True), d_a1[c].data_ptr()
-                    if f16:
-                        op.in_amax, op.w0_amax = self._amax_b(t, i, 0, c), b.conv2.amax_ptr
+                    op.in_amax, op.w0_amax = self._amax_b(t, i, 0, c), b.conv2.amax_ptr
                     op.mask_src = sv['c1'][c].data_ptr()
                     op.mask_scale, op.mask_shift = self._bnf_ptr(b.bn1, 0), self._bnf_ptr(b.bn1, 1)
                     op.stats0 = sp[(id(b.bn1), 'b')] if spart else self._stats_ptr(b.bn1, True)
@@ -1696,9 +1490,8 @@ class Engine:
                         wo.in_, wo.in_scale, wo.in_shift = sv['c1'][c].data_ptr(), self._bnf_ptr(b.bn1, 0), self._bnf_ptr(b.bn1, 1)
                         wo.gout0 = d_c2[c].data_ptr()
                     wo.dw0 = tb['part_ptr'][id(b.conv2)]
-                    if f16:
-                        wo.in_amax, wo.gout0_amax = self._amax_f(t, i, 1, c), self._amax_b(t, i, 0, c)
-                        wo.single_product = int(x1)
+                    wo.in_amax, wo.gout0_amax = self._amax_f(t, i, 1, c), self._amax_b(t, i, 0, c)
+                    wo.single_product = int(x1)
                     wops.append(wo)
                 g_w2 = self.geom('f_conv2', B, Hout, b0)
                 self.wgrad_async(g_w2, wops, self.wg_n_split(g_w2), (sv['a1_h'] + d_c2_h) if pl_bwd else (sv['c1'] + d_c2),
@@ -1712,17 +1505,12 @@ class Engine:
                     ao.g, ao.a, ao.coef_a = d_a1[c].data_ptr(), sv['c1'][c].data_ptr(), self._bnf_ptr(b.bn1, 4)
                     if not pl_bwd:
                         ao.da = d_c1[c].data_ptr()
-                    if f16:
-                        ao.da_amax = self._amax_b(t, i, 1, c)
+                    ao.da_amax = self._amax_b(t, i, 1, c)
                     aops.append(ao)
                 if pl_bwd:           # d_c1 as planes only, scaled by the bound the coefficient kernel just wrote
                     d_c1_h = [torch.empty(cnt * Cs, **f32) for _ in range(3)]
                     check(L.mpose_bn_bwd_apply_h2((BnBwdApplyOperands * 3)(*aops), ptr_array(d_c1_h), None, 3, c_int64(cnt), Cs, st()),
                           'mpose_bn_bwd_apply_h2')
-                elif planes:
-                    d_c1_p = [self.planes_empty(cnt, Cs) for _ in range(3)]
-                    check(L.mpose_bn_bwd_apply_planes((BnBwdApplyOperands * 3)(*aops), ptr_array(d_c1_p), None, 3, c_int64(cnt), Cs, st()),
-                          'mpose_bn_bwd_apply_planes')
                 else:
                     check(L.mpose_bn_bwd_apply((BnBwdApplyOperands * 3)(*aops), 3, Hout * Hout, B, Cs, 0, 0, st()), 'mpose_bn_bwd_apply')
                 # (5) wgrad of conv_in + shortcut: one launch over the fused forward geometry
@@ -1737,17 +1525,16 @@ class Engine:
                         wo.in_ = sv['x'][c].data_ptr()
                         wo.gout0, wo.gout1 = d_c1[c].data_ptr(), d_sc[c].data_ptr()
                     wo.dw0, wo.dw1 = tb['part_ptr'][id(b.conv_in)], tb['part_ptr'][id(b.conv_sc)]
-                    if f16:
-                        wo.in_amax = self._amax_f(t, i, 0, _first_same(sv['x'], c))
-                        wo.gout0_amax, wo.gout1_amax = self._amax_b(t, i, 1, c), self._amax_b(t, i, 2, c)
-                        wo.single_product = int(x1)
+                    wo.in_amax = self._amax_f(t, i, 0, _first_same(sv['x'], c))
+                    wo.gout0_amax, wo.gout1_amax = self._amax_b(t, i, 1, c), self._amax_b(t, i, 2, c)
+                    wo.single_product = int(x1)
                     wops.append(wo)
                 g_w1 = self.geom(gname, B, Hin, b0)
                 self.wgrad_async(g_w1, wops, self.wg_n_split(g_w1), (list(sv['x_h']) + d_c1_h + d_sc_h) if pl_bwd else (list(sv['x']) + d_c1 + d_sc),
                                  self.unpack_after(tb, [b.conv_in for b in grp] + [b.conv_sc for b in grp]))
                 # (6) dgrad of conv_in + the shortcut's dgrad: one launch, the shortcut as a tap on a second input
                 din_h2 = blk_h2 and self.h2_planes       # on conv_h2r_k (its weights are packed for it): both inputs as planes
-                if din_h2 and not pl_bwd:                # (an eval-mode backward / MPOSE_H2_FUSE < 2: measured and split like d_c2 above)
+                if din_h2 and not pl_bwd:                # (an eval-mode backward: measured and split like d_c2 above)
                     d_c1_h = self.split_h2(d_c1, [self._amax_b(t, i, 1, c) for c in range(3)], cnt, Cs)
                     d_sc_h = self.split_h2(d_sc, [self._amax_b(t, i, 2, c) for c in range(3)], cnt, Cs)
                 d_x = [torch.empty(B, Hin, Hin, b0.cin_s, **f32) for _ in range(3)]
@@ -1755,19 +1542,18 @@ class Engine:
                 ops = []
                 for c, b in enumerate(grp):
                     op = ConvOperands()
-                    op.in_ = (d_c1_p[c] if planes else (d_c1_h[c] if din_h2 else d_c1[c])).data_ptr()
-                    op.in1 = (d_sc_p[c] if planes else (d_sc_h[c] if din_h2 else d_sc[c])).data_ptr()
+                    op.in_ = (d_c1_h[c] if din_h2 else d_c1[c]).data_ptr()
+                    op.in1 = (d_sc_h[c] if din_h2 else d_sc[c]).data_ptr()
                     op.w0, op.out0 = self._wptr(b.conv_in, True), d_x[c].data_ptr()
                     op.w1 = self._wptr(b.conv_sc, True)
-                    if f16:
-                        op.in_amax, op.in1_amax = self._amax_b(t, i, 1, c), self._amax_b(t, i, 2, c)
-                        op.w0_amax, op.w1_amax = b.conv_in.amax_ptr, b.conv_sc.amax_ptr
+                    op.in_amax, op.in1_amax = self._amax_b(t, i, 1, c), self._amax_b(t, i, 2, c)
+                    op.w0_amax, op.w1_amax = b.conv_in.amax_ptr, b.conv_sc.amax_ptr
                     if fuse_sums:            # d_x is the previous block's g: its BatchNorm-backward sums while it is stored
                         pb, psv = self.stage_blocks[t][i - 1][c], saved[i - 1]
                         op.red_a, op.red_b = psv['c2'][c].data_ptr(), psv['sc'][c].data_ptr()
                         op.red_scale, op.red_shift = self._bnf_ptr(pb.bn2, 0), self._bnf_ptr(pb.bn2, 1)
                         op.red_sums = sp[(id(pb.bn2), 'b')] if spart else self._stats_ptr(pb.bn2, True)
-                    if h2f and self.h2_fuse >= 2 and i >= 1 and self.stage_blocks[t][i - 1][0].h2:     # d_x is an H2 block's g: its largest magnitude for that block's bound
+                    if h2f and i >= 1 and self.stage_blocks[t][i - 1][0].h2:     # d_x is an H2 block's g: its largest magnitude for that block's bound
                         op.out0_amax = self._amax_b(t, i - 1, 3, c)
                     ops.append(op)
                 self.conv(self.geom(kd, B, Hout, b0), ops, 2 | pflags | (256 if (spart and fuse_sums) else 0) | (128 if din_h2 else 0))

@@ -253,28 +253,20 @@ class MargiPoseModel(nn.Module):
     @property
     def conv_dtype(self):
         """torch.float32 (default: fp32-equivalent convolutions -- three exact fp16 products of two-way split, per-tensor-scaled
-        operands) or one of the reduced-precision modes of BASELINE configs[4] ("fp16 convs with MFMA"):
+        operands) or the reduced-precision mode of BASELINE configs[4] ("fp16 convs with MFMA"):
           torch.float16   EVERY convolution of the model -- feature extractor and columns, forward, data- and weight-gradient --
                           multiplies operands ROUNDED to fp16 after the same per-tensor power-of-two scale (so fp16's 5-bit exponent
-                          never overflows) in a single MFMA pass with fp32 accumulation (MPOSE_CONV_F16X1);
-          torch.bfloat16  round 2's variant: the columns' forward and data-gradient convolutions on bf16-rounded operands (plane
-                          engine), weight gradients and feature extractor fp32.
-        BatchNorm, the losses and the soft-argmax stay fp32 in both.  NOT within the 1e-4 parity bar of the fp32 path: the stated
-        tolerances are in tests/test_model_gpu.py (against the fp64 oracle)."""
-        eng = self.inner.engine()
-        return torch.float16 if eng.conv_f16x1 else (torch.bfloat16 if eng.conv_bf16 else torch.float32)
+                          never overflows) in a single MFMA pass with fp32 accumulation (MPOSE_CONV_F16X1).
+        BatchNorm, the losses and the soft-argmax stay fp32.  NOT within the 1e-4 parity bar of the fp32 path: the stated
+        tolerances are in tests/test_model_gpu.py (against the fp64 oracle).  (Round 2's bf16 variant on the plane engine left the
+        library in round 6: one convolution engine per precision mode.)"""
+        return torch.float16 if self.inner.engine().conv_f16x1 else torch.float32
 
     @conv_dtype.setter
     def conv_dtype(self, dtype):
-        if dtype not in (torch.float32, torch.bfloat16, torch.float16):
-            raise _lib.MposeError('conv_dtype must be torch.float32, torch.float16 or torch.bfloat16')
-        eng = self.inner.engine()
-        if dtype == torch.bfloat16 and eng.planes_mode == '0':
-            raise _lib.MposeError('conv_dtype=bfloat16 needs the plane convolution engine (MPOSE_PLANES=0 is set)')
-        if dtype == torch.float16 and (not eng.f16x3 or eng.planes_mode == '1'):
-            raise _lib.MposeError('conv_dtype=float16 runs on the three-product engine (MPOSE_F16X3=0 / MPOSE_PLANES=1 is set)')
-        eng.conv_bf16 = dtype == torch.bfloat16
-        eng.conv_f16x1 = dtype == torch.float16
+        if dtype not in (torch.float32, torch.float16):
+            raise _lib.MposeError('conv_dtype must be torch.float32 or torch.float16')
+        self.inner.engine().conv_f16x1 = dtype == torch.float16
 
     def forward(self, *inputs):
         self.xy_heatmaps, self.zy_heatmaps, self.xz_heatmaps = self.inner(*inputs)

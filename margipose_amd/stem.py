@@ -35,8 +35,8 @@ from . import _lib
 from ._lib import (BnAddOperands, BnBwdApplyOperands, BnBwdReduceOperands, ConvOperands, WgradOperands, c_int64, c_void_p, check, lib, ptr,
                    stream_ptr)
 
-_POOL_ARG = os.environ.get('MPOSE_POOL_ARG', '1') != '0'       # (0: the max pools' window choices are recomputed in the backward pass: A/B runs)
-_FIRST_WRITES = os.environ.get('MPOSE_STEM_FIRST_WRITES', '1') != '0'      # (0: every node gradient starts from a zero fill: A/B runs)
+_POOL_ARG = True             # the max pools' window choices are kept from the forward pass (round 5: -0.10 ms per step against recomputing them)
+_FIRST_WRITES = True         # a node gradient's first contribution WRITES where its launch covers the node (round 5: -0.21 ms against zero fills)
 
 BN_EPS_STEM = 1e-3        # BasicConv2d's BatchNorm2d(eps=0.001)
 
@@ -338,10 +338,9 @@ class _GraphStem:
                 sp_off += (4 + rows * op.cout_s * 2 + 3) // 4 * 4
         tb['stat_part'] = torch.zeros(max(sp_off, 4), dtype=torch.float32, device=eng.device)
         tb['sp_ptr'] = dict((k_, tb['stat_part'].data_ptr() + 4 * v[0]) for k_, v in sp.items())
-        if eng.stats_part:
-            for pk, (_, rows, ld) in sp.items():
-                j = fin[tb['fin_job'][pk]]
-                j['part'], j['n_part'], j['part_ld'] = tb['sp_ptr'][pk], rows, ld
+        for pk, (_, rows, ld) in sp.items():
+            j = fin[tb['fin_job'][pk]]
+            j['part'], j['n_part'], j['part_ld'] = tb['sp_ptr'][pk], rows, ld
         tb['fin'] = _jobs_to_device(np.array(fin, dtype=BN_DT), eng.device)
         tb['coef'] = _jobs_to_device(np.array(coef, dtype=COEF_DT), eng.device)
         tb['n_fin'] = len(fin)
@@ -380,7 +379,7 @@ class _GraphStem:
                 and op.cin == op.src.C)
 
     # ------------------------------------------------------------------ forward
-    def forward(self, x, train, save, f16=False, features=None):
+    def forward(self, x, train, save, f16=True, features=None):
         """f16: the convolutions run the three-product fp16 form (engine.py); every node's largest consumer-side magnitude is
         measured once, when its BatchNorm vectors are final.
         features (forward only, graphs that name a `feat_node`): a (B, C, H, W) tensor that takes the place of that node -- what
@@ -445,11 +444,8 @@ class _GraphStem:
                 spart = train and eng.part_stats() and (n.name, op.c0) in tb['sp_ptr']
                 if spart:           # statistics as per-workgroup partial rows (no fp64 atomics); the finalize kernel adds them up
                     o.stats0 = tb['sp_ptr'][(n.name, op.c0)]
-                elif train:
+                elif train:          # (a producer without a partial-row buffer: fp64 atomics into the statistics arena)
                     o.stats0 = self.sptr(n, False, op.c0)
-                    job = tb['fin_job'].get((n.name, op.c0))
-                    if eng.fuse_finalize and job is not None:     # the launch finalises this BatchNorm itself
-                        eng.fuse_fin(o, tb['fin'], tb['fin_count'], job)
                 if f16:
                     if src.name not in measured:       # (all of the node's channels: a bound for any channel slice of it)
                         eng.absmax([raw[src.name]], [src.amax_f], src.C, None if sc is None else [sc], None if sc is None else [sh],
@@ -479,7 +475,7 @@ class _GraphStem:
             done.add(id(op))
             if train and all(id(p) in done for p in n.producers):
                 f0, nf = tb['fin_range'][n.name]
-                if nf and not eng.fuse_finalize:       # (otherwise the producing launches have finalised their channel ranges)
+                if nf:
                     bounded = f16 and eng.stem_bounds and all(pp[2] is not None for pp in n.parts)
                     eng.finalize_table(tb['fin'], f0, nf, True, eng.part_stats(), bounds=bounded)
                     if bounded:          # the node's amax slot now holds max_c(|gamma_c| sqrt(N) + |beta_c|): no measuring pass

@@ -324,11 +324,11 @@ class GraphedTrainStep:
         return self.out, self.loss
 
 
-def _check_stamp(eng, stamp, who, table_keys=None):
+def _check_stamp(eng, stamp, who, table_keys=None, backward=True):
     """A launch plan replays raw device addresses.  Those inside its private allocator pool cannot move; the engine's arenas, job
     tables and workspaces and the model's parameters can (model.to(), load_state_dict(assign=True), `p.data = ...`, an eager
     step at a larger batch, a switch flipped on the engine): a replay after such a change would write through stale pointers."""
-    now = eng.plan_stamp(table_keys)
+    now = eng.plan_stamp(table_keys, backward)
     if now != stamp:
         names = ('device', 'parameter / buffer addresses', 'engine arenas', 'reduction workspace', 'job tables', 'engine switches')
         what = [n for n, a, b in zip(names, now or (None,) * 6, stamp or (None,) * 6) if a != b]
@@ -414,6 +414,7 @@ class PlannedTrainStep:
         torch.cuda.synchronize()
         self._eng = eng
         self._table_keys = tuple(sorted(eng._tables))
+        self._cmode = eng._packed_for             # (the packing the recorded iteration leaves in the weight arena)
         self._stamp = eng.plan_stamp(self._table_keys)           # (what the recorded launches point at outside the private pool: checked per replay)
 
     def _stream_array(self):
@@ -447,6 +448,8 @@ class PlannedTrainStep:
         for host_op in self._host_ops:              # (data parallel: issue / wait for the bucket's all-reduce, then go on)
             host_op()
             _lib.check(replay(self._plan, arr, len(arr), nxt.value, ctypes.byref(nxt)), 'mpose_plan_replay')
+        self._eng._packed_for = self._cmode       # (the replayed pack launches rewrote the arena: an eager pass in another mode repacks)
+        self._eng._pack_epoch += 1
         return self.out, self.loss
 
     def __del__(self):
@@ -512,7 +515,7 @@ class PlannedInference:
         self.n_launches, self.n_waits = n[0].value, n[1].value
         self._stamp = self._weights_stamp()
         self._table_keys = tuple(sorted(eng._tables))
-        self._addr_stamp = eng.plan_stamp(self._table_keys)
+        self._addr_stamp = eng.plan_stamp(self._table_keys, backward=False)
         torch.cuda.synchronize()
 
     def _stream_array(self):
@@ -536,11 +539,15 @@ class PlannedInference:
             self.refresh()
         if x is not None:
             self.x.copy_(x, non_blocking=True)
-        _check_stamp(self._eng, self._addr_stamp, 'PlannedInference', self._table_keys)
+        _check_stamp(self._eng, self._addr_stamp, 'PlannedInference', self._table_keys, backward=False)
         self._eng.before_replay()
         arr = self._stream_array()
         nxt = ctypes.c_int(0)
         _lib.check(_lib.lib().mpose_plan_replay(self._plan, arr, len(arr), 0, ctypes.byref(nxt)), 'mpose_plan_replay')
+        if not self._frozen:       # the replayed pack launches rewrote the weight arena in this plan's layout: a pending eager
+            self._eng._packed_for = self._cmode       # backward pass of another engine mode repacks (Engine.backward checks)
+            self._eng._pack_epoch += 1
+            self._stamp = self._weights_stamp()
         for k, v in zip(('xy_heatmaps', 'zy_heatmaps', 'xz_heatmaps'), self._heatmaps):      # (an eager forward in between re-bound them)
             if v is not None:
                 setattr(self.model, k, v)

@@ -574,21 +574,6 @@ def test_dilated_convolution_forward_and_data_gradient(B, hw, cin, cout, dil, pr
     _check(*_errs(dx - base, r64, dgrad(torch.float32)))
 
 
-def test_split_k_launch_plan_in_a_fresh_process():
-    """MPOSE_SLIM (read once per process by conv.hip's launch plan).  The default since round 4 (= 2) runs the single-pass
-    128-channel training launches unsplit on 64-channel tiles, two workgroups per CU (an accumulation chain of 216 instead of 108);
-    MPOSE_SLIM=1 is round 3's plan (that form for inference launches only, training keeps the two-way K split), 0 never uses
-    it.  Every plan ships as a switch: the same fp32-equivalence cases must hold under each (this process runs the default)."""
-    import subprocess, sys
-    for plan in ('1', '0'):
-        env = dict(os.environ, MPOSE_SLIM=plan)
-        r = subprocess.run([sys.executable, '-m', 'pytest', '-q', '-x', '-m', 'gpu', os.path.abspath(__file__), '-k',
-                            'test_conv3x3_fp32_equivalent or test_conv_prologue_and_bn_statistics'],
-                           env=env, capture_output=True, text=True, timeout=600, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-        assert r.returncode == 0, plan + r.stdout[-2000:] + r.stderr[-2000:]
-        assert ' passed' in r.stdout
-
-
 @pytest.mark.parametrize('layout', [2, 3])
 @pytest.mark.parametrize('cout,cin,T,transposed', [(128, 128, 9, False), (192, 128, 9, True), (17, 128, 9, False), (128, 51, 1, False),
                                                    (96, 64, 7, False), (64, 160, 1, True), (32, 27, 1, False), (64, 3, 49, False)])

@@ -122,36 +122,47 @@ def test_planned_iterations_equal_eager_iterations(stem, overlap):
 
 
 def test_stale_launch_plan_is_refused_and_pending_forwards_survive_a_replay():
-    """A launch plan replays raw addresses.  (1) An eager forward whose backward is still to come keeps its BatchNorm vectors across
-    a replay (Engine.before_replay snapshots them like a forward would): its gradients equal those of the same forward / backward
-    with no replay in between.  (2) A larger eager batch regrows the engine's reduction workspace, a re-bound parameter moves a
-    weight: either makes the recorded addresses stale, and the next replay raises instead of writing through them."""
+    """A launch plan replays raw addresses.  (1) A replayed eval forward (PlannedInference) between an eager training
+    forward and its backward overwrites the engine's BatchNorm arenas like any forward does: the pending forward keeps its vectors
+    (Engine.before_replay snapshots them) and its gradients equal those of the same forward / backward with no replay in between.
+    (2) A replayed TRAINING iteration updates the weights: a pending forward's backward afterwards raises autograd's "modified by an
+    inplace operation", like after an eager optimiser step.  (3) A parameter re-bound behind a plan's back (`p.data = ...`,
+    load_state_dict(assign=True), model.to()) makes the recorded addresses stale: the next replay raises instead of writing
+    through them."""
     from margipose_amd._lib import MposeError
-    from margipose_amd.train_helpers import DeviceSGD, PlannedTrainStep, forward_loss
+    from margipose_amd.train_helpers import DeviceSGD, PlannedInference, PlannedTrainStep, forward_loss
     T, seed, B = 1, 61, 2
     x, target, mask = W.seeded_inputs(seed, B)
     m = _model(T, seed, x)
-    opt = DeviceSGD(m.parameters(), lr=0.0, momentum=0.0)          # (lr 0: the replays leave the weights alone)
-    step = PlannedTrainStep(m, opt, x.cuda(), target.cuda(), mask.cuda())
+    m.eval()
+    infer = PlannedInference(m, x.cuda())
+    m.train()
     xb, tb, mb = (t.cuda() for t in W.seeded_inputs(seed + 1, B))
 
-    def grads(replay_between):
+    def grads(between):
         out = m(xb)
         loss = forward_loss(m, out, tb, mb, [1] * B)
-        if replay_between:
-            step()
+        if between is not None:
+            between()
         for p in m.parameters():
             p.grad = None
         loss.backward()
         return [p.grad.clone() for p in m.parameters()]
-    g0, g1 = grads(False), grads(True)
+    g0, g1 = grads(None), grads(infer)
     for a, b in zip(g0, g1):
         assert torch.equal(a, b)
-    step()                                                           # still valid
+    opt = DeviceSGD(m.parameters(), lr=0.0, momentum=0.0)
+    step = PlannedTrainStep(m, opt, x.cuda(), target.cuda(), mask.cuda())
+    with pytest.raises(RuntimeError, match='modified by an inplace operation'):
+        grads(step)
+    step()                                                           # the plans themselves are still valid
+    infer()
     p0 = next(m.parameters())
-    p0.data = p0.data.clone()                                        # a weight re-bound behind the plan's back
+    p0.data = p0.data.clone()                                        # a weight re-bound behind the plans' back
     with pytest.raises(MposeError, match='stale'):
         step()
+    with pytest.raises(MposeError, match='stale'):
+        infer()
 
 
 def test_training_iteration_launches_only_library_kernels():
