@@ -749,6 +749,290 @@ __global__ __launch_bounds__(256) void average_loss_k(const float* __restrict__ 
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Rows beyond 4096 elements (round 6: heatmaps larger than 64 x 64 -- the reference's only constraint on the input size is
+// 192 % (H/16) == 0, models/margipose_model.py:87-97, so a 768 x 768 input has 96 x 96 heatmaps).  A row no longer fits a wave's
+// registers: one workgroup of 256 threads per (batch, joint) row walks the row of each plane in float4 strides, once per
+// reduction (the row stays in L2 between the passes).  Same formulas as the register kernels above, other summation orders.
+// fp32 tensors only.
+// ---------------------------------------------------------------------------------------------
+constexpr int kBigThreads = 256;
+
+__device__ __forceinline__ float block_sum(float v, float* sh) {      // all threads call it; every thread gets the sum
+  v = wave_sum(v);
+  __syncthreads();                                                     // (sh may still be read from an earlier call)
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+__device__ __forceinline__ float block_max(float v, float* sh) {
+  v = wave_max(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+}
+// normalisation of the Gaussian target (dsntnn.py:154-195) with the whole workgroup
+__device__ __forceinline__ Gauss make_gauss_block(const RowGeom& g, float tx, float ty, float sigma, float* sh) {
+  Gauss q;
+  q.tx = tx; q.ty = ty;
+  const float sdx = 2.0f * sigma / (float)g.W, sdy = 2.0f * sigma / (float)g.H;
+  q.kx = -0.5f * (1.0f / sdx) * (1.0f / sdx);
+  q.ky = -0.5f * (1.0f / sdy) * (1.0f / sdy);
+  float ex = 0.0f, ey = 0.0f;
+  for (int w = threadIdx.x; w < g.W; w += kBigThreads) { const float d = cell_coord(w, g.two_over_w, g.first_w) - tx; ex += expf(d * d * q.kx); }
+  for (int h = threadIdx.x; h < g.H; h += kBigThreads) { const float d = cell_coord(h, g.two_over_h, g.first_h) - ty; ey += expf(d * d * q.ky); }
+  ex = block_sum(ex, sh);
+  ey = block_sum(ey, sh);
+  q.inv_norm = 1.0f / (ex * ey + kEps);
+  return q;
+}
+__device__ __forceinline__ void big_hw(const RowGeom& g, int idx, int& h, int& w0) {
+  const int e0 = idx * 4;
+  h = e0 / g.W;
+  w0 = e0 - h * g.W;
+}
+
+template <bool EXP>
+__global__ __launch_bounds__(kBigThreads) void big_softmax_dsnt_fwd_k(SoftmaxArgs a) {
+  __shared__ float sh[4];
+  __shared__ float s_mu[MPOSE_MAX_GROUP][2];
+  const int row = blockIdx.x;
+  const RowGeom g = make_geom(a.H, a.W);
+  const size_t off = (size_t)row * (size_t)(a.H * a.W);
+  for (int plane = 0; plane < a.n_planes; ++plane) {
+    const float4* src = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.logits[plane]) + off);
+    float4* dst = a.heatmaps[plane] != nullptr ? reinterpret_cast<float4*>(reinterpret_cast<float*>(a.heatmaps[plane]) + off) : nullptr;
+    float m = 0.0f, rs = 1.0f;
+    if (EXP) {
+      m = -INFINITY;
+      for (int i = threadIdx.x; i < g.n4; i += kBigThreads) { const float4 v = src[i]; m = fmaxf(m, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w))); }
+      m = block_max(m, sh);
+      float s = 0.0f;
+      for (int i = threadIdx.x; i < g.n4; i += kBigThreads) { const float4 v = src[i]; s += (expf(v.x - m) + expf(v.y - m)) + (expf(v.z - m) + expf(v.w - m)); }
+      s = block_sum(s, sh);
+      rs = 1.0f / s;
+    }
+    float sx = 0.0f, sy = 0.0f;
+    for (int i = threadIdx.x; i < g.n4; i += kBigThreads) {
+      float4 v = src[i];
+      if (EXP) {
+        v.x = expf(v.x - m) * rs; v.y = expf(v.y - m) * rs; v.z = expf(v.z - m) * rs; v.w = expf(v.w - m) * rs;
+        if (dst != nullptr) dst[i] = v;
+      }
+      int h, w0;
+      big_hw(g, i, h, w0);
+      const float y = cell_coord(h, g.two_over_h, g.first_h), x0 = cell_coord(w0, g.two_over_w, g.first_w);
+      sy = fmaf((v.x + v.y) + (v.z + v.w), y, sy);
+      sx += fmaf(v.w, x0 + 3.0f * g.two_over_w, fmaf(v.z, x0 + 2.0f * g.two_over_w, fmaf(v.y, x0 + g.two_over_w, v.x * x0)));
+    }
+    sx = block_sum(sx, sh);
+    sy = block_sum(sy, sh);
+    if (threadIdx.x == 0) {
+      s_mu[plane][0] = sx; s_mu[plane][1] = sy;
+      if (a.plane_coords != nullptr) { float* pc = a.plane_coords + ((size_t)plane * a.rows + row) * 2; pc[0] = sx; pc[1] = sy; }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && a.n_planes == 3 && a.xyz != nullptr) {
+    float* o = a.xyz + (size_t)row * 3;
+    o[0] = s_mu[0][0]; o[1] = s_mu[0][1]; o[2] = 0.5f * (s_mu[1][0] + s_mu[2][1]);     // models/margipose_model.py:259
+  }
+}
+
+struct BigSoftmaxBwdArgs {
+  SoftmaxBwdArgs a;
+  int n_planes;
+};
+__global__ __launch_bounds__(kBigThreads) void big_softmax_bwd_k(BigSoftmaxBwdArgs b) {
+  __shared__ float sh[4];
+  const SoftmaxBwdArgs& a = b.a;
+  const int n4 = a.n >> 2;
+  const size_t off = (size_t)blockIdx.x * (size_t)a.n;
+  for (int plane = 0; plane < b.n_planes; ++plane) {
+    const float4* p = reinterpret_cast<const float4*>(a.hm[plane] + off);
+    const float4* g1 = reinterpret_cast<const float4*>(a.g1[plane] + off);
+    const float4* g2 = a.g2[plane] != nullptr ? reinterpret_cast<const float4*>(a.g2[plane] + off) : nullptr;
+    float4* d = reinterpret_cast<float4*>(a.dlogits[plane] + off);
+    float s = 0.0f;
+    for (int i = threadIdx.x; i < n4; i += kBigThreads) {
+      const float4 pv = p[i];
+      float4 gv = g1[i];
+      if (g2 != nullptr) { const float4 h = g2[i]; gv.x += h.x; gv.y += h.y; gv.z += h.z; gv.w += h.w; }
+      s += (pv.x * gv.x + pv.y * gv.y) + (pv.z * gv.z + pv.w * gv.w);
+    }
+    s = block_sum(s, sh);
+    for (int i = threadIdx.x; i < n4; i += kBigThreads) {
+      const float4 pv = p[i];
+      float4 gv = g1[i];
+      if (g2 != nullptr) { const float4 h = g2[i]; gv.x += h.x; gv.y += h.y; gv.z += h.z; gv.w += h.w; }
+      d[i] = make_float4(pv.x * (gv.x - s), pv.y * (gv.y - s), pv.z * (gv.z - s), pv.w * (gv.w - s));
+    }
+  }
+}
+
+struct BigDsntBwdArgs {
+  DsntBwdArgs a;
+  int n_planes;
+};
+__global__ __launch_bounds__(kBigThreads) void big_dsnt_bwd_k(BigDsntBwdArgs b) {
+  const DsntBwdArgs& a = b.a;
+  const int row = blockIdx.x;
+  const RowGeom g = make_geom(a.H, a.W);
+  const size_t off = (size_t)row * (size_t)(a.H * a.W);
+  for (int plane = 0; plane < b.n_planes; ++plane) {
+    const float* d = a.d_plane_coords + ((size_t)plane * a.rows + row) * 2;
+    const float dmx = d[0], dmy = d[1];
+    float4* o = reinterpret_cast<float4*>(a.d_hm[plane] + off);
+    for (int i = threadIdx.x; i < g.n4; i += kBigThreads) {
+      int h, w0;
+      big_hw(g, i, h, w0);
+      const float yv = dmy * cell_coord(h, g.two_over_h, g.first_h);
+      const float x0 = cell_coord(w0, g.two_over_w, g.first_w);
+      float4 r = make_float4(fmaf(dmx, x0, yv), fmaf(dmx, x0 + g.two_over_w, yv), fmaf(dmx, x0 + 2.0f * g.two_over_w, yv),
+                             fmaf(dmx, x0 + 3.0f * g.two_over_w, yv));
+      if (a.accumulate) { const float4 t = o[i]; r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w; }
+      o[i] = r;
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBigThreads) void big_stage_loss_fwd_k(LossArgs a) {
+  __shared__ float sh[4];
+  __shared__ float s_part[MPOSE_MAX_GROUP][3];
+  const int row = blockIdx.x;
+  const RowGeom g = make_geom(a.H, a.W);
+  const size_t off = (size_t)row * (size_t)(a.H * a.W);
+  const float* t = a.target + (size_t)row * 3;
+  for (int plane = 0; plane < 3; ++plane) {
+    float sx = 0.0f, sy = 0.0f, js = 0.0f;
+    if (a.three_d || plane == 0) {        // (uniform)
+      const float4* src = reinterpret_cast<const float4*>(a.hm[plane] + off);
+      float tx, ty;
+      plane_target(plane, t, tx, ty);
+      Gauss q{};
+      if (a.pixelwise) q = make_gauss_block(g, tx, ty, a.sigma, sh);
+      for (int i = threadIdx.x; i < g.n4; i += kBigThreads) {
+        const float4 v = src[i];
+        int h, w0;
+        big_hw(g, i, h, w0);
+        const float y = cell_coord(h, g.two_over_h, g.first_h), x0 = cell_coord(w0, g.two_over_w, g.first_w);
+        const float pv[4] = {v.x, v.y, v.z, v.w};
+        sy = fmaf((pv[0] + pv[1]) + (pv[2] + pv[3]), y, sy);
+        float gy = 0.0f;
+        if (a.pixelwise) { const float d = y - q.ty; gy = expf(d * d * q.ky) * q.inv_norm; }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float x = x0 + (float)c * g.two_over_w;
+          sx = fmaf(pv[c], x, sx);
+          if (a.pixelwise) { const float d = x - q.tx; js += js_term(pv[c], gy * expf(d * d * q.kx)); }
+        }
+      }
+      sx = block_sum(sx, sh); sy = block_sum(sy, sh); js = block_sum(js, sh);
+    }
+    if (threadIdx.x == 0) { s_part[plane][0] = sx; s_part[plane][1] = sy; s_part[plane][2] = js; }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float x = s_part[0][0], y = s_part[0][1];
+    float z = 0.0f, loss;
+    if (a.three_d) {
+      z = 0.5f * (s_part[1][0] + s_part[2][1]);
+      const float dx = x - t[0], dy = y - t[1], dz = z - t[2];
+      loss = sqrtf(dx * dx + dy * dy + dz * dz) + ((s_part[0][2] + s_part[1][2]) + s_part[2][2]);
+    } else {
+      const float dx = x - t[0], dy = y - t[1];
+      loss = sqrtf(dx * dx + dy * dy) + s_part[0][2];
+    }
+    float* lo = a.losses + row;
+    *lo = a.accumulate ? (*lo + loss) : loss;
+    if (a.xyz_out != nullptr) { float* o = a.xyz_out + (size_t)row * 3; o[0] = x; o[1] = y; o[2] = z; }
+  }
+}
+
+__global__ __launch_bounds__(kBigThreads) void big_stage_loss_bwd_k(LossArgs a) {
+  __shared__ float sh[4];
+  const int row = blockIdx.x;
+  const RowGeom g = make_geom(a.H, a.W);
+  const size_t off = (size_t)row * (size_t)(a.H * a.W);
+  const float* t = a.target + (size_t)row * 3;
+  const float* mu = a.xyz_in + (size_t)row * 3;
+  const float wgt = a.dloss[row];
+  const float dx = mu[0] - t[0], dy = mu[1] - t[1], dz = a.three_d ? (mu[2] - t[2]) : 0.0f;
+  const float dist = sqrtf(dx * dx + dy * dy + dz * dz);
+  const float ex = dx / dist, ey = dy / dist, ez = dz / dist;
+  for (int plane = 0; plane < 3; ++plane) {
+    float4* dst = reinterpret_cast<float4*>(a.g[plane] + off);
+    if (!(a.three_d || plane == 0)) {
+      if (!a.accumulate)
+        for (int i = threadIdx.x; i < g.n4; i += kBigThreads) dst[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      continue;
+    }
+    const float cx = (plane == 0) ? ex : (plane == 1 ? 0.5f * ez : 0.0f);
+    const float cy = (plane == 0) ? ey : (plane == 2 ? 0.5f * ez : 0.0f);
+    const float4* src = reinterpret_cast<const float4*>(a.hm[plane] + off);
+    float tx, ty;
+    plane_target(plane, t, tx, ty);
+    Gauss q{};
+    if (a.pixelwise) q = make_gauss_block(g, tx, ty, a.sigma, sh);
+    for (int i = threadIdx.x; i < g.n4; i += kBigThreads) {
+      const float4 v = src[i];
+      int h, w0;
+      big_hw(g, i, h, w0);
+      const float y = cell_coord(h, g.two_over_h, g.first_h), x0 = cell_coord(w0, g.two_over_w, g.first_w);
+      float gy = 0.0f;
+      if (a.pixelwise) { const float d = y - q.ty; gy = expf(d * d * q.ky) * q.inv_norm; }
+      const float pv[4] = {v.x, v.y, v.z, v.w};
+      float r[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float x = x0 + (float)c * g.two_over_w;
+        float d = cx * x + cy * y;
+        if (a.pixelwise) { const float dd = x - q.tx; d += js_dp(pv[c], gy * expf(dd * dd * q.kx)); }
+        r[c] = wgt * d;
+      }
+      if (a.accumulate) { const float4 o = dst[i]; r[0] += o.x; r[1] += o.y; r[2] += o.z; r[3] += o.w; }
+      dst[i] = make_float4(r[0], r[1], r[2], r[3]);
+    }
+  }
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(kBigThreads) void big_js_k(JsArgs a) {
+  __shared__ float sh[4];
+  const int row = blockIdx.x;
+  const RowGeom g = make_geom(a.H, a.W);
+  const size_t off = (size_t)row * (size_t)(a.H * a.W);
+  const float4* src = reinterpret_cast<const float4*>(a.hm + off);
+  const Gauss q = make_gauss_block(g, a.mu[(size_t)row * 2], a.mu[(size_t)row * 2 + 1], a.sigma, sh);
+  const float wgt = BWD ? a.djs[row] : 0.0f;
+  float js = 0.0f;
+  for (int i = threadIdx.x; i < g.n4; i += kBigThreads) {
+    const float4 v = src[i];
+    int h, w0;
+    big_hw(g, i, h, w0);
+    const float dy = cell_coord(h, g.two_over_h, g.first_h) - q.ty;
+    const float gy = expf(dy * dy * q.ky) * q.inv_norm;
+    const float x0 = cell_coord(w0, g.two_over_w, g.first_w);
+    const float pv[4] = {v.x, v.y, v.z, v.w};
+    float r[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float dxx = x0 + (float)c * g.two_over_w - q.tx;
+      const float gq = gy * expf(dxx * dxx * q.kx);
+      if (BWD) r[c] = wgt * js_dp(pv[c], gq);
+      else js += js_term(pv[c], gq);
+    }
+    if (BWD) reinterpret_cast<float4*>(a.g + off)[i] = make_float4(r[0], r[1], r[2], r[3]);
+  }
+  if (!BWD) {
+    js = block_sum(js, sh);
+    if (threadIdx.x == 0) a.js[row] = js;
+  }
+}
+
+inline bool big_row(long n) { return n > 4096 && (n & 3) == 0 && n <= (1l << 24); }
+
 inline int pick_nv(int n) {
   if (n <= 0 || (n & 3) || n > 4096) return 0;
   const int nv = (n / 4 + 63) / 64;
@@ -779,6 +1063,11 @@ extern "C" int mpose_softmax_dsnt_fwd(const void* const* logits, void* const* he
   for (int p = 0; p < n_planes; ++p) { a.logits[p] = logits[p]; a.heatmaps[p] = heatmaps ? heatmaps[p] : nullptr; }
   a.plane_coords = plane_coords; a.xyz = xyz; a.n_planes = n_planes; a.rows = rows; a.H = H; a.W = W;
   hipStream_t s = (hipStream_t)stream;
+  if (big_row((long)H * W)) {           // heatmaps beyond 64 x 64: the multi-pass form (fp32 only)
+    if (io_dtype != 0) return MPOSE_EINVAL;
+    launch(big_softmax_dsnt_fwd_k<true>, dim3(rows), dim3(kBigThreads), 0, s, a);
+    return launch_status();
+  }
   // variant = rows per workgroup (1, 2) + 16 * NT bits (every variant is bit-identical; profiles/r5_tail_variants.txt).
   // Sizes whose logits + heatmaps exceed the 256 MB Infinity Cache stream (non-temporal both ways, two rows per workgroup);
   // smaller ones keep plain accesses -- their heatmaps are re-read from the cache by the next stage's combiner and the loss kernels.
@@ -861,6 +1150,10 @@ extern "C" int mpose_dsnt_fwd(const float* const* heatmaps, float* plane_coords,
   SoftmaxArgs a{};
   for (int p = 0; p < n_planes; ++p) { a.logits[p] = heatmaps[p]; a.heatmaps[p] = nullptr; }
   a.plane_coords = plane_coords; a.xyz = xyz; a.n_planes = n_planes; a.rows = rows; a.H = H; a.W = W;
+  if (big_row((long)H * W)) {
+    launch(big_softmax_dsnt_fwd_k<false>, dim3(rows), dim3(kBigThreads), 0, (hipStream_t)stream, a);
+    return launch_status();
+  }
   MPOSE_DISPATCH_NV(nv, (launch(softmax_dsnt_fwd_k<NV, false, false, false>, dim3(rows), dim3(64 * n_planes), 0, (hipStream_t)stream, a)));
   return launch_status();
 }
@@ -874,6 +1167,10 @@ extern "C" int mpose_dsnt_bwd(const float* d_plane_coords, float* const* d_heatm
   a.d_plane_coords = d_plane_coords;
   for (int p = 0; p < n_planes; ++p) a.d_hm[p] = d_heatmaps[p];
   a.rows = rows; a.H = H; a.W = W; a.accumulate = accumulate;
+  if (big_row((long)H * W)) {
+    launch(big_dsnt_bwd_k, dim3(rows), dim3(kBigThreads), 0, (hipStream_t)stream, BigDsntBwdArgs{a, n_planes});
+    return launch_status();
+  }
   MPOSE_DISPATCH_NV(nv, (launch(dsnt_bwd_k<NV>, dim3(rows), dim3(64 * n_planes), 0, (hipStream_t)stream, a)));
   return launch_status();
 }
@@ -888,6 +1185,10 @@ extern "C" int mpose_softmax_bwd(const float* const* heatmaps, const float* cons
     a.hm[p] = heatmaps[p]; a.g1[p] = g1[p]; a.g2[p] = g2 ? g2[p] : nullptr; a.dlogits[p] = dlogits[p];
   }
   a.n = n;
+  if (big_row(n)) {
+    launch(big_softmax_bwd_k, dim3(rows), dim3(kBigThreads), 0, (hipStream_t)stream, BigSoftmaxBwdArgs{a, n_planes});
+    return launch_status();
+  }
   MPOSE_DISPATCH_NV(nv, (launch(softmax_bwd_k<NV>, dim3(rows), dim3(64 * n_planes), 0, (hipStream_t)stream, a)));
   return launch_status();
 }
@@ -909,6 +1210,10 @@ extern "C" int mpose_stage_loss_fwd(const float* const* heatmaps, const float* t
   if (rows == 0) return 0;
   a.losses = losses; a.xyz_out = xyz_out;
   const int nv = pick_nv(H * W);
+  if (big_row((long)H * W)) {
+    launch(big_stage_loss_fwd_k, dim3(rows), dim3(kBigThreads), 0, (hipStream_t)stream, a);
+    return launch_status();
+  }
   MPOSE_DISPATCH_NV(nv, (launch(stage_loss_fwd_k<NV>, dim3(rows), dim3(64 * 3), 0, (hipStream_t)stream, a)));
   return launch_status();
 }
@@ -923,6 +1228,10 @@ extern "C" int mpose_stage_loss_bwd(const float* const* heatmaps, const float* t
   a.xyz_in = xyz; a.dloss = dloss;
   for (int p = 0; p < 3; ++p) a.g[p] = g[p];
   const int nv = pick_nv(H * W);
+  if (big_row((long)H * W)) {
+    launch(big_stage_loss_bwd_k, dim3(rows), dim3(kBigThreads), 0, (hipStream_t)stream, a);
+    return launch_status();
+  }
   MPOSE_DISPATCH_NV(nv, (launch(stage_loss_bwd_k<NV>, dim3(rows), dim3(64 * 3), 0, (hipStream_t)stream, a)));
   return launch_status();
 }
@@ -932,6 +1241,10 @@ extern "C" int mpose_js_fwd(const float* heatmaps, const float* mu, float* js, i
   if (rows == 0) return 0;
   JsArgs a{heatmaps, mu, nullptr, js, nullptr, H, W, sigma};
   const int nv = pick_nv(H * W);
+  if (big_row((long)H * W)) {
+    launch(big_js_k<false>, dim3(rows), dim3(kBigThreads), 0, (hipStream_t)stream, a);
+    return launch_status();
+  }
   MPOSE_DISPATCH_NV(nv, (launch(js_k<NV, false>, dim3(rows), dim3(64), 0, (hipStream_t)stream, a)));
   return launch_status();
 }
@@ -942,6 +1255,10 @@ extern "C" int mpose_js_bwd(const float* heatmaps, const float* mu, const float*
   if (rows == 0) return 0;
   JsArgs a{heatmaps, mu, djs, nullptr, g, H, W, sigma};
   const int nv = pick_nv(H * W);
+  if (big_row((long)H * W)) {
+    launch(big_js_k<true>, dim3(rows), dim3(kBigThreads), 0, (hipStream_t)stream, a);
+    return launch_status();
+  }
   MPOSE_DISPATCH_NV(nv, (launch(js_k<NV, true>, dim3(rows), dim3(64), 0, (hipStream_t)stream, a)));
   return launch_status();
 }

@@ -14,8 +14,8 @@ def _rows_hw(t):
     if t.dim() != 4:
         raise _lib.MposeError('expected a (B, J, H, W) tensor, got shape %s' % (tuple(t.shape),))
     b, j, h, w = t.shape
-    if w % 4 != 0 or h * w > 4096:
-        raise _lib.MposeError('heatmap size %dx%d unsupported (need W %% 4 == 0 and H*W <= 4096)' % (h, w))
+    if w % 4 != 0 or h * w > (1 << 24):      # (rows beyond 4096 elements run csrc/tail.hip's multi-pass kernels)
+        raise _lib.MposeError('heatmap size %dx%d unsupported (need W %% 4 == 0)' % (h, w))
     return b * j, h, w
 
 

@@ -705,16 +705,15 @@ class Engine:
                         if self.h2_planes:       # ... of the shortcut's BatchNorm (d_sc) and of bn1 (d_c1, from the largest |d_a1|) too
                             cj[base + 3 + c]['g_amax'], cj[base + 3 + c]['bound_out'] = self._amax_b(t, i, 3, c), self._amax_b(t, i, 2, c)
                             cj[base + 6 + c]['g_amax'], cj[base + 6 + c]['bound_out'] = self._amax_b(t, i, 4, c), self._amax_b(t, i, 1, c)
-        if self.stats_part:
-            for t in range(self.T):
-                for i in range(10):
-                    base = (t * 10 + i) * 9
-                    for c, b in enumerate(self.stage_blocks[t][i]):
-                        for jn, bn in ((1 + base + c, b.bn1), (1 + base + 3 + c, b.bns), (1 + base + 6 + c, b.bn2)):
-                            fj[jn]['part'], fj[jn]['n_part'], fj[jn]['part_ld'] = tb['sp_ptr'][(id(bn), 'f')], sp[(id(bn), 'f')][1], b.cout_s
-                        fj[1 + base + c]['mm_part'] = tb['sp_ptr'][(id(b.bn1), 'mm')]
-                        for jn, pk in ((base + c, (id(b.bn2), 'b')), (base + 3 + c, (id(b.bn2), 'b')), (base + 6 + c, (id(b.bn1), 'b'))):
-                            cj[jn]['part'], cj[jn]['n_part'], cj[jn]['part_ld'] = tb['sp_ptr'][pk], sp[pk][1], b.cout_s
+        for t in range(self.T):
+            for i in range(10):
+                base = (t * 10 + i) * 9
+                for c, b in enumerate(self.stage_blocks[t][i]):
+                    for jn, bn in ((1 + base + c, b.bn1), (1 + base + 3 + c, b.bns), (1 + base + 6 + c, b.bn2)):
+                        fj[jn]['part'], fj[jn]['n_part'], fj[jn]['part_ld'] = tb['sp_ptr'][(id(bn), 'f')], sp[(id(bn), 'f')][1], b.cout_s
+                    fj[1 + base + c]['mm_part'] = tb['sp_ptr'][(id(b.bn1), 'mm')]
+                    for jn, pk in ((base + c, (id(b.bn2), 'b')), (base + 3 + c, (id(b.bn2), 'b')), (base + 6 + c, (id(b.bn1), 'b'))):
+                        cj[jn]['part'], cj[jn]['n_part'], cj[jn]['part_ld'] = tb['sp_ptr'][pk], sp[pk][1], b.cout_s
         tb['n_unpack'] = self.T * 90 + n_stem_convs
         tb['partials'] = torch.empty(part_off, dtype=torch.float32, device=dev)
         pbase = tb['partials'].data_ptr()
@@ -1019,7 +1018,7 @@ class Engine:
         # (beyond 128 MB the library takes the kernel's all-joints form -- every line read once -- when the J rows fit in LDS)
         tail_fused = (self.tail_fuse and (F & 3) == 0 and F * F <= 4096 and
                       (6 * B * F * F * 32 * 4 <= (128 << 20) or self.J * (F * F + 4) * 4 <= 144 * 1024))
-        if 192 % Sm != 0 or (Sm % 4) != 0 or (F * F) % 64 != 0 or F * F > 4096:
+        if 192 % Sm != 0 or (Sm % 4) != 0 or (F * F) % 64 != 0:
             raise _lib.MposeError('unsupported input size %d (mid size %d must divide 192 and be a multiple of 4)' % (S, Sm))
         if save and Sm % 8 != 0:       # the weight-gradient kernel walks slot rows in octets (mpose_conv_wgrad: GW % 8 == 0)
             raise _lib.MposeError('input size %d is inference-only: training needs a mid size (%d = S/16) that is a multiple of 8, '

@@ -380,7 +380,7 @@ class PlannedTrainStep:
             raise
         torch.cuda.synchronize()
         L = _lib.lib()
-        self._sides = [s for s in ((eng.side_stream if eng.overlap_wgrad else None), eng.fwd_side_stream) if s is not None]
+        self._sides = [s for s in ((eng.side_stream if eng.overlap_wgrad else None),) if s is not None]
         dev = x.device.index if x.device.index is not None else torch.cuda.current_device()
         self._pool = torch.cuda.MemPool()
         optimiser.upload_hyper()                  # (outside the recording, see DeviceSGD.step)
@@ -489,7 +489,7 @@ class PlannedInference:
         self._cmode = eng._packed_for          # (the warm-up forward's engine mode: what the recording will run)
         self._stamp = None
         eng.pack_frozen = self._frozen
-        self._sides = [s for s in (eng.side_stream, eng.fwd_side_stream) if s is not None]      # (side_stream: the columns' weight pack)
+        self._sides = []           # (a forward runs on one stream)
         dev = x.device.index if x.device.index is not None else torch.cuda.current_device()
         self._pool = torch.cuda.MemPool()
         arr = self._stream_array()

@@ -331,9 +331,11 @@ def test_full_config_shapes_and_properties():
     assert (full[:4] - half).abs().max() < 1e-4
 
 
-@pytest.mark.parametrize('size,T', [(384, 1), (512, 1), (128, 2)])
+@pytest.mark.parametrize('size,T', [(384, 1), (512, 1), (128, 2), (768, 1)])
 def test_other_input_sizes_vs_oracle(size, T):
-    """The model is fully convolutional (384 -> 48x48 heatmaps / mid 24, 512 -> 64x64 / mid 32)."""
+    """The model is fully convolutional (384 -> 48x48 heatmaps / mid 24, 512 -> 64x64 / mid 32).  768 -> 96x96 / mid 48
+    (round 6): the reference's only size rule is 192 % (S/16) == 0 (models/margipose_model.py:87-97); heatmap rows beyond 4096
+    elements run the tail's multi-pass kernels, the stages' wider images the general tile forms of the convolution kernels."""
     from margipose_amd import dsntnn
     from margipose_amd.models import CanonicalSkeletonDesc, MargiPoseModel
     seed, B = 600 + size, 1 if size > 256 else 2

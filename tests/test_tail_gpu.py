@@ -73,7 +73,7 @@ def test_tail_vs_golden(D, golden_dir, case):
         np.testing.assert_allclose(got, ref, rtol=1e-3, atol=2e-5 * np.abs(ref).max() + 1e-12)
 
 
-@pytest.mark.parametrize('F', [32, 48, 64])
+@pytest.mark.parametrize('F', [32, 48, 64, 96, 128])      # (96, 128: rows beyond 4096 elements -- the multi-pass kernels of round 6)
 def test_individual_ops_vs_oracle(D, F):
     rng = np.random.default_rng(7 + F)
     B = 3
