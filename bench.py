@@ -268,7 +268,7 @@ def configs4_leg(device, steps=8, warmup=3, batch=32):
         step()
     # (the same dispatch as the headline step: the iteration from a launch plan, so that the figure does not depend on the host)
     planned, dispatch = None, 'eager launches (Python / ctypes)'
-    if os.environ.get('MPOSE_PLAN', '1') != '0':
+    if True:
         try:
             from margipose_amd.train_helpers import PlannedTrainStep
             planned = PlannedTrainStep(model, opt, x, target, mask, warmup=1)
@@ -422,10 +422,6 @@ def main():
     target = (torch.rand(B, 17, 3, generator=g) * 2 - 1).to(device)
     mask = torch.ones(B, 17, device=device)
 
-    hi_stream = torch.cuda.Stream(device=device, priority=int(os.environ['MPOSE_MAIN_PRIO'])) if os.environ.get('MPOSE_MAIN_PRIO') else None
-    if hi_stream is not None:          # (experiment: the whole step on a stream of another queue priority than the side stream's)
-        torch.cuda.set_stream(hi_stream)
-
     def eager_step():
         out = model(x)
         loss = dsntnn.average_loss(model.forward_3d_losses(out, target), mask)
@@ -455,7 +451,7 @@ def main():
     # eager two-stream schedule, kernel for kernel, without ~700 Python-issued launches per step (15 ms of host time on the pool's
     # fast hosts, 28 ms on its slow ones, where the eager step is host-bound).  --eager issues every launch from Python.
     planned = None
-    if graphed is None and not args.eager and not args.no_plan and os.environ.get('MPOSE_PLAN', '1') != '0':
+    if graphed is None and not args.eager and not args.no_plan:
         try:
             planned = PlannedTrainStep(model, opt, x, target, mask, warmup=2)
         except Exception as e:          # a failed recording must not cost the measurement: fall back to eager launches

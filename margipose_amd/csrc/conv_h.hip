@@ -758,6 +758,7 @@ __global__ __launch_bounds__(256, 2) void conv_h2r_k(ConvHRArgs a) {
       }
       const int k_hi = (ja + 1) * la < ngw ? (ja + 1) * la : ngw;
       for (int k = ja * la; k < k_hi; ++k) {
+        if (X1 && wave + 4 * k >= 2 * a.NG) continue;      // (an odd NG: the last ids of the list are the l plane's sub-arrays, which X1 neither reads nor has room for)
         const unsigned q = q0 + (unsigned)__builtin_amdgcn_readlane(tab_arow, k);
         const unsigned vo = (a_live && q < (unsigned)npix && !(CH_EXP & 1)) ? q * 16u : kOob;
         const unsigned soff = a_live ? __builtin_amdgcn_readlane(tab_asoff, k) + (unsigned)ca * a_chunk : 0u;

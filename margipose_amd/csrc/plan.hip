@@ -137,8 +137,19 @@ static inline unsigned grid_of(long n, int per_block, unsigned cap) {
 
 using namespace mpose;
 
+// A recording that failed or was aborted is not freed on the spot: a launch on another thread (autograd's device thread) may have
+// loaded the recorder pointer just before it was cleared and be about to lock the plan's mutex.  It is parked and freed
+// by the NEXT mpose_plan_begin / mpose_plan_abort, by which time that launch has long returned.
+static std::atomic<Plan*> g_plan_dead{nullptr};
+static void park_dead_plan(Plan* p) {
+  if (p != nullptr) { std::lock_guard<std::mutex> lock(p->mu); }      // (a recorder that is inside right now finishes first)
+  Plan* old = g_plan_dead.exchange(p, std::memory_order_acq_rel);
+  if (old != nullptr) delete old;
+}
+
 extern "C" int mpose_plan_begin(void* const* streams, int n_streams) {
   if (n_streams < 1 || n_streams > 8 || !streams) return MPOSE_EINVAL;
+  park_dead_plan(nullptr);
   Plan* p = new Plan();
   for (int i = 0; i < n_streams; ++i) p->rec_streams.push_back((hipStream_t)streams[i]);
   Plan* expected = nullptr;
@@ -168,7 +179,7 @@ extern "C" int mpose_plan_end(void** plan_out) {
       for (auto e : p->events) if (e) (void)hipEventDestroy(e);
   }
   if (!ok) {
-    delete p;
+    park_dead_plan(p);
     return MPOSE_EINVAL;
   }
   *plan_out = p;
@@ -177,7 +188,7 @@ extern "C" int mpose_plan_end(void** plan_out) {
 
 extern "C" int mpose_plan_abort(void) {
   Plan* p = g_plan_rec.exchange(nullptr, std::memory_order_acq_rel);
-  if (p != nullptr) delete p;
+  if (p != nullptr) park_dead_plan(p);
   return 0;
 }
 

@@ -1364,7 +1364,8 @@ class Engine:
         # combiners: mpose_reduce_partials): no zero fill then (24 us for 178 MB).  A stage without any gradient is skipped and
         # its parameters keep the fill's zeros.  MPOSE_GFLAT_FILL=1 always fills, =2 fills with NaNs instead of skipping
         # (test_every_gradient_element_is_written: no gradient may keep one)
-        if _GFLAT_FILL == 1 or all(g_hms[p][self.T - 1] is None for p in range(3)):
+        # (a frozen parameter -- requires_grad False -- may change what the pass writes: the fill runs, 24 us)
+        if _GFLAT_FILL == 1 or all(g_hms[p][self.T - 1] is None for p in range(3)) or not all(p.requires_grad for p in self.param_list()):
             _lib.fill_zero(self.gflat)
         elif _GFLAT_FILL == 2:
             check(lib().mpose_fill_u32(c_void_p(self.gflat.data_ptr()), 0x7fc00000, c_int64(4 * self.gflat.numel()), stream_ptr()), 'mpose_fill_u32')

@@ -390,3 +390,54 @@ def test_weight_gradient_from_plane_operands(B, H, n_split, single, loosen):
     wo.in_, wo.gout0, wo.dw0 = big.data_ptr(), big.data_ptr(), torch.zeros(9 * 192 * 192, device='cuda').data_ptr()
     wo.in_amax, wo.gout0_amax, wo.planes_in = slots[0].data_ptr(), slots[1].data_ptr(), 1
     assert L.mpose_conv_wgrad(ctypes.byref(g_bad), (WgradOperands * 1)(wo), 1, 1, _lib.stream_ptr()) != 0
+
+
+@pytest.mark.parametrize('B,H', [(2, 32), (3, 16), (2, 24)])
+def test_single_product_mode_reads_the_h_planes(B, H):
+    """MPOSE_CONV_F16X1 | MPOSE_CONV_H2_IN (round 6: conv_h2r_k<., ., X1>): the fp16-rounded mode on producer-split planes -- the kernel
+    reads the h planes alone (half the DMA and fragment reads, one product) -- against conv_igemm_k's MPOSE_CONV_F16X1 on the fp32
+    tensors those planes were split from: the same fp16-rounded operands (same slots, same scale exponents), exact products, fp32
+    accumulation in another order.  All three launch kinds of a regular block: the 3x3, the 3x3 + fused 1x1 shortcut (two outputs),
+    the two-input sum; image widths whose halo tile has an odd and an even number of 64-row groups."""
+    L, _lib, eng = _lib_eng()
+    from margipose_amd._lib import ConvOperands
+    C, X1 = 128, 64
+    rng = np.random.default_rng(H)
+    x0 = torch.from_numpy(_data(rng, (B, H, H, C), 'relu')).float().cuda()
+    x1 = torch.from_numpy(rng.standard_normal((B, H, H, C)) * 0.1).float().cuda()
+    w3 = torch.from_numpy(rng.standard_normal((C, C, 3, 3)) * (2.0 / (9 * C)) ** 0.5).float().cuda()
+    w1 = torch.from_numpy(rng.standard_normal((C, C, 1, 1)) * (2.0 / C) ** 0.5).float().cuda()
+    slots = _amax([x0, x1], C)
+    x0h, x1h = _split([x0, x1], slots, C)
+    packs = {lay: (_pack(w3, C, C, 9, lay), _pack(w1, C, C, 1, lay)) for lay in (2, 3)}
+    geoms = {0: eng._geom(B, H, C, H, C, 0, H, 1, 1, [(0, 0, T9(eng))], 128),
+             1: eng._geom(B, H, C, H, C, C, H, 1, 1, [(0, 0, T9(eng) + [(0, 0, 0, 1)])], 128, 128),
+             2: eng._geom(B, H, C, H, C, C, H, 1, 1, [(0, 0, T9D(eng) + [(0, 0, 0, 1)])], 128, 128)}
+
+    def run(mode, h2):
+        (p3, a3, _), (p1, a1, _) = packs[3 if h2 else 2]
+        out0 = torch.full((B, H, H, C), float('nan'), device='cuda'); out1 = out0.clone()
+        op = ConvOperands()
+        op.in_, op.in_amax = (x0h if h2 else x0).data_ptr(), slots[0].data_ptr()
+        op.w0, op.w0_amax, op.out0 = p3.data_ptr(), a3.data_ptr(), out0.data_ptr()
+        if mode:
+            op.w1, op.w1_amax = p1.data_ptr(), a1.data_ptr()
+        if mode == 1:
+            op.out1 = out1.data_ptr()
+        if mode == 2:
+            op.in1, op.in1_amax = (x1h if h2 else x1).data_ptr(), slots[1].data_ptr()
+        flags = F16X3 | X1 | (H2 if h2 else 0) | (2 if mode == 2 else 0)
+        _lib.check(L.mpose_conv_fwd(ctypes.byref(geoms[mode]), (ConvOperands * 1)(op), 1, flags, _lib.stream_ptr()), 'conv')
+        torch.cuda.synchronize()
+        return out0, out1
+    for mode in (0, 1, 2):
+        a0, a1_ = run(mode, True)
+        b0, b1_ = run(mode, False)
+        assert bool(torch.isfinite(a0).all())
+        assert float((a0 - b0).abs().max() / b0.abs().max()) < 2e-6, mode
+        if mode == 1:
+            assert float((a1_ - b1_).abs().max() / b1_.abs().max()) < 2e-6
+    # and it IS the reduced-precision arithmetic: 2^-11-sized roundings against the fp32-equivalent form
+    ref = F.conv2d(x0.permute(0, 3, 1, 2).double().cpu(), w3.double().cpu(), padding=1).permute(0, 2, 3, 1)
+    e = float((run(0, True)[0].cpu().double() - ref).abs().max() / ref.abs().max())
+    assert 1e-6 < e < 3e-3, e

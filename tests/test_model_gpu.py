@@ -496,24 +496,35 @@ def test_unused_stage_gets_zero_grads():
     assert float(m.inner.xy_hm_cnns[0].down_layers[0].module[0].weight.grad.abs().max()) > 0
 
 
-@pytest.mark.parametrize('stem', ['patch8', 'inceptionv4'])
-def test_every_gradient_element_is_written(stem, monkeypatch):
+@pytest.mark.parametrize('stem,variant', [('patch8', 'default'), ('inceptionv4', 'default'), ('patch8', 'stage_unpack'), ('patch8', 'eval_bn'),
+                                          ('patch8', 'frozen')])
+def test_every_gradient_element_is_written(stem, variant, monkeypatch):
     """The backward pass does not zero the flat gradient buffer when every stage runs (engine.py, MPOSE_GFLAT_FILL): with the
     buffer poisoned with NaNs first, no parameter's gradient may keep one, and the gradients equal those of a zero-filled run
-    bit for bit."""
+    bit for bit -- on the default schedule, with the split-K partials unpacked once per stage and the coefficient jobs as their
+    own launches ('stage_unpack'), through eval-mode BatchNorm ('eval_bn': other coefficient jobs write the BatchNorm gradients),
+    and with a frozen parameter ('frozen': the engine falls back to the zero fill -- ADVICE r5)."""
     import copy
     from margipose_amd import engine as eng_mod
     from margipose_amd.models import CanonicalSkeletonDesc, MargiPoseModel
     torch.manual_seed(11)
     m0 = MargiPoseModel(CanonicalSkeletonDesc, 2, True, stem, 'jsd').cuda().train()
+    if variant == 'eval_bn':
+        m0.eval()
+    if variant == 'frozen':
+        next(m0.parameters()).requires_grad_(False)
     m1 = copy.deepcopy(m0)
     x = torch.randn(2, 3, 256, 256, device='cuda')
     tgt = torch.rand(2, 17, 3, device='cuda') * 2 - 1
     grads = []
     for m, mode in ((m0, 1), (m1, 2)):
         monkeypatch.setattr(eng_mod, '_GFLAT_FILL', mode)
+        if variant == 'stage_unpack':
+            m.inner.engine().inline_unpack = False
+            m.inner.engine().fuse_coef = False
         m.forward_3d_losses(m(x), tgt).mean().backward()
-        grads.append(dict((k, p.grad.clone()) for k, p in m.named_parameters()))
+        grads.append(dict((k, p.grad.clone()) for k, p in m.named_parameters() if p.grad is not None))
+    assert grads[0].keys() == grads[1].keys() and len(grads[1]) > 50
     for k, g in grads[1].items():
         assert bool(torch.isfinite(g).all()), k
         assert torch.equal(g, grads[0][k]), k
