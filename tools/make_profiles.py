@@ -53,20 +53,22 @@ labels = {   # bench.py kernel tag -> (template, threads in the grid, algorithmi
     # round 4: the regular 128-channel blocks' forward launches and second-3x3 data gradient run conv_h.hip's conv_h2r_k<RN, MODE> on
     # producer-split fp16 planes (4 bytes per element, like fp32); MODE 0 = one pass (f_conv2 AND d_conv2: the PMC average mixes the two,
     # so does its algorithmic figure below), MODE 1 = the fused shortcut as a second pass into a second output (f_in_regular)
-    'conv:f_conv2/32x32/128->128': ('conv_h2r_k<2, 0>', None, 3 * 32768 * (128 * 4 + 128 * 4) + 3 * 9 * 128 * 128 * 4),
-    'conv:d_conv2/32x32/128->128': ('conv_h2r_k<2, 0>', None, 3 * 32768 * (128 * 4 + 128 * 4 + 128 * 4) + 3 * 9 * 128 * 128 * 4),
-    'conv:f_in_regular/32x32/128->128': ('conv_h2r_k<2, 1>', None, 3 * 32768 * (128 * 4 + 2 * 128 * 4) + 3 * 10 * 128 * 128 * 4),
-    'conv:d_in_regular/32x32/128->128': ('conv_igemm_k<4, 2, 2, false, 2, true>', 256 * 3 * 256, 3 * 32768 * (2 * 128 * 4 + 128 * 4) + 3 * 10 * 128 * 128 * 4),
+    'conv:f_conv2/32x32/128->128': ('conv_h2r_k<2, 0, false>', None, 3 * 32768 * (128 * 4 + 128 * 4) + 3 * 9 * 128 * 128 * 4),
+    'conv:d_conv2/32x32/128->128': ('conv_h2r_k<2, 0, false>', None, 3 * 32768 * (128 * 4 + 128 * 4 + 128 * 4) + 3 * 9 * 128 * 128 * 4),
+    'conv:f_in_regular/32x32/128->128': ('conv_h2r_k<2, 1, false>', None, 3 * 32768 * (128 * 4 + 2 * 128 * 4) + 3 * 10 * 128 * 128 * 4),
+    # round 6: the two-input data gradient on conv_h2r_k<2, 2> (both inputs as planes; + the consumer block's c2 and sc read for its BatchNorm-backward sums)
+    'conv:d_in_regular/32x32/128->128': ('conv_h2r_k<2, 2, false>', None, 3 * 32768 * (2 * 128 * 4 + 128 * 4 + 2 * 128 * 4) + 3 * 10 * 128 * 128 * 4),
     'conv:f_conv2/16x16/192->192': ('conv_igemm_k<3, 0, 1, true, 2, true>', None, 3 * 8192 * (192 * 4 + 192 * 4) + 3 * 9 * 192 * 192 * 4),
     'conv:d_conv2/16x16/192->192': ('conv_igemm_k<3, 0, 1, false, 2, true>', None, 3 * 8192 * (192 * 4 + 192 * 8) + 3 * 9 * 192 * 192 * 4),
     'conv:f_in_regular/16x16/192->192': ('conv_igemm_k<3, 1, 1, false, 2, true>', None, 3 * 8192 * (192 * 4 + 2 * 192 * 4) + 3 * 10 * 192 * 192 * 4),
     'conv:d_in_regular/16x16/192->192': ('conv_igemm_k<3, 2, 1, false, 2, true>', None, 3 * 8192 * (2 * 192 * 4 + 192 * 4) + 3 * 10 * 192 * 192 * 4),
     # round 3: the row-of-taps weight gradient (wgrad.hip), template <WK, WN, KB, NB, PRO, PAIR, X1>; algorithmic bytes = the input and the
     # gradient(s) read once + the split-K partial sums written once (n_split x taps x Cin x Cout x 4: 28 / 21 / 9 / 7 splits at B = 32)
-    'wgrad:f_conv2/32x32/128->128': ('conv_wgrad_rows_k<2, 2, 2, 2, true, true, false>', None, 3 * 32768 * 128 * 8 + 3 * 28 * 9 * 128 * 128 * 4),
-    'wgrad:f_in_regular/32x32/128->128': ('conv_wgrad_rows_k<2, 2, 2, 2, false, true, false>', None, 3 * 32768 * 128 * 12 + 3 * 21 * 10 * 128 * 128 * 4),
-    'wgrad:f_conv2/16x16/192->192': ('conv_wgrad_rows_k<2, 2, 3, 1, true, true, false>', None, 3 * 8192 * 192 * 8 + 3 * 9 * 9 * 192 * 192 * 4),
-    'wgrad:f_in_regular/16x16/192->192': ('conv_wgrad_rows_k<2, 2, 3, 1, false, true, false>', None, 3 * 8192 * 192 * 12 + 3 * 7 * 10 * 192 * 192 * 4),
+    # round 6: both weight gradients of an H2 block read planes (template ..., PL = true): the PMC average mixes the two launches
+    'wgrad:f_conv2/32x32/128->128': ('conv_wgrad_rows_k<2, 2, 2, 2, false, true, false, true>', None, 3 * 32768 * 128 * 8 + 3 * 28 * 9 * 128 * 128 * 4),
+    'wgrad:f_in_regular/32x32/128->128': ('conv_wgrad_rows_k<2, 2, 2, 2, false, true, false, true>', None, 3 * 32768 * 128 * 12 + 3 * 21 * 10 * 128 * 128 * 4),
+    'wgrad:f_conv2/16x16/192->192': ('conv_wgrad_rows_k<2, 2, 3, 1, true, true, false, false>', None, 3 * 8192 * 192 * 8 + 3 * 9 * 9 * 192 * 192 * 4),
+    'wgrad:f_in_regular/16x16/192->192': ('conv_wgrad_rows_k<2, 2, 3, 1, false, true, false, false>', None, 3 * 8192 * 192 * 12 + 3 * 7 * 10 * 192 * 192 * 4),
 }
 out = {'_source': 'rocprofv3 --kernel-trace --pmc <one counter group per run> of `python bench.py --steps 1 --warmup 1 --no-cpu-baseline '
                   '--no-kernel-timing --no-overlap-wgrad --eager --no-inference` (tools/profile.sh %s): per-dispatch averages of the kernel '
