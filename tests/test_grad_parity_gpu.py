@@ -69,7 +69,9 @@ def mask_flips(a, b):
     return sum(int((a[k] != b[k]).sum()) for k in a), n
 
 
-@pytest.mark.parametrize('T,B,engine', [(1, 3, 'auto'), (2, 2, 'auto'), (1, 8, 'auto'), (1, 2, 'inceptionv4')])
+@pytest.mark.parametrize('T,B,engine', [(1, 3, 'auto'), (2, 2, 'auto'), (1, 2, 'inceptionv4'),
+                                        pytest.param(1, 8, 'auto', marks=pytest.mark.skipif(os.environ.get('MPOSE_LONG_TESTS', '0') == '0',
+                                                                                            reason='suite time budget: MPOSE_LONG_TESTS=1'))])
 def test_grads_on_the_same_relu_piece(T, B, engine):
     """What training runs (one convolution engine per launch kind since round 6): three fp16 products everywhere; the regular
     128-channel blocks on conv_h2r_k with planes end to end (forward, both data gradients, both weight gradients read

@@ -396,7 +396,7 @@ def test_overlap_wgrad_matches_serial():
     assert all(torch.equal(u, v) for u, v in zip(a, b)) and all(torch.equal(u, v) for u, v in zip(b, c))
 
 
-@pytest.mark.parametrize('stem,overlap', [('patch8', False), ('inceptionv4', False), ('patch8', True)])
+@pytest.mark.parametrize('stem,overlap', [('inceptionv4', False), ('patch8', True)])
 def test_data_parallel_two_ranks_share_one_gpu(stem, overlap):
     """tools/dp_check.py under torch.distributed.run: 2 ranks on cuda:0 over gloo (RCCL needs distinct devices), 2 stages:
     averaged gradients == mean of the shards' gradients, for this engine's own shard gradients (1e-5) AND for the fp64

@@ -24,7 +24,10 @@ by = collections.defaultdict(list)
 for r in rows:
     dur = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
     if 'softmax_dsnt' in r['Kernel_Name']:
-        by[(short(r['Kernel_Name']).split('(')[0], int(r['Grid_Size_X']) // 192 // 17)].append(dur)
+        k_ = short(r['Kernel_Name']).split('(')[0]
+        ta = [t.strip() for t in k_[k_.index('<') + 1:k_.rindex('>')].split(',')] if '<' in k_ else []
+        rpw = int(ta[4]) if len(ta) > 4 and ta[4].isdigit() else 1          # rows per workgroup (softmax_dsnt_fwd_k<NV, BI, BO, EXP, RPW, NT>)
+        by[(k_, int(r['Grid_Size_X']) // 192 // 17 * rpw)].append(dur)
     elif 'bn_add_softmax_k' in r['Kernel_Name']:      # grid (B, 3, 5) x 256 threads: Grid_Size_X = B * 256
         by[(short(r['Kernel_Name']).split('(')[0], int(r['Grid_Size_X']) // 256)].append(dur)
 tail = {}
