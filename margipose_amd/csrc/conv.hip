@@ -185,15 +185,28 @@ template <int RN, int MODE, int NPL, bool ROWG>
 constexpr bool slim_tile() { return ROWG && MODE == 0 && RN == 2 && NPL <= 2; }
 constexpr int RG_SLIM_ROWS = 68;
 
+// (round 6) the per-tap form of the narrow tiles, unsplit: 68 KB of LDS with two staged planes -- two workgroups per CU once the
+// registers fit too (the feature extractors' 32- / 64-channel layers, stride-2 and output-parity launches: short K loops between a
+// prologue and an epilogue, which a second resident workgroup fills: 65 -> 50 us and 49 -> 37 us on the launches that fitted as they were)
+// (which variants fit 256 registers without scratch was read off the build log: the 96-channel tile only without a prologue / second
+//  output in the three-product form)
 template <int RN, int MODE, int KS, bool PRO, int NPL, bool ROWG>
-__global__ __launch_bounds__(256, (slim_tile<RN, MODE, NPL, ROWG>() ? 2 : 1)) void conv_igemm_k(ConvArgs a) {
+constexpr bool pair_tile() {
+  return !ROWG && KS == 1 && NPL <= 2 && MODE <= 1 && (RN <= 2 || (RN == 3 && (NPL == 1 || (MODE == 0 && !PRO))));
+}
+
+template <int RN, int MODE, int KS, bool PRO, int NPL, bool ROWG>
+__global__ __launch_bounds__(256, ((slim_tile<RN, MODE, NPL, ROWG>() || pair_tile<RN, MODE, KS, PRO, NPL, ROWG>()) ? 2 : 1)) void conv_igemm_k(ConvArgs a) {
   constexpr bool ACC1 = MODE == 1, SUM2 = MODE == 2;
   constexpr bool F16 = NPL <= 2;          // NPL == 1: the h planes only (MPOSE_CONV_F16X1: operands rounded to fp16, one product)
   constexpr int NPM = F16 ? 2 : 3;        // planes of the packed weights in memory
   constexpr bool SLIM = slim_tile<RN, MODE, NPL, ROWG>();
   constexpr int RG_PL = (SLIM ? RG_SLIM_ROWS : RG_ROWS) * A_ROW_B;     // bytes of one plane of a row-group tile
   constexpr int RG_TL = 2 * RG_PL;
-  constexpr int TILE_B = ROWG ? RG_TL : A_TILE_B;          // LDS bytes reserved per staging buffer
+  constexpr int PT_B = (F16 && KS == 1) ? 2 * A_PLANE_B : A_TILE_B;     // a per-tap tile (K-split launches park accumulators in the same area and keep its size): the planes the form stages (round 6: two for the fp16 forms -- 68 KB
+                                                           // per workgroup instead of 100, so that the narrow tiles' launches, whose registers allow it,
+                                                           // run two workgroups per CU: their short K loops are all prologue and epilogue otherwise)
+  constexpr int TILE_B = ROWG ? RG_TL : PT_B;              // LDS bytes reserved per staging buffer
   constexpr int WAVE_B = 2 * TILE_B + (SLIM ? 16 * A_ROW_B : 0);      // a wave's two buffers (+ its zero rows)
   static_assert(!ROWG || F16, "row-group tiles hold two planes");
   constexpr int NPASS = MODE ? 2 : 1;
@@ -377,7 +390,7 @@ __global__ __launch_bounds__(256, (slim_tile<RN, MODE, NPL, ROWG>() ? 2 : 1)) vo
         v.z = pad ? 0.f : fmaxf(fmaf(v.z, sc.z, sh.z), 0.f); v.w = pad ? 0.f : fmaxf(fmaf(v.w, sc.w, sh.w), 0.f);
       }
       // row (lane >> 3) + 8 j: its swizzle is ((lane >> 5) + 2 j) & 3 -- one of two per-lane values (j is a compile-time constant)
-      unsigned char* dA = sA + buf * A_TILE_B + ((lane >> 3) + 8 * j) * A_ROW_B + ((j & 1) ? st_off_odd : st_off_even);
+      unsigned char* dA = sA + buf * PT_B + ((lane >> 3) + 8 * j) * A_ROW_B + ((j & 1) ? st_off_odd : st_off_even);
       if constexpr (NPL == 1) {
         if (!pro) { v.x *= a_mul; v.y *= a_mul; v.z *= a_mul; v.w *= a_mul; }
         uint2 h;
@@ -403,7 +416,7 @@ __global__ __launch_bounds__(256, (slim_tile<RN, MODE, NPL, ROWG>() ? 2 : 1)) vo
     auto stage_row = [&](int buf, int j) { stage(buf, j, ra[j], pad_c, rsc_c, rsh_c); };
     auto rotate_stage_state = [&]() { pad_c = pad_n; rsc_c = rsc_n; rsh_c = rsh_n; };
     auto read_frags = [&](int buf, int s_, u32x4 (&af)[2][NPL]) {
-      const unsigned char* cA = sA + buf * A_TILE_B + li * A_ROW_B + (s_ ? rd_off1 : rd_off0);    // (rows li and li + 32 swizzle alike)
+      const unsigned char* cA = sA + buf * PT_B + li * A_ROW_B + (s_ ? rd_off1 : rd_off0);    // (rows li and li + 32 swizzle alike)
 #pragma unroll
       for (int rm = 0; rm < 2; ++rm)
 #pragma unroll
@@ -768,7 +781,7 @@ __global__ __launch_bounds__(256, (slim_tile<RN, MODE, NPL, ROWG>() ? 2 : 1)) vo
       if (KS == 2) return rm == kh;
       return rm == (kh & 1) && ((rn * 2) / RN) == (kh >> 1);
     };
-    if (KS > 1 && !(CV_EXP & 4)) {
+    if constexpr (KS > 1 && !(CV_EXP & 4)) {
       constexpr int BLK = 16 * 64;                       // floats of one accumulator block
       constexpr int STRIDE = (KS == 2 ? RN : 2 * RN - RN / 2) * BLK;    // most blocks a wave can have to park
       static_assert(4 * STRIDE * 4 <= 4 * WAVE_B, "exchange area must fit in the A-tile region");
@@ -1094,7 +1107,7 @@ template <int RN, int MODE, int KS, bool PRO, int NPL, bool ROWG>
 int launch_conv(const ConvArgs& a0, int n_groups, hipStream_t s) {
   constexpr int BN = 32 * RN;
   constexpr bool SLIM = slim_tile<RN, MODE, NPL, ROWG>();
-  constexpr int wave_b = SLIM ? 2 * 2 * RG_SLIM_ROWS * A_ROW_B + 16 * A_ROW_B : 2 * (ROWG ? RG_TILE_B : A_TILE_B);
+  constexpr int wave_b = SLIM ? 2 * 2 * RG_SLIM_ROWS * A_ROW_B + 16 * A_ROW_B : 2 * (ROWG ? RG_TILE_B : ((NPL <= 2 && KS == 1) ? 2 * A_PLANE_B : A_TILE_B));
   constexpr int lds = 4 * wave_b + 2 * 4 * BN * 2 * 4 + 4 * 64 * 4 + 4 * BN * 2 * 4;
   static_assert(!SLIM || 2 * lds <= 160 * 1024, "two workgroups per CU");
   if (mpose_dry_rows) { *mpose_dry_rows += ((a0.M + 256 / KS - 1) / (256 / KS)) * a0.g.n_classes; return 0; }     // (mpose_conv_stat_rows)

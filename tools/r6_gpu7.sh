@@ -1,0 +1,5 @@
+mkdir -p gpurun_out
+timeout 900 python -m pytest tests/test_conv_f16x3_gpu.py tests/test_conv_gpu.py tests/test_stem_gpu.py tests/test_chatterbox_gpu.py -q -m gpu -p no:cacheprovider -x 2>&1 | tail -3
+timeout 900 python -m pytest tests/test_grad_parity_gpu.py tests/test_model_gpu.py -q -m gpu -p no:cacheprovider -k "1-2-inceptionv4 or 1-3-auto or fp16_convolution" 2>&1 | tail -3
+bash tools/step_stats.sh r6d 2>&1 | head -6
+bash tools/ab_sweep.sh "X=1" 2>&1 | tail -4
