@@ -182,7 +182,7 @@ __device__ __forceinline__ f32x16 mfma_f16(const u32x4 a, const u32x4 b, const f
 // one per plane and buffer brings the workgroup to 79 KB of LDS: the second workgroup's waves issue their MFMAs into the gaps
 // the first one's leave (prologue, exchange, epilogue, every s_waitcnt) -- see slim_tile().
 template <int RN, int MODE, int NPL, bool ROWG>
-constexpr bool slim_tile() { return ROWG && MODE == 0 && RN == 2 && NPL <= 2; }
+constexpr bool slim_tile() { return ROWG && MODE == 0 && RN <= 2 && NPL <= 2; }
 constexpr int RG_SLIM_ROWS = 68;
 
 // (round 6) the per-tap form of the narrow tiles, unsplit: 68 KB of LDS with two staged planes -- two workgroups per CU once the

@@ -119,9 +119,9 @@ def test_inference_config_batch64_vs_oracle():
         sd = weights(T, seed, x, True)
         sd = OrderedDict((k, v.double() if v.is_floating_point() else v) for k, v in sd.items())
         un = {}
-        # eval mode: every frame is independent of its batch mates, so the fp64 oracle checks every fourth frame of the batch
-        # the GPU ran whole (a quarter of the CPU time: the suite's budget)
-        sub = torch.arange(0, B, 4)
+        # eval mode: every frame is independent of its batch mates, so the fp64 oracle checks every eighth frame of the batch
+        # the GPU ran whole (an eighth of the CPU time: the suite's budget; every fourth under MPOSE_LONG_TESTS)
+        sub = torch.arange(0, B, 4 if os.environ.get('MPOSE_LONG_TESTS', '0') != '0' else 8)
         xy, zy, xz = R.inner_forward(sd, x[sub].double(), T, False, True, heatmap_dtype=torch.bfloat16, unrounded=un)
         ref = R.heatmaps_to_coords(un['xy'], un['zy'], un['xz'])
     err = rel(out.cpu()[sub], ref)
@@ -730,6 +730,9 @@ def test_default_model_single_frame_vs_oracle():
     report('default_T4_inceptionv4_B1', errs)
 
 
+@pytest.mark.skipif(os.environ.get('MPOSE_LONG_TESTS', '0') == '0', reason='suite time budget (a CPU fp64 pass of five stages at 384 x 384: up to a '
+                    'minute on the pool\'s slow hosts): MPOSE_LONG_TESTS=1 (tools/final_check.sh) runs it; the default suite keeps configs[4]\'s '
+                    'shape in test_fp16_convolution_mode_vs_oracle[5-384-patch8-1] and 384 x 384 in test_other_input_sizes_vs_oracle')
 def test_five_stage_model_at_384_vs_oracle():
     """BASELINE configs[4]'s shape: 5 stages at 384x384 input (48x48 heatmaps, 24x24 mid resolution; the size constraint of
     models/margipose_model.py:87-97), one training step against the fp64 oracle: forward quantities free running, gradients on
@@ -772,7 +775,7 @@ def _oracle_step(sd, x, target, mask, T, dtype=torch.float64):
     return R.heatmaps_to_coords(xy[-1], zy[-1], xz[-1]).detach(), float(loss.detach()), OrderedDict((k, p.grad) for k, p in params.items())
 
 
-@pytest.mark.parametrize('T,size,stem,B', [(5, 384, 'patch8', 1), (1, 128, 'inceptionv4', 2), (2, 384, 'inceptionv4', 2),
+@pytest.mark.parametrize('T,size,stem,B', [(5, 384, 'patch8', 1), (1, 128, 'inceptionv4', 2), (2, 384, 'inceptionv4', 1),
                                            pytest.param(5, 384, 'inceptionv4', 2, marks=pytest.mark.skipif(
                                                os.environ.get('MPOSE_LONG_TESTS', '0') == '0', reason='suite time budget: the bench leg\'s own '
                                                'combination at full depth runs under MPOSE_LONG_TESTS=1 (tools/final_check.sh); the default suite '

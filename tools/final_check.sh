@@ -9,7 +9,7 @@ timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('SMOKE OK')
 # the cases the default suite skips for time: configuration-size patch8 same-piece + the free-running statistics, the other feature
 # extractors' train steps, the five-stage InceptionV4 fp16 case, T = 2 train step, eight gloo ranks on the one GPU
 MPOSE_LONG_TESTS=1 timeout 1800 python -m pytest tests/test_grad_parity_gpu.py -x -q -m gpu -k "config_size or 1-8-auto" -p no:cacheprovider > gpurun_out/final_long_config.txt 2>&1; tail -3 gpurun_out/final_long_config.txt
-MPOSE_LONG_TESTS=1 timeout 1500 python -m pytest tests/test_model_gpu.py tests/test_stem_gpu.py -q -m gpu -p no:cacheprovider -k "eight_ranks or (stem_train_step and not resnet34) or (fp16_convolution and 5-384-inceptionv4) or (eval_mode_batchnorm and inceptionv4) or (train_step_vs_oracle and 2-2)" > gpurun_out/final_long_rest.txt 2>&1; tail -3 gpurun_out/final_long_rest.txt
+MPOSE_LONG_TESTS=1 timeout 1500 python -m pytest tests/test_model_gpu.py tests/test_stem_gpu.py -q -m gpu -p no:cacheprovider -k "eight_ranks or (stem_train_step and not resnet34) or (fp16_convolution and 5-384-inceptionv4) or (eval_mode_batchnorm and inceptionv4) or (train_step_vs_oracle and 2-2) or five_stage_model_at_384 or (stem_eval_forward and (resnet18 or resnet50)) or inference_config_batch64" > gpurun_out/final_long_rest.txt 2>&1; tail -3 gpurun_out/final_long_rest.txt
 python tools/collect_gradparity.py $TAG
 timeout 900 python bench.py > gpurun_out/bench_final.json 2> gpurun_out/bench_final.err; tail -c 600 gpurun_out/bench_final.json
 bash tools/profile.sh $TAG > gpurun_out/profile_$TAG.log 2>&1; tail -5 gpurun_out/profile_$TAG.log
