@@ -28,6 +28,17 @@ def sources():
     return sorted(glob.glob(os.path.join(CSRC, '*.hip')))
 
 
+def _included_sources(src):
+    """csrc/*.hip files a source pulls in with #include "x.hip"."""
+    out = []
+    with open(src) as f:
+        for line in f:
+            line = line.strip()
+            if line.startswith('#include "') and line.endswith('.hip"'):
+                out.append(line[len('#include "'):-1])
+    return out
+
+
 def is_stale():
     if not os.path.exists(LIB_PATH):
         return True
@@ -42,12 +53,14 @@ def build(force=False, verbose=False):
         return LIB_PATH
     objs = []
     procs = []
-    # a source is recompiled when it, or any header, is newer than its object (conv.hip alone takes four minutes)
+    # a source is recompiled when it, or any header, is newer than its object (conv.hip's three units take about two minutes each, side by side)
     hdrs = glob.glob(os.path.join(CSRC, '*.h')) + glob.glob(os.path.join(PKG_DIR, '..', 'include', '*.h'))
     t_hdr = max(os.path.getmtime(h) for h in hdrs)
     for src in sources():
         obj = os.path.splitext(src)[0] + '.o'
-        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), t_hdr):
+        # (conv_rn3.hip / conv_rn4.hip are conv.hip compiled again for a part of its instantiations: they age with it)
+        t_src = max([os.path.getmtime(src)] + [os.path.getmtime(os.path.join(CSRC, inc)) for inc in _included_sources(src)])
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(t_src, t_hdr):
             objs.append(obj)
             continue
         cmd = [_hipcc()] + HIPCC_FLAGS + EXTRA_FLAGS.get(os.path.basename(src), []) + ['-Rpass-analysis=kernel-resource-usage', '-c', src, '-o', obj]

@@ -25,6 +25,9 @@
 #include "common.h"
 #include <stdlib.h>
 
+#ifndef CV_PART
+#define CV_PART 0          // 0: this unit; 3 / 4: conv_igemm_k's RN = 3 / 4 instantiations alone (conv_rn3.hip, conv_rn4.hip; see the end of the anonymous namespace)
+#endif
 #ifndef MFMA_SPREAD
 #define MFMA_SPREAD 1      // 0: round 2's rm-major MFMA chains (A/B builds)
 #endif
@@ -1230,6 +1233,7 @@ int launch_conv_ks(const ConvArgs& a, int mode, int cmax, int n_groups, hipStrea
   return launch_conv_ks_p<RN, 3, false>(a, mode, cmax, n_groups, s);
 }
 
+#if CV_PART == 0     // (weight gradients, weight packing and the C entry points: the main translation unit only)
 // ---------------------------------------------------------------------------------------------
 // Weight gradient: dWp[split][widx][k/4][n][4] = sum_{slots in split} X_tap[slot][k] * G[slot][n]
 // MFMA roles: i = k (input channel), j = n (output channel), reduction index = slot (pixel); bf16x6 like the
@@ -1723,8 +1727,28 @@ __global__ __launch_bounds__(256) void unpack_wgrads_k(const mpose_unpack_job* _
   }
 }
 
+#endif   // CV_PART == 0
 }  // namespace
 }  // namespace mpose
+
+// conv_igemm_k's 96- and 128-channel tiles -- two thirds of its instantiations by compile time -- are built in translation units of
+// their own: conv_rn3.hip / conv_rn4.hip compile THIS file with CV_PART = 3 / 4 (the kernel, its launchers and one entry point each;
+// ConvArgs is the same struct in every unit, passed as an untyped pointer because its type lives in an anonymous namespace).
+namespace mpose {
+int conv_igemm_rn3(const void* args, int mode, int cmax, int n_groups, hipStream_t s);
+int conv_igemm_rn4(const void* args, int mode, int cmax, int n_groups, hipStream_t s);
+#if CV_PART == 3
+int conv_igemm_rn3(const void* args, int mode, int cmax, int n_groups, hipStream_t s) {
+  return launch_conv_ks<3>(*static_cast<const ConvArgs*>(args), mode, cmax, n_groups, s);
+}
+#elif CV_PART == 4
+int conv_igemm_rn4(const void* args, int mode, int cmax, int n_groups, hipStream_t s) {
+  return launch_conv_ks<4>(*static_cast<const ConvArgs*>(args), mode, cmax, n_groups, s);
+}
+#endif
+}  // namespace mpose
+
+#if CV_PART == 0
 
 using namespace mpose;
 
@@ -1917,8 +1941,8 @@ extern "C" int mpose_conv_fwd(const mpose_conv_geom* geom_, const mpose_conv_ope
   if (slim && (slim == 2 || a.op[0].epi_scale0 != nullptr || (flags & MPOSE_CONV_F16X1)) && mode == 0 && (flags & MPOSE_CONV_F16X3) &&
       (cmax % 128) == 0 && rowg_env() && rowg_eligible(a.g))
     return launch_conv_ks<2>(a, mode, cmax, n_groups, s);
-  if (cmax % 128 == 0) return launch_conv_ks<4>(a, mode, cmax, n_groups, s);
-  if (cmax % 96 == 0 && npad % 96 == 0) return launch_conv_ks<3>(a, mode, cmax, n_groups, s);
+  if (cmax % 128 == 0) return conv_igemm_rn4(&a, mode, cmax, n_groups, s);
+  if (cmax % 96 == 0 && npad % 96 == 0) return conv_igemm_rn3(&a, mode, cmax, n_groups, s);
   return launch_conv_ks<2>(a, mode, cmax, n_groups, s);
 }
 
@@ -2081,3 +2105,4 @@ extern "C" int mpose_unpack_wgrads(const mpose_unpack_job* jobs_dev, int n_jobs,
   launch(unpack_wgrads_k, dim3(dim3(bx, n_jobs)), dim3(256), 0, (hipStream_t)stream, jobs_dev);
   return launch_status();
 }
+#endif   // CV_PART == 0
