@@ -24,7 +24,7 @@ def timeit(fn, iters=50, warm=5):
 def main():
     L = _lib.lib()
     res = []
-    fwd_only = '--fwd-only' in sys.argv          # (tools/tail_variants.sh: the forward kernel at the cache-defeating sizes only)
+    fwd_only = '--fwd-only' in sys.argv          # (the forward kernel at the cache-defeating sizes only)
     cases = ((2048, 32, False), (2048, 32, True), (910, 48, False), (512, 64, False)) if fwd_only else \
         ((64, 32, False), (64, 32, True), (32, 32, False), (2048, 32, False), (2048, 32, True), (512, 64, False))
     for B, F, bf16 in cases:
@@ -37,7 +37,7 @@ def main():
                    iters=200 if fwd_only else 50)
         bpe = 2 if bf16 else 4
         res.append(dict(kernel='softmax_dsnt_fwd', B=B, F=F, dtype=str(dt), us=t * 1e6, GBps=E * 2 * bpe / t / 1e9,
-                        frac_of_8TBps=E * 2 * bpe / t / 8e12, variant=os.environ.get('MPOSE_TAIL_VARIANT', 'default')))
+                        frac_of_8TBps=E * 2 * bpe / t / 8e12))
         if bf16 or fwd_only:
             continue
         tgt = torch.rand(B, 17, 3, device='cuda') * 2 - 1

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Micro-benchmark + quick check of the weight-gradient kernels on the model's dominant shapes (B=32, 3 column groups, the
-three-product fp16 form).  MPOSE_WGRAD_ROWS=0 selects conv.hip's conv_wgrad_k, the default wgrad.hip's row-of-taps kernel.
+three-product fp16 form): wgrad.hip's row-of-taps kernel where it takes the geometry, conv.hip's conv_wgrad_k otherwise.
 
     python tools/bench_wgrad.py [--check]
 """
