@@ -465,8 +465,15 @@ def test_bench_with_eight_ranks_on_one_gpu():
     env = dict(os.environ, MPOSE_DIST_BACKEND='gloo', MPOSE_SINGLE_DEVICE='1')
     for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '8', '--steps', '2', '--warmup', '1', '--batch', '2', '--stages', '1',
-                        '--stem', 'patch8', '--no-cpu-baseline', '--no-inference'], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500)
+    # Eight processes on ONE GPU is not what the 8-GPU node runs, and this runtime does not survive it every time: in 10-20 % of the runs one
+    # rank dies of HSA_STATUS_ERROR_ILLEGAL_INSTRUCTION inside a torch.zeros() of its set-up, before any kernel of this library has been
+    # launched (profiles/r6_eight_rank_flake.txt: stacks taken with HIP_LAUNCH_BLOCKING=1; 0 of 20 runs with four ranks, 0 of 36 with
+    # two).  A run that died of exactly that is repeated; anything else fails the test at once.
+    for attempt in range(4):
+        r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '8', '--steps', '2', '--warmup', '1', '--batch', '2', '--stages', '1',
+                            '--stem', 'patch8', '--no-cpu-baseline', '--no-inference'], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500)
+        if r.returncode == 0 or b'HSA_STATUS_ERROR_ILLEGAL_INSTRUCTION' not in r.stderr:
+            break
     out = r.stdout.decode(errors='replace')
     js = [l for l in out.splitlines() if l.startswith('{')]
     assert r.returncode == 0 and len(js) == 1, (r.returncode, out[-2000:], r.stderr.decode(errors='replace')[-3000:])
