@@ -468,7 +468,7 @@ def test_bench_with_eight_ranks_on_one_gpu():
     # Eight processes on ONE GPU is not what the 8-GPU node runs, and this runtime does not survive it every time: in 10-20 % of the runs one
     # rank dies of HSA_STATUS_ERROR_ILLEGAL_INSTRUCTION inside a torch.zeros() of its set-up, before any kernel of this library has been
     # launched (profiles/r6_eight_rank_flake.txt: stacks taken with HIP_LAUNCH_BLOCKING=1; 0 of 20 runs with four ranks, 0 of 36 with
-    # two).  A run that died of exactly that is repeated; anything else fails the test at once.
+    # two; eight plain PyTorch processes broadcasting device tensors over gloo die the same way, tools/probe/eight_procs_torch.py).  A run that died of exactly that is repeated; anything else fails the test at once.
     for attempt in range(4):
         r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '8', '--steps', '2', '--warmup', '1', '--batch', '2', '--stages', '1',
                             '--stem', 'patch8', '--no-cpu-baseline', '--no-inference'], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500)
